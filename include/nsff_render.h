@@ -1,0 +1,187 @@
+/*
+ * nsff_render.h -- C-ABI of the MI355X (gfx950) NSFF ray renderer.
+ *
+ * Drop-in boundary for ONE hot path of kwea123/nsff_pl: models/rendering.py
+ * (render_rays, inference, render_transient_warping, sample_pdf) and
+ * models/nerf.py (PosEmbedding, NeRF).  The reference has no FFI of its own
+ * (pure Python on torch); these entry points are what a maintainer would bind
+ * with ctypes to replace the torch ops of that path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (int32 where said);
+ *     the library never allocates, frees or copies user-visible memory;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     the call returns without synchronising;
+ *   - return value: 0 = ok, <0 = NSFF_ERR_* (no exceptions cross the ABI);
+ *   - not thread-safe per stream; re-entrant across streams (no global state).
+ */
+#ifndef NSFF_RENDER_H
+#define NSFF_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSFF_OK               0
+#define NSFF_ERR_INVALID     -1   /* bad shape / flag / unsupported architecture */
+#define NSFF_ERR_NULL        -2   /* required pointer missing                      */
+#define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
+#define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
+
+#define NSFF_ABI_VERSION      1
+#define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
+#define NSFF_MAX_FREQS       16
+#define NSFF_MAX_LAYERS       8
+
+/* Raw field record (what NeRF.forward returns per point, reference nerf.py:187-213):
+ *   [0..2] static rgb (sigmoid)  [3] static sigma (raw)
+ *   [4..6] transient rgb         [7] transient sigma (raw)
+ *   [8..10] flow_fw = flow_scale*tanh(.)   [11..13] flow_bw   [14..15] unused */
+
+/* ---- model description: mirrors NeRF.__init__ (reference nerf.py:34-40) ---- */
+typedef struct NsffModelDesc {
+    int32_t D;              /* trunk depth, must be 8                              */
+    int32_t W;              /* width, must be 256                                  */
+    int32_t skip;           /* layer index (0-based) that re-reads the input, 4    */
+    int32_t in_xyz;         /* 63                                                  */
+    int32_t in_dir;         /* 27                                                  */
+    int32_t in_a;           /* appearance code width or 0                          */
+    int32_t in_t;           /* transient code width or 0                           */
+    int32_t use_viewdir;    /* static_dir_encoding present                         */
+    int32_t has_transient;  /* encode_transient                                    */
+    int32_t has_flow;       /* transient_flow_fw / _bw heads present               */
+    float   flow_scale;     /* 0.2                                                 */
+} NsffModelDesc;
+
+/* Size in bytes of the packed-weight buffer for `desc`. */
+int nsff_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
+
+/* Number of parameter tensors nsff_pack_weights expects, in this order
+ * (PyTorch Linear layout, weight (out,in) row-major then bias):
+ *   static_xyz_encoding_{1..D}.0, static_xyz_encoding_final,
+ *   [static_dir_encoding.0], static_sigma, static_rgb.0,
+ *   [transient_xyz_encoding_{1..D}.0, transient_xyz_encoding_final,
+ *    transient_sigma, transient_rgb.0, [transient_flow_fw.0, transient_flow_bw.0]] */
+int nsff_param_count(const NsffModelDesc* desc);
+
+/* Repack the module parameters into MFMA B-operand tiles (DESIGN.md "weight pack").
+ * `params`: HOST array of nsff_param_count() device pointers. */
+int nsff_pack_weights(const NsffModelDesc* desc, const float* const* params,
+                      float* packed, void* stream);
+
+/* ---- a1: PosEmbedding.forward (reference nerf.py:17-30) ---- */
+int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_freqs,
+                float* out, void* stream);
+
+/* ---- a3/a5: fused field query = encode -> trunk(s) -> heads (NeRF.forward) ---- */
+typedef struct NsffFieldArgs {
+    int64_t n_points;        /* P                                                   */
+    int32_t pts_per_ray;     /* ray index of point p is p / pts_per_ray             */
+    int32_t static_mode;     /* 0 skip, 1 sigma only, 2 rgb+sigma                   */
+    int32_t transient_mode;  /* 0 skip, 1 sigma only, 2 rgb+sigma(+flow heads)      */
+    int32_t flow_heads;      /* flow heads the caller consumes (0,1,2); the kernel always
+                                evaluates every head the model has, this only feeds the
+                                algorithmic-FLOP accounting of nsff_prof_collect          */
+    /* input A: raw positions, encoded in-kernel (render path) */
+    const float* xyz;        /* (P,3) or NULL                                       */
+    int32_t n_freqs;         /* of the xyz embedding                                */
+    float   freqs[NSFF_MAX_FREQS];
+    const float* dir_emb;    /* (n_rays, in_dir) per-ray, needed iff use_viewdir    */
+    const float* a_emb;      /* (n_rays, in_a)   per-ray, needed iff in_a>0 && use_viewdir */
+    const float* t_emb;      /* (n_rays, in_t)   per-ray, needed iff transient_mode */
+    /* input B: rows already embedded by the caller (NeRF.forward API) */
+    const float* x_emb;      /* (P, ld_emb) or NULL                                 */
+    int32_t ld_emb;
+    int32_t off_xyz, off_dir, off_a, off_t;  /* column offsets in x_emb, -1 = absent */
+    float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
+} NsffFieldArgs;
+
+int nsff_field_query(const NsffModelDesc* desc, const float* packed,
+                     const NsffFieldArgs* args, void* stream);
+
+/* ---- a4: coarse sample placement (reference rendering.py:314-324,332) ----
+ * zs[n][i] = z_lin[i]                                   (perturb == 0)
+ *          = lower + (upper-lower) * perturb * rnd[n][i] (perturb > 0)
+ * xyz[n][i] = o[n] + d[n]*zs[n][i]                                             */
+int nsff_coarse_samples(const float* rays, int64_t n_rays, const float* z_lin, int32_t n_samples,
+                        float perturb, const float* perturb_rand,
+                        float* zs, float* xyz, void* stream);
+
+/* ---- a9: sample_pdf x{1,2} + merge + sort (reference rendering.py:10-49,335-348,359) ----
+ * weights_* are the (n_rays, n_samples) coarse weights (the [1:-1] slice is taken here).
+ * u_* : (n_importance) when u_per_ray==0 (deterministic linspace), else (n_rays, n_importance).
+ * zs_fine: (n_rays, n_samples + k*n_importance) sorted ascending, k = 1 + (weights_transient!=NULL)
+ * xyz_fine = o + d*zs_fine.  samples_static/transient (n_rays,n_importance) optional. */
+int nsff_fine_samples(const float* rays, int64_t n_rays, const float* z_lin, const float* zs_coarse,
+                      int32_t n_samples, int32_t n_importance,
+                      const float* weights_static, const float* weights_transient,
+                      const float* u_static, const float* u_transient, int32_t u_per_ray,
+                      float* samples_static, float* samples_transient,
+                      float* zs_fine, float* xyz_fine, void* stream);
+
+/* standalone sample_pdf(bins, weights, N_importance) with explicit u (reference rendering.py:10-49) */
+int nsff_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int32_t n_bins_minus1,
+                    const float* u, int32_t n_importance, int32_t u_per_ray, float eps,
+                    float* samples, void* stream);
+
+/* ---- a8 (first half): xyzs_fw = xyz + flow_fw, xyzs_bw = xyz + flow_bw with the
+ * z > z_far flow zeroing (reference rendering.py:187-188,218,224) ---- */
+int nsff_warp_points(const float* raw, const float* xyz, const float* zs, int64_t n_points,
+                     float z_far, float* xyz_fw, float* xyz_bw, void* stream);
+
+/* ---- a7/a8: sigma->alpha compositing and every per-ray / per-sample output ---- */
+typedef struct NsffCompositeArgs {
+    int64_t n_rays;
+    int32_t n_samples;          /* S of this pass                                   */
+    int32_t has_transient;      /* output_transient                                 */
+    int32_t has_rgb;            /* 0 for the sigma-only coarse test-time pass       */
+    int32_t flow_mode;          /* 0 none, 1 per-ray/per-sample flow outputs, 2 + warped renders */
+    int32_t want_disocc;        /* 'disocc' in output_transient_flow (flow_mode 2)   */
+    float   noise_std;
+    float   z_far;              /* 0.95                                             */
+    const float* raw;           /* (N*S,16) field records at xyz                    */
+    const float* raw_fw;        /* (N*S,16) records at xyz+flow_fw, t+1 (flow_mode 2)*/
+    const float* raw_bw;        /* (N*S,16) records at xyz+flow_bw, t-1             */
+    const float* zs;            /* (N,S)                                            */
+    const float* xyz;           /* (N,S,3)                                          */
+    const float* xyz_fw;        /* (N,S,3) (flow_mode 2)                            */
+    const float* xyz_bw;
+    const float* noise_static;  /* (N,S) standard normal draws or NULL (=> 0)       */
+    const float* noise_transient;
+    const float* noise_fw;
+    const float* noise_bw;
+    const float* visibility;    /* (N*S) or NULL; ==0 => raw transient sigma := -10 (rendering.py:200) */
+    /* per-sample outputs (NULL = not wanted) */
+    float* static_rgbs;  float* transient_rgbs;        /* (N,S,3) */
+    float* flows_fw;     float* flows_bw;              /* (N,S,3) zeroed beyond z_far */
+    float* static_sigmas; float* transient_sigmas;     /* (N,S) softplus'd */
+    float* static_alphas; float* transient_alphas;     /* (N,S) */
+    float* static_weights; float* transient_weights; float* weights;   /* (N,S) */
+    float* xyzs_fw_bw;   float* xyzs_bw_fw;            /* (N,S,3) */
+    float* disoccs_fw;   float* disoccs_bw;            /* (N,S) */
+    /* per-ray outputs */
+    float* depth;  float* rgb;  float* transient_alpha;  float* transient_rgb;
+    float* static_only_rgb;  float* static_only_depth;
+    float* xyz_exp;  float* flow_fw_exp;  float* flow_bw_exp;  float* xyz_fw_exp;  float* xyz_bw_exp;
+    float* rgb_fw;   float* rgb_bw;
+    float* disocc_fw;  float* disocc_bw;
+} NsffCompositeArgs;
+
+int nsff_composite(const NsffCompositeArgs* args, void* stream);
+
+/* ---- profiling hooks used by bench.py (HIP events around field-query launches) ---- */
+int nsff_prof_enable(int on);
+/* Synchronises the recorded events; returns launches, summed milliseconds and summed
+ * algorithmic FLOPs (2*MACs of the Linear layers, unpadded K) since the last reset. */
+int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
+
+int         nsff_abi_version(void);
+const char* nsff_last_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSFF_RENDER_H */

@@ -1,0 +1,259 @@
+"""ctypes binding of ``libnsff_hip.so`` (C-ABI declared in ``include/nsff_render.h``).
+
+PyTorch is used here only as the owner of device memory and of the HIP stream; every
+call below passes raw device pointers and the current stream handle to the library.
+There is no CPU fallback: a missing library, a CPU tensor or a non-zero return code
+raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsff_hip.so")
+
+RAW_STRIDE = 16
+MAX_FREQS = 16
+
+_ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
+        -2: "NSFF_ERR_NULL (required pointer missing)",
+        -3: "NSFF_ERR_ALIGN (pointer not 16-byte aligned)",
+        -4: "NSFF_ERR_HIP"}
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("skip", C.c_int32),
+                ("in_xyz", C.c_int32), ("in_dir", C.c_int32), ("in_a", C.c_int32),
+                ("in_t", C.c_int32), ("use_viewdir", C.c_int32),
+                ("has_transient", C.c_int32), ("has_flow", C.c_int32),
+                ("flow_scale", C.c_float)]
+
+
+class FieldArgs(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("pts_per_ray", C.c_int32),
+                ("static_mode", C.c_int32), ("transient_mode", C.c_int32),
+                ("flow_heads", C.c_int32),
+                ("xyz", _fp), ("n_freqs", C.c_int32), ("freqs", C.c_float * MAX_FREQS),
+                ("dir_emb", _fp), ("a_emb", _fp), ("t_emb", _fp),
+                ("x_emb", _fp), ("ld_emb", C.c_int32),
+                ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
+                ("off_t", C.c_int32), ("raw", _fp)]
+
+
+_COMPOSITE_PTRS_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "xyz_fw", "xyz_bw",
+                      "noise_static", "noise_transient", "noise_fw", "noise_bw", "visibility"]
+_COMPOSITE_PTRS_OUT = ["static_rgbs", "transient_rgbs", "flows_fw", "flows_bw",
+                       "static_sigmas", "transient_sigmas", "static_alphas", "transient_alphas",
+                       "static_weights", "transient_weights", "weights",
+                       "xyzs_fw_bw", "xyzs_bw_fw", "disoccs_fw", "disoccs_bw",
+                       "depth", "rgb", "transient_alpha", "transient_rgb",
+                       "static_only_rgb", "static_only_depth",
+                       "xyz_exp", "flow_fw_exp", "flow_bw_exp", "xyz_fw_exp", "xyz_bw_exp",
+                       "rgb_fw", "rgb_bw", "disocc_fw", "disocc_bw"]
+
+
+class CompositeArgs(C.Structure):
+    _fields_ = ([("n_rays", C.c_int64), ("n_samples", C.c_int32), ("has_transient", C.c_int32),
+                 ("has_rgb", C.c_int32), ("flow_mode", C.c_int32), ("want_disocc", C.c_int32),
+                 ("noise_std", C.c_float), ("z_far", C.c_float)]
+                + [(n, _fp) for n in _COMPOSITE_PTRS_IN]
+                + [(n, _fp) for n in _COMPOSITE_PTRS_OUT])
+
+
+# name -> (restype, argtypes); also the list of symbols the header declares
+_SIGNATURES = {
+    "nsff_abi_version": (C.c_int, []),
+    "nsff_last_hip_error": (C.c_char_p, []),
+    "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
+    "nsff_param_count": (C.c_int, [C.POINTER(ModelDesc)]),
+    "nsff_pack_weights": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp]),
+    "nsff_posenc": (C.c_int, [_fp, C.c_int64, C.POINTER(C.c_float), C.c_int, _fp, _fp]),
+    "nsff_field_query": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldArgs), _fp]),
+    "nsff_coarse_samples": (C.c_int, [_fp, C.c_int64, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, _fp]),
+    "nsff_fine_samples": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp,
+                                    C.c_int32, _fp, _fp, _fp, _fp, _fp]),
+    "nsff_sample_pdf": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, C.c_int32, C.c_int32,
+                                  C.c_float, _fp, _fp]),
+    "nsff_warp_points": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_float, _fp, _fp, _fp]),
+    "nsff_composite": (C.c_int, [C.POINTER(CompositeArgs), _fp]),
+    "nsff_prof_enable": (C.c_int, [C.c_int]),
+    "nsff_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C nsff_pl_amd/csrc`).  There is no CPU fallback for the render path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.nsff_abi_version() != 1:
+            raise RuntimeError("libnsff_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _ERR.get(rc, f"error {rc}")
+        if rc == -4:
+            msg += ": " + load().nsff_last_hip_error().decode()
+        raise RuntimeError(f"{what} failed: {msg}")
+
+
+def require_gpu_tensor(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{what} must be a GPU tensor: the NSFF render path runs only on the "
+                           "HIP kernels of libnsff_hip.so (no CPU fallback)")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "need contiguous fp32 GPU tensor"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------------
+def model_desc(model):
+    if len(model.skips) != 1:
+        raise RuntimeError("the gfx950 field kernel supports exactly one skip layer")
+    return ModelDesc(D=model.D, W=model.W, skip=model.skips[0], in_xyz=model.in_channels_xyz,
+                     in_dir=model.in_channels_dir,
+                     in_a=model.in_channels_a if model.use_viewdir else 0,
+                     in_t=model.in_channels_t, use_viewdir=int(model.use_viewdir),
+                     has_transient=int(model.encode_transient),
+                     has_flow=int(getattr(model, "has_flow_heads", hasattr(model, "transient_flow_fw"))),
+                     flow_scale=float(getattr(model, "flow_scale", 0.0)))
+
+
+def param_list(model):
+    """Parameter tensors in the order nsff_pack_weights documents."""
+    def lin(m):
+        layer = m[0] if isinstance(m, torch.nn.Sequential) else m
+        return [layer.weight, layer.bias]
+    out = []
+    for i in range(model.D):
+        out += lin(getattr(model, f"static_xyz_encoding_{i + 1}"))
+    out += lin(model.static_xyz_encoding_final)
+    if model.use_viewdir:
+        out += lin(model.static_dir_encoding)
+    out += lin(model.static_sigma) + lin(model.static_rgb)
+    if model.encode_transient:
+        for i in range(model.D):
+            out += lin(getattr(model, f"transient_xyz_encoding_{i + 1}"))
+        out += lin(model.transient_xyz_encoding_final)
+        out += lin(model.transient_sigma) + lin(model.transient_rgb)
+        if hasattr(model, "transient_flow_fw"):
+            out += lin(model.transient_flow_fw) + lin(model.transient_flow_bw)
+    return out
+
+
+def packed_bytes(desc):
+    n = C.c_size_t(0)
+    _check(load().nsff_packed_bytes(C.byref(desc), C.byref(n)), "nsff_packed_bytes")
+    return n.value
+
+
+def pack_weights(desc, params, packed):
+    lib = load()
+    if lib.nsff_param_count(C.byref(desc)) != len(params):
+        raise RuntimeError("parameter list does not match the model description")
+    keep = [p.detach().contiguous().float() for p in params]
+    for p in keep:
+        require_gpu_tensor(p, "model parameter")
+    arr = (_fp * len(keep))(*[p.data_ptr() for p in keep])
+    _check(lib.nsff_pack_weights(C.byref(desc), arr, _ptr(packed), _stream()), "nsff_pack_weights")
+    return keep  # caller keeps temporaries alive until the stream has consumed them
+
+
+def posenc(x, freqs, out):
+    f = [float(v) for v in freqs]
+    arr = (C.c_float * len(f))(*f)
+    _check(load().nsff_posenc(_ptr(x), x.shape[0], arr, len(f), _ptr(out), _stream()), "nsff_posenc")
+
+
+def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
+                xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
+                x_emb=None, emb_offsets=(0, -1, -1, -1)):
+    desc = model_desc(model)
+    packed = model.packed()
+    a = FieldArgs()
+    a.n_points, a.pts_per_ray = int(n_points), int(pts_per_ray)
+    a.static_mode, a.transient_mode, a.flow_heads = int(static_mode), int(transient_mode), int(flow_heads)
+    a.xyz = _ptr(xyz)
+    if freqs is not None:
+        f = [float(v) for v in freqs]
+        if len(f) > MAX_FREQS:
+            raise RuntimeError("too many embedding frequencies")
+        a.n_freqs = len(f)
+        for i, v in enumerate(f):
+            a.freqs[i] = v
+    a.dir_emb, a.a_emb, a.t_emb = _ptr(dir_emb), _ptr(a_emb), _ptr(t_emb)
+    a.x_emb = _ptr(x_emb)
+    a.ld_emb = int(x_emb.shape[1]) if x_emb is not None else 0
+    a.off_xyz, a.off_dir, a.off_a, a.off_t = [int(v) for v in emb_offsets]
+    a.raw = _ptr(raw)
+    _check(load().nsff_field_query(C.byref(desc), _ptr(packed), C.byref(a), _stream()), "nsff_field_query")
+
+
+def coarse_samples(rays, z_lin, perturb, perturb_rand, zs, xyz):
+    _check(load().nsff_coarse_samples(_ptr(rays), rays.shape[0], _ptr(z_lin), z_lin.shape[0],
+                                      float(perturb), _ptr(perturb_rand), _ptr(zs), _ptr(xyz), _stream()),
+           "nsff_coarse_samples")
+
+
+def fine_samples(rays, z_lin, zs_coarse, n_importance, w_static, w_transient, u_static, u_transient,
+                 u_per_ray, samples_static, samples_transient, zs_fine, xyz_fine):
+    _check(load().nsff_fine_samples(_ptr(rays), rays.shape[0], _ptr(z_lin), _ptr(zs_coarse),
+                                    z_lin.shape[0], int(n_importance), _ptr(w_static), _ptr(w_transient),
+                                    _ptr(u_static), _ptr(u_transient), int(u_per_ray),
+                                    _ptr(samples_static), _ptr(samples_transient),
+                                    _ptr(zs_fine), _ptr(xyz_fine), _stream()), "nsff_fine_samples")
+
+
+def sample_pdf(bins, weights, u, u_per_ray, eps, samples):
+    _check(load().nsff_sample_pdf(_ptr(bins), _ptr(weights), weights.shape[0], weights.shape[1],
+                                  _ptr(u), samples.shape[1], int(u_per_ray), float(eps),
+                                  _ptr(samples), _stream()), "nsff_sample_pdf")
+
+
+def warp_points(raw, xyz, zs, z_far, xyz_fw, xyz_bw):
+    _check(load().nsff_warp_points(_ptr(raw), _ptr(xyz), _ptr(zs), zs.numel(), float(z_far),
+                                   _ptr(xyz_fw), _ptr(xyz_bw), _stream()), "nsff_warp_points")
+
+
+def composite(**kw):
+    a = CompositeArgs()
+    for k, v in kw.items():
+        if k in _COMPOSITE_PTRS_IN or k in _COMPOSITE_PTRS_OUT:
+            setattr(a, k, _ptr(v))
+        else:
+            setattr(a, k, v)
+    _check(load().nsff_composite(C.byref(a), _stream()), "nsff_composite")
+
+
+def prof_enable(on):
+    _check(load().nsff_prof_enable(int(bool(on))), "nsff_prof_enable")
+
+
+def prof_collect():
+    n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
+    _check(load().nsff_prof_collect(C.byref(n), C.byref(ms), C.byref(fl)), "nsff_prof_collect")
+    return n.value, ms.value, fl.value

@@ -1,0 +1,486 @@
+// Per-ray stages of render_rays for gfx950: sample placement, inverse-CDF fine sampling
+// with merge+sort, flow warping of the sample points, and sigma->alpha compositing.
+//
+// These stages are HBM/latency-bound (a few hundred bytes per sample, no reuse), so the
+// design rules are the streaming ones: one 64-lane wavefront per ray, lane i owns sample
+// i (+64, +128 ...) so every global access of the wave is a contiguous run, transmittance
+// is an exclusive product scan over the wave with a carry between 64-sample chunks, and
+// per-ray sums are butterfly reductions.  Compiled with -ffp-contract=off so that
+// o + d*z, w*z ... round like the reference's separate torch multiply / add kernels.
+//
+// Reference: models/rendering.py:10-49 (sample_pdf), :98-140 (render_transient_warping),
+// :187-188, :202-298 (inference), :314-324, :332-348, :359 (render_rays).
+#include <hip/hip_runtime.h>
+#include "nsff_common.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int RS = NSFF_RAW_STRIDE;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Inclusive product scan across the 64 lanes of a wave.
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float u = __shfl_up(v, off);
+        if (lane >= off) v *= u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float u = __shfl_up(v, off);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+// torch.nn.Softplus(beta=1, threshold=20)
+__device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// ---------------------------------------------------------------------------------
+__global__ void coarse_samples_kernel(const float* __restrict__ rays, long long n_rays,
+                                      const float* __restrict__ z_lin, int S, float perturb,
+                                      const float* __restrict__ rnd, float* __restrict__ zs,
+                                      float* __restrict__ xyz) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rays * S) return;
+    const long long n = idx / S;
+    const int i = (int)(idx - n * S);
+    float z = z_lin[i];
+    if (perturb > 0.f) {
+        const float lower = i > 0 ? 0.5f * (z_lin[i - 1] + z_lin[i]) : z_lin[0];
+        const float upper = i < S - 1 ? 0.5f * (z_lin[i] + z_lin[i + 1]) : z_lin[S - 1];
+        z = lower + (upper - lower) * (perturb * rnd[idx]);
+    }
+    zs[idx] = z;
+    const float* r = rays + n * 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xyz[idx * 3 + c] = r[c] + r[3 + c] * z;
+}
+
+// ---------------------------------------------------------------------------------
+// One ray's inverse-CDF draw.  `w` points at the M interior weights, `bins` at M+1 bin
+// edges (LDS or global), `cdf` is an LDS scratch of M+1 floats owned by this wave.
+// Every lane of the wave must call this (it contains block barriers).
+__device__ __forceinline__ void sample_pdf_ray(const float* w, const float* bins, int M, float eps,
+                                               const float* u, int n_imp, float* cdf,
+                                               float* out_a, float* out_b, int lane, bool active) {
+    // pdf = (w+eps) / sum(w+eps);  cdf = [0, cumsum(pdf)]
+    float part = 0.f;
+    for (int j = lane; j < M; j += 64) part += (active ? w[j] : 0.f) + eps;
+    const float total = wave_sum(part);
+    float carry = 0.f;
+    if (lane == 0) cdf[0] = 0.f;
+    for (int base = 0; base < M; base += 64) {
+        const int j = base + lane;
+        const float pdf = j < M ? ((active ? w[j] : 0.f) + eps) / total : 0.f;
+        const float inc = wave_scan_add(pdf, lane) + carry;
+        if (j < M) cdf[j + 1] = inc;
+        carry = __shfl(inc, 63);
+    }
+    __syncthreads();
+    for (int k = lane; k < n_imp; k += 64) {
+        const float uk = active ? u[k] : 0.f;
+        // searchsorted(cdf, u, right=True): number of entries <= u
+        int lo = 0, hi = M + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uk) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, M);
+        const float cb = cdf[below], ca = cdf[above];
+        const float bb = bins[below], ba = bins[above];
+        float denom = ca - cb;
+        if (denom < eps) denom = 1.f;
+        const float s = bb + (uk - cb) / denom * (ba - bb);
+        if (active) {
+            if (out_a) out_a[k] = s;
+            if (out_b) out_b[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+struct FineArgs {
+    const float* rays; long long n_rays; const float* z_lin; const float* zs_coarse;
+    int S, n_imp;
+    const float* w_static; const float* w_transient;
+    const float* u_static; const float* u_transient; int u_per_ray;
+    float* samples_static; float* samples_transient;
+    float* zs_fine; float* xyz_fine;
+};
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void fine_samples_kernel(const FineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ray_raw = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const bool active = ray_raw < a.n_rays;
+    const long long ray = active ? ray_raw : a.n_rays - 1;
+    const int S = a.S, n_imp = a.n_imp;
+    const int k_sets = a.w_transient ? 2 : 1;
+    const int Sf = S + k_sets * n_imp;
+    float* cdf = smem + wave * (2 * S + Sf);   // S-1 used
+    float* bins = cdf + S;                     // S-1 used: interval mid points (rendering.py:315)
+    float* merged = bins + S;                  // Sf
+    for (int j = lane; j < S - 1; j += 64) bins[j] = 0.5f * (a.z_lin[j] + a.z_lin[j + 1]);
+    for (int j = lane; j < S; j += 64) merged[j] = a.zs_coarse[ray * S + j];
+    __syncthreads();
+    for (int set = 0; set < k_sets; ++set) {
+        const float* w = (set == 0 ? a.w_static : a.w_transient) + ray * S + 1;   // weights[:, 1:-1]
+        const float* ub = set == 0 ? a.u_static : a.u_transient;
+        const float* u = a.u_per_ray ? ub + ray * n_imp : ub;
+        float* keep = set == 0 ? a.samples_static : a.samples_transient;
+        sample_pdf_ray(w, bins, S - 2, 1e-5f, u, n_imp, cdf, merged + S + set * n_imp,
+                       keep ? keep + ray * n_imp : nullptr, lane, active);
+    }
+    // torch.sort(cat([zs, zs_static, zs_transient]))[0]: stable rank sort, Sf^2/64 compares per lane
+    for (int i = lane; i < Sf; i += 64) {
+        const float v = merged[i];
+        int rank = 0;
+        for (int j = 0; j < Sf; ++j) {
+            const float o = merged[j];
+            rank += (o < v || (o == v && j < i)) ? 1 : 0;
+        }
+        if (active) {
+            const long long dst = ray * Sf + rank;
+            a.zs_fine[dst] = v;
+            const float* r = a.rays + ray * 6;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.xyz_fine[dst * 3 + c] = r[c] + r[3 + c] * v;
+        }
+    }
+}
+
+struct PdfArgs {
+    const float* bins; const float* weights; long long n_rays; int M;
+    const float* u; int n_imp; int u_per_ray; float eps; float* samples;
+};
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sample_pdf_kernel(const PdfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ray_raw = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const bool active = ray_raw < a.n_rays;
+    const long long ray = active ? ray_raw : a.n_rays - 1;
+    float* cdf = smem + wave * (a.M + 1);
+    const float* u = a.u_per_ray ? a.u + ray * a.n_imp : a.u;
+    sample_pdf_ray(a.weights + ray * a.M, a.bins + ray * (a.M + 1), a.M, a.eps, u, a.n_imp, cdf,
+                   active ? a.samples + ray * a.n_imp : nullptr, nullptr, lane, true);
+}
+
+// ---------------------------------------------------------------------------------
+__global__ void warp_points_kernel(const float* __restrict__ raw, const float* __restrict__ xyz,
+                                   const float* __restrict__ zs, long long n_points, float z_far,
+                                   float* __restrict__ xyz_fw, float* __restrict__ xyz_bw) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_points * 3) return;
+    const long long p = idx / 3;
+    const int c = (int)(idx - p * 3);
+    const bool far = zs[p] > z_far;
+    const float x = xyz[idx];
+    xyz_fw[idx] = x + (far ? 0.f : raw[p * RS + 8 + c]);
+    xyz_bw[idx] = x + (far ? 0.f : raw[p * RS + 11 + c]);
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_kernel(const NsffCompositeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;     // whole wave exits; no block-level barrier below
+    const int S = a.n_samples;
+    const bool tr = a.has_transient != 0;
+    const bool flows = tr && a.flow_mode >= 1;
+    const bool warps = tr && a.flow_mode >= 2;
+
+    float cT = 1.f, cTs = 1.f, cTfw = 1.f, cTbw = 1.f;     // running products between chunks
+    float s_depth = 0.f, s_rgb[3] = {0, 0, 0}, s_talpha = 0.f, s_trgb[3] = {0, 0, 0};
+    float s_sorgb[3] = {0, 0, 0}, s_sodepth = 0.f;
+    float s_xyz[3] = {0, 0, 0}, s_ffw[3] = {0, 0, 0}, s_fbw[3] = {0, 0, 0};
+    float s_rgbfw[3] = {0, 0, 0}, s_rgbbw[3] = {0, 0, 0}, s_occfw = 0.f, s_occbw = 0.f;
+
+    for (int base = 0; base < S; base += 64) {
+        const int i = base + lane;
+        const bool on = i < S;
+        const long long idx = ray * S + (on ? i : S - 1);
+        const float z = a.zs[idx];
+        const bool last = i >= S - 1;
+        const float dz = last ? 0.f : a.zs[idx + 1] - z;
+        const float d_s = last ? 100.f : dz;        // rendering.py:203
+        const float d_t = last ? 1e-3f : dz;        // rendering.py:204
+        const float* rec = a.raw + idx * RS;
+
+        float sig_s = rec[3];
+        if (a.noise_static) sig_s += a.noise_static[idx] * a.noise_std;
+        sig_s = softplus(sig_s);
+        const float al_s = 1.f - expf(-d_s * sig_s);
+        float rgb_s[3] = {0, 0, 0};
+        if (a.has_rgb) { rgb_s[0] = rec[0]; rgb_s[1] = rec[1]; rgb_s[2] = rec[2]; }
+
+        float sig_t = 0.f, al_t = 0.f, alpha = al_s;
+        float rgb_t[3] = {0, 0, 0};
+        if (tr) {
+            sig_t = rec[7];
+            if (a.visibility && a.visibility[idx] == 0.f) sig_t = -10.f;     // rendering.py:200
+            if (a.noise_transient) sig_t += a.noise_transient[idx] * a.noise_std;
+            sig_t = softplus(sig_t);
+            al_t = 1.f - expf(-d_t * sig_t);
+            alpha = 1.f - (1.f - al_s) * (1.f - al_t);
+            if (a.has_rgb) { rgb_t[0] = rec[4]; rgb_t[1] = rec[5]; rgb_t[2] = rec[6]; }
+        }
+        // exclusive cumprod of (1 - alpha), no epsilon (rendering.py:234-235)
+        const float om = on ? 1.f - alpha : 1.f;
+        const float inc = wave_scan_mul(om, lane);
+        float exc = __shfl_up(inc, 1);
+        if (lane == 0) exc = 1.f;
+        const float T = cT * exc;
+        cT *= __shfl(inc, 63);
+        const float w = alpha * T, w_s = al_s * T, w_t = al_t * T;
+
+        if (on) {
+            if (a.static_sigmas) a.static_sigmas[idx] = sig_s;
+            if (a.has_rgb && a.static_rgbs) {
+                a.static_rgbs[idx * 3 + 0] = rgb_s[0]; a.static_rgbs[idx * 3 + 1] = rgb_s[1];
+                a.static_rgbs[idx * 3 + 2] = rgb_s[2];
+            }
+            if (tr) {
+                if (a.transient_sigmas) a.transient_sigmas[idx] = sig_t;
+                if (a.has_rgb && a.transient_rgbs) {
+                    a.transient_rgbs[idx * 3 + 0] = rgb_t[0]; a.transient_rgbs[idx * 3 + 1] = rgb_t[1];
+                    a.transient_rgbs[idx * 3 + 2] = rgb_t[2];
+                }
+                if (a.static_alphas) a.static_alphas[idx] = al_s;
+                if (a.transient_alphas) a.transient_alphas[idx] = al_t;
+                if (a.static_weights) a.static_weights[idx] = w_s;
+                if (a.transient_weights) a.transient_weights[idx] = w_t;
+                if (a.weights) a.weights[idx] = w;
+            } else {
+                if (a.static_weights) a.static_weights[idx] = w;     // rendering.py:248
+                if (a.weights) a.weights[idx] = w;
+            }
+        }
+        if (!a.has_rgb) continue;     // sigma-only coarse pass stops at the weights (rendering.py:253)
+
+        if (on) {
+            s_depth += w * z;
+            if (tr) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { s_rgb[c] += w_s * rgb_s[c]; s_trgb[c] += w_t * rgb_t[c]; }
+                s_talpha += w_t;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) s_rgb[c] += w * rgb_s[c];
+            }
+        }
+        if (!tr) continue;
+
+        // static field alone, with its own transmittance (rendering.py:270-278)
+        {
+            const float oms = on ? 1.f - al_s : 1.f;
+            const float incs = wave_scan_mul(oms, lane);
+            float excs = __shfl_up(incs, 1);
+            if (lane == 0) excs = 1.f;
+            const float Ts = cTs * excs;
+            cTs *= __shfl(incs, 63);
+            const float wso = al_s * Ts;
+            if (on) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) s_sorgb[c] += wso * rgb_s[c];
+                s_sodepth += wso * z;
+            }
+        }
+        if (!flows) continue;
+
+        const bool far = z > a.z_far;
+        float ffw[3], fbw[3], x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ffw[c] = far ? 0.f : rec[8 + c];       // rendering.py:187-188
+            fbw[c] = far ? 0.f : rec[11 + c];
+            x[c] = a.xyz[idx * 3 + c];
+        }
+        if (on) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (a.flows_fw) a.flows_fw[idx * 3 + c] = ffw[c];
+                if (a.flows_bw) a.flows_bw[idx * 3 + c] = fbw[c];
+                s_xyz[c] += w * x[c]; s_ffw[c] += w * ffw[c]; s_fbw[c] += w * fbw[c];
+            }
+        }
+        if (!warps) continue;
+
+        // re-composite with the warped transient field and the CURRENT static field
+        // (render_transient_warping, rendering.py:98-140)
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const float* recw = (dir == 0 ? a.raw_fw : a.raw_bw) + idx * RS;
+            const float* nz = dir == 0 ? a.noise_fw : a.noise_bw;
+            float sg = recw[7];
+            if (nz) sg += nz[idx] * a.noise_std;
+            const float al_tw = 1.f - expf(-d_t * softplus(sg));
+            const float al_w = 1.f - (1.f - al_s) * (1.f - al_tw);
+            const float omw = on ? 1.f - al_w : 1.f;
+            const float incw = wave_scan_mul(omw, lane);
+            float excw = __shfl_up(incw, 1);
+            if (lane == 0) excw = 1.f;
+            float& cw = dir == 0 ? cTfw : cTbw;
+            const float Tw = cw * excw;
+            cw *= __shfl(incw, 63);
+            const float ws_w = al_s * Tw, wt_w = al_tw * Tw;
+            if (on) {
+                float* srgb = dir == 0 ? s_rgbfw : s_rgbbw;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) srgb[c] += ws_w * rgb_s[c] + wt_w * recw[4 + c];
+                // cycle point: the warped query's flow back (fw warp -> 'bw' head and vice versa)
+                const float* xw = (dir == 0 ? a.xyz_fw : a.xyz_bw) + idx * 3;
+                float* cyc = dir == 0 ? a.xyzs_fw_bw : a.xyzs_bw_fw;
+                const int head = dir == 0 ? 11 : 8;
+                if (cyc) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cyc[idx * 3 + c] = xw[c] + (far ? 0.f : recw[head + c]);
+                }
+                const float occ = wt_w - w_t;              // rendering.py:290-291
+                if (dir == 0) { s_occfw += occ; if (a.disoccs_fw) a.disoccs_fw[idx] = 1.f - fabsf(occ); }
+                else          { s_occbw += occ; if (a.disoccs_bw) a.disoccs_bw[idx] = 1.f - fabsf(occ); }
+            }
+        }
+    }
+    if (!a.has_rgb) return;
+
+    s_depth = wave_sum(s_depth);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);
+    if (tr) {
+        s_talpha = wave_sum(s_talpha); s_sodepth = wave_sum(s_sodepth);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s_trgb[c] = wave_sum(s_trgb[c]); s_sorgb[c] = wave_sum(s_sorgb[c]); }
+    }
+    if (flows) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s_xyz[c] = wave_sum(s_xyz[c]); s_ffw[c] = wave_sum(s_ffw[c]); s_fbw[c] = wave_sum(s_fbw[c]); }
+    }
+    if (warps) {
+        s_occfw = wave_sum(s_occfw); s_occbw = wave_sum(s_occbw);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s_rgbfw[c] = wave_sum(s_rgbfw[c]); s_rgbbw[c] = wave_sum(s_rgbbw[c]); }
+    }
+    if (lane != 0) return;
+    if (a.depth) a.depth[ray] = s_depth;
+    if (!tr) {
+        if (a.rgb) for (int c = 0; c < 3; ++c) a.rgb[ray * 3 + c] = s_rgb[c];
+        return;
+    }
+    for (int c = 0; c < 3; ++c) {
+        if (a.rgb) a.rgb[ray * 3 + c] = s_rgb[c] + s_trgb[c];                                   // :262
+        if (a.transient_rgb) a.transient_rgb[ray * 3 + c] = s_trgb[c] + 0.8f * (1.f - s_talpha);  // :264-265
+        if (a.static_only_rgb) a.static_only_rgb[ray * 3 + c] = s_sorgb[c];
+    }
+    if (a.transient_alpha) a.transient_alpha[ray] = s_talpha;
+    if (a.static_only_depth) a.static_only_depth[ray] = s_sodepth;
+    if (flows) {
+        for (int c = 0; c < 3; ++c) {
+            if (a.xyz_exp) a.xyz_exp[ray * 3 + c] = s_xyz[c];
+            if (a.flow_fw_exp) a.flow_fw_exp[ray * 3 + c] = s_ffw[c];
+            if (a.flow_bw_exp) a.flow_bw_exp[ray * 3 + c] = s_fbw[c];
+            if (a.xyz_fw_exp) a.xyz_fw_exp[ray * 3 + c] = s_xyz[c] + s_ffw[c];
+            if (a.xyz_bw_exp) a.xyz_bw_exp[ray * 3 + c] = s_xyz[c] + s_fbw[c];
+        }
+    }
+    if (warps) {
+        for (int c = 0; c < 3; ++c) {
+            if (a.rgb_fw) a.rgb_fw[ray * 3 + c] = s_rgbfw[c];
+            if (a.rgb_bw) a.rgb_bw[ray * 3 + c] = s_rgbbw[c];
+        }
+        if (a.disocc_fw) a.disocc_fw[ray] = 1.f - fabsf(s_occfw);
+        if (a.disocc_bw) a.disocc_bw[ray] = 1.f - fabsf(s_occbw);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsff_coarse_samples(const float* rays, int64_t n_rays, const float* z_lin, int32_t n_samples,
+                        float perturb, const float* perturb_rand, float* zs, float* xyz, void* stream) {
+    if (n_rays < 0 || n_samples < 1) return NSFF_ERR_INVALID;
+    if (n_rays == 0) return NSFF_OK;
+    if (!rays || !z_lin || !zs || !xyz) return NSFF_ERR_NULL;
+    if (perturb > 0.f && !perturb_rand) return NSFF_ERR_NULL;
+    const long long total = (long long)n_rays * n_samples;
+    hipLaunchKernelGGL(coarse_samples_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, rays, (long long)n_rays, z_lin, n_samples, perturb,
+                       perturb_rand, zs, xyz);
+    return nsff_launch_status();
+}
+
+int nsff_fine_samples(const float* rays, int64_t n_rays, const float* z_lin, const float* zs_coarse,
+                      int32_t n_samples, int32_t n_importance,
+                      const float* weights_static, const float* weights_transient,
+                      const float* u_static, const float* u_transient, int32_t u_per_ray,
+                      float* samples_static, float* samples_transient,
+                      float* zs_fine, float* xyz_fine, void* stream) {
+    if (n_rays < 0 || n_samples < 3 || n_importance < 1) return NSFF_ERR_INVALID;
+    if (n_rays == 0) return NSFF_OK;
+    if (!rays || !z_lin || !zs_coarse || !weights_static || !u_static || !zs_fine || !xyz_fine) return NSFF_ERR_NULL;
+    if (weights_transient && !u_transient) return NSFF_ERR_NULL;
+    FineArgs a{rays, (long long)n_rays, z_lin, zs_coarse, n_samples, n_importance,
+               weights_static, weights_transient, u_static, u_transient, u_per_ray,
+               samples_static, samples_transient, zs_fine, xyz_fine};
+    const int Sf = n_samples + (weights_transient ? 2 : 1) * n_importance;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (2 * n_samples + Sf) * sizeof(float);
+    if (lds > 64 * 1024) return NSFF_ERR_INVALID;
+    const unsigned blocks = (unsigned)((n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(fine_samples_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds,
+                       (hipStream_t)stream, a);
+    return nsff_launch_status();
+}
+
+int nsff_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int32_t n_bins_minus1,
+                    const float* u, int32_t n_importance, int32_t u_per_ray, float eps,
+                    float* samples, void* stream) {
+    if (n_rays < 0 || n_bins_minus1 < 1 || n_importance < 1) return NSFF_ERR_INVALID;
+    if (n_rays == 0) return NSFF_OK;
+    if (!bins || !weights || !u || !samples) return NSFF_ERR_NULL;
+    PdfArgs a{bins, weights, (long long)n_rays, n_bins_minus1, u, n_importance, u_per_ray, eps, samples};
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (n_bins_minus1 + 1) * sizeof(float);
+    if (lds > 64 * 1024) return NSFF_ERR_INVALID;
+    const unsigned blocks = (unsigned)((n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds,
+                       (hipStream_t)stream, a);
+    return nsff_launch_status();
+}
+
+int nsff_warp_points(const float* raw, const float* xyz, const float* zs, int64_t n_points,
+                     float z_far, float* xyz_fw, float* xyz_bw, void* stream) {
+    if (n_points < 0) return NSFF_ERR_INVALID;
+    if (n_points == 0) return NSFF_OK;
+    if (!raw || !xyz || !zs || !xyz_fw || !xyz_bw) return NSFF_ERR_NULL;
+    const long long total = (long long)n_points * 3;
+    hipLaunchKernelGGL(warp_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, raw, xyz, zs, (long long)n_points, z_far, xyz_fw, xyz_bw);
+    return nsff_launch_status();
+}
+
+int nsff_composite(const NsffCompositeArgs* args, void* stream) {
+    if (!args) return NSFF_ERR_NULL;
+    const NsffCompositeArgs& a = *args;
+    if (a.n_rays < 0 || a.n_samples < 1 || a.flow_mode < 0 || a.flow_mode > 2) return NSFF_ERR_INVALID;
+    if (a.n_rays == 0) return NSFF_OK;
+    if (!a.raw || !a.zs) return NSFF_ERR_NULL;
+    if (a.flow_mode && (!a.has_transient || !a.has_rgb)) return NSFF_ERR_INVALID;
+    if (a.flow_mode >= 1 && !a.xyz) return NSFF_ERR_NULL;
+    if (a.flow_mode == 2 && (!a.raw_fw || !a.raw_bw || !a.xyz_fw || !a.xyz_bw)) return NSFF_ERR_NULL;
+    const unsigned blocks = (unsigned)((a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0,
+                       (hipStream_t)stream, a);
+    return nsff_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""``render_rays`` / ``sample_pdf`` with the reference's signatures, on the gfx950 kernels.
+
+Drop-in for ``models/rendering.py:10-49`` (sample_pdf) and ``:52-362`` (render_rays) of
+kwea123/nsff_pl: same positional/keyword arguments, same result keys, shapes and dtypes,
+same torch RNG draw order.  This module contains no arithmetic of the path itself: it
+resolves flags, draws the random tensors with torch exactly where the reference does,
+allocates the result tensors and enqueues the C-ABI stages of ``include/nsff_render.h``
+on the current stream:
+
+    coarse_samples -> field_query(coarse) -> composite -> fine_samples
+                   -> field_query(fine) [-> warp_points -> field_query x2] -> composite
+
+Only the eval-time frustum-visibility mask (rendering.py:190-200, one camera, a 4x4
+inverse) is evaluated with torch ops on the device, in :mod:`nsff_pl_amd.ray_geometry`.
+"""
+import torch
+
+from . import _lib
+from . import ray_geometry
+
+Z_FAR = 0.95  # flows are zeroed beyond this depth (reference rendering.py:316)
+
+
+def _new(ref, *shape):
+    return torch.empty(*shape, device=ref.device, dtype=torch.float32)
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
+    """Inverse-CDF sampling (reference rendering.py:10-49).
+
+    bins: (N_rays, M+1), weights: (N_rays, M) -> (N_rays, N_importance).
+    ``det=False`` draws ``torch.rand(N_rays, N_importance)`` like the reference.
+    """
+    _lib.require_gpu_tensor(bins, "sample_pdf bins")
+    bins = bins.contiguous().float()
+    weights = weights.contiguous().float()
+    n_rays = weights.shape[0]
+    if det:
+        u = torch.linspace(0, 1, N_importance, device=bins.device)
+    else:
+        u = torch.rand(n_rays, N_importance, device=bins.device)
+    out = _new(bins, n_rays, N_importance)
+    if n_rays:
+        _lib.sample_pdf(bins, weights, u.contiguous(), 0 if det else 1, eps, out)
+    return out
+
+
+class _Pass:
+    """Inputs shared by the coarse and the fine pass of one render_rays call."""
+    __slots__ = ("embeddings", "rays", "ts", "max_t", "noise_std", "test_time", "kwargs",
+                 "freqs_xyz", "dir_embedded", "n_rays")
+
+
+def _embed_rows(embeddings, key, idx):
+    return embeddings[key](idx).detach().contiguous().float()
+
+
+def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
+               t_embedded, a_embedded):
+    """One model pass: field query, optional flow-warp re-queries, compositing.
+
+    Mirrors the nested ``inference`` of the reference (rendering.py:83-300), including the
+    order of its ``torch.randn`` draws.
+    """
+    typ = model.typ
+    n_rays, S = zs.shape
+    test_time = ctx.test_time
+    results[f'zs_{typ}'] = zs
+    results[f'xyzs_{typ}'] = xyz
+    P = n_rays * S
+    sigma_only = typ == 'coarse' and test_time
+    want_flow = bool(output_transient_flow) and output_transient and not sigma_only
+    warps = want_flow and not test_time
+    disocc = warps and 'disocc' in output_transient_flow
+    if want_flow and not hasattr(model, "transient_flow_fw"):
+        raise AttributeError(f"{typ} model has no flow heads")
+
+    raw = _new(zs, P, _lib.RAW_STRIDE)
+    side = dict(dir_emb=ctx.dir_embedded if model.use_viewdir and not sigma_only else None,
+                a_emb=a_embedded if (model.use_viewdir and model.in_channels_a > 0 and not sigma_only) else None)
+    if P:
+        _lib.field_query(model, raw, P, S,
+                         static_mode=1 if sigma_only else 2,
+                         transient_mode=0 if not output_transient else (1 if sigma_only else 2),
+                         flow_heads=2 if want_flow else 0,
+                         xyz=xyz, freqs=ctx.freqs_xyz, t_emb=t_embedded if output_transient else None, **side)
+
+    visibility = None
+    if test_time and output_transient and 'dataset' in ctx.kwargs:
+        visibility = ray_geometry.training_view_visibility(xyz.view(-1, 3), ctx.kwargs['dataset'], ctx.ts)
+
+    # RNG draws, in the reference's order (rendering.py:207, 213, then 128 for fw and bw)
+    nstd = float(ctx.noise_std)
+    noise_s = torch.randn(n_rays, S, device=zs.device)
+    noise_t = torch.randn(n_rays, S, device=zs.device) if output_transient else None
+
+    args = dict(n_rays=n_rays, n_samples=S, has_transient=int(output_transient),
+                has_rgb=int(not sigma_only), flow_mode=0, want_disocc=int(disocc),
+                noise_std=nstd, z_far=Z_FAR, raw=raw, zs=zs, xyz=xyz, visibility=visibility,
+                noise_static=noise_s if nstd != 0 else None,
+                noise_transient=noise_t if (nstd != 0 and output_transient) else None)
+
+    def out(key, *shape):
+        t = _new(zs, *shape)
+        results[key] = t
+        return t
+
+    if not sigma_only:
+        args['static_rgbs'] = out(f'static_rgbs_{typ}', n_rays, S, 3)
+        if output_transient:
+            args['transient_rgbs'] = out(f'transient_rgbs_{typ}', n_rays, S, 3)
+            if want_flow:
+                args['flows_fw'] = out('transient_flows_fw', n_rays, S, 3)
+                args['flows_bw'] = out('transient_flows_bw', n_rays, S, 3)
+    args['static_sigmas'] = out(f'static_sigmas_{typ}', n_rays, S)
+    if output_transient:
+        args['transient_sigmas'] = out(f'transient_sigmas_{typ}', n_rays, S)
+
+    if warps:
+        # points pushed along their own scene flow, re-queried one frame later / earlier
+        ts = ctx.ts
+        xyz_fw = out('xyzs_fw', n_rays, S, 3)
+        xyz_bw = _new(zs, n_rays, S, 3)
+        raw_fw = _new(zs, P, _lib.RAW_STRIDE)
+        raw_bw = _new(zs, P, _lib.RAW_STRIDE)
+        tp1 = _embed_rows(ctx.embeddings, 't', torch.clamp(ts + 1, max=ctx.max_t))
+        if P:
+            _lib.warp_points(raw, xyz, zs, Z_FAR, xyz_fw, xyz_bw)
+            _lib.field_query(model, raw_fw, P, S, static_mode=0, transient_mode=2, flow_heads=1,
+                             xyz=xyz_fw, freqs=ctx.freqs_xyz, t_emb=tp1)
+        noise_fw = torch.randn(n_rays, S, device=zs.device)
+        out('rgb_fw', n_rays, 3)
+        results['xyzs_bw'] = xyz_bw
+        tm1 = _embed_rows(ctx.embeddings, 't', torch.clamp(ts - 1, min=0))
+        if P:
+            _lib.field_query(model, raw_bw, P, S, static_mode=0, transient_mode=2, flow_heads=1,
+                             xyz=xyz_bw, freqs=ctx.freqs_xyz, t_emb=tm1)
+        noise_bw = torch.randn(n_rays, S, device=zs.device)
+        out('rgb_bw', n_rays, 3)
+        args.update(raw_fw=raw_fw, raw_bw=raw_bw, xyz_fw=xyz_fw, xyz_bw=xyz_bw,
+                    noise_fw=noise_fw if nstd != 0 else None,
+                    noise_bw=noise_bw if nstd != 0 else None,
+                    rgb_fw=results['rgb_fw'], rgb_bw=results['rgb_bw'],
+                    xyzs_fw_bw=out('xyzs_fw_bw', n_rays, S, 3),
+                    xyzs_bw_fw=out('xyzs_bw_fw', n_rays, S, 3))
+
+    if output_transient:
+        args['static_weights'] = out(f'static_weights_{typ}', n_rays, S)
+        args['transient_weights'] = out(f'transient_weights_{typ}', n_rays, S)
+        args['weights'] = out(f'weights_{typ}', n_rays, S)
+    else:
+        args['static_weights'] = out(f'static_weights_{typ}', n_rays, S)
+    if test_time and output_transient:
+        args['static_alphas'] = out(f'static_alphas_{typ}', n_rays, S)
+        args['transient_alphas'] = out(f'transient_alphas_{typ}', n_rays, S)
+
+    if not sigma_only:
+        args['depth'] = out(f'depth_{typ}', n_rays)
+        args['rgb'] = out(f'rgb_{typ}', n_rays, 3)
+        if output_transient:
+            args['transient_alpha'] = out(f'transient_alpha_{typ}', n_rays)
+            args['transient_rgb'] = out(f'transient_rgb_{typ}', n_rays, 3)
+            args['static_only_rgb'] = out(f'_static_rgb_{typ}', n_rays, 3)
+            args['static_only_depth'] = out(f'_static_depth_{typ}', n_rays)
+            if want_flow:
+                args['flow_mode'] = 2 if warps else 1
+                args['xyz_exp'] = out('xyz_fine', n_rays, 3)
+                args['flow_fw_exp'] = out('transient_flow_fw', n_rays, 3)
+                args['xyz_fw_exp'] = out('xyz_fw', n_rays, 3)
+                args['flow_bw_exp'] = out('transient_flow_bw', n_rays, 3)
+                args['xyz_bw_exp'] = out('xyz_bw', n_rays, 3)
+                if disocc:
+                    args['disocc_fw'] = out('disocc_fw', n_rays, 1)
+                    args['disoccs_fw'] = out('disoccs_fw', n_rays, S, 1)
+                    args['disocc_bw'] = out('disocc_bw', n_rays, 1)
+                    args['disoccs_bw'] = out('disoccs_bw', n_rays, S, 1)
+    if n_rays:
+        _lib.composite(**args)
+
+
+def render_rays(models,
+                embeddings,
+                rays,
+                ts,
+                max_t,
+                N_samples=64,
+                perturb=0,
+                noise_std=0,
+                N_importance=0,
+                chunk=1024 * 32,
+                test_time=False,
+                **kwargs):
+    """Render rays through the NSFF fields (reference rendering.py:52-362).
+
+    models: {'fine': NeRF[, 'coarse': NeRF]}; embeddings: {'xyz','dir'[, 't', 'a']};
+    rays: (N_rays, 6) origins+directions (NDC); ts: (N_rays,) int64 or None; max_t: int.
+    Recognised kwargs: output_transient, output_transient_flow, view_dir, t_embedded,
+    a_embedded, dataset (eval visibility); others (epoch, K, ...) are ignored like the
+    reference does.  ``_zs_fine`` (N_rays, S_fine) is a test hook that overrides the merged
+    fine depths.  ``chunk`` is accepted and ignored: the fused field kernel tiles the
+    points itself, so there is no inner point-chunk loop to size.
+    Forward only (inference / no_grad); results are fresh contiguous fp32 GPU tensors.
+    """
+    _lib.require_gpu_tensor(rays, "rays")
+    _lib.load()
+    with torch.cuda.device(rays.device), torch.no_grad():
+        results = {}
+        rays = rays.contiguous().float()
+        n_rays = rays.shape[0]
+        embedding_xyz, embedding_dir = embeddings['xyz'], embeddings['dir']
+
+        ctx = _Pass()
+        ctx.embeddings, ctx.rays, ctx.ts, ctx.max_t = embeddings, rays, ts, max_t
+        ctx.noise_std, ctx.test_time, ctx.kwargs, ctx.n_rays = noise_std, test_time, kwargs, n_rays
+        ctx.freqs_xyz = [float(f) for f in embedding_xyz.freqs]
+        ctx.dir_embedded = None
+        if any(m.use_viewdir for m in models.values()):
+            view_dir = kwargs.get('view_dir', rays[:, 3:6])
+            ctx.dir_embedded = embedding_dir(view_dir.contiguous().float())
+
+        # coarse depths: one linspace shared by all rays, optional stratified jitter
+        z_lin = torch.linspace(0, 1, N_samples, device=rays.device)
+        perturb_rand = torch.rand(n_rays, N_samples, device=rays.device) if perturb > 0 else None
+        zs = _new(rays, n_rays, N_samples)
+        xyz_coarse = _new(rays, n_rays, N_samples, 3)
+        if n_rays:
+            _lib.coarse_samples(rays, z_lin, perturb, perturb_rand, zs, xyz_coarse)
+
+        t_embedded = None
+        if N_importance > 0:  # coarse to fine
+            model = models['coarse']
+            output_transient = bool(kwargs.get('output_transient', True) and model.encode_transient)
+            if output_transient:
+                t_embedded = kwargs['t_embedded'] if 't_embedded' in kwargs else embeddings['t'](ts)
+                t_embedded = t_embedded.detach().contiguous().float()
+            _inference(results, ctx, model, xyz_coarse, zs, output_transient, [], t_embedded, None)
+
+            det = perturb == 0
+            if det:
+                u_s = torch.linspace(0, 1, N_importance, device=rays.device)
+                u_t = u_s
+            else:
+                u_s = torch.rand(n_rays, N_importance, device=rays.device)
+                u_t = torch.rand(n_rays, N_importance, device=rays.device) if output_transient else None
+            S_fine = N_samples + (2 if output_transient else 1) * N_importance
+            zs_static = _new(rays, n_rays, N_importance) if test_time else None
+            zs_transient = _new(rays, n_rays, N_importance) if (test_time and output_transient) else None
+            zs_fine = _new(rays, n_rays, S_fine)
+            xyz_fine = _new(rays, n_rays, S_fine, 3)
+            if n_rays:
+                _lib.fine_samples(rays, z_lin, zs, N_importance,
+                                  results['static_weights_coarse'],
+                                  results['transient_weights_coarse'] if output_transient else None,
+                                  u_s, u_t if output_transient else None, 0 if det else 1,
+                                  zs_static, zs_transient, zs_fine, xyz_fine)
+            if test_time:
+                results['static_zs_fine'] = zs_static
+                if output_transient:
+                    results['transient_zs_fine'] = zs_transient
+            if kwargs.get('_zs_fine') is not None:
+                # test hook: evaluate the fine pass at caller-supplied depths (the inverse-CDF
+                # draw is ill-conditioned in near-empty bins, see tests/parity.py)
+                zs_fine = kwargs['_zs_fine'].to(rays.device).contiguous().float()
+                xyz_fine = (rays[:, None, 0:3] + rays[:, None, 3:6] * zs_fine[..., None]).contiguous()
+            zs, xyz = zs_fine, xyz_fine
+        else:
+            xyz = xyz_coarse
+
+        model = models['fine']
+        a_embedded = None
+        if model.encode_appearance:
+            a_embedded = kwargs['a_embedded'] if 'a_embedded' in kwargs else embeddings['a'](ts)
+            a_embedded = a_embedded.detach().contiguous().float()
+        if N_importance == 0:
+            output_transient = bool(kwargs.get('output_transient', True) and model.encode_transient)
+            if output_transient:
+                t_embedded = kwargs['t_embedded'] if 't_embedded' in kwargs else embeddings['t'](ts)
+                t_embedded = t_embedded.detach().contiguous().float()
+        output_transient_flow = [] if not output_transient else kwargs.get('output_transient_flow', [])
+        _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
+                   t_embedded, a_embedded)
+        return results

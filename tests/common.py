@@ -1,0 +1,72 @@
+"""Fixture loading and oracle invocation shared by CPU and GPU tests."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import scenes
+from oracle import nsff_oracle as orc
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# keys produced by a second, chained field query at positions that already carry fp32
+# rounding (x + flow, then sin(512 x)): two correct fp32 paths differ more there.
+CHAINED_KEYS = ("xyzs_fw_bw", "xyzs_bw_fw", "rgb_fw", "rgb_bw", "disocc_fw", "disocc_bw",
+                "disoccs_fw", "disoccs_bw")
+SAMPLE_KEYS = ("static_zs_fine", "transient_zs_fine", "zs_fine", "xyzs_fine")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    out = {k[4:]: z[k] for k in z.files if k.startswith("out/")}
+    return meta, out
+
+
+def build_case(name, nerf_cls, posemb_cls):
+    """Scene of a golden case built with the given classes, weights verified by checksum."""
+    meta, want = load_golden(name)
+    cfg, rays, ts = scenes.case_inputs(name)
+    models, emb = scenes.build_scene(nerf_cls, posemb_cls, cfg)
+    chk = scenes.weight_checksum(models, emb)
+    assert abs(chk - meta["weight_checksum"]) <= 1e-9 * abs(chk), \
+        "seeded weights differ from the ones the golden was generated with (torch init/RNG drift)"
+    dataset = scenes.DatasetStub(cfg["seed"]) if cfg.get("dataset") else None
+    return cfg, meta, rays, ts, models, emb, dataset, want
+
+
+def oracle_render(cfg, models, emb, rays, ts, draws=None, dataset=None, zs_fine_override=None):
+    fields = {k: orc.field_from_module(m) for k, m in models.items()}
+    return orc.render_rays(
+        fields, emb["xyz"].freqs.numpy(), emb["dir"].freqs.numpy(), np.asarray(rays),
+        None if ts is None else np.asarray(ts), scenes.N_FRAMES - 1,
+        emb_t=emb["t"].weight.detach().cpu().numpy() if "t" in emb else None,
+        emb_a=emb["a"].weight.detach().cpu().numpy() if "a" in emb else None,
+        N_samples=cfg["N_samples"], perturb=cfg.get("perturb", 0), noise_std=cfg.get("noise_std", 0),
+        N_importance=cfg["N_importance"], test_time=cfg["test_time"],
+        z_lin=torch.linspace(0, 1, cfg["N_samples"]).numpy(),
+        u_lin=torch.linspace(0, 1, max(cfg["N_importance"], 1)).numpy(), draws=draws,
+        output_transient_flow=cfg["flow"], dataset=dataset.as_oracle_dict() if dataset else None,
+        zs_fine_override=zs_fine_override)
+
+
+def key_rtol(key, cfg):
+    """1e-4 everywhere; chained re-query keys of the gain-3 stress scene get 2e-3."""
+    import parity
+    if key in CHAINED_KEYS and cfg["gain"] > 2.5:
+        return 2e-3
+    return parity.RTOL
+
+
+def fine_sample_tolerances(cfg, coarse, u_s, u_t):
+    """Conditioning-aware tolerance of the fine samples given the coarse weights (parity.py)."""
+    import parity
+    z = torch.linspace(0, 1, cfg["N_samples"]).numpy()
+    n = coarse["static_weights_coarse"].shape[0]
+    mids = np.broadcast_to(0.5 * (z[:-1] + z[1:]), (n, cfg["N_samples"] - 1))
+    tol_s = parity.sample_tolerance(mids, coarse["static_weights_coarse"][:, 1:-1], u_s)
+    tol_t = None
+    if "transient_weights_coarse" in coarse:
+        tol_t = parity.sample_tolerance(mids, coarse["transient_weights_coarse"][:, 1:-1], u_t)
+    return tol_s, tol_t

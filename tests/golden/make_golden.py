@@ -1,0 +1,147 @@
+"""Generate the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Build-container only: imports kwea123/nsff_pl from /root/reference (read-only mount,
+absent on the GPU box) on CPU torch and records inputs + every output key of
+``render_rays`` / ``NeRF.forward`` / ``PosEmbedding`` / ``sample_pdf`` for the seeded
+scenes of ``tests/scenes.py``.  Only data is written (inputs, expected outputs, a weight
+checksum); no reference source travels.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Import recipe: models/rendering.py pulls kornia, cupy (via
+models/softsplat) and the datasets package (cv2, torchvision) at import time although the
+render path needs none of them; three stub modules are inserted before the import.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    kornia = types.ModuleType("kornia")
+    kornia.create_meshgrid = lambda *a, **k: None
+    sys.modules["kornia"] = kornia
+    datasets = types.ModuleType("datasets")
+    datasets.__path__ = [REF + "/datasets"]
+    sys.modules["datasets"] = datasets
+    import models  # noqa: F401  (reference package)
+    softsplat = types.ModuleType("models.softsplat")
+    softsplat.FunctionSoftsplat = None
+    sys.modules["models.softsplat"] = softsplat
+    from models.nerf import NeRF, PosEmbedding
+    from models.rendering import render_rays, sample_pdf
+    return NeRF, PosEmbedding, render_rays, sample_pdf
+
+
+def to_np(d):
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in d.items()}
+
+
+def main():
+    import scenes
+    from oracle import nsff_oracle as orc
+    NeRF, PosEmbedding, render_rays, sample_pdf = import_reference()
+    torch.set_grad_enabled(False)
+    DRAW_SEED = 4242
+
+    worst = 0.0
+    for name in scenes.CASES:
+        cfg, rays, ts = scenes.case_inputs(name)
+        models, embeddings = scenes.build_scene(NeRF, PosEmbedding, cfg)
+        dataset = scenes.DatasetStub(cfg["seed"]) if cfg.get("dataset") else None
+        kw = scenes.render_kwargs(cfg, dataset)
+        torch.manual_seed(DRAW_SEED)
+        res = render_rays(models, embeddings, rays, ts, scenes.N_FRAMES - 1, cfg["N_samples"],
+                          cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"],
+                          1024 * 32, test_time=cfg["test_time"], **kw)
+        res = to_np(res)
+        meta = dict(case=name, cfg={k: v for k, v in cfg.items()}, draw_seed=DRAW_SEED,
+                    weight_checksum=scenes.weight_checksum(models, embeddings),
+                    torch=torch.__version__, keys=sorted(res))
+        save = {"out/" + k: v for k, v in res.items()}
+        save["in/rays"] = rays.numpy()
+        if ts is not None:
+            save["in/ts"] = ts.numpy()
+        save["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **save)
+
+        # cross-check the oracle against the reference right here
+        fields = {k: orc.field_from_module(m) for k, m in models.items()}
+        draws = scenes.replay_draws(cfg, DRAW_SEED)
+        o = orc.render_rays(
+            fields, embeddings["xyz"].freqs.numpy(), embeddings["dir"].freqs.numpy(), rays.numpy(),
+            None if ts is None else ts.numpy(), scenes.N_FRAMES - 1,
+            emb_t=embeddings["t"].weight.numpy() if "t" in embeddings else None,
+            emb_a=embeddings["a"].weight.numpy() if "a" in embeddings else None,
+            N_samples=cfg["N_samples"], perturb=cfg.get("perturb", 0), noise_std=cfg.get("noise_std", 0),
+            N_importance=cfg["N_importance"], test_time=cfg["test_time"],
+            z_lin=torch.linspace(0, 1, cfg["N_samples"]).numpy(),
+            u_lin=torch.linspace(0, 1, max(cfg["N_importance"], 1)).numpy(), draws=draws,
+            output_transient_flow=cfg["flow"], dataset=dataset.as_oracle_dict() if dataset else None)
+        assert sorted(o) == sorted(res), (sorted(set(o) ^ set(res)))
+        case_worst = 0.0
+        for k in res:
+            assert o[k].shape == res[k].shape, (k, o[k].shape, res[k].shape)
+            err = float(np.abs(o[k] - res[k]).max() / (np.abs(res[k]).max() + 1e-12))
+            case_worst = max(case_worst, err)
+        worst = max(worst, case_worst)
+        size = os.path.getsize(os.path.join(HERE, name + ".npz")) / 1024
+        print(f"{name:28s} keys={len(res):2d} oracle-vs-reference max-norm rel err {case_worst:.2e}  ({size:.0f} KiB)")
+
+    # ---- stage goldens ----
+    g = torch.Generator().manual_seed(77)
+    stage = {}
+    x = torch.cat([torch.rand(96, 3, generator=g) * 2.6 - 1.3, torch.tensor([[0., 0., 0.], [1.2, -1.2, 1.0]])], 0)
+    stage["posenc/x"] = x.numpy()
+    stage["posenc/xyz_9_10"] = PosEmbedding(9, 10)(x).numpy()
+    stage["posenc/dir_3_4"] = PosEmbedding(3, 4)(x).numpy()
+
+    cfg = dict(seed=11, transient=True, appearance=True, viewdir=True, flow=['fw', 'bw'], N_importance=64, gain=2.5)
+    models, _ = scenes.build_scene(NeRF, PosEmbedding, cfg)
+    fine, coarse = models["fine"], models["coarse"]
+    B = 70   # not a multiple of the 64-point tile
+    xin = torch.randn(B, 63 + 27 + scenes.N_A + scenes.N_TAU, generator=g) * 0.7
+    stage["nerf/x_full"] = xin.numpy()
+    stage["nerf/weight_checksum"] = np.float64(scenes.weight_checksum(models, {}))
+    x_sig_t = torch.cat([xin[:, :63], xin[:, -scenes.N_TAU:]], 1)
+    x_static = xin[:, :63 + 27 + scenes.N_A]
+    x_coarse = torch.cat([xin[:, :63 + 27], xin[:, -scenes.N_TAU:]], 1)   # coarse: no appearance code
+    stage["nerf/fine_sigma_only_static"] = fine(xin[:, :63], sigma_only=True, output_transient=False).numpy()
+    stage["nerf/fine_sigma_only_both"] = fine(x_sig_t, sigma_only=True, output_transient=True).numpy()
+    stage["nerf/fine_static"] = fine(x_static, output_transient=False).numpy()
+    stage["nerf/fine_both_noflow"] = fine(xin, output_transient=True, output_transient_flow=[]).numpy()
+    stage["nerf/fine_both_flow"] = fine(xin, output_transient=True, output_transient_flow=['fw', 'bw', 'disocc']).numpy()
+    stage["nerf/fine_transient_bw"] = fine(xin, output_static=False, output_transient=True, output_transient_flow=['bw']).numpy()
+    stage["nerf/fine_transient_fw"] = fine(xin, output_static=False, output_transient=True, output_transient_flow=['fw']).numpy()
+    stage["nerf/coarse_both_noflow"] = coarse(x_coarse, output_transient=True).numpy()
+    stage["nerf/coarse_sigma_only_both"] = coarse(x_sig_t, sigma_only=True, output_transient=True).numpy()
+
+    n, m = 37, 62
+    bins = torch.sort(torch.rand(n, m + 1, generator=g), 1)[0]
+    w = torch.rand(n, m, generator=g) ** 4
+    w[3] = 0                       # all-zero weights
+    w[4, :] = 0; w[4, 17] = 1.0    # a single spike: every other bin has pdf < eps
+    stage["pdf/bins"], stage["pdf/weights"] = bins.numpy(), w.numpy()
+    stage["pdf/det_64"] = sample_pdf(bins, w, 64, det=True).numpy()
+    torch.manual_seed(99)
+    stage["pdf/rand_40"] = sample_pdf(bins, w, 40, det=False).numpy()
+    torch.manual_seed(99)
+    stage["pdf/u_40"] = torch.rand(n, 40).numpy()
+    np.savez_compressed(os.path.join(HERE, "g8_stages.npz"), **stage)
+    print("g8_stages written;", "oracle worst", f"{worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+"""Seeded synthetic scenes shared by the golden generator and the tests.
+
+The SAME construction code is run with the reference's classes (in
+``tests/golden/make_golden.py``, build container only) and with the build's classes (in
+the tests), so ``torch.manual_seed`` yields bit-identical weights on both sides and the
+fixtures only need to store inputs, expected outputs and a weight checksum.
+
+Synthetic inputs follow SURVEY.md section 8(d): NDC-like rays o=(U(-1,1),U(-1,1),-1),
+d=(N(0,.1),N(0,.1),2); ts ~ randint(0,30); max_t=29; N_tau=48; default init with every
+``*.weight`` of the NeRFs scaled by ``gain`` ("sharp" init) so outputs are not
+near-constant.
+"""
+import numpy as np
+import torch
+
+N_FRAMES = 30
+N_TAU = 48
+N_A = 48
+
+# name -> config.  'flow' is output_transient_flow; 'draws' marks cases with perturb/noise.
+CASES = {
+    "g1_static_c1": dict(n_rays=32, N_samples=64, N_importance=0, transient=False, viewdir=False,
+                         appearance=False, test_time=False, flow=[], gain=2.5, seed=0),
+    "g2_static_c2f": dict(n_rays=16, N_samples=64, N_importance=64, transient=False, viewdir=False,
+                          appearance=False, test_time=False, flow=[], gain=2.5, seed=1),
+    "g3_nsff_train": dict(n_rays=16, N_samples=64, N_importance=64, transient=True, viewdir=False,
+                          appearance=False, test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=2),
+    "g3b_nsff_train_gain3": dict(n_rays=8, N_samples=64, N_importance=64, transient=True, viewdir=False,
+                                 appearance=False, test_time=False, flow=['fw', 'bw', 'disocc'], gain=3.0, seed=3),
+    "g4_nsff_test": dict(n_rays=16, N_samples=64, N_importance=64, transient=True, viewdir=False,
+                         appearance=False, test_time=True, flow=[], gain=2.5, seed=4),
+    "g5_nsff_test_vis": dict(n_rays=24, N_samples=64, N_importance=64, transient=True, viewdir=False,
+                             appearance=False, test_time=True, flow=['fw', 'bw'], gain=2.5, seed=5,
+                             dataset=True),
+    "g6_readme_viewdir": dict(n_rays=8, N_samples=128, N_importance=0, transient=True, viewdir=True,
+                              appearance=True, test_time=True, flow=['fw', 'bw'], gain=2.5, seed=6),
+    "g7_nsff_train_noise": dict(n_rays=16, N_samples=64, N_importance=64, transient=True, viewdir=False,
+                                appearance=False, test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5,
+                                seed=7, perturb=1.0, noise_std=1.0),
+    "g7b_static_noise_odd": dict(n_rays=9, N_samples=48, N_importance=40, transient=False, viewdir=True,
+                                 appearance=False, test_time=False, flow=[], gain=2.5, seed=8,
+                                 perturb=0.5, noise_std=0.7),
+}
+
+
+def synthetic_rays(n_rays, seed):
+    g = torch.Generator().manual_seed(1000 + seed)
+    o = torch.cat([torch.rand(n_rays, 2, generator=g) * 2 - 1, -torch.ones(n_rays, 1)], 1)
+    d = torch.cat([torch.randn(n_rays, 2, generator=g) * 0.1, 2 * torch.ones(n_rays, 1)], 1)
+    ts = torch.randint(0, N_FRAMES, (n_rays,), generator=g)
+    return torch.cat([o, d], 1).float(), ts
+
+
+def build_scene(nerf_cls, posemb_cls, cfg):
+    """Construct embeddings + models in a fixed order under cfg['seed'] and apply the gain."""
+    torch.manual_seed(cfg["seed"])
+    embeddings = {"xyz": posemb_cls(9, 10), "dir": posemb_cls(3, 4)}
+    if cfg["transient"]:
+        embeddings["t"] = torch.nn.Embedding(N_FRAMES, N_TAU)
+    if cfg["appearance"]:
+        embeddings["a"] = torch.nn.Embedding(N_FRAMES, N_A)
+    flow = bool(cfg["flow"])
+    models = {"fine": nerf_cls("fine", use_viewdir=cfg["viewdir"],
+                               encode_appearance=cfg["appearance"], in_channels_a=N_A,
+                               encode_transient=cfg["transient"], in_channels_t=N_TAU,
+                               output_flow=flow)}
+    if cfg["N_importance"] > 0:
+        models["coarse"] = nerf_cls("coarse", use_viewdir=cfg["viewdir"],
+                                    encode_transient=cfg["transient"], in_channels_t=N_TAU)
+    with torch.no_grad():
+        for m in models.values():
+            for name, p in m.named_parameters():
+                if name.endswith(".weight"):
+                    p.mul_(cfg["gain"])
+    return models, embeddings
+
+
+def weight_checksum(models, embeddings):
+    """Order-sensitive float64 checksum of every parameter (detects init / RNG drift)."""
+    tot, k = 0.0, 1
+    mods = [models[k_] for k_ in sorted(models)] + [embeddings[k_] for k_ in sorted(embeddings)
+                                                     if isinstance(embeddings[k_], torch.nn.Embedding)]
+    for m in mods:
+        for _, p in sorted(m.state_dict().items()):
+            tot += float((p.double().abs().sum() + p.double().sum() * 0.5)) * (1 + 0.001 * (k % 97))
+            k += 1
+    return tot
+
+
+class DatasetStub:
+    """The attributes render_rays reads from kwargs['dataset'] (rendering.py:192-199)."""
+
+    def __init__(self, seed):
+        rng = np.random.RandomState(seed)
+        W, H, f = 512, 288, 400.0
+        K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], np.float32)
+        self.Ks = torch.from_numpy(K)[None]
+        self.img_wh = (W, H)
+        self.cam_train = [0]
+        self.N_frames = N_FRAMES
+        poses = np.tile(np.eye(4, dtype=np.float32)[None, :3], (N_FRAMES, 1, 1))
+        poses[:, :, 3] = rng.uniform(-0.15, 0.15, (N_FRAMES, 3)).astype(np.float32)
+        ang = rng.uniform(-0.2, 0.2, N_FRAMES).astype(np.float32)
+        poses[:, 0, 0], poses[:, 0, 2] = np.cos(ang), np.sin(ang)
+        poses[:, 2, 0], poses[:, 2, 2] = -np.sin(ang), np.cos(ang)
+        self.poses = poses
+
+    def as_oracle_dict(self):
+        return dict(K=self.Ks[0].numpy(), H=self.img_wh[1], W=self.img_wh[0], N_frames=self.N_frames,
+                    n_cam_train=len(self.cam_train), poses=self.poses)
+
+
+def wide_rays(n_rays, seed):
+    """Rays covering a wider NDC range so that the frustum test of case g5 is not trivial."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    o = torch.cat([torch.rand(n_rays, 2, generator=g) * 3 - 1.5, -torch.ones(n_rays, 1)], 1)
+    d = torch.cat([torch.randn(n_rays, 2, generator=g) * 0.4, 2 * torch.ones(n_rays, 1)], 1)
+    ts = torch.full((n_rays,), int(torch.randint(0, N_FRAMES, (1,), generator=g)))
+    return torch.cat([o, d], 1).float(), ts
+
+
+def case_inputs(name):
+    cfg = CASES[name]
+    if cfg.get("dataset"):
+        rays, ts = wide_rays(cfg["n_rays"], cfg["seed"])
+    else:
+        rays, ts = synthetic_rays(cfg["n_rays"], cfg["seed"])
+    return cfg, rays, (ts if cfg["transient"] else None)
+
+
+def render_kwargs(cfg, dataset=None):
+    kw = {}
+    if cfg["transient"]:
+        kw["output_transient"] = True
+        kw["output_transient_flow"] = list(cfg["flow"])
+    if dataset is not None:
+        kw["dataset"] = dataset
+    return kw
+
+
+def draw_plan(cfg):
+    """(key, shape, kind) of every torch RNG draw render_rays makes, in order."""
+    n, S, Ni = cfg["n_rays"], cfg["N_samples"], cfg["N_importance"]
+    tr = cfg["transient"]
+    plan = []
+    if cfg.get("perturb", 0) > 0:
+        plan.append(("perturb", (n, S), "rand"))
+    if Ni > 0:
+        plan.append(("coarse_static", (n, S), "randn"))
+        if tr:
+            plan.append(("coarse_transient", (n, S), "randn"))
+        if cfg.get("perturb", 0) != 0:
+            plan.append(("u_static", (n, Ni), "rand"))
+            if tr:
+                plan.append(("u_transient", (n, Ni), "rand"))
+    Sf = S + (2 if tr else 1) * Ni if Ni > 0 else S
+    plan.append(("fine_static", (n, Sf), "randn"))
+    if tr:
+        plan.append(("fine_transient", (n, Sf), "randn"))
+        if cfg["flow"] and not cfg["test_time"]:
+            plan += [("warp_fw", (n, Sf), "randn"), ("warp_bw", (n, Sf), "randn")]
+    return plan
+
+
+def replay_draws(cfg, seed):
+    torch.manual_seed(seed)
+    out = {}
+    for key, shape, kind in draw_plan(cfg):
+        out[key] = (torch.rand(*shape) if kind == "rand" else torch.randn(*shape)).numpy()
+    return out
