@@ -1,0 +1,262 @@
+"""Parity of the HIP path (through the C-ABI) against the reference goldens and the oracle.
+
+All tests here need the MI355X (`-m gpu`).  They never read /root/reference: expected
+values come from tests/golden/*.npz (generated from the reference in the build container)
+and from oracle/nsff_oracle.py run on the same seeded inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import parity
+import scenes
+import nsff_pl_amd as A
+from nsff_pl_amd import _lib
+from oracle import nsff_oracle as orc
+from test_oracle_golden import nerf_mode_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _to_dev(models, emb):
+    for m in models.values():
+        m.to(DEV)
+    for k in ("t", "a"):
+        if k in emb:
+            emb[k].to(DEV)
+
+
+def _np(d):
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+class _Replay:
+    """Feeds render_rays the recorded torch draws (moved to the GPU) in order."""
+
+    def __init__(self, cfg, draws):
+        self.queue = [(key, kind, torch.from_numpy(draws[key])) for key, _, kind in scenes.draw_plan(cfg)]
+
+    def _pop(self, kind, shape):
+        key, k, t = self.queue.pop(0)
+        assert k == kind and tuple(t.shape) == tuple(shape), (key, k, kind, t.shape, shape)
+        return t.to(DEV)
+
+    def rand(self, *shape, **kw):
+        return self._pop("rand", shape)
+
+    def randn(self, *shape, **kw):
+        return self._pop("randn", shape)
+
+
+def _render(cfg, models, emb, rays, ts, dataset, monkeypatch, draws=None, zs_fine=None):
+    kw = scenes.render_kwargs(cfg, dataset)
+    if zs_fine is not None:
+        kw["_zs_fine"] = torch.from_numpy(zs_fine)
+    replay = None
+    if draws is not None:
+        replay = _Replay(cfg, draws)
+        import nsff_pl_amd.rendering as R
+        monkeypatch.setattr(R.torch, "rand", replay.rand)
+        monkeypatch.setattr(R.torch, "randn", replay.randn)
+    try:
+        out = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV),
+                            scenes.N_FRAMES - 1, cfg["N_samples"], cfg.get("perturb", 0),
+                            cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
+                            test_time=cfg["test_time"], **kw)
+    finally:
+        monkeypatch.undo()
+    if replay is not None:
+        assert not replay.queue, "render_rays drew fewer random tensors than the reference"
+    return _np(out)
+
+
+@pytest.mark.parametrize("name", list(scenes.CASES))
+def test_render_rays_matches_reference_goldens(name, hip_lib, monkeypatch):
+    cfg, meta, rays, ts, models, emb, dataset, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+    _to_dev(models, emb)
+    draws = scenes.replay_draws(cfg, meta["draw_seed"])
+    use_draws = draws if (cfg.get("perturb", 0) or cfg.get("noise_std", 0)) else None
+
+    got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, use_draws)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].shape == want[k].shape and got[k].dtype == np.float32, k
+    first_pass = [k for k in want if k.endswith("_coarse")] if cfg["N_importance"] > 0 else list(want)
+    for k in first_pass:
+        parity.assert_close(k, got[k], want[k], common.key_rtol(k, cfg))
+
+    if cfg["N_importance"] > 0:
+        u_lin = torch.linspace(0, 1, cfg["N_importance"]).numpy()
+        u_s, u_t = draws.get("u_static", u_lin), draws.get("u_transient", u_lin)
+        tol_s, tol_t = common.fine_sample_tolerances(cfg, want, u_s, u_t)
+        if "static_zs_fine" in want:
+            parity.assert_samples_close("static_zs_fine", got["static_zs_fine"], want["static_zs_fine"], tol_s)
+        if "transient_zs_fine" in want:
+            parity.assert_samples_close("transient_zs_fine", got["transient_zs_fine"],
+                                        want["transient_zs_fine"], tol_t)
+        tol = tol_s.max(1, keepdims=True)
+        if tol_t is not None:
+            tol = np.maximum(tol, tol_t.max(1, keepdims=True))
+        parity.assert_samples_close("zs_fine", got["zs_fine"], want["zs_fine"], tol)
+        assert (np.diff(got["zs_fine"], axis=1) >= 0).all(), "zs_fine not sorted"
+
+        got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, use_draws, zs_fine=want["zs_fine"])
+        for k in want:
+            if k in ("static_zs_fine", "transient_zs_fine"):
+                continue
+            parity.assert_close(k, got[k], want[k], common.key_rtol(k, cfg))
+
+
+@pytest.fixture(scope="module")
+def stages():
+    return np.load(common.GOLDEN_DIR + "/g8_stages.npz")
+
+
+def test_pos_embedding(stages, hip_lib):
+    x = torch.from_numpy(stages["posenc/x"]).to(DEV)
+    for key, (ms, nf) in {"xyz_9_10": (9, 10), "dir_3_4": (3, 4)}.items():
+        got = A.PosEmbedding(ms, nf)(x).cpu().numpy()
+        parity.assert_close(key, got, stages["posenc/" + key], 2e-6)
+    # edge cases: empty batch, large magnitudes (args up to ~1e4 rad)
+    assert A.PosEmbedding(9, 10)(torch.empty(0, 3, device=DEV)).shape == (0, 63)
+    big = (torch.rand(257, 3, device=DEV) - 0.5) * 40
+    want = orc.pos_embedding(big.cpu().numpy(), A.PosEmbedding(9, 10).freqs.numpy())
+    parity.assert_close("big", A.PosEmbedding(9, 10)(big).cpu().numpy(), want, 2e-6)
+
+
+def test_nerf_forward_modes(stages, hip_lib):
+    cfg = dict(seed=11, transient=True, appearance=True, viewdir=True, flow=['fw', 'bw'],
+               N_importance=64, gain=2.5)
+    models, _ = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    assert abs(scenes.weight_checksum(models, {}) - float(stages["nerf/weight_checksum"])) < 1e-6
+    _to_dev(models, {})
+    for key, typ, x, kw in nerf_mode_inputs(stages):
+        got = models[typ](torch.from_numpy(np.ascontiguousarray(x)).to(DEV), **kw).cpu().numpy()
+        parity.assert_close(key, got, stages["nerf/" + key], parity.RTOL)
+
+
+def test_nerf_forward_rejects_cpu_and_bad_shapes(hip_lib):
+    m = A.NeRF("fine", use_viewdir=False)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, 63 + 27))                       # CPU tensor: no fallback
+    m.to(DEV)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, 10, device=DEV), output_transient=False)
+    assert m(torch.zeros(0, 63 + 27, device=DEV), output_transient=False).shape == (0, 4)
+
+
+def test_weight_repack_follows_parameter_updates(hip_lib):
+    torch.manual_seed(3)
+    m = A.NeRF("fine", use_viewdir=False).to(DEV)
+    x = torch.randn(130, 63 + 27, device=DEV)
+    y0 = m(x, output_transient=False).clone()
+    with torch.no_grad():
+        m.static_rgb[0].bias.add_(0.5)                   # bumps the version counter
+    y1 = m(x, output_transient=False)
+    assert (y1[:, :3] - y0[:, :3]).abs().max() > 1e-3 and torch.equal(y1[:, 3], y0[:, 3])
+    f = orc.field_from_module(m)
+    parity.assert_close("after update", y1.cpu().numpy(),
+                        orc.nerf_forward(f["params"], f["cfg"], x.cpu().numpy(), output_transient=False))
+
+
+def test_sample_pdf(stages, hip_lib, monkeypatch):
+    bins, w = stages["pdf/bins"], stages["pdf/weights"]
+    tb, tw = torch.from_numpy(bins).to(DEV), torch.from_numpy(w).to(DEV)
+    u_det = torch.linspace(0, 1, 64).numpy()
+    got = A.sample_pdf(tb, tw, 64, det=True).cpu().numpy()
+    parity.assert_samples_close("det", got, stages["pdf/det_64"], parity.sample_tolerance(bins, w, u_det))
+    u = stages["pdf/u_40"]
+    import nsff_pl_amd.rendering as R
+    monkeypatch.setattr(R.torch, "rand", lambda *s, **k: torch.from_numpy(u).to(DEV))
+    got = A.sample_pdf(tb, tw, 40, det=False).cpu().numpy()
+    monkeypatch.undo()
+    parity.assert_samples_close("rand", got, stages["pdf/rand_40"], parity.sample_tolerance(bins, w, u))
+    parity.assert_samples_close("rand-vs-oracle", got, orc.sample_pdf(bins, w, u),
+                                parity.sample_tolerance(bins, w, u))
+
+
+def test_rng_draw_order_matches_reference_on_device(hip_lib):
+    """Same seed -> render_rays consumes the device generator exactly like the reference would."""
+    cfg = dict(scenes.CASES["g7_nsff_train_noise"], n_rays=8)
+    rays, ts = scenes.synthetic_rays(8, 7)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    torch.manual_seed(123)
+    A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 1.0, 1.0, 64, 32768, test_time=False,
+                  **scenes.render_kwargs(cfg))
+    after = torch.rand(4, device=DEV)
+    torch.manual_seed(123)
+    for _, shape, kind in scenes.draw_plan(cfg):
+        (torch.rand if kind == "rand" else torch.randn)(*shape, device=DEV)
+    assert torch.equal(after, torch.rand(4, device=DEV))
+
+
+# ---- full-size configuration (BASELINE.json configs[1]): size-independent properties ----
+def test_c2_full_size_properties(hip_lib):
+    cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024)
+    rays, ts = scenes.synthetic_rays(1024, 42)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    kw = scenes.render_kwargs(cfg)
+    rd, td = rays.to(DEV), ts.to(DEV)
+    full = A.render_rays(models, emb, rd, td, 29, 64, 0, 0, 64, 32768, test_time=False, **kw)
+    # (1) rays are independent: a render of two half batches concatenates to the full render, bit for bit
+    halves = [A.render_rays(models, emb, rd[i:i + 512], td[i:i + 512], 29, 64, 0, 0, 64, 32768,
+                            test_time=False, **kw) for i in (0, 512)]
+    for k, v in full.items():
+        assert torch.equal(v, torch.cat([h[k] for h in halves], 0)), k
+    out = _np(full)
+    assert out["zs_fine"].shape == (1024, 192) and out["disoccs_fw"].shape == (1024, 192, 1)
+    for k, v in out.items():
+        assert np.isfinite(v).all(), k
+    # (2) compositing invariants
+    assert (np.diff(out["zs_fine"], axis=1) >= 0).all()
+    w = out["weights_fine"]
+    assert (w >= 0).all() and (w.sum(1) <= 1 + 1e-5).all()
+    np.testing.assert_allclose(out["depth_fine"], (w * out["zs_fine"]).sum(1), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["transient_alpha_fine"], out["transient_weights_fine"].sum(1), atol=2e-6)
+    np.testing.assert_allclose(out["xyz_fw"], out["xyz_fine"] + out["transient_flow_fw"], atol=1e-6)
+    np.testing.assert_allclose(out["xyzs_fw"], out["xyzs_fine"] + out["transient_flows_fw"], atol=1e-6)
+    assert (np.abs(out["transient_flows_fw"]) <= 0.2 + 1e-6).all()
+    assert (out["transient_flows_fw"][out["zs_fine"] > 0.95] == 0).all()
+    # (3) a random subset of rays against the oracle at the same fine depths
+    idx = np.random.RandomState(0).choice(1024, 24, replace=False)
+    want = common.oracle_render(cfg, {k: m for k, m in models.items()}, emb, rays.numpy()[idx],
+                                ts.numpy()[idx], zs_fine_override=out["zs_fine"][idx])
+    for k in want:
+        parity.assert_close(k, out[k][idx], want[k], 1e-3 if k in common.CHAINED_KEYS else parity.RTOL)
+
+
+def test_ragged_and_empty_batches(hip_lib):
+    cfg = dict(scenes.CASES["g4_nsff_test"])
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    kw = scenes.render_kwargs(cfg)
+    rays, ts = scenes.synthetic_rays(7, 5)            # 7*64 and 7*192 points: partial 64-point tiles
+    out = _np(A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 0, 0, 64, 32768,
+                            test_time=True, **kw))
+    want = common.oracle_render(cfg, models, emb, rays.numpy(), ts.numpy(), zs_fine_override=out["zs_fine"])
+    for k in want:
+        if k not in ("static_zs_fine", "transient_zs_fine"):
+            parity.assert_close(k, out[k], want[k])
+    empty = A.render_rays(models, emb, rays[:0].to(DEV), ts[:0].to(DEV), 29, 64, 0, 0, 64, 32768,
+                          test_time=True, **kw)
+    assert empty["rgb_fine"].shape == (0, 3) and empty["zs_fine"].shape == (0, 192)
+    # odd sample counts (not multiples of the 64-lane wave)
+    out = _np(A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 37, 0, 0, 21, 32768, test_time=True, **kw))
+    cfg2 = dict(cfg, N_samples=37, N_importance=21)
+    want = common.oracle_render(cfg2, models, emb, rays.numpy(), ts.numpy(), zs_fine_override=out["zs_fine"])
+    for k in want:
+        if k not in ("static_zs_fine", "transient_zs_fine"):
+            parity.assert_close(k, out[k], want[k])
+
+
+def test_native_library_is_the_one_loaded(hip_lib):
+    with open("/proc/self/maps") as f:
+        assert any("libnsff_hip.so" in line for line in f), "HIP extension not loaded in this process"
+    assert os.path.samefile(_lib.LIB_PATH, os.path.join(os.path.dirname(A.__file__), "libnsff_hip.so"))
