@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Headline benchmark: ray-samples/s of render_rays on BASELINE.json configs[1] (C2).
+
+One "step" = one ``render_rays`` call on a synthetic 1024-ray batch per GPU: static+dynamic
+NSFF, 64 coarse + 64 importance samples (-> 192 fine points per ray), train-mode flags
+(fw/bw flow warp into t+-1 with re-query, disocclusion), all 47 result tensors left on
+the device.  value = n_gpus * 1024 * (64+64) * steps / time  ("nominal" ray-samples, the
+accounting of SURVEY.md 8d).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU is weak scaling: every rank renders its own 1024 rays (no data-path collective)
+and the step ends with ONE RCCL all-gather of the rendered pixels (rgb_fine, depth_fine).
+
+Extra objects on the JSON line:
+  roofline     -- the field (MLP) kernel: algorithmic FLOPs (2*MACs, unpadded K)
+                  per launch / average launch duration from HIP events recorded on the
+                  launch stream inside the timed region, against the fp32 MFMA peak.
+  cpu_baseline -- the numpy oracle (a port of the reference algorithm) timed on this host's
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_RAYS, N_SAMPLES, N_IMPORTANCE = 1024, 64, 64
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
+FLOP_PER_RAY_C2_TRAIN = 1031.80e6
+
+
+def build(device):
+    import scenes
+    import nsff_pl_amd as A
+    cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=N_RAYS, seed=0)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    host = dict(models={k: m for k, m in models.items()}, emb=emb, cfg=cfg)
+    return cfg, models, emb, host
+
+
+def cpu_baseline(cfg, models_cpu, emb_cpu, n_rays=24, reps=2):
+    """Time the oracle on a bounded sample (same per-ray workload, fewer rays)."""
+    import scenes
+    from oracle import nsff_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    rays, ts = scenes.synthetic_rays(n_rays, 0)
+    fields = {k: orc.field_from_module(m) for k, m in models_cpu.items()}
+    draws = scenes.replay_draws(dict(cfg, n_rays=n_rays, perturb=1.0, noise_std=1.0), 1)
+    kw = dict(emb_t=emb_cpu["t"].weight.detach().numpy(), N_samples=N_SAMPLES, perturb=1.0, noise_std=1.0,
+              N_importance=N_IMPORTANCE, test_time=False, draws=draws, output_transient_flow=cfg["flow"])
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        orc.render_rays(fields, emb_cpu["xyz"].freqs.numpy(), emb_cpu["dir"].freqs.numpy(), rays.numpy(),
+                        ts.numpy(), 29, **kw)
+        best = min(best, time.perf_counter() - t0)
+    return dict(value=n_rays * (N_SAMPLES + N_IMPORTANCE) / best, unit="ray-samples/s", cores=int(cores),
+                kind="port", sample=f"{n_rays} rays of the same C2 train-mode workload, numpy oracle, best of {reps}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import scenes
+    import nsff_pl_amd as A
+    from nsff_pl_amd import _lib, dist as ndist
+    import torch.distributed as dist
+
+    rank, world, device = ndist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert device.type == "cuda", "bench.py needs the MI355X"
+
+    cfg, models, emb, _ = build(device)
+    cpu_models = {k: m for k, m in models.items()}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, cpu_models, emb)
+    for m in list(models.values()) + [emb["t"]]:
+        m.to(device)
+    rays, ts = scenes.synthetic_rays(N_RAYS, 100 + rank)
+    rays, ts = rays.to(device), ts.to(device)
+    kw = scenes.render_kwargs(cfg)
+
+    def step():
+        out = A.render_rays(models, emb, rays, ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
+                            N_IMPORTANCE, 1024 * 32, test_time=False, **kw)
+        if world > 1:
+            ndist.all_gather_pixels(out, ("rgb_fine", "depth_fine"))
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms, kernel_flops = _lib.prof_collect()
+    _lib.prof_enable(False)
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * N_RAYS * (N_SAMPLES + N_IMPORTANCE) * args.steps / elapsed
+        achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "ray-samples/sec (coarse+fine, static+dynamic)",
+            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 (BASELINE.json configs[1]): static+dynamic NSFF, 1024 rays/GPU x (64 coarse + "
+                                   "64 importance -> 192 fine pts), train-mode fwd, fw/bw flow warp t+-1, "
+                                   "perturb=1 noise_std=1, 8x256 MLPs, N_tau=48, all 47 outputs on device",
+                       "rays_per_gpu": N_RAYS, "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE,
+                       "parallelism": f"ray-shard x{world}, pixel all-gather" if world > 1 else "single GPU",
+                       "rays_per_s": world * N_RAYS * args.steps / elapsed,
+                       "mlp_tflops_whole_step": world * N_RAYS * args.steps * FLOP_PER_RAY_C2_TRAIN / elapsed / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "nsff_field_kernel",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
+                         "flop_per_launch": kernel_flops / max(launches, 1)},
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""Multi-process test of the ray-sharding path (world_size 2, gloo, CPU).
+
+The GPU kernels cannot run here, so the per-rank renderer is a stand-in with the signature
+of ``render_rays`` that evaluates the oracle; what is under test is
+``nsff_pl_amd.dist``: shard bounds, per-ray kwarg slicing, the packed single-collective
+pixel all-gather (uneven shards included) and that sharded == unsharded per ray.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_render_fn(cfg):
+    import common
+
+    def fn(models, embeddings, rays, ts, *args, **kwargs):
+        out = common.oracle_render(cfg, models, embeddings, rays.numpy(), ts.numpy())
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
+    return fn
+
+
+def _worker(rank, world, port, n_rays, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import scenes
+    import nsff_pl_amd as A
+    from nsff_pl_amd import dist as ndist
+    r, w, dev = ndist.init_from_env("gloo")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    cfg = dict(scenes.CASES["g4_nsff_test"], n_rays=n_rays)
+    rays, ts = scenes.synthetic_rays(n_rays, 9)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    fn = _oracle_render_fn(cfg)
+    keys = ("rgb_fine", "depth_fine", "transient_alpha_fine")
+    merged, local = ndist.render_rays_sharded(fn, models, emb, rays, ts, gather_keys=keys)
+    lo, hi = ndist.shard_bounds(n_rays, world, rank)
+    assert local["rgb_fine"].shape[0] == hi - lo
+    full = fn(models, emb, rays, ts)
+    ok = all(merged[k].shape == full[k].shape and torch.equal(merged[k], full[k]) for k in keys)
+    # weak-scaling form used by bench.py: every rank contributes its own equal-sized batch
+    both = ndist.all_gather_pixels({k: full[k][:4] + rank for k in keys}, keys)
+    ok = ok and both["rgb_fine"].shape == (4 * world, 3) and \
+        torch.equal(both["depth_fine"][4:], full["depth_fine"][:4] + 1)
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rays", [6, 7])     # even and uneven shards
+def test_sharded_render_equals_single_process(n_rays):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.spawn(_worker, args=(world, _free_port(), n_rays, ret), nprocs=world, join=False)
+    ctx.join(timeout=600)
+    assert dict(ret) == {0: True, 1: True}

@@ -1,0 +1,129 @@
+"""CPU-only checks of the host side: module/state_dict contract, flag plumbing, the C-ABI
+library's exported symbols and its argument validation (no GPU compute is launched)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+import nsff_pl_amd as A
+from nsff_pl_amd import _lib, dist as ndist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_contract_matches_reference_probe():
+    """Key names, shapes and parameter counts recorded from the reference."""
+    fine = A.NeRF('fine', use_viewdir=False, encode_transient=True, in_channels_t=48, output_flow=True)
+    coarse = A.NeRF('coarse', use_viewdir=False, encode_transient=True, in_channels_t=48)
+    assert sum(p.numel() for p in fine.parameters()) == 1145870
+    assert sum(p.numel() for p in coarse.parameters()) == 1144328
+    sd = fine.state_dict()
+    assert sd['static_xyz_encoding_1.0.weight'].shape == (256, 63)
+    assert sd['static_xyz_encoding_5.0.weight'].shape == (256, 319)
+    assert sd['transient_xyz_encoding_1.0.weight'].shape == (256, 111)
+    assert sd['transient_xyz_encoding_5.0.weight'].shape == (256, 367)
+    assert sd['static_sigma.weight'].shape == (1, 256) and sd['static_rgb.0.weight'].shape == (3, 256)
+    assert sd['transient_flow_fw.0.weight'].shape == (3, 256) and 'transient_flow_bw.0.bias' in sd
+    assert 'transient_flow_fw.0.weight' not in coarse.state_dict()
+    assert 'static_dir_encoding.0.weight' not in sd
+    vd = A.NeRF('fine', use_viewdir=True, encode_appearance=True, encode_transient=True, in_channels_t=48,
+                output_flow=True)
+    assert vd.state_dict()['static_dir_encoding.0.weight'].shape == (256, 256 + 27 + 48)
+    assert sum(p.numel() for p in A.NeRF('fine', use_viewdir=True, encode_transient=True, in_channels_t=48,
+                                         output_flow=True).parameters()) == 1218574
+    # coarse models never take the appearance code (reference nerf.py:67)
+    assert A.NeRF('coarse', encode_appearance=True).encode_appearance is False
+    assert A.PosEmbedding(9, 10).state_dict() == {} and len(A.PosEmbedding(9, 10).freqs) == 10
+    assert torch.equal(A.PosEmbedding(3, 4).freqs, torch.tensor([1., 2., 4., 8.]))
+
+
+def test_seeded_weights_reproduce_golden_checksums():
+    import common
+    for name in scenes.CASES:
+        common.build_case(name, A.NeRF, A.PosEmbedding)      # asserts the checksum
+
+
+def test_header_symbols_are_exported_and_bound():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "nsff_render.h")).read()
+    declared = set(re.findall(r"\b(nsff_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations found in the header"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
+    assert lib.nsff_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header_sizes():
+    # natural-alignment layout of the C structs (pointer = 8 bytes)
+    assert C.sizeof(_lib.ModelDesc) == 44
+    assert C.sizeof(_lib.FieldArgs) == 8 + 16 + 8 + 4 + 64 + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8
+    n_ptr = len(_lib._COMPOSITE_PTRS_IN) + len(_lib._COMPOSITE_PTRS_OUT)
+    assert C.sizeof(_lib.CompositeArgs) == 40 + 8 * n_ptr
+
+
+def test_layout_and_argument_validation_without_gpu():
+    lib = _lib.load()
+    m = A.NeRF('fine', use_viewdir=False, encode_transient=True, in_channels_t=48, output_flow=True)
+    d = _lib.model_desc(m)
+    n = C.c_size_t()
+    assert lib.nsff_packed_bytes(C.byref(d), C.byref(n)) == 0
+    # every Linear element appears once (+ zero padding of K to multiples of 8, vectors to 4)
+    assert n.value // 4 >= sum(p.numel() for p in m.parameters())
+    assert n.value // 4 < 1.03 * sum(p.numel() for p in m.parameters())
+    assert lib.nsff_param_count(C.byref(d)) == len(_lib.param_list(m)) == 48
+    bad = _lib.model_desc(m); bad.W = 128
+    assert lib.nsff_packed_bytes(C.byref(bad), C.byref(n)) == -1            # NSFF_ERR_INVALID
+    bad = _lib.model_desc(m); bad.skip = 0
+    assert lib.nsff_packed_bytes(C.byref(bad), C.byref(n)) == -1
+    assert lib.nsff_packed_bytes(None, C.byref(n)) == -2                    # NSFF_ERR_NULL
+    a = _lib.FieldArgs()
+    a.n_points, a.pts_per_ray, a.static_mode = 64, 1, 2
+    assert lib.nsff_field_query(C.byref(d), None, C.byref(a), None) == -2
+    c = _lib.CompositeArgs()
+    c.n_rays, c.n_samples = 4, 0
+    assert lib.nsff_composite(C.byref(c), None) == -1
+    assert lib.nsff_coarse_samples(None, 4, None, 0, 0.0, None, None, None, None) == -1
+    assert lib.nsff_coarse_samples(None, 0, None, 8, 0.0, None, None, None, None) == 0   # empty batch is ok
+
+
+def test_product_path_refuses_cpu_tensors():
+    models = {'fine': A.NeRF('fine', use_viewdir=False)}
+    emb = {'xyz': A.PosEmbedding(9, 10), 'dir': A.PosEmbedding(3, 4)}
+    with pytest.raises(RuntimeError, match="GPU"):
+        A.render_rays(models, emb, torch.zeros(4, 6), None, 0, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        A.PosEmbedding(9, 10)(torch.zeros(4, 3))
+    with pytest.raises(RuntimeError, match="GPU"):
+        A.sample_pdf(torch.zeros(2, 5), torch.zeros(2, 4), 8, det=True)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "nsff_pl_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no CPU oracle", ""), fn
+
+
+def test_draw_plan_matches_reference_order():
+    cfg = scenes.CASES["g7_nsff_train_noise"]
+    keys = [k for k, _, _ in scenes.draw_plan(cfg)]
+    assert keys == ["perturb", "coarse_static", "coarse_transient", "u_static", "u_transient",
+                    "fine_static", "fine_transient", "warp_fw", "warp_bw"]
+    keys = [k for k, _, _ in scenes.draw_plan(scenes.CASES["g1_static_c1"])]
+    assert keys == ["fine_static"]
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 1024, 147456):
+        for world in (1, 2, 3, 8):
+            b = [ndist.shard_bounds(n, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
