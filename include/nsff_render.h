@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      1
+#define NSFF_ABI_VERSION      2
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -56,8 +56,15 @@ typedef struct NsffModelDesc {
     float   flow_scale;     /* 0.2                                                 */
 } NsffModelDesc;
 
-/* Size in bytes of the packed-weight buffer for `desc`. */
-int nsff_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
+/* Arithmetic of the field kernel's dense layers (results agree to fp32 rounding level):
+ *   NSFF_PREC_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   NSFF_PREC_F16X3 fp32 operands split into two halfs, three f16 MFMAs per product,
+ *                   fp32 accumulate (v_mfma_f32_32x32x16_f16)                              */
+#define NSFF_PREC_F32     0
+#define NSFF_PREC_F16X3   1
+
+/* Size in bytes of the packed-weight buffer for `desc` at `precision`. */
+int nsff_packed_bytes(const NsffModelDesc* desc, int precision, size_t* bytes);
 
 /* Number of parameter tensors nsff_pack_weights expects, in this order
  * (PyTorch Linear layout, weight (out,in) row-major then bias):
@@ -69,8 +76,8 @@ int nsff_param_count(const NsffModelDesc* desc);
 
 /* Repack the module parameters into MFMA B-operand tiles (DESIGN.md "weight pack").
  * `params`: HOST array of nsff_param_count() device pointers. */
-int nsff_pack_weights(const NsffModelDesc* desc, const float* const* params,
-                      float* packed, void* stream);
+int nsff_pack_weights(const NsffModelDesc* desc, int precision, const float* const* params,
+                      void* packed, void* stream);
 
 /* ---- a1: PosEmbedding.forward (reference nerf.py:17-30) ---- */
 int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_freqs,
@@ -79,6 +86,8 @@ int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_f
 /* ---- a3/a5: fused field query = encode -> trunk(s) -> heads (NeRF.forward) ---- */
 typedef struct NsffFieldArgs {
     int64_t n_points;        /* P                                                   */
+    int32_t precision;       /* NSFF_PREC_*: must match the packed buffer           */
+    int32_t tile_points;     /* F16X3 only: points per workgroup, 0 (default 128), 64 or 128 */
     int32_t pts_per_ray;     /* ray index of point p is p / pts_per_ray             */
     int32_t static_mode;     /* 0 skip, 1 sigma only, 2 rgb+sigma                   */
     int32_t transient_mode;  /* 0 skip, 1 sigma only, 2 rgb+sigma(+flow heads)      */
@@ -99,7 +108,7 @@ typedef struct NsffFieldArgs {
     float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
 } NsffFieldArgs;
 
-int nsff_field_query(const NsffModelDesc* desc, const float* packed,
+int nsff_field_query(const NsffModelDesc* desc, const void* packed,
                      const NsffFieldArgs* args, void* stream);
 
 /* ---- a4: coarse sample placement (reference rendering.py:314-324,332) ----

@@ -7,7 +7,8 @@ Public surface = the reference's own interface for that path:
 All arithmetic runs in the gfx950 kernels of ``csrc/`` behind the C-ABI declared in
 ``include/nsff_render.h``; see DESIGN.md / INTEGRATION.md.
 """
+from .config import get_precision, set_precision
 from .nerf import NeRF, PosEmbedding
 from .rendering import render_rays, sample_pdf
 
-__all__ = ["NeRF", "PosEmbedding", "render_rays", "sample_pdf"]
+__all__ = ["NeRF", "PosEmbedding", "render_rays", "sample_pdf", "set_precision", "get_precision"]

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
+ABI_VERSION = 2
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -34,7 +35,8 @@ class ModelDesc(C.Structure):
 
 
 class FieldArgs(C.Structure):
-    _fields_ = [("n_points", C.c_int64), ("pts_per_ray", C.c_int32),
+    _fields_ = [("n_points", C.c_int64), ("precision", C.c_int32), ("tile_points", C.c_int32),
+                ("pts_per_ray", C.c_int32),
                 ("static_mode", C.c_int32), ("transient_mode", C.c_int32),
                 ("flow_heads", C.c_int32),
                 ("xyz", _fp), ("n_freqs", C.c_int32), ("freqs", C.c_float * MAX_FREQS),
@@ -68,9 +70,9 @@ class CompositeArgs(C.Structure):
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
     "nsff_last_hip_error": (C.c_char_p, []),
-    "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
+    "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
     "nsff_param_count": (C.c_int, [C.POINTER(ModelDesc)]),
-    "nsff_pack_weights": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp]),
+    "nsff_pack_weights": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_fp), _fp, _fp]),
     "nsff_posenc": (C.c_int, [_fp, C.c_int64, C.POINTER(C.c_float), C.c_int, _fp, _fp]),
     "nsff_field_query": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldArgs), _fp]),
     "nsff_coarse_samples": (C.c_int, [_fp, C.c_int64, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, _fp]),
@@ -100,7 +102,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.nsff_abi_version() != 1:
+        if lib.nsff_abi_version() != ABI_VERSION:
             raise RuntimeError("libnsff_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -166,13 +168,13 @@ def param_list(model):
     return out
 
 
-def packed_bytes(desc):
+def packed_bytes(desc, precision=0):
     n = C.c_size_t(0)
-    _check(load().nsff_packed_bytes(C.byref(desc), C.byref(n)), "nsff_packed_bytes")
+    _check(load().nsff_packed_bytes(C.byref(desc), int(precision), C.byref(n)), "nsff_packed_bytes")
     return n.value
 
 
-def pack_weights(desc, params, packed):
+def pack_weights(desc, params, packed, precision=0):
     lib = load()
     if lib.nsff_param_count(C.byref(desc)) != len(params):
         raise RuntimeError("parameter list does not match the model description")
@@ -180,7 +182,8 @@ def pack_weights(desc, params, packed):
     for p in keep:
         require_gpu_tensor(p, "model parameter")
     arr = (_fp * len(keep))(*[p.data_ptr() for p in keep])
-    _check(lib.nsff_pack_weights(C.byref(desc), arr, _ptr(packed), _stream()), "nsff_pack_weights")
+    _check(lib.nsff_pack_weights(C.byref(desc), int(precision), arr, _ptr(packed), _stream()),
+           "nsff_pack_weights")
     return keep  # caller keeps temporaries alive until the stream has consumed them
 
 
@@ -193,9 +196,12 @@ def posenc(x, freqs, out):
 def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
                 xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
                 x_emb=None, emb_offsets=(0, -1, -1, -1)):
+    from . import config
     desc = model_desc(model)
-    packed = model.packed()
+    prec = config.PRECISIONS[config.get_precision()]
+    packed = model.packed(prec)
     a = FieldArgs()
+    a.precision, a.tile_points = prec, config.get_tile_points()
     a.n_points, a.pts_per_ray = int(n_points), int(pts_per_ray)
     a.static_mode, a.transient_mode, a.flow_heads = int(static_mode), int(transient_mode), int(flow_heads)
     a.xyz = _ptr(xyz)

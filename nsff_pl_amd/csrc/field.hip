@@ -19,6 +19,7 @@
 #include <mutex>
 #include "nsff_layout.h"
 #include "nsff_common.h"
+#include "nsff_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -438,8 +439,10 @@ extern "C" {
 int nsff_abi_version(void) { return NSFF_ABI_VERSION; }
 const char* nsff_last_hip_error(void) { return hipGetErrorString(g_nsff_last_err); }
 
-int nsff_packed_bytes(const NsffModelDesc* desc, size_t* bytes) {
+int nsff_packed_bytes(const NsffModelDesc* desc, int precision, size_t* bytes) {
     if (!desc || !bytes) return NSFF_ERR_NULL;
+    if (precision == NSFF_PREC_F16X3) return nsff_h3_packed_bytes(desc, bytes);
+    if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
     NsffLayout L;
     const int rc = nsff_make_layout(*desc, L);
     if (rc) return rc;
@@ -454,9 +457,13 @@ int nsff_param_count(const NsffModelDesc* d) {
     return n;
 }
 
-int nsff_pack_weights(const NsffModelDesc* desc, const float* const* params, float* packed, void* stream) {
-    if (!desc || !params || !packed) return NSFF_ERR_NULL;
-    if ((uintptr_t)packed & 15) return NSFF_ERR_ALIGN;
+int nsff_pack_weights(const NsffModelDesc* desc, int precision, const float* const* params, void* packed_v,
+                      void* stream) {
+    if (!desc || !params || !packed_v) return NSFF_ERR_NULL;
+    if ((uintptr_t)packed_v & 15) return NSFF_ERR_ALIGN;
+    if (precision == NSFF_PREC_F16X3) return nsff_h3_pack_weights(desc, params, packed_v, (hipStream_t)stream);
+    if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
+    float* packed = reinterpret_cast<float*>(packed_v);
     NsffLayout L;
     const int rc = nsff_make_layout(*desc, L);
     if (rc) return rc;
@@ -544,7 +551,8 @@ int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_f
     return e == hipSuccess ? NSFF_OK : nsff_hip_fail(e);
 }
 
-int nsff_field_query(const NsffModelDesc* desc, const float* packed, const NsffFieldArgs* args, void* stream) {
+int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const NsffFieldArgs* args, void* stream) {
+    const float* packed = reinterpret_cast<const float*>(packed_v);
     if (!desc || !packed || !args) return NSFF_ERR_NULL;
     const NsffModelDesc& d = *desc;
     const NsffFieldArgs& g = *args;
@@ -555,6 +563,8 @@ int nsff_field_query(const NsffModelDesc* desc, const float* packed, const NsffF
     if (g.static_mode < 0 || g.static_mode > 2 || g.transient_mode < 0 || g.transient_mode > 2) return NSFF_ERR_INVALID;
     if (g.static_mode == 0 && g.transient_mode == 0) return NSFF_ERR_INVALID;
     if (g.flow_heads < 0 || g.flow_heads > 2 || (g.flow_heads && !d.has_flow)) return NSFF_ERR_INVALID;
+    if (g.precision != NSFF_PREC_F32 && g.precision != NSFF_PREC_F16X3) return NSFF_ERR_INVALID;
+    if (g.tile_points != 0 && g.tile_points != 64 && g.tile_points != 128) return NSFF_ERR_INVALID;
     if (g.transient_mode && !d.has_transient) return NSFF_ERR_INVALID;
     if (g.n_points == 0) return NSFF_OK;
     if (!g.raw) return NSFF_ERR_NULL;
@@ -596,8 +606,14 @@ int nsff_field_query(const NsffModelDesc* desc, const float* packed, const NsffF
         e = hipEventCreate(&pr.e1); if (e != hipSuccess) return nsff_hip_fail(e);
         hipEventRecord(pr.e0, st);
     }
-    hipLaunchKernelGGL(nsff_field_kernel, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipSuccess;
+    if (g.precision == NSFF_PREC_F16X3) {
+        const int rc3 = nsff_h3_field_query(desc, packed_v, args, g.tile_points ? g.tile_points : 128, st);
+        if (rc3 != NSFF_OK) return rc3;
+    } else {
+        hipLaunchKernelGGL(nsff_field_kernel, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
+        e = hipGetLastError();
+    }
     if (prof) {
         hipEventRecord(pr.e1, st);
         pr.flops = field_flops_per_point(d, g.static_mode, g.transient_mode,

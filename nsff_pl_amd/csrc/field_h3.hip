@@ -1,0 +1,517 @@
+// fp16-split ("f16x3") variant of the fused NSFF field query for gfx950.
+//
+// Same function as field.hip (encode -> trunk(s) -> heads == PosEmbedding + NeRF.forward,
+// reference models/nerf.py:17-30,118-213) but every fp32 GEMM operand is carried as two halfs
+// (x = hi + lo, 22 significant bits) and each product is three f16 MFMAs accumulated in fp32:
+//
+//        W.x  ~=  Wh.xh + Wh.xl + Wl.xh            (the dropped Wl.xl term is < 2^-22 relative)
+//
+// which reproduces the fp32 result to fp32-rounding level (measured through the
+// whole pipeline against the reference goldens) on the 16x faster f16 matrix pipe.
+//
+// Formulation is transposed w.r.t. field.hip:  D[neuron][point] = sum_k W[neuron][k] X[point][k]
+//   * A operand = weights, streamed from L2 as pre-packed hi/lo tiles (nsff_layout_h3.h);
+//   * B operand = activations, kept in LDS as two fp16 planes Xh/Xl [points][264] (528-B rows:
+//     conflict-free ds_read_b128);
+//   * the 32x32 accumulator then holds 4 consecutive neurons of one point per register quad, so
+//     the epilogue packs them to 8-byte hi / lo stores (ds_write_b64).
+// Wave w owns neurons [64w, 64w+64) for all points of the tile: 2 x NT accumulator tiles.
+// NT = 4 (128 points, one workgroup per CU) halves the weight stream per FLOP; NT = 2
+// (64 points, two workgroups per CU) hides epilogues behind the other workgroup's MFMAs.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
+#include "nsff_layout_h3.h"
+#include "nsff_common.h"
+#include "nsff_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int LDH = 264;          // halfs per LDS row (528 B; 528/16 = 33 odd)
+constexpr int NTHREADS = 256;
+
+struct H3KArgs {
+    NsffLayoutH3 L;
+    const uint32_t* packed;
+    const float* xyz;
+    const float* x_emb;
+    const float* dir_emb;
+    const float* a_emb;
+    const float* t_emb;
+    float* raw;
+    long long n_points;
+    int pts_per_ray;
+    int static_mode, transient_mode;
+    int D, skip;
+    int in_xyz, in_dir, in_a, in_t;
+    int use_viewdir;
+    float flow_scale;
+    int n_freqs;
+    float freqs[NSFF_MAX_FREQS];
+    int ld_emb, off_xyz, off_dir, off_a, off_t;
+};
+
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx, float v) {
+    const _Float16 hi = (_Float16)v;
+    xh[idx] = hi;
+    xl[idx] = (_Float16)(v - (float)hi);
+}
+
+template <int NT>
+struct Frags {
+    h8 wh[2], wl[2];       // weights (A operand), two 32-neuron tiles
+    h8 xh[NT], xl[NT];     // activations (B operand), NT 32-point tiles
+};
+
+template <int NT>
+__device__ __forceinline__ void load_frags(Frags<NT>& f, const uint4* __restrict__ w, const _Float16* sBh,
+                                           const _Float16* sBl, int ks) {
+    // weights: [ks][mt][part][lane] 16-byte chunks, this lane's pointer already includes `lane`
+    const uint4* wk = w + ks * 4 * 64;
+    const uint4 a0 = wk[0], a1 = wk[64], a2 = wk[128], a3 = wk[192];
+    f.wh[0] = __builtin_bit_cast(h8, a0); f.wl[0] = __builtin_bit_cast(h8, a1);
+    f.wh[1] = __builtin_bit_cast(h8, a2); f.wl[1] = __builtin_bit_cast(h8, a3);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f.xh[nt] = *reinterpret_cast<const h8*>(sBh + nt * 32 * LDH + ks * 16);
+        f.xl[nt] = *reinterpret_cast<const h8*>(sBl + nt * 32 * LDH + ks * 16);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[2][NT], const Frags<NT>& f) {
+    // three passes so that consecutive MFMAs never touch the same accumulator
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(f.wl[mt], f.xh[nt], acc[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(f.wh[mt], f.xl[nt], acc[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(f.wh[mt], f.xh[nt], acc[mt][nt]);
+}
+
+// acc += W_seg . X[:, 0:16*nks]^T  for this wave's 64 neurons and all 32*NT points.
+template <int NT>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const uint4* __restrict__ w,
+                                         const _Float16* sBh, const _Float16* sBl, int nks) {
+    Frags<NT> f0, f1;
+    load_frags<NT>(f0, w, sBh, sBl, 0);
+    int ks = 0;
+    for (; ks + 2 <= nks; ks += 2) {
+        load_frags<NT>(f1, w, sBh, sBl, ks + 1);
+        mma_step<NT>(acc, f0);
+        if (ks + 2 < nks) load_frags<NT>(f0, w, sBh, sBl, ks + 2);
+        mma_step<NT>(acc, f1);
+    }
+    if (ks < nks) mma_step<NT>(acc, f0);
+}
+
+// accumulators start at the bias: row (neuron) = 64w + 32mt + 8q + 4h + e, e = 0..3
+template <int NT>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const float* __restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt][4 * q + 0] = b.x; acc[mt][nt][4 * q + 1] = b.y;
+                acc[mt][nt][4 * q + 2] = b.z; acc[mt][nt][4 * q + 3] = b.w;
+            }
+        }
+}
+
+template <int NT, bool RELU>
+__device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[2][NT], int wave, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[mt][nt][4 * q + e];
+                    if (RELU) v[e] = fmaxf(v[e], 0.0f);
+                }
+                const h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+                const h2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                const h2 l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
+                const h2 l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+                const int idx = (32 * nt + (lane & 31)) * LDH + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5);
+                h4 hv, lv;
+                hv[0] = (_Float16)h01[0]; hv[1] = (_Float16)h01[1]; hv[2] = (_Float16)h23[0]; hv[3] = (_Float16)h23[1];
+                lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
+                *reinterpret_cast<h4*>(sXh + idx) = hv;
+                *reinterpret_cast<h4*>(sXl + idx) = lv;
+            }
+}
+
+template <int NT>
+__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t) {
+    constexpr int M = 32 * NT;
+    constexpr int G = NTHREADS / M;              // threads per point row
+    const int r = threadIdx.x % M, q = threadIdx.x / M;
+    const long long p = p0 + r;
+    const bool valid = p < a.n_points;
+    const int base = r * LDH;
+    const int k0s = (int)a.L.k0s;
+    if (a.xyz != nullptr) {
+        float x[3] = {0.f, 0.f, 0.f};
+        if (valid) { x[0] = a.xyz[p * 3 + 0]; x[1] = a.xyz[p * 3 + 1]; x[2] = a.xyz[p * 3 + 2]; }
+        if (q == 0) {
+            split_store(sXh, sXl, base + 0, x[0]); split_store(sXh, sXl, base + 1, x[1]);
+            split_store(sXh, sXl, base + 2, x[2]);
+            for (int c = a.in_xyz; c < k0s; ++c) { sXh[base + c] = (_Float16)0.f; sXl[base + c] = (_Float16)0.f; }
+        }
+        const int nf3 = 3 * a.n_freqs;
+        for (int j = q; j < nf3; j += G) {
+            const int f = j / 3, c = j - 3 * f;
+            float s, co;
+            sincosf(a.freqs[f] * x[c], &s, &co);
+            split_store(sXh, sXl, base + 3 + 6 * f + c, s);
+            split_store(sXh, sXl, base + 3 + 6 * f + 3 + c, co);
+        }
+    } else {
+        const float* src = a.x_emb + p * a.ld_emb + a.off_xyz;
+        for (int c = q; c < k0s; c += G) split_store(sXh, sXl, base + c, (valid && c < a.in_xyz) ? src[c] : 0.f);
+    }
+    if (with_t) {
+        const float* src = nullptr;
+        if (valid) src = (a.xyz != nullptr) ? a.t_emb + (p / a.pts_per_ray) * a.in_t
+                                            : a.x_emb + p * a.ld_emb + a.off_t;
+        const int kt = (int)a.L.kt;
+        for (int c = q; c < kt; c += G) split_store(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0) {
+    constexpr int M = 32 * NT;
+    constexpr int G = NTHREADS / M;
+    const int r = threadIdx.x % M, q = threadIdx.x / M;
+    const long long p = p0 + r;
+    const bool valid = p < a.n_points;
+    const float* sd = nullptr; const float* sa = nullptr;
+    if (valid) {
+        if (a.xyz != nullptr) {
+            const long long ray = p / a.pts_per_ray;
+            sd = a.dir_emb + ray * a.in_dir;
+            if (a.in_a > 0) sa = a.a_emb + ray * a.in_a;
+        } else {
+            sd = a.x_emb + p * a.ld_emb + a.off_dir;
+            if (a.in_a > 0) sa = a.x_emb + p * a.ld_emb + a.off_a;
+        }
+    }
+    const int sk = (int)a.L.side_k;
+    for (int c = q; c < sk; c += G) {
+        float v = 0.f;
+        if (valid) {
+            if (c < a.in_dir) v = sd[c];
+            else if (c < a.in_dir + a.in_a) v = sa[c - a.in_dir];
+        }
+        split_store(sXh, sXl, r * LDH + c, v);
+    }
+}
+
+enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
+
+// Narrow heads as one zero-padded 32-row MFMA tile; wave w evaluates the 32 points of tile w.
+// out row = (r&3) + 8*(r>>2) + 4*(lane>>5); only r < 8 (rows < 16) can be live.
+template <int NT>
+__device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, const uint32_t* __restrict__ pk,
+                                      uint32_t w_off, uint32_t b_off, int n_rows, unsigned kinds, float flow_scale,
+                                      float* raw, long long p0, long long n_points, int slot0, int wave, int lane) {
+    if (wave >= NT) return;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane;
+    const _Float16* bh = sXh + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
+    const _Float16* bl = sXl + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
+#pragma unroll 4
+    for (int ks = 0; ks < NSFF_W / 16; ++ks) {
+        const h8 wh = __builtin_bit_cast(h8, w[(ks * 2 + 0) * 64]);
+        const h8 wl = __builtin_bit_cast(h8, w[(ks * 2 + 1) * 64]);
+        const h8 xh = *reinterpret_cast<const h8*>(bh + ks * 16);
+        const h8 xl = *reinterpret_cast<const h8*>(bl + ks * 16);
+        acc = MFMA_H(wl, xh, acc);
+        acc = MFMA_H(wh, xl, acc);
+        acc = MFMA_H(wh, xh, acc);
+    }
+    const long long p = p0 + 32 * wave + (lane & 31);
+    const float* bias = reinterpret_cast<const float*>(pk + b_off);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < n_rows) {
+            float v = acc[r] + bias[row];
+            const unsigned kind = (kinds >> (2 * row)) & 3u;
+            if (kind == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+            else if (kind == ACT_FLOW) v = flow_scale * tanhf(v);
+            if (p < n_points) raw[p * NSFF_RAW_STRIDE + slot0 + row] = v;
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NTHREADS, (NT == 2 ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
+    constexpr int M = 32 * NT;
+    __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
+    _Float16* sXh = sX;
+    _Float16* sXl = sX + M * LDH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long p0 = (long long)blockIdx.x * M;
+    const uint32_t* __restrict__ pk = a.packed;
+    const _Float16* sBh = sXh + (lane & 31) * LDH + 8 * (lane >> 5);
+    const _Float16* sBl = sXl + (lane & 31) * LDH + 8 * (lane >> 5);
+
+    f32x16 acc[2][NT];
+    auto seg = [&](uint32_t off, int nks) {
+        return reinterpret_cast<const uint4*>(pk + off) + (wave * nks) * 4 * 64 + lane;
+    };
+    auto fbias = [&](uint32_t off) { return reinterpret_cast<const float*>(pk + off); };
+    auto trunk = [&](const NsffTrunkLayoutH3& T, bool with_t) {
+        const int nk0 = (int)T.k0 / 16;
+        for (int l = 0; l < a.D; ++l) {
+            acc_init<NT>(acc, fbias(T.bias[l]), wave, lane);
+            if (l == 0) {
+                gemm_seg<NT>(acc, seg(T.seg_x[0], nk0), sBh, sBl, nk0);
+            } else {
+                gemm_seg<NT>(acc, seg(T.seg_h[l], NSFF_W / 16), sBh, sBl, NSFF_W / 16);
+                if (l == a.skip) {
+                    __syncthreads();
+                    build_input<NT>(sXh, sXl, a, p0, with_t);
+                    __syncthreads();
+                    gemm_seg<NT>(acc, seg(T.seg_x[l], nk0), sBh, sBl, nk0);
+                }
+            }
+            __syncthreads();
+            acc_store<NT, true>(sXh, sXl, acc, wave, lane);
+            __syncthreads();
+        }
+    };
+    auto final_layer = [&](const NsffTrunkLayoutH3& T) {
+        acc_init<NT>(acc, fbias(T.final_b), wave, lane);
+        gemm_seg<NT>(acc, seg(T.final_w, NSFF_W / 16), sBh, sBl, NSFF_W / 16);
+        __syncthreads();
+        acc_store<NT, false>(sXh, sXl, acc, wave, lane);
+        __syncthreads();
+    };
+
+    if (a.static_mode != 0) {
+        build_input<NT>(sXh, sXl, a, p0, false);
+        __syncthreads();
+        trunk(a.L.st, false);
+        heads<NT>(sXh, sXl, pk, a.L.s_sigma_w, a.L.s_sigma_b, 1, ACT_NONE, 0.f, a.raw, p0, a.n_points, 3, wave, lane);
+        if (a.static_mode == 2) {
+            final_layer(a.L.st);
+            if (a.use_viewdir) {
+                acc_init<NT>(acc, fbias(a.L.dir_b), wave, lane);
+                gemm_seg<NT>(acc, seg(a.L.dir_h, NSFF_W / 16), sBh, sBl, NSFF_W / 16);
+                __syncthreads();
+                build_side<NT>(sXh, sXl, a, p0);
+                __syncthreads();
+                const int nks = (int)a.L.side_k / 16;
+                gemm_seg<NT>(acc, seg(a.L.dir_x, nks), sBh, sBl, nks);
+                __syncthreads();
+                acc_store<NT, true>(sXh, sXl, acc, wave, lane);
+                __syncthreads();
+            }
+            heads<NT>(sXh, sXl, pk, a.L.s_rgb_w, a.L.s_rgb_b, 3, 0x15u, 0.f, a.raw, p0, a.n_points, 0, wave, lane);
+        }
+        __syncthreads();
+    }
+    if (a.transient_mode != 0) {
+        build_input<NT>(sXh, sXl, a, p0, true);
+        __syncthreads();
+        trunk(a.L.tr, true);
+        final_layer(a.L.tr);
+        const unsigned kinds = 0x15u | (0xAAAu << 8);
+        heads<NT>(sXh, sXl, pk, a.L.t_head_w, a.L.t_head_b, (int)a.L.t_head_rows, kinds, a.flow_scale,
+                  a.raw, p0, a.n_points, 4, wave, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+struct PackSegH3 {
+    const float* src;
+    uint32_t dst;       // word offset
+    int32_t kind;       // 0 flat fp32 copy, 1 tiled hi/lo segment, 2 head rows
+    int32_t ld;
+    int32_t kpad;       // tiled: padded K; flat: element count; head: K (=256)
+    int32_t n0, s0, p1, n1, s1;   // column map (tiled)
+    int32_t row0, nrows;          // head: destination row range
+};
+constexpr int PACK_BATCH = 12;
+struct PackArgsH3 { PackSegH3 seg[PACK_BATCH]; uint32_t* dst; };
+
+__device__ __forceinline__ float seg_value(const PackSegH3& s, int n, int c) {
+    if (c < s.n0) return s.src[(long long)n * s.ld + s.s0 + c];
+    if (c >= s.p1 && c < s.p1 + s.n1) return s.src[(long long)n * s.ld + s.s1 + (c - s.p1)];
+    return 0.f;
+}
+
+__global__ void nsff_pack_kernel_h3(const PackArgsH3 a) {
+    const PackSegH3& s = a.seg[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s.kind == 0) {
+        if (idx < s.kpad) reinterpret_cast<float*>(a.dst + s.dst)[idx] = s.src[idx];
+        return;
+    }
+    const int nks = s.kpad / 16;
+    int lane, part, n, ks;
+    if (s.kind == 1) {
+        if (idx >= 4 * nks * 4 * 64) return;          // chunks: [wave][ks][mt][part][lane]
+        lane = idx & 63; part = (idx >> 6) & 1;
+        const int mt = (idx >> 7) & 1;
+        const int wk = idx >> 8;
+        ks = wk % nks;
+        n = 64 * (wk / nks) + 32 * mt + (lane & 31);
+    } else {
+        if (idx >= nks * 2 * 64) return;              // chunks: [ks][part][lane]
+        lane = idx & 63; part = (idx >> 6) & 1; ks = idx >> 7;
+        n = (lane & 31) - s.row0;
+        if (n < 0 || n >= s.nrows) return;            // other rows stay zero (buffer is memset first)
+    }
+    h8 out;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int c = ks * 16 + 8 * (lane >> 5) + t;
+        const float x = s.kind == 1 ? seg_value(s, n, c) : s.src[(long long)n * s.ld + c];
+        const _Float16 hi = (_Float16)x;
+        out[t] = part == 0 ? hi : (_Float16)(x - (float)hi);
+    }
+    reinterpret_cast<h8*>(a.dst + s.dst)[idx] = out;
+}
+
+}  // namespace
+
+int nsff_h3_packed_bytes(const NsffModelDesc* desc, size_t* bytes) {
+    NsffLayoutH3 L;
+    const int rc = nsff_make_layout_h3(*desc, L);
+    if (rc) return rc;
+    *bytes = (size_t)L.total * 4;
+    return NSFF_OK;
+}
+
+int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st) {
+    NsffLayoutH3 L;
+    const int rc = nsff_make_layout_h3(*desc, L);
+    if (rc) return rc;
+    const NsffModelDesc& d = *desc;
+    std::vector<PackSegH3> segs;
+    int pi = 0;
+    auto tiled = [&](const float* src, uint32_t dst, int ld, int kpad, int n0, int s0, int p1, int n1, int s1) {
+        segs.push_back(PackSegH3{src, dst, 1, ld, kpad, n0, s0, p1, n1, s1, 0, 0});
+    };
+    auto flat = [&](const float* src, uint32_t dst, int count) {
+        segs.push_back(PackSegH3{src, dst, 0, 0, count, 0, 0, 0, 0, 0, 0, 0});
+    };
+    auto head = [&](const float* src, uint32_t dst, int row0, int nrows) {
+        segs.push_back(PackSegH3{src, dst, 2, NSFF_W, NSFF_W, 0, 0, 0, 0, 0, row0, nrows});
+    };
+    auto trunk = [&](const NsffTrunkLayoutH3& T, int in_t) {
+        const int in = d.in_xyz + in_t;
+        for (int l = 0; l < d.D; ++l) {
+            const float* w = params[pi++]; const float* b = params[pi++];
+            if (l == 0) {
+                tiled(w, T.seg_x[0], in, (int)T.k0, d.in_xyz, 0, (int)L.k0s, in_t, d.in_xyz);
+            } else if (l == d.skip) {
+                tiled(w, T.seg_x[l], in + NSFF_W, (int)T.k0, d.in_xyz, 0, (int)L.k0s, in_t, d.in_xyz);
+                tiled(w, T.seg_h[l], in + NSFF_W, NSFF_W, NSFF_W, in, 0, 0, 0);
+            } else {
+                tiled(w, T.seg_h[l], NSFF_W, NSFF_W, NSFF_W, 0, 0, 0, 0);
+            }
+            flat(b, T.bias[l], NSFF_W);
+        }
+        const float* w = params[pi++]; const float* b = params[pi++];
+        tiled(w, T.final_w, NSFF_W, NSFF_W, NSFF_W, 0, 0, 0, 0);
+        flat(b, T.final_b, NSFF_W);
+    };
+    trunk(L.st, 0);
+    if (d.use_viewdir) {
+        const float* w = params[pi++]; const float* b = params[pi++];
+        const int ld = NSFF_W + d.in_dir + d.in_a;
+        tiled(w, L.dir_h, ld, NSFF_W, NSFF_W, 0, 0, 0, 0);
+        tiled(w, L.dir_x, ld, (int)L.side_k, d.in_dir + d.in_a, NSFF_W, 0, 0, 0);
+        flat(b, L.dir_b, NSFF_W);
+    }
+    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_sigma_w, 0, 1); flat(b, L.s_sigma_b, 1); }
+    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_rgb_w, 0, 3); flat(b, L.s_rgb_b, 3); }
+    if (d.has_transient) {
+        trunk(L.tr, d.in_t);
+        const float* ws = params[pi++]; const float* bs = params[pi++];
+        const float* wc = params[pi++]; const float* bc = params[pi++];
+        head(wc, L.t_head_w, 0, 3); flat(bc, L.t_head_b, 3);
+        head(ws, L.t_head_w, 3, 1); flat(bs, L.t_head_b + 3, 1);
+        if (d.has_flow) {
+            const float* wf = params[pi++]; const float* bf = params[pi++];
+            const float* wb = params[pi++]; const float* bb = params[pi++];
+            head(wf, L.t_head_w, 4, 3); flat(bf, L.t_head_b + 4, 3);
+            head(wb, L.t_head_w, 7, 3); flat(bb, L.t_head_b + 7, 3);
+        }
+    }
+    for (int i = 0; i < pi; ++i) if (!params[i]) return NSFF_ERR_NULL;
+    hipError_t e = hipMemsetAsync(packed, 0, (size_t)L.total * 4, st);
+    if (e != hipSuccess) return nsff_hip_fail(e);
+    for (size_t base = 0; base < segs.size(); base += PACK_BATCH) {
+        PackArgsH3 pa{};
+        pa.dst = reinterpret_cast<uint32_t*>(packed);
+        const int n = (int)std::min<size_t>(PACK_BATCH, segs.size() - base);
+        int max_threads = 0;
+        for (int i = 0; i < n; ++i) {
+            pa.seg[i] = segs[base + i];
+            const PackSegH3& s = pa.seg[i];
+            const int thr = s.kind == 0 ? s.kpad : (s.kind == 1 ? 64 * s.kpad : 8 * s.kpad);
+            max_threads = std::max(max_threads, thr);
+        }
+        hipLaunchKernelGGL(nsff_pack_kernel_h3, dim3((max_threads + 255) / 256, n), dim3(256), 0, st, pa);
+    }
+    return nsff_launch_status();
+}
+
+int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
+                        int points_per_block, hipStream_t st) {
+    const NsffModelDesc& d = *desc;
+    const NsffFieldArgs& g = *args;
+    H3KArgs k{};
+    const int rc = nsff_make_layout_h3(d, k.L);
+    if (rc) return rc;
+    if (g.xyz && 3 + 6 * g.n_freqs != d.in_xyz) return NSFF_ERR_INVALID;
+    k.packed = reinterpret_cast<const uint32_t*>(packed);
+    k.xyz = g.xyz; k.x_emb = g.x_emb; k.dir_emb = g.dir_emb; k.a_emb = g.a_emb; k.t_emb = g.t_emb;
+    k.raw = g.raw; k.n_points = g.n_points; k.pts_per_ray = g.pts_per_ray;
+    k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
+    k.D = d.D; k.skip = d.skip;
+    k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;
+    k.use_viewdir = d.use_viewdir; k.flow_scale = d.flow_scale;
+    k.n_freqs = g.n_freqs;
+    for (int i = 0; i < NSFF_MAX_FREQS; ++i) k.freqs[i] = g.freqs[i];
+    k.ld_emb = g.ld_emb; k.off_xyz = g.off_xyz; k.off_dir = g.off_dir; k.off_a = g.off_a; k.off_t = g.off_t;
+    if (points_per_block == 64) {
+        const long long tiles = (g.n_points + 63) / 64;
+        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        hipLaunchKernelGGL(nsff_field_kernel_h3<2>, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
+    } else {
+        const long long tiles = (g.n_points + 127) / 128;
+        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        hipLaunchKernelGGL(nsff_field_kernel_h3<4>, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
+    }
+    return nsff_launch_status();
+}

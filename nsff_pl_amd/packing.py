@@ -12,23 +12,24 @@ from . import _lib
 
 class PackCache:
     def __init__(self):
-        self._key = None
-        self._buf = None
+        self._key = {}
+        self._buf = {}
 
     def invalidate(self):
-        self._key = None
+        self._key = {}
 
-    def get(self, model):
+    def get(self, model, precision=0):
         params = _lib.param_list(model)
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if key != self._key:
+        if key != self._key.get(precision):
             dev = params[0].device
             _lib.require_gpu_tensor(params[0], "model parameter")
             desc = _lib.model_desc(model)
-            nbytes = _lib.packed_bytes(desc)
-            if self._buf is None or self._buf.numel() * 4 != nbytes or self._buf.device != dev:
-                self._buf = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+            nbytes = _lib.packed_bytes(desc, precision)
+            buf = self._buf.get(precision)
+            if buf is None or buf.numel() * 4 != nbytes or buf.device != dev:
+                buf = self._buf[precision] = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
-                _lib.pack_weights(desc, params, self._buf)
-            self._key = key
-        return self._buf
+                _lib.pack_weights(desc, params, buf, precision)
+            self._key[precision] = key
+        return self._buf[precision]

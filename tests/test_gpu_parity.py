@@ -22,6 +22,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["f32", "f16x3-128", "f16x3-64"])
+def precision(request):
+    """Every test runs on the exact fp32 MFMA path and on both tilings of the fp16-split path."""
+    from nsff_pl_amd import config
+    name, _, tile = request.param.partition("-")
+    config.set_precision(name)
+    config.set_tile_points(int(tile) if tile else 0)
+    yield request.param
+    config.set_precision("f32")
+    config.set_tile_points(0)
+
+
 def _to_dev(models, emb):
     for m in models.values():
         m.to(DEV)

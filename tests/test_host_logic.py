@@ -55,13 +55,13 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == 1
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_the_header_sizes():
     # natural-alignment layout of the C structs (pointer = 8 bytes)
     assert C.sizeof(_lib.ModelDesc) == 44
-    assert C.sizeof(_lib.FieldArgs) == 8 + 16 + 8 + 4 + 64 + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8
+    assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 64 + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8
     n_ptr = len(_lib._COMPOSITE_PTRS_IN) + len(_lib._COMPOSITE_PTRS_OUT)
     assert C.sizeof(_lib.CompositeArgs) == 40 + 8 * n_ptr
 
@@ -71,16 +71,19 @@ def test_layout_and_argument_validation_without_gpu():
     m = A.NeRF('fine', use_viewdir=False, encode_transient=True, in_channels_t=48, output_flow=True)
     d = _lib.model_desc(m)
     n = C.c_size_t()
-    assert lib.nsff_packed_bytes(C.byref(d), C.byref(n)) == 0
+    assert lib.nsff_packed_bytes(C.byref(d), 1, C.byref(n)) == 0       # f16x3: hi+lo halfs = same bytes/weight
+    assert 1.0 <= n.value / 4 / sum(p.numel() for p in m.parameters()) < 1.08
+    assert lib.nsff_packed_bytes(C.byref(d), 7, C.byref(n)) == -1
+    assert lib.nsff_packed_bytes(C.byref(d), 0, C.byref(n)) == 0
     # every Linear element appears once (+ zero padding of K to multiples of 8, vectors to 4)
     assert n.value // 4 >= sum(p.numel() for p in m.parameters())
     assert n.value // 4 < 1.03 * sum(p.numel() for p in m.parameters())
     assert lib.nsff_param_count(C.byref(d)) == len(_lib.param_list(m)) == 48
     bad = _lib.model_desc(m); bad.W = 128
-    assert lib.nsff_packed_bytes(C.byref(bad), C.byref(n)) == -1            # NSFF_ERR_INVALID
+    assert lib.nsff_packed_bytes(C.byref(bad), 0, C.byref(n)) == -1         # NSFF_ERR_INVALID
     bad = _lib.model_desc(m); bad.skip = 0
-    assert lib.nsff_packed_bytes(C.byref(bad), C.byref(n)) == -1
-    assert lib.nsff_packed_bytes(None, C.byref(n)) == -2                    # NSFF_ERR_NULL
+    assert lib.nsff_packed_bytes(C.byref(bad), 0, C.byref(n)) == -1
+    assert lib.nsff_packed_bytes(None, 0, C.byref(n)) == -2                    # NSFF_ERR_NULL
     a = _lib.FieldArgs()
     a.n_points, a.pts_per_ray, a.static_mode = 64, 1, 2
     assert lib.nsff_field_query(C.byref(d), None, C.byref(a), None) == -2
