@@ -35,8 +35,26 @@ namespace {
 constexpr int LDH = 264;          // halfs per LDS row (528 B; 528/16 = 33 odd)
 constexpr int NTHREADS = 256;
 
+// The network is executed as a short program of GEMM steps (built on the host), so that the
+// kernel holds exactly one copy of the GEMM loop, the epilogue, the input builders and the heads.
+struct H3Step {
+    uint32_t w_off;      // packed weight segment (words)
+    uint32_t bias_off;   // bias that (re)starts the accumulator, or NSFF_NONE to keep accumulating
+    uint16_t nks;        // k-steps of 16 columns (multiple of 4)
+    uint8_t pre;         // PRE_*: rebuild the LDS tile before this GEMM
+    uint8_t post;        // POST_*: epilogue after this GEMM
+    uint8_t head;        // HEAD_*: narrow heads evaluated on the stored activations
+    uint8_t pad[3];
+};
+enum { PRE_NONE = 0, PRE_INPUT = 1, PRE_INPUT_T = 2, PRE_SIDE = 3 };
+enum { POST_NONE = 0, POST_RELU = 1, POST_LINEAR = 2 };
+enum { HEAD_NONE = 0, HEAD_S_SIGMA = 1, HEAD_S_RGB = 2, HEAD_T = 3 };
+constexpr int MAX_STEPS = 28;
+
 struct H3KArgs {
     NsffLayoutH3 L;
+    H3Step steps[MAX_STEPS];
+    int n_steps;
     const uint32_t* packed;
     const float* xyz;
     const float* x_emb;
@@ -64,20 +82,22 @@ __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx,
     xl[idx] = (_Float16)(v - (float)hi);
 }
 
-template <int NT>
-struct Frags {
-    h8 wh[2], wl[2];       // weights (A operand), two 32-neuron tiles
-    h8 xh[NT], xl[NT];     // activations (B operand), NT 32-point tiles
-};
+struct WFrag { h8 wh[2], wl[2]; };                 // weights (A operand) of one k-step: 16 VGPRs
+template <int NT> struct XFrag { h8 xh[NT], xl[NT]; };  // activations (B operand) of one k-step
+struct WRing { WFrag r[4]; };                       // four k-steps of weights in flight (L2 latency)
+struct BiasRegs { float4 b[2][4]; };
 
-template <int NT>
-__device__ __forceinline__ void load_frags(Frags<NT>& f, const uint4* __restrict__ w, const _Float16* sBh,
-                                           const _Float16* sBl, int ks) {
-    // weights: [ks][mt][part][lane] 16-byte chunks, this lane's pointer already includes `lane`
-    const uint4* wk = w + ks * 4 * 64;
-    const uint4 a0 = wk[0], a1 = wk[64], a2 = wk[128], a3 = wk[192];
+// Weights are read through a bumped pointer so that every load is base + small immediate
+// ([ks][mt][part][lane] 16-byte chunks = 4 KiB per k-step; the lane offset is in the pointer).
+__device__ __forceinline__ void load_w(WFrag& f, const uint4* __restrict__& wp) {
+    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
+    wp += 256;
     f.wh[0] = __builtin_bit_cast(h8, a0); f.wl[0] = __builtin_bit_cast(h8, a1);
     f.wh[1] = __builtin_bit_cast(h8, a2); f.wl[1] = __builtin_bit_cast(h8, a3);
+}
+
+template <int NT>
+__device__ __forceinline__ void load_x(XFrag<NT>& f, const _Float16* sBh, const _Float16* sBl, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f.xh[nt] = *reinterpret_cast<const h8*>(sBh + nt * 32 * LDH + ks * 16);
@@ -85,47 +105,85 @@ __device__ __forceinline__ void load_frags(Frags<NT>& f, const uint4* __restrict
     }
 }
 
+// Issue the weight loads of the first four k-steps of a segment (called BEFORE the barriers /
+// epilogue that precede the segment's GEMM, so the L2 round trip hides behind them).
+// Returns the pointer of k-step 4.
+__device__ __forceinline__ const uint4* prefetch_w(WRing& ring, const uint4* __restrict__ w) {
+    const uint4* __restrict__ wp = w;
+    load_w(ring.r[0], wp);
+    load_w(ring.r[1], wp);
+    load_w(ring.r[2], wp);
+    load_w(ring.r[3], wp);
+    return wp;
+}
+
 template <int NT>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[2][NT], const Frags<NT>& f) {
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[2][NT], const WFrag& w, const XFrag<NT>& x) {
     // three passes so that consecutive MFMAs never touch the same accumulator
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(f.wl[mt], f.xh[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wl[mt], x.xh[nt], acc[mt][nt]);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(f.wh[mt], f.xl[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wh[mt], x.xl[nt], acc[mt][nt]);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(f.wh[mt], f.xh[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wh[mt], x.xh[nt], acc[mt][nt]);
 }
 
 // acc += W_seg . X[:, 0:16*nks]^T  for this wave's 64 neurons and all 32*NT points.
+// `ring` already holds k-steps 0..3 and `wp` points at k-step 4 (prefetch_w); weights run four
+// k-steps ahead of the MFMAs, activations (LDS) one.
 template <int NT>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const uint4* __restrict__ w,
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], WRing& ring, const uint4* __restrict__ wp,
                                          const _Float16* sBh, const _Float16* sBl, int nks) {
-    Frags<NT> f0, f1;
-    load_frags<NT>(f0, w, sBh, sBl, 0);
-    int ks = 0;
-    for (; ks + 2 <= nks; ks += 2) {
-        load_frags<NT>(f1, w, sBh, sBl, ks + 1);
-        mma_step<NT>(acc, f0);
-        if (ks + 2 < nks) load_frags<NT>(f0, w, sBh, sBl, ks + 2);
-        mma_step<NT>(acc, f1);
+    // nks is a multiple of 4 (every K-segment is zero-padded to 64 columns): no per-step branches.
+    XFrag<NT> x0, x1;
+    load_x<NT>(x0, sBh, sBl, 0);
+#pragma unroll 1
+    for (int ks = 4; ks < nks; ks += 4) {        // every group but the last: refill the ring
+        load_x<NT>(x1, sBh, sBl, 1);
+        mma_step<NT>(acc, ring.r[0], x0);
+        load_w(ring.r[0], wp);
+        load_x<NT>(x0, sBh, sBl, 2);
+        mma_step<NT>(acc, ring.r[1], x1);
+        load_w(ring.r[1], wp);
+        load_x<NT>(x1, sBh, sBl, 3);
+        mma_step<NT>(acc, ring.r[2], x0);
+        load_w(ring.r[2], wp);
+        load_x<NT>(x0, sBh, sBl, 4);
+        mma_step<NT>(acc, ring.r[3], x1);
+        load_w(ring.r[3], wp);
+        sBh += 64; sBl += 64;                    // four k-steps of 16 halfs
     }
-    if (ks < nks) mma_step<NT>(acc, f0);
+    load_x<NT>(x1, sBh, sBl, 1);
+    mma_step<NT>(acc, ring.r[0], x0);
+    load_x<NT>(x0, sBh, sBl, 2);
+    mma_step<NT>(acc, ring.r[1], x1);
+    load_x<NT>(x1, sBh, sBl, 3);
+    mma_step<NT>(acc, ring.r[2], x0);
+    mma_step<NT>(acc, ring.r[3], x1);
 }
 
-// accumulators start at the bias: row (neuron) = 64w + 32mt + 8q + 4h + e, e = 0..3
+// bias of row (neuron) 64w + 32mt + 8q + 4h + e, e = 0..3 -- loaded early, applied by acc_init
+__device__ __forceinline__ void load_bias(BiasRegs& br, const float* __restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            br.b[mt][q] = *reinterpret_cast<const float4*>(bias + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
+}
+
 template <int NT>
-__device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const float* __restrict__ bias, int wave, int lane) {
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const BiasRegs& br) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4*>(bias + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
+            const float4 b = br.b[mt][q];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 acc[mt][nt][4 * q + 0] = b.x; acc[mt][nt][4 * q + 1] = b.y;
@@ -243,15 +301,26 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
     const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane;
     const _Float16* bh = sXh + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
     const _Float16* bl = sXl + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
-#pragma unroll 4
-    for (int ks = 0; ks < NSFF_W / 16; ++ks) {
-        const h8 wh = __builtin_bit_cast(h8, w[(ks * 2 + 0) * 64]);
-        const h8 wl = __builtin_bit_cast(h8, w[(ks * 2 + 1) * 64]);
-        const h8 xh = *reinterpret_cast<const h8*>(bh + ks * 16);
-        const h8 xl = *reinterpret_cast<const h8*>(bl + ks * 16);
-        acc = MFMA_H(wl, xh, acc);
-        acc = MFMA_H(wh, xl, acc);
-        acc = MFMA_H(wh, xh, acc);
+    // weights are requested eight k-steps (8 KiB per wave) at a time, ahead of their MFMAs
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint4 wr[8][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wr[j][0] = w[((half * 8 + j) * 2 + 0) * 64];
+            wr[j][1] = w[((half * 8 + j) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ks = half * 8 + j;
+            const h8 wh = __builtin_bit_cast(h8, wr[j][0]);
+            const h8 wl = __builtin_bit_cast(h8, wr[j][1]);
+            const h8 xh = *reinterpret_cast<const h8*>(bh + ks * 16);
+            const h8 xl = *reinterpret_cast<const h8*>(bl + ks * 16);
+            acc = MFMA_H(wl, xh, acc);
+            acc = MFMA_H(wh, xl, acc);
+            acc = MFMA_H(wh, xh, acc);
+        }
     }
     const long long p = p0 + 32 * wave + (lane & 31);
     const float* bias = reinterpret_cast<const float*>(pk + b_off);
@@ -282,69 +351,52 @@ __global__ __launch_bounds__(NTHREADS, (NT == 2 ? 2 : 1)) void nsff_field_kernel
     const _Float16* sBl = sXl + (lane & 31) * LDH + 8 * (lane >> 5);
 
     f32x16 acc[2][NT];
+    WRing ring;
+    BiasRegs br;
     auto seg = [&](uint32_t off, int nks) {
         return reinterpret_cast<const uint4*>(pk + off) + (wave * nks) * 4 * 64 + lane;
     };
     auto fbias = [&](uint32_t off) { return reinterpret_cast<const float*>(pk + off); };
-    auto trunk = [&](const NsffTrunkLayoutH3& T, bool with_t) {
-        const int nk0 = (int)T.k0 / 16;
-        for (int l = 0; l < a.D; ++l) {
-            acc_init<NT>(acc, fbias(T.bias[l]), wave, lane);
-            if (l == 0) {
-                gemm_seg<NT>(acc, seg(T.seg_x[0], nk0), sBh, sBl, nk0);
-            } else {
-                gemm_seg<NT>(acc, seg(T.seg_h[l], NSFF_W / 16), sBh, sBl, NSFF_W / 16);
-                if (l == a.skip) {
-                    __syncthreads();
-                    build_input<NT>(sXh, sXl, a, p0, with_t);
-                    __syncthreads();
-                    gemm_seg<NT>(acc, seg(T.seg_x[l], nk0), sBh, sBl, nk0);
-                }
-            }
-            __syncthreads();
-            acc_store<NT, true>(sXh, sXl, acc, wave, lane);
-            __syncthreads();
-        }
-    };
-    auto final_layer = [&](const NsffTrunkLayoutH3& T) {
-        acc_init<NT>(acc, fbias(T.final_b), wave, lane);
-        gemm_seg<NT>(acc, seg(T.final_w, NSFF_W / 16), sBh, sBl, NSFF_W / 16);
-        __syncthreads();
-        acc_store<NT, false>(sXh, sXl, acc, wave, lane);
-        __syncthreads();
-    };
 
-    if (a.static_mode != 0) {
-        build_input<NT>(sXh, sXl, a, p0, false);
-        __syncthreads();
-        trunk(a.L.st, false);
-        heads<NT>(sXh, sXl, pk, a.L.s_sigma_w, a.L.s_sigma_b, 1, ACT_NONE, 0.f, a.raw, p0, a.n_points, 3, wave, lane);
-        if (a.static_mode == 2) {
-            final_layer(a.L.st);
-            if (a.use_viewdir) {
-                acc_init<NT>(acc, fbias(a.L.dir_b), wave, lane);
-                gemm_seg<NT>(acc, seg(a.L.dir_h, NSFF_W / 16), sBh, sBl, NSFF_W / 16);
-                __syncthreads();
-                build_side<NT>(sXh, sXl, a, p0);
-                __syncthreads();
-                const int nks = (int)a.L.side_k / 16;
-                gemm_seg<NT>(acc, seg(a.L.dir_x, nks), sBh, sBl, nks);
-                __syncthreads();
-                acc_store<NT, true>(sXh, sXl, acc, wave, lane);
-                __syncthreads();
-            }
-            heads<NT>(sXh, sXl, pk, a.L.s_rgb_w, a.L.s_rgb_b, 3, 0x15u, 0.f, a.raw, p0, a.n_points, 0, wave, lane);
+    // weights of step 0 start their L2 round trip before the tile's input is even encoded
+    const uint4* wnext = prefetch_w(ring, seg(a.steps[0].w_off, a.steps[0].nks));
+    load_bias(br, fbias(a.steps[0].bias_off), wave, lane);
+#pragma unroll 1
+    for (int i = 0; i < a.n_steps; ++i) {
+        const H3Step st = a.steps[i];
+        if (st.pre != PRE_NONE) {
+            __syncthreads();                       // everyone is done reading the previous tile
+            if (st.pre == PRE_SIDE) build_side<NT>(sXh, sXl, a, p0);
+            else build_input<NT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (a.transient_mode != 0) {
-        build_input<NT>(sXh, sXl, a, p0, true);
-        __syncthreads();
-        trunk(a.L.tr, true);
-        final_layer(a.L.tr);
-        const unsigned kinds = 0x15u | (0xAAAu << 8);
-        heads<NT>(sXh, sXl, pk, a.L.t_head_w, a.L.t_head_b, (int)a.L.t_head_rows, kinds, a.flow_scale,
-                  a.raw, p0, a.n_points, 4, wave, lane);
+        if (st.bias_off != NSFF_NONE) acc_init<NT>(acc, br);
+        gemm_seg<NT>(acc, ring, wnext, sBh, sBl, st.nks);
+        if (i + 1 < a.n_steps) {                   // next segment's weights + bias fly during the epilogue
+            const H3Step nx = a.steps[i + 1];
+            wnext = prefetch_w(ring, seg(nx.w_off, nx.nks));
+            if (nx.bias_off != NSFF_NONE) load_bias(br, fbias(nx.bias_off), wave, lane);
+        }
+        if (st.post != POST_NONE) {
+            __syncthreads();
+            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, lane);
+            else acc_store<NT, false>(sXh, sXl, acc, wave, lane);
+            __syncthreads();
+            if (st.head != HEAD_NONE) {
+                // static sigma reads the last trunk activation, before *_final (nerf.py:169);
+                // dynamic rows: rgb(3) sigmoid, sigma raw, fw(3)/bw(3) = flow_scale*tanh (nerf.py:197-208)
+                uint32_t w_off = a.L.s_sigma_w, b_off = a.L.s_sigma_b;
+                int n_rows = 1, slot0 = 3;
+                unsigned kinds = ACT_NONE;
+                if (st.head == HEAD_S_RGB) { w_off = a.L.s_rgb_w; b_off = a.L.s_rgb_b; n_rows = 3; slot0 = 0; kinds = 0x15u; }
+                if (st.head == HEAD_T) {
+                    w_off = a.L.t_head_w; b_off = a.L.t_head_b; n_rows = (int)a.L.t_head_rows; slot0 = 4;
+                    kinds = 0x15u | (0xAAAu << 8);
+                }
+                heads<NT>(sXh, sXl, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points, slot0,
+                          wave, lane);
+            }
+        }
     }
 }
 
@@ -504,6 +556,44 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.n_freqs = g.n_freqs;
     for (int i = 0; i < NSFF_MAX_FREQS; ++i) k.freqs[i] = g.freqs[i];
     k.ld_emb = g.ld_emb; k.off_xyz = g.off_xyz; k.off_dir = g.off_dir; k.off_a = g.off_a; k.off_t = g.off_t;
+
+    // ---- step program (reference nerf.py:162-208) ----
+    int n = 0;
+    auto push = [&](uint32_t w, uint32_t b, uint32_t kcols, int pre, int post, int head) {
+        H3Step& s = k.steps[n++];
+        s.w_off = w; s.bias_off = b; s.nks = (uint16_t)(kcols / 16);
+        s.pre = (uint8_t)pre; s.post = (uint8_t)post; s.head = (uint8_t)head;
+    };
+    auto trunk = [&](const NsffTrunkLayoutH3& T, int pre_kind, int last_head) {
+        for (int l = 0; l < d.D; ++l) {
+            const int head = (l == d.D - 1) ? last_head : HEAD_NONE;
+            if (l == 0) {
+                push(T.seg_x[0], T.bias[0], T.k0, pre_kind, POST_RELU, HEAD_NONE);
+            } else if (l == d.skip) {
+                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
+                push(T.seg_x[l], NSFF_NONE, T.k0, pre_kind, POST_RELU, head);
+            } else {
+                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_RELU, head);
+            }
+        }
+    };
+    if (g.static_mode) {
+        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA);
+        if (g.static_mode == 2) {
+            push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB);
+            if (d.use_viewdir) {
+                push(k.L.dir_h, k.L.dir_b, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
+                push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB);
+            }
+        }
+    }
+    if (g.transient_mode) {
+        trunk(k.L.tr, PRE_INPUT_T, HEAD_NONE);
+        push(k.L.tr.final_w, k.L.tr.final_b, NSFF_W, PRE_NONE, POST_LINEAR, HEAD_T);
+    }
+    if (n > MAX_STEPS) return NSFF_ERR_INVALID;
+    k.n_steps = n;
+
     if (points_per_block == 64) {
         const long long tiles = (g.n_points + 63) / 64;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;

@@ -2,7 +2,7 @@
 //
 // Every fp32 weight w is stored as two halfs  hi = f16(w), lo = f16(w - hi)  (22 significant
 // bits; gfx950's f16 MFMA takes subnormal inputs exactly, so no pre-scaling is needed).
-// A Linear segment W (256, K), K padded to a multiple of 16, is stored as A-operand tiles of
+// A Linear segment W (256, K), K padded to a multiple of 64, is stored as A-operand tiles of
 // v_mfma_f32_32x32x16_f16 in the order one wave streams them:
 //
 //     seg[wave 0..3][ks 0..K/16-1][mt 0..1][part hi,lo][lane 0..63][8 halfs]      (16 B per lane)
@@ -29,7 +29,7 @@ struct NsffTrunkLayoutH3 {
 
 struct NsffLayoutH3 {
     NsffTrunkLayoutH3 st, tr;
-    uint32_t k0s, kt, side_k;          // ceil16 of in_xyz, in_t, in_dir+in_a
+    uint32_t k0s, kt, side_k;          // ceil64 of in_xyz, in_t, in_dir+in_a
     uint32_t dir_h, dir_x, dir_b;
     uint32_t s_sigma_w, s_sigma_b;     // head tile + 32 fp32 biases
     uint32_t s_rgb_w, s_rgb_b;
@@ -38,21 +38,22 @@ struct NsffLayoutH3 {
     uint32_t total;                    // words
 };
 
-static inline uint32_t nsff_ceil16(uint32_t v) { return (v + 15u) & ~15u; }
+// every K-segment is zero-padded to a multiple of 64 columns (= 4 k-steps of the weight ring)
+static inline uint32_t nsff_ceil64(uint32_t v) { return (v + 63u) & ~63u; }
 
 static inline int nsff_make_layout_h3(const NsffModelDesc& d, NsffLayoutH3& L) {
     if (d.W != NSFF_W || d.D < 2 || d.D > NSFF_MAX_LAYERS) return NSFF_ERR_INVALID;
     if (d.skip < 1 || d.skip >= d.D) return NSFF_ERR_INVALID;
-    if (d.in_xyz < 1 || d.in_xyz > 240) return NSFF_ERR_INVALID;
+    if (d.in_xyz < 1 || d.in_xyz > 192) return NSFF_ERR_INVALID;
     if (d.in_t < 0 || d.in_a < 0 || d.in_dir < 0) return NSFF_ERR_INVALID;
     if (d.has_transient && d.in_t < 1) return NSFF_ERR_INVALID;
     if (d.has_flow && !d.has_transient) return NSFF_ERR_INVALID;
     uint32_t off = 0;
     auto take = [&](uint32_t n) { uint32_t o = off; off += (n + 3u) & ~3u; return o; };
-    L.k0s = nsff_ceil16((uint32_t)d.in_xyz);
-    L.kt = d.has_transient ? nsff_ceil16((uint32_t)d.in_t) : 0;
+    L.k0s = nsff_ceil64((uint32_t)d.in_xyz);
+    L.kt = d.has_transient ? nsff_ceil64((uint32_t)d.in_t) : 0;
     if (L.k0s + L.kt > NSFF_W) return NSFF_ERR_INVALID;
-    L.side_k = d.use_viewdir ? nsff_ceil16((uint32_t)(d.in_dir + d.in_a)) : 0;
+    L.side_k = d.use_viewdir ? nsff_ceil64((uint32_t)(d.in_dir + d.in_a)) : 0;
     if (L.side_k > NSFF_W) return NSFF_ERR_INVALID;
     auto trunk = [&](NsffTrunkLayoutH3& T, uint32_t k0) {
         T.k0 = k0;
