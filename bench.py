@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_RAYS, N_SAMPLES, N_IMPORTANCE = 1024, 64, 64
-PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
+# MI355X_MICROARCH.md dense peaks: fp32 MFMA (v_mfma_f32_32x32x2_f32) and f16 MFMA (32x32x16)
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
 FLOP_PER_RAY_C2_TRAIN = 1031.80e6
 
 
@@ -77,12 +78,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3"],
+                    help="arithmetic of the dense layers; both modes pass the same 1e-4 parity tests")
+    ap.add_argument("--tile-points", type=int, default=int(os.environ.get("NSFF_TILE_POINTS", "64")))
     args = ap.parse_args()
 
     import scenes
     import nsff_pl_amd as A
-    from nsff_pl_amd import _lib, dist as ndist
+    from nsff_pl_amd import _lib, config, dist as ndist
     import torch.distributed as dist
+    config.set_precision(args.precision)
+    config.set_tile_points(args.tile_points if args.precision == "f16x3" else 0)
 
     rank, world, device = ndist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -137,7 +143,8 @@ def main():
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "f16x3 (fp32 operands split into 2 halfs, 3 f16 MFMAs per product, fp32 accumulate; same 1e-4 parity as f32)",
+            "data": "synthetic",
             "config": {"workload": "C2 (BASELINE.json configs[1]): static+dynamic NSFF, 1024 rays/GPU x (64 coarse + "
                                    "64 importance -> 192 fine pts), train-mode fwd, fw/bw flow warp t+-1, "
                                    "perturb=1 noise_std=1, 8x256 MLPs, N_tau=48, all 47 outputs on device",
@@ -146,8 +153,11 @@ def main():
                        "rays_per_s": world * N_RAYS * args.steps / elapsed,
                        "mlp_tflops_whole_step": world * N_RAYS * args.steps * FLOP_PER_RAY_C2_TRAIN / elapsed / 1e12},
             "roofline": {"bound": "mfma", "kernel": "nsff_field_kernel",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
+                         "mfma_issue_frac": achieved * (3 if args.precision == "f16x3" else 1) / PEAK_TFLOPS[args.precision],
+                         "note": "achieved = algorithmic FLOPs (2*MACs of the fp32 Linear layers); the f16x3 mode "
+                                 "issues 3 f16 MFMAs per algorithmic product, so frac <= 1/3 there",
                          "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
                          "flop_per_launch": kernel_flops / max(launches, 1)},
         }

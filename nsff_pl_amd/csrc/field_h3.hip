@@ -90,6 +90,10 @@ struct BiasRegs { float4 b[2][4]; };
 // Weights are read through a bumped pointer so that every load is base + small immediate
 // ([ks][mt][part][lane] 16-byte chunks = 4 KiB per k-step; the lane offset is in the pointer).
 __device__ __forceinline__ void load_w(WFrag& f, const uint4* __restrict__& wp) {
+#ifdef H3_EXP_NOW
+    asm volatile("" : "+v"(f.wh[0]), "+v"(f.wl[0]), "+v"(f.wh[1]), "+v"(f.wl[1]));
+    return;
+#endif
     const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
     wp += 256;
     f.wh[0] = __builtin_bit_cast(h8, a0); f.wl[0] = __builtin_bit_cast(h8, a1);
@@ -98,6 +102,13 @@ __device__ __forceinline__ void load_w(WFrag& f, const uint4* __restrict__& wp) 
 
 template <int NT>
 __device__ __forceinline__ void load_x(XFrag<NT>& f, const _Float16* sBh, const _Float16* sBl, int ks) {
+#ifdef H3_EXP_NOX
+    if (ks != 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(f.xh[nt]), "+v"(f.xl[nt]));
+        return;
+    }
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f.xh[nt] = *reinterpret_cast<const h8*>(sBh + nt * 32 * LDH + ks * 16);
@@ -366,8 +377,10 @@ __global__ __launch_bounds__(NTHREADS, (NT == 2 ? 2 : 1)) void nsff_field_kernel
         const H3Step st = a.steps[i];
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
+#ifndef H3_EXP_NOBUILD
             if (st.pre == PRE_SIDE) build_side<NT>(sXh, sXl, a, p0);
             else build_input<NT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
+#endif
             __syncthreads();
         }
         if (st.bias_off != NSFF_NONE) acc_init<NT>(acc, br);
@@ -379,10 +392,18 @@ __global__ __launch_bounds__(NTHREADS, (NT == 2 ? 2 : 1)) void nsff_field_kernel
         }
         if (st.post != POST_NONE) {
             __syncthreads();
+#ifndef H3_EXP_NOSTORE
             if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, lane);
             else acc_store<NT, false>(sXh, sXl, acc, wave, lane);
+#else
+            asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+#endif
             __syncthreads();
+#ifdef H3_EXP_NOHEADS
+            if (false) {
+#else
             if (st.head != HEAD_NONE) {
+#endif
                 // static sigma reads the last trunk activation, before *_final (nerf.py:169);
                 // dynamic rows: rgb(3) sigmoid, sigma raw, fw(3)/bw(3) = flow_scale*tanh (nerf.py:197-208)
                 uint32_t w_off = a.L.s_sigma_w, b_off = a.L.s_sigma_b;
