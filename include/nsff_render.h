@@ -59,9 +59,12 @@ typedef struct NsffModelDesc {
 /* Arithmetic of the field kernel's dense layers (results agree to fp32 rounding level):
  *   NSFF_PREC_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   NSFF_PREC_F16X3 fp32 operands split into two halfs, three f16 MFMAs per product,
- *                   fp32 accumulate (v_mfma_f32_32x32x16_f16)                              */
-#define NSFF_PREC_F32     0
-#define NSFF_PREC_F16X3   1
+ *                   fp32 accumulate (v_mfma_f32_32x32x16_f16), activations staged in LDS
+ *   NSFF_PREC_F16X3_RA same arithmetic, register-resident activations + LDS weight ring (D = 8 only)
+ */
+#define NSFF_PREC_F32        0
+#define NSFF_PREC_F16X3      1
+#define NSFF_PREC_F16X3_RA   2
 
 /* Size in bytes of the packed-weight buffer for `desc` at `precision`. */
 int nsff_packed_bytes(const NsffModelDesc* desc, int precision, size_t* bytes);

@@ -198,7 +198,7 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
                 x_emb=None, emb_offsets=(0, -1, -1, -1)):
     from . import config
     desc = model_desc(model)
-    prec = config.PRECISIONS[config.get_precision()]
+    prec = config.precision_code(model)
     packed = model.packed(prec)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()

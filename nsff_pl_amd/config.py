@@ -9,7 +9,16 @@ Select with ``set_precision`` or the environment variable ``NSFF_PRECISION``.
 """
 import os
 
-PRECISIONS = {"f32": 0, "f16x3": 1}
+# "f16x3" resolves per model: the register-resident kernel (2) for the reference depth D = 8,
+# the LDS-activation kernel (1) otherwise; "f16x3_lds" forces the latter (A/B comparisons).
+PRECISIONS = {"f32": 0, "f16x3_lds": 1, "f16x3": 2}
+
+
+def precision_code(model):
+    code = PRECISIONS[_precision]
+    if code == 2 and (model.D != 8 or model.in_channels_xyz > 63 or model.in_channels_t > 64):
+        code = 1
+    return code
 _precision = os.environ.get("NSFF_PRECISION", "f32")
 _tile_points = int(os.environ.get("NSFF_TILE_POINTS", "0"))
 if _precision not in PRECISIONS:
