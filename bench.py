@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_RAYS, N_SAMPLES, N_IMPORTANCE = 1024, 64, 64
 # MI355X_MICROARCH.md dense peaks: fp32 MFMA (v_mfma_f32_32x32x2_f32) and f16 MFMA (32x32x16)
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x3_lds": 2500.0}
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x3_ra": 2500.0}
 FLOP_PER_RAY_C2_TRAIN = 1031.80e6
 
 
@@ -78,9 +78,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x3_lds"],
+    ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x3_ra"],
                     help="arithmetic of the dense layers; both modes pass the same 1e-4 parity tests")
-    ap.add_argument("--tile-points", type=int, default=int(os.environ.get("NSFF_TILE_POINTS", "64")))
+    ap.add_argument("--tile-points", type=int, default=int(os.environ.get("NSFF_TILE_POINTS", "0")))
     args = ap.parse_args()
 
     import scenes
@@ -88,7 +88,7 @@ def main():
     from nsff_pl_amd import _lib, config, dist as ndist
     import torch.distributed as dist
     config.set_precision(args.precision)
-    config.set_tile_points(args.tile_points if args.precision == "f16x3_lds" else 0)
+    config.set_tile_points(args.tile_points if args.precision == "f16x3" else 0)
 
     rank, world, device = ndist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -152,7 +152,7 @@ def main():
                        "parallelism": f"ray-shard x{world}, pixel all-gather" if world > 1 else "single GPU",
                        "rays_per_s": world * N_RAYS * args.steps / elapsed,
                        "mlp_tflops_whole_step": world * N_RAYS * args.steps * FLOP_PER_RAY_C2_TRAIN / elapsed / 1e12},
-            "roofline": {"bound": "mfma", "kernel": "nsff_field_kernel",
+            "roofline": {"bound": "mfma", "kernel": {"f32": "nsff_field_kernel", "f16x3": "nsff_field_kernel_h3<2,1>", "f16x3_ra": "nsff_field_kernel_ra"}[args.precision],
                          "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
                          "mfma_issue_frac": achieved * (1 if args.precision == "f32" else 3) / PEAK_TFLOPS[args.precision],

@@ -4,14 +4,15 @@ precision
     "f32"   -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
     "f16x3" -- every fp32 operand split into two halfs, three f16 MFMAs per product, fp32
                accumulation; agrees with "f32" to fp32-rounding level and passes the same
-               1e-4 parity tests, ~3x faster.
+               1e-4 parity tests, ~2.7x faster.
+    "f16x3_ra" -- same arithmetic, register-resident activations + LDS weight ring (experimental).
 Select with ``set_precision`` or the environment variable ``NSFF_PRECISION``.
 """
 import os
 
-# "f16x3" resolves per model: the register-resident kernel (2) for the reference depth D = 8,
-# the LDS-activation kernel (1) otherwise; "f16x3_lds" forces the latter (A/B comparisons).
-PRECISIONS = {"f32": 0, "f16x3_lds": 1, "f16x3": 2}
+# "f16x3" = LDS-activation kernel (fastest so far); "f16x3_ra" = register-resident-activation
+# kernel (experimental, reference depth D = 8 only; falls back to "f16x3" for other models).
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16x3_ra": 2}
 
 
 def precision_code(model):
@@ -39,7 +40,7 @@ def get_precision():
 def set_tile_points(n):
     """f16x3 only: points per workgroup (0 = library default, 64 or 128)."""
     global _tile_points
-    if n not in (0, 64, 128):
+    if n not in (0, 64, 128, 129):
         raise ValueError("tile_points must be 0, 64 or 128")
     _tile_points = n
 

@@ -55,6 +55,7 @@ struct H3KArgs {
     NsffLayoutH3 L;
     H3Step steps[MAX_STEPS];
     int n_steps;
+    int n_static_steps;   // steps [0, n_static_steps) = static trunk; the rest = dynamic trunk
     const uint32_t* packed;
     const float* xyz;
     const float* x_emb;
@@ -75,6 +76,11 @@ struct H3KArgs {
 };
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#ifndef H3_NO_PIN
+#define H3_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define H3_PIN()
+#endif
 
 __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx, float v) {
     const _Float16 hi = (_Float16)v;
@@ -156,18 +162,24 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], WRing& ring, cons
     load_x<NT>(x0, sBh, sBl, 0);
 #pragma unroll 1
     for (int ks = 4; ks < nks; ks += 4) {        // every group but the last: refill the ring
+        // sched_barrier pins each refill right behind the MFMAs that free its ring slot: left alone,
+        // hipcc sinks all 16 loads to the end of the group and the ring never runs ahead
         load_x<NT>(x1, sBh, sBl, 1);
         mma_step<NT>(acc, ring.r[0], x0);
         load_w(ring.r[0], wp);
+        H3_PIN();
         load_x<NT>(x0, sBh, sBl, 2);
         mma_step<NT>(acc, ring.r[1], x1);
         load_w(ring.r[1], wp);
+        H3_PIN();
         load_x<NT>(x1, sBh, sBl, 3);
         mma_step<NT>(acc, ring.r[2], x0);
         load_w(ring.r[2], wp);
+        H3_PIN();
         load_x<NT>(x0, sBh, sBl, 4);
         mma_step<NT>(acc, ring.r[3], x1);
         load_w(ring.r[3], wp);
+        H3_PIN();
         sBh += 64; sBl += 64;                    // four k-steps of 16 halfs
     }
     load_x<NT>(x1, sBh, sBl, 1);
@@ -204,7 +216,7 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const BiasRegs& b
 }
 
 template <int NT, bool RELU>
-__device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[2][NT], int wave, int lane) {
+__device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[2][NT], int wave, int nt0, int lane) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -221,7 +233,7 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
                 const h2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                 const h2 l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
                 const h2 l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
-                const int idx = (32 * nt + (lane & 31)) * LDH + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5);
+                const int idx = (32 * (nt0 + nt) + (lane & 31)) * LDH + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5);
                 h4 hv, lv;
                 hv[0] = (_Float16)h01[0]; hv[1] = (_Float16)h01[1]; hv[2] = (_Float16)h23[0]; hv[3] = (_Float16)h23[1];
                 lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
@@ -230,10 +242,9 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
             }
 }
 
-template <int NT>
+template <int M, int THREADS>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t) {
-    constexpr int M = 32 * NT;
-    constexpr int G = NTHREADS / M;              // threads per point row
+    constexpr int G = THREADS / M;               // threads per point row
     const int r = threadIdx.x % M, q = threadIdx.x / M;
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
@@ -268,10 +279,9 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
     }
 }
 
-template <int NT>
+template <int M, int THREADS>
 __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0) {
-    constexpr int M = 32 * NT;
-    constexpr int G = NTHREADS / M;
+    constexpr int G = THREADS / M;
     const int r = threadIdx.x % M, q = threadIdx.x / M;
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
@@ -299,7 +309,7 @@ __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H
 
 enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
 
-// Narrow heads as one zero-padded 32-row MFMA tile; wave w evaluates the 32 points of tile w.
+// Narrow heads as one zero-padded 32-row MFMA tile; wave w evaluates the 32 points of tile w (w < NT).
 // out row = (r&3) + 8*(r>>2) + 4*(lane>>5); only r < 8 (rows < 16) can be live.
 template <int NT>
 __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, const uint32_t* __restrict__ pk,
@@ -348,18 +358,25 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(NTHREADS, (NT == 2 ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
-    constexpr int M = 32 * NT;
+// NT = point tiles (of 32) per wave, WM = wave rows: the workgroup has 4*WM waves and 32*NT*WM points.
+//   <2,1>: 64 points, 2 workgroups per CU;  <4,1>: 128 points, 1 workgroup per CU, 1 wave per SIMD;
+//   <2,2>: 128 points, 8 waves (2 per SIMD): the two wave rows request identical weight lines back to
+//          back, so the L1 merges them and the L2 weight stream per FLOP is halved.
+template <int NT, int WM>
+__global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
+    constexpr int M = 32 * NT * WM;
+    constexpr int THREADS = 256 * WM;
     __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
     _Float16* sXh = sX;
     _Float16* sXl = sX + M * LDH;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_id & 3;                 // neuron block [64*wave, 64*wave+64)
+    const int nt0 = (wave_id >> 2) * NT;          // first point tile of this wave
     const long long p0 = (long long)blockIdx.x * M;
     const uint32_t* __restrict__ pk = a.packed;
-    const _Float16* sBh = sXh + (lane & 31) * LDH + 8 * (lane >> 5);
-    const _Float16* sBl = sXl + (lane & 31) * LDH + 8 * (lane >> 5);
+    const _Float16* sBh = sXh + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
+    const _Float16* sBl = sXl + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
 
     f32x16 acc[2][NT];
     WRing ring;
@@ -370,31 +387,42 @@ __global__ __launch_bounds__(NTHREADS, (NT == 2 ? 2 : 1)) void nsff_field_kernel
     auto fbias = [&](uint32_t off) { return reinterpret_cast<const float*>(pk + off); };
 
     // weights of step 0 start their L2 round trip before the tile's input is even encoded
-    const uint4* wnext = prefetch_w(ring, seg(a.steps[0].w_off, a.steps[0].nks));
-    load_bias(br, fbias(a.steps[0].bias_off), wave, lane);
+    // Every workgroup streams the same weights; if all of them walk the program in the same order
+    // they hit the same few L2 channels at the same instant.  Half of the workgroups therefore run
+    // the dynamic trunk first (the two trunks are independent: separate outputs, the tile is rebuilt).
+#ifndef H3_NO_ROTATE
+    const int rot = (a.n_static_steps > 0 && a.n_static_steps < a.n_steps && ((blockIdx.x >> 3) & 1))
+                        ? a.n_static_steps : 0;
+#else
+    const int rot = 0;
+#endif
+    auto step_at = [&](int i) { int j = i + rot; if (j >= a.n_steps) j -= a.n_steps; return a.steps[j]; };
+    const H3Step s0 = step_at(0);
+    const uint4* wnext = prefetch_w(ring, seg(s0.w_off, s0.nks));
+    load_bias(br, fbias(s0.bias_off), wave, lane);
 #pragma unroll 1
     for (int i = 0; i < a.n_steps; ++i) {
-        const H3Step st = a.steps[i];
+        const H3Step st = step_at(i);
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
 #ifndef H3_EXP_NOBUILD
-            if (st.pre == PRE_SIDE) build_side<NT>(sXh, sXl, a, p0);
-            else build_input<NT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
+            if (st.pre == PRE_SIDE) build_side<M, THREADS>(sXh, sXl, a, p0);
+            else build_input<M, THREADS>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
 #endif
             __syncthreads();
         }
         if (st.bias_off != NSFF_NONE) acc_init<NT>(acc, br);
         gemm_seg<NT>(acc, ring, wnext, sBh, sBl, st.nks);
         if (i + 1 < a.n_steps) {                   // next segment's weights + bias fly during the epilogue
-            const H3Step nx = a.steps[i + 1];
+            const H3Step nx = step_at(i + 1);
             wnext = prefetch_w(ring, seg(nx.w_off, nx.nks));
             if (nx.bias_off != NSFF_NONE) load_bias(br, fbias(nx.bias_off), wave, lane);
         }
         if (st.post != POST_NONE) {
             __syncthreads();
 #ifndef H3_EXP_NOSTORE
-            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, lane);
-            else acc_store<NT, false>(sXh, sXl, acc, wave, lane);
+            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, nt0, lane);
+            else acc_store<NT, false>(sXh, sXl, acc, wave, nt0, lane);
 #else
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
 #endif
@@ -414,8 +442,8 @@ __global__ __launch_bounds__(NTHREADS, (NT == 2 ? 2 : 1)) void nsff_field_kernel
                     w_off = a.L.t_head_w; b_off = a.L.t_head_b; n_rows = (int)a.L.t_head_rows; slot0 = 4;
                     kinds = 0x15u | (0xAAAu << 8);
                 }
-                heads<NT>(sXh, sXl, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points, slot0,
-                          wave, lane);
+                heads<NT * WM>(sXh, sXl, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points, slot0,
+                              wave_id, lane);
             }
         }
     }
@@ -608,6 +636,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             }
         }
     }
+    k.n_static_steps = n;
     if (g.transient_mode) {
         trunk(k.L.tr, PRE_INPUT_T, HEAD_NONE);
         push(k.L.tr.final_w, k.L.tr.final_b, NSFF_W, PRE_NONE, POST_LINEAR, HEAD_T);
@@ -618,11 +647,15 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     if (points_per_block == 64) {
         const long long tiles = (g.n_points + 63) / 64;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL(nsff_field_kernel_h3<2>, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
+        hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1>), dim3((unsigned)tiles), dim3(256), 0, st, k);
+    } else if (points_per_block == 129) {         // experiment: 128 points, one wave per SIMD
+        const long long tiles = (g.n_points + 127) / 128;
+        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1>), dim3((unsigned)tiles), dim3(256), 0, st, k);
     } else {
         const long long tiles = (g.n_points + 127) / 128;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL(nsff_field_kernel_h3<4>, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
+        hipLaunchKernelGGL((nsff_field_kernel_h3<2, 2>), dim3((unsigned)tiles), dim3(512), 0, st, k);
     }
     return nsff_launch_status();
 }

@@ -22,10 +22,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3_lds-128", "f16x3_lds-64"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-128", "f16x3_ra"])
 def precision(request):
-    """Every test runs on the exact fp32 MFMA path, the register-resident fp16-split kernel and both
-    tilings of the LDS-activation fp16-split kernel."""
+    """Every test runs on the exact fp32 MFMA path, both tilings of the fp16-split kernel and the
+    experimental register-resident fp16-split kernel."""
     from nsff_pl_amd import config
     name, _, tile = request.param.partition("-")
     config.set_precision(name)
