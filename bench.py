@@ -138,6 +138,10 @@ def main():
     if rank == 0:
         value = world * N_RAYS * (N_SAMPLES + N_IMPORTANCE) * args.steps / elapsed
         achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        try:    # measured separately with rocprofv3 --pmc (profiles/collect_pmc.sh); not measurable from here
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "field_traffic.json"))).get(args.precision)
+        except Exception:
+            traffic = None
         line = {
             "metric": "ray-samples/sec (coarse+fine, static+dynamic)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
@@ -154,7 +158,8 @@ def main():
                        "mlp_tflops_whole_step": world * N_RAYS * args.steps * FLOP_PER_RAY_C2_TRAIN / elapsed / 1e12},
             "roofline": {"bound": "mfma", "kernel": {"f32": "nsff_field_kernel", "f16x3": "nsff_field_kernel_h3<2,1>", "f16x3_ra": "nsff_field_kernel_ra"}[args.precision],
                          "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
+                         "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/field_traffic.json)",
                          "mfma_issue_frac": achieved * (1 if args.precision == "f32" else 3) / PEAK_TFLOPS[args.precision],
                          "note": "achieved = algorithmic FLOPs (2*MACs of the fp32 Linear layers); the f16x3 mode "
                                  "issues 3 f16 MFMAs per algorithmic product, so frac <= 1/3 there",

@@ -144,6 +144,13 @@ int nsff_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int
 int nsff_warp_points(const float* raw, const float* xyz, const float* zs, int64_t n_points,
                      float z_far, float* xyz_fw, float* xyz_bw, void* stream);
 
+/* ---- N3 (step before the path): NDC camera rays of a pinhole frame, generated on the device
+ * (reference datasets/ray_utils.py:7-106 via datasets/monocular.py:268-276).
+ * K4_host = {fx, fy, cx, cy}, c2w_host = row-major (3,4), both HOST pointers; pixel p = row*W + col;
+ * rays: (n_pixels, 6) = NDC origin | NDC direction for pixels [first_pixel, first_pixel+n_pixels). */
+int nsff_frame_rays(const float* K4_host, const float* c2w_host, int32_t H, int32_t W, float near, float shift_near,
+                    int64_t first_pixel, int64_t n_pixels, float* rays, void* stream);
+
 /* ---- a7/a8: sigma->alpha compositing and every per-ray / per-sample output ---- */
 typedef struct NsffCompositeArgs {
     int64_t n_rays;

@@ -82,6 +82,8 @@ _SIGNATURES = {
                                   C.c_float, _fp, _fp]),
     "nsff_warp_points": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_float, _fp, _fp, _fp]),
     "nsff_composite": (C.c_int, [C.POINTER(CompositeArgs), _fp]),
+    "nsff_frame_rays": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float,
+                                  C.c_float, C.c_int64, C.c_int64, _fp, _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
     "nsff_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -254,6 +256,13 @@ def composite(**kw):
         else:
             setattr(a, k, v)
     _check(load().nsff_composite(C.byref(a), _stream()), "nsff_composite")
+
+
+def frame_rays(K4, c2w12, H, W, near, shift_near, first, count, rays):
+    k = (C.c_float * 4)(*[float(v) for v in K4])
+    m = (C.c_float * 12)(*[float(v) for v in c2w12])
+    _check(load().nsff_frame_rays(k, m, int(H), int(W), float(near), float(shift_near), int(first), int(count),
+                                  _ptr(rays), _stream()), "nsff_frame_rays")
 
 
 def prof_enable(on):

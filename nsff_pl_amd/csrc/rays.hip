@@ -177,6 +177,47 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sample_pdf_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------
+// Camera rays of a pinhole frame, straight to NDC (reference datasets/ray_utils.py:7-36
+// get_ray_directions, :39-59 get_rays, :62-106 get_ndc_rays; called from monocular.py:268-276).
+struct FrameRayArgs {
+    float fx, fy, cx, cy;
+    float c2w[12];           // row-major (3,4)
+    int W;
+    float near, shift_near;
+    long long first, count;
+    float* rays;             // (count, 6)
+};
+
+__global__ void frame_rays_kernel(const FrameRayArgs a) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.count) return;
+    const long long pix = a.first + idx;
+    const float i = (float)(pix % a.W), j = (float)(pix / a.W);      // no +0.5 pixel centring (ray_utils.py:26)
+    const float dc[3] = {(i - a.cx) / a.fx, -(j - a.cy) / a.fy, -1.0f};
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = dc[0] * a.c2w[4 * r + 0] + dc[1] * a.c2w[4 * r + 1] + dc[2] * a.c2w[4 * r + 2];
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] /= nrm;
+    float o[3] = {a.c2w[3], a.c2w[7], a.c2w[11]};
+    // shift the origin to the near plane, then project
+    const float t = -(a.shift_near + o[2]) / d[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o[r] = o[r] + t * d[r];
+    const float ox_oz = o[0] / o[2], oy_oz = o[1] / o[2];
+    const float sx = -1.0f / (a.cx / a.fx), sy = -1.0f / (a.cy / a.fy);
+    const float o2 = 1.0f + 2.0f * a.near / o[2];
+    float* r = a.rays + idx * 6;
+    r[0] = sx * ox_oz;
+    r[1] = sy * oy_oz;
+    r[2] = o2;
+    r[3] = sx * (d[0] / d[2] - ox_oz);
+    r[4] = sy * (d[1] / d[2] - oy_oz);
+    r[5] = 1.0f - o2;
+}
+
+// ---------------------------------------------------------------------------------
 __global__ void warp_points_kernel(const float* __restrict__ raw, const float* __restrict__ xyz,
                                    const float* __restrict__ zs, long long n_points, float z_far,
                                    float* __restrict__ xyz_fw, float* __restrict__ xyz_bw) {
@@ -465,6 +506,20 @@ int nsff_warp_points(const float* raw, const float* xyz, const float* zs, int64_
     const long long total = (long long)n_points * 3;
     hipLaunchKernelGGL(warp_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, raw, xyz, zs, (long long)n_points, z_far, xyz_fw, xyz_bw);
+    return nsff_launch_status();
+}
+
+int nsff_frame_rays(const float* K4_host, const float* c2w_host, int32_t H, int32_t W, float near, float shift_near,
+                    int64_t first_pixel, int64_t n_pixels, float* rays, void* stream) {
+    if (!K4_host || !c2w_host) return NSFF_ERR_NULL;
+    if (H < 1 || W < 1 || first_pixel < 0 || n_pixels < 0 || first_pixel + n_pixels > (int64_t)H * W) return NSFF_ERR_INVALID;
+    if (n_pixels == 0) return NSFF_OK;
+    if (!rays) return NSFF_ERR_NULL;
+    FrameRayArgs a{};
+    a.fx = K4_host[0]; a.fy = K4_host[1]; a.cx = K4_host[2]; a.cy = K4_host[3];
+    for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host[i];
+    a.W = W; a.near = near; a.shift_near = shift_near; a.first = first_pixel; a.count = n_pixels; a.rays = rays;
+    hipLaunchKernelGGL(frame_rays_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return nsff_launch_status();
 }
 

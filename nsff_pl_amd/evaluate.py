@@ -1,0 +1,78 @@
+"""Frame-level callers of ``render_rays``: on-device ray generation, the chunked evaluation loop
+and PSNR -- the renderer-side pieces of the reference's ``eval.py`` / ``datasets/monocular.py``.
+
+* :func:`frame_rays`    -- NDC rays of a pinhole frame generated on the GPU
+                           (reference datasets/ray_utils.py:7-106 as called at monocular.py:268-276);
+                           the reference builds them on the CPU and uploads 3.5 MB per frame.
+* :func:`render_frame`  -- the ray-chunk loop of ``eval.f`` (eval.py:81-110): ``test_time=True``,
+                           ``perturb = noise_std = 0``, per-key concatenation.  Results stay on the GPU and
+                           ``keys=`` selects what is kept (the reference copies EVERY key of every chunk
+                           to the host, eval.py:106-107; pass ``to_cpu=True`` for that behaviour).
+* :func:`render_frame_sharded` -- the same frame split across the ranks of ``torch.distributed``
+                           with one pixel all-gather (:mod:`nsff_pl_amd.dist`).
+* :func:`psnr`          -- metrics.py:6-16.
+"""
+import torch
+
+from . import _lib
+from . import dist as ndist
+from .rendering import render_rays
+
+
+def frame_rays(K, c2w, H, W, near=1.0, device="cuda", first_pixel=0, n_pixels=None):
+    """(n_pixels, 6) NDC rays of the frame with intrinsics K (3,3) and pose c2w (3,4).
+
+    Same conventions as the reference dataset: pixel order row-major, no +0.5 centring,
+    ``shift_near = -min(-1, c2w[2,3])`` (monocular.py:270).
+    """
+    K = torch.as_tensor(K, dtype=torch.float32).cpu()
+    c2w = torch.as_tensor(c2w, dtype=torch.float32).cpu()
+    n = H * W - first_pixel if n_pixels is None else n_pixels
+    shift_near = -min(-1.0, float(c2w[2, 3]))
+    rays = torch.empty(n, 6, device=device, dtype=torch.float32)
+    with torch.cuda.device(rays.device):
+        _lib.frame_rays([K[0, 0], K[1, 1], K[0, 2], K[1, 2]], c2w.reshape(-1).tolist(), H, W, near, shift_near,
+                        first_pixel, n, rays)
+    return rays
+
+
+@torch.no_grad()
+def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, chunk=1024 * 32,
+                 keys=None, to_cpu=False, **kwargs):
+    """Batched inference on the rays of one frame (reference eval.py:81-110).
+
+    keys: iterable of result keys to keep (default: all, like the reference).
+    """
+    B = rays.shape[0]
+    results = {}
+    for i in range(0, B, chunk):
+        kw = dict(kwargs)
+        for per_ray in ("view_dir", "t_embedded", "a_embedded"):
+            if per_ray in kw and kw[per_ray] is not None:
+                kw[per_ray] = kw[per_ray][i:i + chunk]
+        out = render_rays(models, embeddings, rays[i:i + chunk], None if ts is None else ts[i:i + chunk],
+                          max_t, N_samples, 0, 0, N_importance, chunk, test_time=True, **kw)
+        for k, v in out.items():
+            if keys is not None and k not in keys:
+                continue
+            results.setdefault(k, []).append(v.cpu() if to_cpu else v)
+    return {k: torch.cat(v, 0) for k, v in results.items()}
+
+
+@torch.no_grad()
+def render_frame_sharded(models, embeddings, rays, ts, max_t, N_samples, N_importance, chunk=1024 * 32,
+                         gather_keys=ndist.DEFAULT_PIXEL_KEYS, **kwargs):
+    """Every rank passes the full frame; rank r renders block r; pixels are all-gathered (one collective)."""
+    def fn(models_, embeddings_, rays_, ts_, *a, **kw):
+        return render_frame(models_, embeddings_, rays_, ts_, max_t, N_samples, N_importance, chunk,
+                            keys=gather_keys, **kw)
+    merged, _ = ndist.render_rays_sharded(fn, models, embeddings, rays, ts, gather_keys=gather_keys, **kwargs)
+    return merged
+
+
+def psnr(image_pred, image_gt, valid_mask=None):
+    """-10 log10(mean squared error) (reference metrics.py:6-16)."""
+    err = (image_pred - image_gt) ** 2
+    if valid_mask is not None:
+        err = err[valid_mask]
+    return -10 * torch.log10(err.mean())

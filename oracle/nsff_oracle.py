@@ -7,6 +7,7 @@ A plain numpy (fp32) restatement of the reference algorithm of kwea123/nsff_pl:
     sample_pdf         <- models/rendering.py:10-49
     ndc_to_world       <- datasets/ray_utils.py:127-151
     world_visibility   <- datasets/ray_utils.py:154-181
+    frame_rays         <- datasets/ray_utils.py:7-106 (get_ray_directions, get_rays, get_ndc_rays)
     render_rays        <- models/rendering.py:52-362 (inference :83-300,
                           render_transient_warping :98-140)
 
@@ -356,6 +357,27 @@ def render_rays(fields, freqs_xyz, freqs_dir, rays, ts, max_t, emb_t=None, emb_a
                a_embedded=a_embedded, t_embedded=t_embedded, t_next=t_next, t_prev=t_prev,
                draw_prefix="fine", **common)
     return results
+
+
+# ------------------------------------------------------------------------- ray_utils.py
+def frame_rays(K, c2w, H, W, near=1.0):
+    """NDC rays of a full frame: get_ray_directions -> get_rays -> get_ndc_rays
+    (datasets/ray_utils.py:7-106 as called from datasets/monocular.py:268-276)."""
+    K, c2w = np.asarray(K, F), np.asarray(c2w, F)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    j, i = np.meshgrid(np.arange(H, dtype=F), np.arange(W, dtype=F), indexing="ij")
+    dirs = np.stack([(i - cx) / fx, -(j - cy) / fy, -np.ones_like(i)], -1).reshape(-1, 3)
+    d = (dirs @ c2w[:, :3].T).astype(F)
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.broadcast_to(c2w[:, 3], d.shape)
+    shift_near = F(-min(-1.0, float(c2w[2, 3])))
+    t = -(shift_near + o[:, 2]) / d[:, 2]
+    o = o + t[:, None] * d
+    ox_oz, oy_oz = o[:, 0] / o[:, 2], o[:, 1] / o[:, 2]
+    sx, sy = F(-1.0) / (cx / fx), F(-1.0) / (cy / fy)
+    o2 = F(1.0) + F(2.0) * F(near) / o[:, 2]
+    return np.stack([sx * ox_oz, sy * oy_oz, o2, sx * (d[:, 0] / d[:, 2] - ox_oz),
+                     sy * (d[:, 1] / d[:, 2] - oy_oz), F(1.0) - o2], -1).astype(F)
 
 
 # ------------------------------------------------------------------ helpers for callers

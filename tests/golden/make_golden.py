@@ -31,7 +31,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def import_reference():
     sys.path.insert(0, REF)
     kornia = types.ModuleType("kornia")
-    kornia.create_meshgrid = lambda *a, **k: None
+
+    def create_meshgrid(H, W, normalized_coordinates=False):      # functional stand-in used only for ray-gen goldens
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        return torch.stack([xs, ys], -1)[None]
+    kornia.create_meshgrid = create_meshgrid
     sys.modules["kornia"] = kornia
     datasets = types.ModuleType("datasets")
     datasets.__path__ = [REF + "/datasets"]
@@ -139,6 +143,20 @@ def main():
     stage["pdf/rand_40"] = sample_pdf(bins, w, 40, det=False).numpy()
     torch.manual_seed(99)
     stage["pdf/u_40"] = torch.rand(n, 40).numpy()
+    # ---- N3: frame ray generation (datasets/ray_utils.py as called by monocular.py:268-276) ----
+    from datasets import ray_utils
+    H, W = 18, 32
+    K = torch.tensor([[25.0, 0, W / 2], [0, 24.0, H / 2 + 0.5], [0, 0, 1]])
+    ang = 0.3
+    c2w = torch.tensor([[np.cos(ang), 0.05, np.sin(ang), 0.12], [0.02, 0.999, -0.03, -0.07],
+                        [-np.sin(ang), 0.03, np.cos(ang), -1.3]], dtype=torch.float32)
+    dirs = ray_utils.get_ray_directions(H, W, K)
+    ro, rd = ray_utils.get_rays(dirs, c2w)
+    shift_near = -min(-1.0, c2w[2, 3])
+    ro, rd = ray_utils.get_ndc_rays(K, 1.0, shift_near, ro, rd)
+    stage["rays/K"], stage["rays/c2w"], stage["rays/HW"] = K.numpy(), c2w.numpy(), np.array([H, W])
+    stage["rays/ndc"] = torch.cat([ro, rd], 1).numpy()
+    assert np.abs(orc.frame_rays(K.numpy(), c2w.numpy(), H, W) - stage["rays/ndc"]).max() < 1e-5
     np.savez_compressed(os.path.join(HERE, "g8_stages.npz"), **stage)
     print("g8_stages written;", "oracle worst", f"{worst:.2e}")
 

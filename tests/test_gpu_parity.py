@@ -30,7 +30,7 @@ def precision(request):
     name, _, tile = request.param.partition("-")
     config.set_precision(name)
     config.set_tile_points(int(tile) if tile else 0)
-    yield request.param
+    yield name if not tile else request.param
     config.set_precision("f32")
     config.set_tile_points(0)
 
@@ -273,3 +273,46 @@ def test_native_library_is_the_one_loaded(hip_lib):
     with open("/proc/self/maps") as f:
         assert any("libnsff_hip.so" in line for line in f), "HIP extension not loaded in this process"
     assert os.path.samefile(_lib.LIB_PATH, os.path.join(os.path.dirname(A.__file__), "libnsff_hip.so"))
+
+
+# ---- N3 / eval loop: frame ray generation and the chunked frame renderer (BASELINE configs[2]) ----
+def test_frame_rays_match_reference(stages, hip_lib):
+    from nsff_pl_amd import evaluate
+    H, W = [int(v) for v in stages["rays/HW"]]
+    got = evaluate.frame_rays(stages["rays/K"], stages["rays/c2w"], H, W, device=DEV).cpu().numpy()
+    parity.assert_close("ndc rays", got, stages["rays/ndc"], 1e-5)
+    part = evaluate.frame_rays(stages["rays/K"], stages["rays/c2w"], H, W, device=DEV, first_pixel=100, n_pixels=77)
+    assert np.array_equal(part.cpu().numpy(), got[100:177])
+
+
+def test_full_frame_eval_512x288(hip_lib, precision):
+    """One 512x288 frame, test-time flags, 32768-ray chunks like eval.f; PSNR against the oracle on a subset."""
+    if precision not in ("f32", "f16x3"):
+        pytest.skip("full-frame run only on the two shipped modes")
+    from nsff_pl_amd import evaluate
+    cfg = dict(scenes.CASES["g4_nsff_test"])
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    H, W = 288, 512
+    K = np.array([[400., 0, W / 2], [0, 400., H / 2], [0, 0, 1]], np.float32)
+    c2w = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
+    rays = evaluate.frame_rays(K, c2w, H, W, device=DEV)
+    ts = torch.full((H * W,), 7, dtype=torch.long, device=DEV)
+    kw = scenes.render_kwargs(cfg)
+    keys = ("rgb_fine", "depth_fine", "transient_alpha_fine", "zs_fine")
+    out = evaluate.render_frame(models, emb, rays, ts, 29, 64, 64, chunk=32768, keys=keys, **kw)
+    assert set(out) == set(keys) and out["rgb_fine"].shape == (H * W, 3)
+    img = out["rgb_fine"].view(H, W, 3)
+    assert torch.isfinite(img).all()
+    # a frame rendered in one call equals the chunked one (rays are independent)
+    one = evaluate.render_frame(models, emb, rays[:40000], ts[:40000], 29, 64, 64, chunk=40000, keys=("rgb_fine",), **kw)
+    assert torch.equal(one["rgb_fine"], out["rgb_fine"][:40000])
+    # oracle on 96 pixels spread over the frame, at the same fine depths
+    idx = np.linspace(0, H * W - 1, 96).astype(np.int64)
+    want = common.oracle_render(cfg, models, emb, rays.cpu().numpy()[idx], ts.cpu().numpy()[idx],
+                                zs_fine_override=out["zs_fine"].cpu().numpy()[idx])
+    got = out["rgb_fine"].cpu().numpy()[idx]
+    parity.assert_close("rgb_fine", got, want["rgb_fine"])
+    parity.assert_close("depth_fine", out["depth_fine"].cpu().numpy()[idx], want["depth_fine"])
+    p = float(evaluate.psnr(torch.from_numpy(got), torch.from_numpy(want["rgb_fine"])))
+    assert p > 80.0, f"PSNR(build, oracle) = {p:.1f} dB"
