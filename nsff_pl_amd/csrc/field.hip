@@ -50,13 +50,6 @@ struct FieldKArgs {
     int ld_emb, off_xyz, off_dir, off_a, off_t;
 };
 
-#ifndef NSFF_STAGGER
-#define NSFF_STAGGER 0      // start-up delay (in 64-cycle s_sleep units x 100) of every second co-resident workgroup
-#endif
-#ifndef NSFF_PF
-#define NSFF_PF 1           // weight prefetch distance in 8-column blocks
-#endif
-
 #define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ void mma8(f32x16 (&acc)[2][2], const float4& a0, const float4& a1,
@@ -86,49 +79,17 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][2], const float* sA,
                                          const float4* __restrict__ wB, int nkb) {
     const float4* __restrict__ w0 = wB;
     const float4* __restrict__ w1 = wB + nkb * 64;
-#if NSFF_PF == 1
     float4 b0 = w0[0], b1 = w1[0];
     float4 a0 = *reinterpret_cast<const float4*>(sA);
     float4 a1 = *reinterpret_cast<const float4*>(sA + 32 * LDA);
     for (int kb = 1; kb < nkb; ++kb) {
-#ifdef NSFF_EXP_NOB
-        float4 nb0 = b0, nb1 = b1;
-        asm volatile("" : "+v"(nb0.x), "+v"(nb1.x));
-#else
         const float4 nb0 = w0[kb * 64], nb1 = w1[kb * 64];
-#endif
-#ifdef NSFF_EXP_NOA
-        float4 na0 = a0, na1 = a1;
-        asm volatile("" : "+v"(na0.x), "+v"(na1.x));
-#else
         const float4 na0 = *reinterpret_cast<const float4*>(sA + kb * 8);
         const float4 na1 = *reinterpret_cast<const float4*>(sA + 32 * LDA + kb * 8);
-#endif
         mma8(acc, a0, a1, b0, b1);
         a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     mma8(acc, a0, a1, b0, b1);
-#else
-    // two blocks of weights in flight (nkb is even for every segment: K multiples of 16 ... or odd tail)
-    float4 b0 = w0[0], b1 = w1[0];
-    float4 c0 = nkb > 1 ? w0[64] : b0, c1 = nkb > 1 ? w1[64] : b1;
-    float4 a0 = *reinterpret_cast<const float4*>(sA);
-    float4 a1 = *reinterpret_cast<const float4*>(sA + 32 * LDA);
-    for (int kb = 2; kb < nkb; ++kb) {
-        const float4 nb0 = w0[kb * 64], nb1 = w1[kb * 64];
-        const float4 na0 = *reinterpret_cast<const float4*>(sA + (kb - 1) * 8);
-        const float4 na1 = *reinterpret_cast<const float4*>(sA + 32 * LDA + (kb - 1) * 8);
-        mma8(acc, a0, a1, b0, b1);
-        a0 = na0; a1 = na1; b0 = c0; b1 = c1; c0 = nb0; c1 = nb1;
-    }
-    if (nkb > 1) {
-        const float4 na0 = *reinterpret_cast<const float4*>(sA + (nkb - 1) * 8);
-        const float4 na1 = *reinterpret_cast<const float4*>(sA + 32 * LDA + (nkb - 1) * 8);
-        mma8(acc, a0, a1, b0, b1);
-        a0 = na0; a1 = na1; b0 = c0; b1 = c1;
-    }
-    mma8(acc, a0, a1, b0, b1);
-#endif
 }
 
 __device__ __forceinline__ void acc_init(f32x16 (&acc)[2][2], const float* __restrict__ bias,
@@ -259,11 +220,8 @@ __device__ __forceinline__ void heads(const float* sX, const float* __restrict__
     }
 }
 
-#ifndef NSFF_EXP_PADLDS
-#define NSFF_EXP_PADLDS 0
-#endif
 __global__ __launch_bounds__(NTHREADS, 2) void nsff_field_kernel(const FieldKArgs a) {
-    __shared__ __attribute__((aligned(16))) float sX[TM * LDA + NSFF_EXP_PADLDS];
+    __shared__ __attribute__((aligned(16))) float sX[TM * LDA];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long p0 = (long long)blockIdx.x * TM;
@@ -272,16 +230,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void nsff_field_kernel(const FieldKArg
     const bool valid = (p0 + lane) < a.n_points;
     float* raw_rec = a.raw + (p0 + lane) * NSFF_RAW_STRIDE;
 
-#if NSFF_STAGGER > 0
-    // Co-resident workgroups would otherwise run the identical layer sequence in lockstep and
-    // hit their barrier / epilogue phases together, idling the matrix pipe.  Delay the second
-    // resident workgroup of each CU (dispatch is breadth-first: blocks 256..511 of the first
-    // wave) by a fraction of a layer; later workgroups inherit the offset from their slot.
-    // HW_REG_LDS_ALLOC[7:0] = LDS base of this workgroup: non-zero for the second resident one
-    if ((__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) & 0xff) != 0 && blockIdx.x < 512) {
-        for (int i = 0; i < NSFF_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
-    }
-#endif
     f32x16 acc[2][2];
     auto seg = [&](uint32_t off, int nkb) {
         return reinterpret_cast<const float4*>(pk + off) + (2 * wave * nkb) * 64 + lane;

@@ -76,11 +76,7 @@ struct H3KArgs {
 };
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-#ifndef H3_NO_PIN
 #define H3_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define H3_PIN()
-#endif
 
 __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx, float v) {
     const _Float16 hi = (_Float16)v;
@@ -96,10 +92,6 @@ struct BiasRegs { float4 b[2][4]; };
 // Weights are read through a bumped pointer so that every load is base + small immediate
 // ([ks][mt][part][lane] 16-byte chunks = 4 KiB per k-step; the lane offset is in the pointer).
 __device__ __forceinline__ void load_w(WFrag& f, const uint4* __restrict__& wp) {
-#ifdef H3_EXP_NOW
-    asm volatile("" : "+v"(f.wh[0]), "+v"(f.wl[0]), "+v"(f.wh[1]), "+v"(f.wl[1]));
-    return;
-#endif
     const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
     wp += 256;
     f.wh[0] = __builtin_bit_cast(h8, a0); f.wl[0] = __builtin_bit_cast(h8, a1);
@@ -108,13 +100,6 @@ __device__ __forceinline__ void load_w(WFrag& f, const uint4* __restrict__& wp) 
 
 template <int NT>
 __device__ __forceinline__ void load_x(XFrag<NT>& f, const _Float16* sBh, const _Float16* sBl, int ks) {
-#ifdef H3_EXP_NOX
-    if (ks != 0) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(f.xh[nt]), "+v"(f.xl[nt]));
-        return;
-    }
-#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f.xh[nt] = *reinterpret_cast<const h8*>(sBh + nt * 32 * LDH + ks * 16);
@@ -390,12 +375,8 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
     // Every workgroup streams the same weights; if all of them walk the program in the same order
     // they hit the same few L2 channels at the same instant.  Half of the workgroups therefore run
     // the dynamic trunk first (the two trunks are independent: separate outputs, the tile is rebuilt).
-#ifndef H3_NO_ROTATE
     const int rot = (a.n_static_steps > 0 && a.n_static_steps < a.n_steps && ((blockIdx.x >> 3) & 1))
                         ? a.n_static_steps : 0;
-#else
-    const int rot = 0;
-#endif
     auto step_at = [&](int i) { int j = i + rot; if (j >= a.n_steps) j -= a.n_steps; return a.steps[j]; };
     const H3Step s0 = step_at(0);
     const uint4* wnext = prefetch_w(ring, seg(s0.w_off, s0.nks));
@@ -405,10 +386,8 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
         const H3Step st = step_at(i);
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
-#ifndef H3_EXP_NOBUILD
             if (st.pre == PRE_SIDE) build_side<M, THREADS>(sXh, sXl, a, p0);
             else build_input<M, THREADS>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
-#endif
             __syncthreads();
         }
         if (st.bias_off != NSFF_NONE) acc_init<NT>(acc, br);
@@ -420,18 +399,10 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
         }
         if (st.post != POST_NONE) {
             __syncthreads();
-#ifndef H3_EXP_NOSTORE
             if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, nt0, lane);
             else acc_store<NT, false>(sXh, sXl, acc, wave, nt0, lane);
-#else
-            asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
-#endif
             __syncthreads();
-#ifdef H3_EXP_NOHEADS
-            if (false) {
-#else
             if (st.head != HEAD_NONE) {
-#endif
                 // static sigma reads the last trunk activation, before *_final (nerf.py:169);
                 // dynamic rows: rgb(3) sigmoid, sigma raw, fw(3)/bw(3) = flow_scale*tanh (nerf.py:197-208)
                 uint32_t w_off = a.L.s_sigma_w, b_off = a.L.s_sigma_b;
