@@ -16,6 +16,7 @@ inverse) is evaluated with torch ops on the device, in :mod:`nsff_pl_amd.ray_geo
 import torch
 
 from . import _lib
+from . import autograd
 from . import ray_geometry
 
 Z_FAR = 0.95  # flows are zeroed beyond this depth (reference rendering.py:316)
@@ -48,7 +49,7 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
 class _Pass:
     """Inputs shared by the coarse and the fine pass of one render_rays call."""
     __slots__ = ("embeddings", "rays", "ts", "max_t", "noise_std", "test_time", "kwargs",
-                 "freqs_xyz", "dir_embedded", "n_rays")
+                 "freqs_xyz", "dir_embedded", "n_rays", "rec")
 
 
 def _embed_rows(embeddings, key, idx):
@@ -93,6 +94,8 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
     nstd = float(ctx.noise_std)
     noise_s = torch.randn(n_rays, S, device=zs.device)
     noise_t = torch.randn(n_rays, S, device=zs.device) if output_transient else None
+    if ctx.rec is not None and nstd != 0:        # the draws are needed again when gradients are taken
+        ctx.rec[f"{typ}_static"], ctx.rec[f"{typ}_transient"] = noise_s, noise_t
 
     args = dict(n_rays=n_rays, n_samples=S, has_transient=int(output_transient),
                 has_rgb=int(not sigma_only), flow_mode=0, want_disocc=int(disocc),
@@ -136,6 +139,8 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
             _lib.field_query(model, raw_bw, P, S, static_mode=0, transient_mode=2, flow_heads=1,
                              xyz=xyz_bw, freqs=ctx.freqs_xyz, t_emb=tm1)
         noise_bw = torch.randn(n_rays, S, device=zs.device)
+        if ctx.rec is not None and nstd != 0:
+            ctx.rec[f"{typ}_warp_fw"], ctx.rec[f"{typ}_warp_bw"] = noise_fw, noise_bw
         out('rgb_bw', n_rays, 3)
         args.update(raw_fw=raw_fw, raw_bw=raw_bw, xyz_fw=xyz_fw, xyz_bw=xyz_bw,
                     noise_fw=noise_fw if nstd != 0 else None,
@@ -199,10 +204,17 @@ def render_rays(models,
     reference does.  ``_zs_fine`` (N_rays, S_fine) is a test hook that overrides the merged
     fine depths.  ``chunk`` is accepted and ignored: the fused field kernel tiles the
     points itself, so there is no inner point-chunk loop to size.
-    Forward only (inference / no_grad); results are fresh contiguous fp32 GPU tensors.
+    Results are fresh contiguous fp32 GPU tensors computed by the HIP kernels.  With autograd enabled,
+    ``test_time=False`` and parameters that require grad, the results carry a graph to the model /
+    embedding parameters (see :mod:`nsff_pl_amd.autograd`).
     """
     _lib.require_gpu_tensor(rays, "rays")
     _lib.load()
+    # Gradients (training): forward values still come from the kernels below; the autograd graph is
+    # attached afterwards and differentiates a torch re-evaluation at the recorded depths / draws.
+    want_grad = (torch.is_grad_enabled() and not test_time and
+                 bool(autograd.grad_parameters(models, embeddings)))
+    rec = {} if want_grad else None
     with torch.cuda.device(rays.device), torch.no_grad():
         results = {}
         rays = rays.contiguous().float()
@@ -213,6 +225,7 @@ def render_rays(models,
         ctx.embeddings, ctx.rays, ctx.ts, ctx.max_t = embeddings, rays, ts, max_t
         ctx.noise_std, ctx.test_time, ctx.kwargs, ctx.n_rays = noise_std, test_time, kwargs, n_rays
         ctx.freqs_xyz = [float(f) for f in embedding_xyz.freqs]
+        ctx.rec = rec
         ctx.dir_embedded = None
         if any(m.use_viewdir for m in models.values()):
             view_dir = kwargs.get('view_dir', rays[:, 3:6])
@@ -279,4 +292,10 @@ def render_rays(models,
         output_transient_flow = [] if not output_transient else kwargs.get('output_transient_flow', [])
         _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
                    t_embedded, a_embedded)
+    if rec is None:
         return results
+    rec.update(N_importance=N_importance, noise_std=float(noise_std), output_transient=output_transient,
+               flows=list(output_transient_flow), zs_coarse=results.get('zs_coarse', results.get('zs_fine')),
+               zs_fine=results['zs_fine'], view_dir=kwargs.get('view_dir', rays[:, 3:6]),
+               t_embedded_override=kwargs.get('t_embedded'), a_embedded_override=kwargs.get('a_embedded'))
+    return autograd.attach(results, models, embeddings, rays, ts, max_t, rec)

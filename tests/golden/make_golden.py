@@ -104,6 +104,45 @@ def main():
         size = os.path.getsize(os.path.join(HERE, name + ".npz")) / 1024
         print(f"{name:28s} keys={len(res):2d} oracle-vs-reference max-norm rel err {case_worst:.2e}  ({size:.0f} KiB)")
 
+    # ---- gradient goldens: d<outputs, fixed cotangents>/d(parameters) from the reference ----
+    torch.set_grad_enabled(True)
+    for name in scenes.GRAD_CASES:
+        cfg, rays, ts = scenes.case_inputs(name)
+        models, embeddings = scenes.build_scene(NeRF, PosEmbedding, cfg)
+        kw = scenes.render_kwargs(cfg)
+        torch.manual_seed(DRAW_SEED)
+        res = render_rays(models, embeddings, rays, ts, scenes.N_FRAMES - 1, cfg["N_samples"],
+                          cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"],
+                          1024 * 32, test_time=False, **kw)
+        loss = scenes.cotangent_loss(res)
+        loss.backward()
+        stats, full = scenes.grad_stats(models, embeddings)
+        save = {"full/" + k: v for k, v in full.items()}
+        save["stats"] = np.frombuffer(json.dumps(stats).encode(), dtype=np.uint8)
+        save["loss"] = np.float64(float(loss))
+        if not (cfg.get("perturb", 0) or cfg.get("noise_std", 0)):
+            # the same gradient from the reference evaluated in float64 (the fp32 one scatters by up to a few
+            # 1e-3 of |g|_1 around it, machine to machine: sin(512 x) under the warped re-queries)
+            models64, embeddings64 = scenes.build_scene(NeRF, PosEmbedding, cfg)
+            for m in list(models64.values()) + [e for k_, e in embeddings64.items() if k_ in ("t", "a")]:
+                m.double()
+            # zs_fine must be the fp32 run's (sampling is not differentiated): feed it through a patched sort
+            import models.rendering as R
+            zs32 = res["zs_fine"].detach().double()
+            orig_sort = R.torch.sort
+            R.torch.sort = lambda *a, **k_: (zs32, None)
+            try:
+                res64 = render_rays(models64, embeddings64, rays.double(), ts, scenes.N_FRAMES - 1,
+                                    cfg["N_samples"], 0, 0, cfg["N_importance"], 1024 * 32, test_time=False, **kw)
+            finally:
+                R.torch.sort = orig_sort
+            scenes.cotangent_loss(res64).backward()
+            stats64, _ = scenes.grad_stats(models64, embeddings64)
+            save["stats64"] = np.frombuffer(json.dumps(stats64).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, "g9_grads_" + name + ".npz"), **save)
+        print(f"g9 {name}: loss {float(loss):.6f}, {len(stats)} parameter tensors")
+    torch.set_grad_enabled(False)
+
     # ---- stage goldens ----
     g = torch.Generator().manual_seed(77)
     stage = {}

@@ -168,3 +168,45 @@ def replay_draws(cfg, seed):
     for key, shape, kind in draw_plan(cfg):
         out[key] = (torch.rand(*shape) if kind == "rand" else torch.randn(*shape)).numpy()
     return out
+
+
+# ---- gradient goldens (G9): a fixed random cotangent per differentiable output key ----
+GRAD_CASES = ("g3_nsff_train", "g7_nsff_train_noise", "g2_static_c2f")
+NON_DIFF_KEYS = ("zs_coarse", "xyzs_coarse", "zs_fine", "xyzs_fine")
+FULL_GRAD_PARAMS = ("t.weight", "fine.transient_flow_fw.0.weight", "fine.static_sigma.weight",
+                    "fine.static_xyz_encoding_5.0.bias", "coarse.transient_rgb.0.bias", "coarse.static_rgb.0.weight")
+
+
+def cotangent_loss(results):
+    """sum_k <results[k], C_k> with C_k ~ N(0,1) drawn in sorted-key order from a fixed generator."""
+    gen = torch.Generator().manual_seed(555)
+    loss = 0.0
+    for k in sorted(results):
+        c = torch.randn(results[k].shape, generator=gen)
+        if k in NON_DIFF_KEYS or not results[k].requires_grad:
+            continue
+        loss = loss + (results[k] * c.to(device=results[k].device, dtype=results[k].dtype)).sum()
+    return loss
+
+
+def named_grad_params(models, embeddings):
+    out = []
+    for key in sorted(models):
+        out += [(f"{key}.{n}", p) for n, p in models[key].named_parameters()]
+    for key in ("t", "a"):
+        if key in embeddings:
+            out += [(f"{key}.{n}", p) for n, p in embeddings[key].named_parameters()]
+    return out
+
+
+def grad_stats(models, embeddings):
+    """{name: [sum g, sum |g|, <g, r>]} with r ~ N(0,1) from a fixed generator, plus a few full gradients."""
+    gen = torch.Generator().manual_seed(777)
+    stats, full = {}, {}
+    for name, p in named_grad_params(models, embeddings):
+        r = torch.randn(p.shape, generator=gen)
+        g = torch.zeros_like(p).cpu() if p.grad is None else p.grad.detach().cpu()
+        stats[name] = [float(g.double().sum()), float(g.double().abs().sum()), float((g.double() * r.double()).sum())]
+        if name in FULL_GRAD_PARAMS:
+            full[name] = g.numpy().copy()
+    return stats, full
