@@ -37,6 +37,14 @@ def import_reference():
         return torch.stack([xs, ys], -1)[None]
     kornia.create_meshgrid = create_meshgrid
     sys.modules["kornia"] = kornia
+    kfilters = types.ModuleType("kornia.filters")
+
+    def filter2d(x, kernel, border_type="constant"):             # only the default thickness=1 (1x1x1 box) is pinned
+        assert kernel.numel() == 1 and float(kernel) == 1.0
+        return x
+    kfilters.filter2d = filter2d
+    kornia.filters = kfilters
+    sys.modules["kornia.filters"] = kfilters
     datasets = types.ModuleType("datasets")
     datasets.__path__ = [REF + "/datasets"]
     sys.modules["datasets"] = datasets
@@ -141,6 +149,48 @@ def main():
             save["stats64"] = np.frombuffer(json.dumps(stats64).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, "g9_grads_" + name + ".npz"), **save)
         print(f"g9 {name}: loss {float(loss):.6f}, {len(stats)} parameter tensors")
+    torch.set_grad_enabled(False)
+
+    # ---- loss goldens (row N1): reference NeRFWLoss on the reference render, values + parameter gradients ----
+    torch.set_grad_enabled(True)
+    sys.path.insert(0, REF)
+    import losses as ref_losses
+    for name in scenes.LOSS_CASES:
+        cfg, rays, ts = scenes.case_inputs(name)
+        save = {}
+        for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+            if dt == torch.float64 and (cfg.get("perturb", 0) or cfg.get("noise_std", 0)):
+                continue
+            models, embeddings = scenes.build_scene(NeRF, PosEmbedding, cfg)
+            for m in list(models.values()) + [embeddings["t"]]:
+                m.to(dt)
+            kw = scenes.render_kwargs(cfg)
+            loss_fn = ref_losses.NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0)
+            Ks, Ps, max_t = scenes.camera_buffers()
+            loss_fn.register_buffer("Ks", Ks.to(dt)); loss_fn.register_buffer("Ps", Ps.to(dt)); loss_fn.max_t = max_t
+            targets = {k: (v.to(dt) if v.is_floating_point() else v)
+                       for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+            torch.manual_seed(DRAW_SEED)
+            if dt == torch.float64:
+                import models.rendering as R
+                zs32 = torch.from_numpy(np.load(os.path.join(HERE, name + ".npz"))["out/zs_fine"]).double()
+                orig_sort = R.torch.sort
+                R.torch.sort = lambda *a, **k_: (zs32, None)
+            try:
+                res = render_rays(models, embeddings, rays.to(dt), ts, scenes.N_FRAMES - 1, cfg["N_samples"],
+                                  cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"],
+                                  1024 * 32, test_time=False, **kw)
+            finally:
+                if dt == torch.float64:
+                    R.torch.sort = orig_sort
+            ld = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+            total = sum(ld.values())
+            total.backward()
+            stats, _ = scenes.grad_stats(models, embeddings)
+            save["terms" + tag] = np.frombuffer(json.dumps({k: float(v) for k, v in ld.items()}).encode(), dtype=np.uint8)
+            save["stats" + tag] = np.frombuffer(json.dumps(stats).encode(), dtype=np.uint8)
+            print(f"loss golden {name} fp{tag}: total {float(total):.6f}  terms {len(ld)}")
+        np.savez_compressed(os.path.join(HERE, "g10_loss_" + name + ".npz"), **save)
     torch.set_grad_enabled(False)
 
     # ---- stage goldens ----

@@ -210,3 +210,31 @@ def grad_stats(models, embeddings):
         if name in FULL_GRAD_PARAMS:
             full[name] = g.numpy().copy()
     return stats, full
+
+
+# ---- trainer-side synthetic data for the loss goldens (reference losses.py / train.py:136-138,178-198) ----
+LOSS_CASES = ("g3_nsff_train", "g7_nsff_train_noise")
+LOSS_EPOCH = 5
+
+
+def camera_buffers():
+    """Ks (1,3,3), Ps (1,N_frames,3,4) world->image, max_t -- what train.py registers on the loss module."""
+    g = torch.Generator().manual_seed(31337)
+    W, H, f = 512.0, 288.0, 400.0
+    K = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]])
+    Ps = []
+    for _ in range(N_FRAMES):
+        ang = float(torch.rand(1, generator=g)) * 0.2 - 0.1
+        R = torch.tensor([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=torch.float32)
+        t = (torch.rand(3, 1, generator=g) - 0.5) * 0.2
+        flip = torch.diag(torch.tensor([1.0, -1.0, -1.0]))          # world (right-up-back) -> camera (right-down-front)
+        Ps.append(K @ torch.cat([flip @ R, flip @ t], 1))
+    return K[None], torch.stack(Ps)[None], N_FRAMES - 1
+
+
+def synthetic_targets(n_rays, ts, seed):
+    g = torch.Generator().manual_seed(4000 + seed)
+    return dict(rgbs=torch.rand(n_rays, 3, generator=g), disps=torch.rand(n_rays, generator=g) * 2 + 0.1,
+                ts=ts, cam_ids=torch.zeros(n_rays, dtype=torch.long),
+                uv_fw=torch.rand(n_rays, 2, generator=g) * torch.tensor([512.0, 288.0]),
+                uv_bw=torch.rand(n_rays, 2, generator=g) * torch.tensor([512.0, 288.0]))

@@ -71,3 +71,30 @@ def test_sharded_render_equals_single_process(n_rays):
     ctx = mp.spawn(_worker, args=(world, _free_port(), n_rays, ret), nprocs=world, join=False)
     ctx.join(timeout=600)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _grad_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from nsff_pl_amd import dist as ndist
+    from nsff_pl_amd.training import allreduce_gradients
+    ndist.init_from_env("gloo")
+    params = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    params[0].grad = torch.full((3, 4), float(rank + 1))
+    if rank == 0:                       # a parameter one rank never touched (e.g. unused flow head) still averages
+        params[1].grad = torch.arange(5.0)
+    allreduce_gradients(params)
+    ok = torch.equal(params[0].grad, torch.full((3, 4), 1.5)) and torch.equal(params[1].grad, torch.arange(5.0) / 2) \
+        and torch.equal(params[2].grad, torch.zeros(2))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce():
+    world = 2
+    ret = mp.Manager().dict()
+    ctx = mp.spawn(_grad_worker, args=(world, _free_port(), ret), nprocs=world, join=False)
+    ctx.join(timeout=300)
+    assert dict(ret) == {0: True, 1: True}

@@ -25,14 +25,34 @@ GRAD_RTOL = 2e-3
 _TRUTH = {}
 
 
-def _load_grads(name):
+def _load_grads(name, objective="cotangent"):
+    if objective == "nsff_loss":                 # g10: reference NeRFWLoss, statistics only
+        z = np.load(common.GOLDEN_DIR + f"/g10_loss_{name}.npz")
+        dec = lambda k: json.loads(bytes(z[k]).decode()) if k in z.files else None
+        return dec("stats32"), {}, sum(dec("terms32").values()), dec("stats64")
     z = np.load(common.GOLDEN_DIR + f"/g9_grads_{name}.npz")
     stats64 = json.loads(bytes(z["stats64"]).decode()) if "stats64" in z.files else None
     return (json.loads(bytes(z["stats"]).decode()), {k[5:]: z[k] for k in z.files if k.startswith("full/")},
             float(z["loss"]), stats64)
 
 
-def _torch_path_stats(name, dt):
+def objective_fn(name, objective, dt=torch.float32, device="cpu"):
+    """res -> scalar: the fixed-cotangent functional (G9) or the summed reference-style NeRFWLoss (G10)."""
+    if objective == "cotangent":
+        return scenes.cotangent_loss
+    from nsff_pl_amd.losses import NeRFWLoss
+    cfg, _, ts = scenes.case_inputs(name)
+    loss_fn = NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0)
+    Ks, Ps, max_t = scenes.camera_buffers()
+    loss_fn.register_buffer("Ks", Ks.to(dt)); loss_fn.register_buffer("Ps", Ps.to(dt)); loss_fn.max_t = max_t
+    loss_fn.to(device)
+    targets = {k: (v.to(dt) if v.is_floating_point() else v).to(device)
+               for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+    kw = scenes.render_kwargs(cfg)
+    return lambda res: sum(loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw).values())
+
+
+def _torch_path_stats(name, dt, objective="cotangent"):
     cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
     draws = scenes.replay_draws(cfg, meta["draw_seed"])
     for m in list(models.values()) + [e for k, e in emb.items() if k in ("t", "a")]:
@@ -40,27 +60,28 @@ def _torch_path_stats(name, dt):
     rec = _record(cfg, want, draws, rays.to(dt))
     rec = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in rec.items()}
     res = nauto.recompute(models, emb, rays.to(dt), ts, scenes.N_FRAMES - 1, rec)
-    scenes.cotangent_loss(res).backward()
+    objective_fn(name, objective, dt)(res).backward()
     return scenes.grad_stats(models, emb)
 
 
-def grad_truth(name):
+def grad_truth(name, objective="cotangent"):
     """(float64 statistics, float64 full gradients, per-statistic fp32 scatter) of a gradient case."""
-    if name not in _TRUTH:
-        ref32, _, _, ref64 = _load_grads(name)
-        s64, full64 = _torch_path_stats(name, torch.float64)
-        s32, _ = _torch_path_stats(name, torch.float32)
+    key = (name, objective)
+    if key not in _TRUTH:
+        ref32, _, _, ref64 = _load_grads(name, objective)
+        s64, full64 = _torch_path_stats(name, torch.float64, objective)
+        s32, _ = _torch_path_stats(name, torch.float32, objective)
         if ref64 is not None:                   # the float64 torch path IS the reference's float64 gradient
             for k in ref64:
                 for a, b in zip(s64[k], ref64[k]):
                     assert abs(a - b) <= 1e-8 * max(abs(ref64[k][1]), 1e-12), (k, a, b)
         scatter = {k: [max(abs(s32[k][i] - s64[k][i]), abs(ref32[k][i] - s64[k][i])) for i in range(3)] for k in s64}
-        _TRUTH[name] = (s64, full64, scatter)
-    return _TRUTH[name]
+        _TRUTH[key] = (s64, full64, scatter)
+    return _TRUTH[key]
 
 
-def _check_grads(models, emb, name):
-    s64, full64, scatter = grad_truth(name)
+def _check_grads(models, emb, name, objective="cotangent"):
+    s64, full64, scatter = grad_truth(name, objective)
     stats, full = scenes.grad_stats(models, emb)
     assert sorted(stats) == sorted(s64)
     scale = max(abs(v[1]) for v in s64.values())

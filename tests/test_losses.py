@@ -1,0 +1,167 @@
+"""NeRFWLoss parity (golden G10): the eleven loss terms and d(sum)/d(parameters)
+against the reference's losses.py evaluated on the reference's own render.
+
+CPU: the loss on the differentiable torch path at the golden depths.  GPU: render_rays (HIP forward) ->
+NeRFWLoss -> backward(), i.e. one training_step of train.py:178-198 without the optimizer.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import scenes
+import nsff_pl_amd as A
+from nsff_pl_amd import autograd as nauto
+from nsff_pl_amd.losses import NeRFWLoss, ndc2world, shiftscale_invariant_depthloss
+from test_gradients import _check_grads, _record
+
+TERM_RTOL = 1e-4
+
+
+def _golden_terms(name):
+    z = np.load(common.GOLDEN_DIR + f"/g10_loss_{name}.npz")
+    return json.loads(bytes(z["terms32"]).decode())
+
+
+def _loss_module(name, device="cpu"):
+    cfg, _, ts = scenes.case_inputs(name)
+    loss_fn = NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0)
+    Ks, Ps, max_t = scenes.camera_buffers()
+    loss_fn.register_buffer("Ks", Ks); loss_fn.register_buffer("Ps", Ps); loss_fn.max_t = max_t
+    targets = {k: v.to(device) for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+    return loss_fn.to(device), targets
+
+
+def _check_terms(got, name):
+    want = _golden_terms(name)
+    assert sorted(got) == sorted(want)
+    for k, v in want.items():
+        g = float(got[k].detach())
+        assert abs(g - v) <= TERM_RTOL * max(abs(v), 1e-6), (k, g, v)
+
+
+@pytest.mark.parametrize("name", scenes.LOSS_CASES)
+def test_loss_terms_on_golden_render(name):
+    """The loss restatement alone: fed with the reference's render (golden tensors)."""
+    cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+    loss_fn, targets = _loss_module(name)
+    res = {k: torch.from_numpy(v) for k, v in want.items()}
+    _check_terms(loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **scenes.render_kwargs(cfg)), name)
+
+
+@pytest.mark.parametrize("name", scenes.LOSS_CASES)
+def test_loss_and_gradients_torch_path(name):
+    cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+    draws = scenes.replay_draws(cfg, meta["draw_seed"])
+    res = nauto.recompute(models, emb, rays, ts, scenes.N_FRAMES - 1, _record(cfg, want, draws, rays))
+    loss_fn, targets = _loss_module(name)
+    terms = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **scenes.render_kwargs(cfg))
+    _check_terms(terms, name)
+    sum(terms.values()).backward()
+    _check_grads(models, emb, name, "nsff_loss")
+
+
+def test_loss_options():
+    """topk < 1, per-ray weights, thickness > 1 and the static-only configuration run and reduce as documented."""
+    name = "g3_nsff_train"
+    cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+    res = {k: torch.from_numpy(v) for k, v in want.items()}
+    kw = scenes.render_kwargs(cfg)
+    loss_fn, targets = _loss_module(name)
+    base = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+    w = torch.tensor(2.0)         # (per-ray weights need every term per-ray: masked flow terms are not)
+    dbl = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, weights=w, **{k: v for k, v in kw.items()})
+    for k in ("col_l", "disp_l", "pho_l"):
+        assert abs(float(dbl[k]) - 2 * float(base[k])) <= 1e-6 * abs(float(base[k])) + 1e-12
+    loss_fn.topk = 0.5
+    top = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+    assert all(float(top[k]) >= float(base[k]) - 1e-9 for k in base)
+    loss_fn.topk, loss_fn.thickness = 1.0, 3
+    thick = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+    tw, sw = res["transient_weights_fine"], res["static_weights_fine"]
+    pad = torch.nn.functional.pad(tw, (1, 1))
+    dil = pad[:, :-2] + pad[:, 1:-1] + pad[:, 2:]
+    want_ce = (1e-3 / 5 * scenes.LOSS_EPOCH / 10) * (dil * torch.log(sw + 1e-8)).sum(1).mean()
+    assert abs(float(thick["cross_entropy_l"]) - float(want_ce)) <= 1e-6 * abs(float(want_ce)) + 1e-12
+    static = loss_fn({k: res[k] for k in ("rgb_fine", "rgb_coarse", "depth_fine", "depth_coarse")}, targets,
+                     epoch=0, output_transient_flow=[])
+    assert sorted(static) == ["col_l", "disp_l"]
+
+
+def test_depth_loss_and_ndc2world_properties():
+    g = torch.Generator().manual_seed(3)
+    d, disp = torch.rand(64, generator=g), torch.rand(64, generator=g) + 0.1
+    a = shiftscale_invariant_depthloss(d, disp)
+    b = shiftscale_invariant_depthloss(3 * d + 2, 5 * disp + 1)           # invariance to shift/scale of both
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    K = scenes.camera_buffers()[0][0]
+    ndc = torch.rand(7, 3, generator=g) * torch.tensor([2.0, 2.0, 1.9]) - 1
+    w2 = ndc2world(ndc, K)
+    w3 = ndc2world(ndc[:, None], K[None].expand(7, 3, 3))[:, 0]
+    assert torch.allclose(w2, w3, rtol=1e-6)
+    # forward NDC map (ray_utils.py:74-106 with near=1): x_ndc = -fx/cx * X/Z, z_ndc = 1 + 2/Z
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    back = torch.stack([-fx / cx * w2[:, 0] / w2[:, 2], -fy / cy * w2[:, 1] / w2[:, 2], 1 + 2 / w2[:, 2]], -1)
+    assert torch.allclose(back, ndc, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", scenes.LOSS_CASES)
+def test_training_step_matches_reference(name, precision, hip_lib, monkeypatch):
+    from test_gpu_parity import _Replay, _to_dev, DEV
+    A.set_precision(precision)
+    try:
+        cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+        _to_dev(models, emb)
+        draws = scenes.replay_draws(cfg, meta["draw_seed"])
+        kw = scenes.render_kwargs(cfg)
+        if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
+            replay = _Replay(cfg, draws)
+            import nsff_pl_amd.rendering as R
+            monkeypatch.setattr(R.torch, "rand", replay.rand)
+            monkeypatch.setattr(R.torch, "randn", replay.randn)
+        res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
+                            cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
+                            test_time=False, _zs_fine=torch.from_numpy(want["zs_fine"]), **kw)
+        monkeypatch.undo()
+        loss_fn, targets = _loss_module(name, DEV)
+        terms = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+        _check_terms({k: v.detach().cpu() for k, v in terms.items()}, name)
+        sum(terms.values()).backward()
+        torch.cuda.synchronize()
+        _check_grads(models, emb, name, "nsff_loss")
+    finally:
+        A.set_precision("f32")
+
+
+@pytest.mark.gpu
+def test_trainer_steps_reduce_the_loss(hip_lib):
+    """NSFFTrainer.step (train.py:178-198 + Adam): the first step reproduces the golden loss terms, and a few
+    steps on one fixed batch lower the objective."""
+    from test_gpu_parity import DEV
+    from nsff_pl_amd.training import NSFFTrainer
+    name = "g3_nsff_train"
+    A.set_precision("f16x3")
+    try:
+        cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+        Ks, Ps, _ = scenes.camera_buffers()
+        hp = dict(N_samples=cfg["N_samples"], N_importance=cfg["N_importance"], perturb=0, noise_std=0)
+        tr = NSFFTrainer(models, emb, scenes.N_FRAMES, hp, Ks, Ps, output_transient_flow=cfg["flow"]).to(DEV)
+        tr.on_train_epoch_start(scenes.LOSS_EPOCH)
+        batch = {k: v.to(DEV) for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+        batch["rays"] = rays.to(DEV)
+        before = {k: p.detach().clone() for k, p in enumerate(tr.params)}
+        logs = [tr.step(batch) for _ in range(8)]
+        torch.cuda.synchronize()
+        gold = _golden_terms(name)
+        for k, v in gold.items():                  # zs_fine is resampled here, so 1e-3 rather than TERM_RTOL
+            assert abs(float(logs[0][f"train/{k}"]) - v) <= 1e-3 * max(abs(v), 1e-6), (k, float(logs[0][f"train/{k}"]), v)
+        assert float(logs[-1]["train/loss"]) < float(logs[0]["train/loss"])
+        assert all(np.isfinite(float(l["train/loss"])) and np.isfinite(float(l["train/psnr"])) for l in logs)
+        assert any(not torch.equal(before[k], p.detach()) for k, p in enumerate(tr.params))
+        assert logs[0]["lr"] == 5e-4
+    finally:
+        A.set_precision("f32")
