@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x3_ra"],
                     help="arithmetic of the dense layers; both modes pass the same 1e-4 parity tests")
+    ap.add_argument("--workload", default="render", choices=["render", "train"],
+                    help="render = C2 (headline, default); train = C4: the same batch through NSFFTrainer.step "
+                         "(HIP forward, NeRFWLoss, backward, flat RCCL gradient all-reduce, Adam)")
     ap.add_argument("--tile-points", type=int, default=int(os.environ.get("NSFF_TILE_POINTS", "0")))
     args = ap.parse_args()
 
@@ -105,7 +108,19 @@ def main():
     rays, ts = rays.to(device), ts.to(device)
     kw = scenes.render_kwargs(cfg)
 
+    trainer = None
+    if args.workload == "train":
+        from nsff_pl_amd.training import NSFFTrainer
+        Ks, Ps, _ = scenes.camera_buffers()
+        trainer = NSFFTrainer(models, emb, scenes.N_FRAMES, dict(N_samples=N_SAMPLES, N_importance=N_IMPORTANCE),
+                              Ks, Ps, output_transient_flow=cfg["flow"]).to(device)
+        trainer.on_train_epoch_start(0)
+        batch = {k: v.to(device) for k, v in scenes.synthetic_targets(N_RAYS, ts.cpu(), 100 + rank).items()}
+        batch["rays"] = rays
+
     def step():
+        if trainer is not None:
+            return trainer.step(batch)
         out = A.render_rays(models, emb, rays, ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
                             N_IMPORTANCE, 1024 * 32, test_time=False, **kw)
         if world > 1:
@@ -143,7 +158,7 @@ def main():
         except Exception:
             traffic = None
         line = {
-            "metric": "ray-samples/sec (coarse+fine, static+dynamic)",
+            "metric": "ray-samples/sec (coarse+fine, static+dynamic)" + (" -- TRAINING step" if trainer else ""),
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -166,6 +181,12 @@ def main():
                          "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
                          "flop_per_launch": kernel_flops / max(launches, 1)},
         }
+        if trainer is not None:
+            line["config"]["workload"] = ("C4 (BASELINE.json configs[3]) per GPU: the C2 batch through one training step = "
+                                          "HIP forward + NeRFWLoss (11 terms) + backward (torch/rocBLAS re-evaluation) + "
+                                          "flat RCCL gradient all-reduce + Adam")
+            line["config"]["parallelism"] = f"data-parallel x{world}, one flat gradient all-reduce per step"
+            line["config"].pop("mlp_tflops_whole_step")
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -191,6 +191,37 @@ typedef struct NsffCompositeArgs {
 
 int nsff_composite(const NsffCompositeArgs* args, void* stream);
 
+/* ---- N2: time interpolation of two test-time renders (reference models/rendering.py:365-460 with
+ * models/softsplat.py:6-44,303-326 'average' splatting).  The S sample planes of a frame are splatted by ONE
+ * launch (the reference: 2*S cupy launches with host round trips) into a per-pixel, per-plane accumulator
+ *     accum[(pixel*S + s)*8 + c],  c = r*1, g*1, b*1, a*1 (bilinear-weighted sums), 4 = sum of weights, 5..7 unused
+ * with hardware fp32 atomic adds; nsff_mpi_composite normalises (zeros -> 1) and composites front to back. ---- */
+typedef struct NsffSplatArgs {
+    int32_t H, W, n_planes;     /* n_planes = S = samples per ray (xyzs_fine.shape[1])                      */
+    float   K4[4];              /* fx, fy, cx, cy (ndc2world, datasets/ray_utils.py:127-151)                 */
+    float   P[12];              /* row-major (3,4) K @ w2c with rows 1,2 of w2c negated (rendering.py:390-394) */
+    float   scale;              /* dt for the forward splat of frame t, 1-dt for the backward splat of t+1  */
+    const float* xyz;           /* (H*W, S, 3) NDC sample points (xyzs_fine)                                 */
+    const float* flow;          /* (H*W, S, 3) transient_flows_fw of t  /  transient_flows_bw of t+1         */
+    const float* rgb;           /* (H*W, S, 3) transient_rgbs_fine                                           */
+    const float* alpha;         /* (H*W, S)    transient_alphas_fine                                         */
+    float*       accum;         /* (H*W, S, 8) OUT; cleared by this call                                     */
+} NsffSplatArgs;
+int nsff_splat_planes(const NsffSplatArgs* args, void* stream);
+
+typedef struct NsffMpiArgs {
+    int32_t H, W, n_planes;
+    float   dt;
+    const float* accum_fw;      /* nsff_splat_planes of (t, flows_fw, dt)                                    */
+    const float* accum_bw;      /* nsff_splat_planes of (t+1, flows_bw, 1-dt)                                */
+    const float* static_rgb;    /* (H*W, S, 3) static_rgbs_fine of t                                         */
+    const float* static_alpha;  /* (H*W, S)    static_alphas_fine of t                                       */
+    const float* zs;            /* (H*W, S)    zs_fine of t                                                  */
+    float* rgb;                 /* (H*W, 3) OUT                                                              */
+    float* depth;               /* (H*W)    OUT (NDC)                                                        */
+} NsffMpiArgs;
+int nsff_mpi_composite(const NsffMpiArgs* args, void* stream);
+
 /* ---- profiling hooks used by bench.py (HIP events around field-query launches) ---- */
 int nsff_prof_enable(int on);
 /* Synchronises the recorded events; returns launches, summed milliseconds and summed

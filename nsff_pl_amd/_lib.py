@@ -66,6 +66,18 @@ class CompositeArgs(C.Structure):
                 + [(n, _fp) for n in _COMPOSITE_PTRS_OUT])
 
 
+class SplatArgs(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("n_planes", C.c_int32), ("K4", C.c_float * 4),
+                ("P", C.c_float * 12), ("scale", C.c_float),
+                ("xyz", _fp), ("flow", _fp), ("rgb", _fp), ("alpha", _fp), ("accum", _fp)]
+
+
+class MpiArgs(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("n_planes", C.c_int32), ("dt", C.c_float),
+                ("accum_fw", _fp), ("accum_bw", _fp), ("static_rgb", _fp), ("static_alpha", _fp), ("zs", _fp),
+                ("rgb", _fp), ("depth", _fp)]
+
+
 # name -> (restype, argtypes); also the list of symbols the header declares
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
@@ -84,6 +96,8 @@ _SIGNATURES = {
     "nsff_composite": (C.c_int, [C.POINTER(CompositeArgs), _fp]),
     "nsff_frame_rays": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float,
                                   C.c_float, C.c_int64, C.c_int64, _fp, _fp]),
+    "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
+    "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
     "nsff_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -263,6 +277,21 @@ def frame_rays(K4, c2w12, H, W, near, shift_near, first, count, rays):
     m = (C.c_float * 12)(*[float(v) for v in c2w12])
     _check(load().nsff_frame_rays(k, m, int(H), int(W), float(near), float(shift_near), int(first), int(count),
                                   _ptr(rays), _stream()), "nsff_frame_rays")
+
+
+def splat_planes(H, W, S, K4, P12, scale, xyz, flow, rgb, alpha, accum):
+    a = SplatArgs(H=int(H), W=int(W), n_planes=int(S), scale=float(scale), xyz=_ptr(xyz), flow=_ptr(flow),
+                  rgb=_ptr(rgb), alpha=_ptr(alpha), accum=_ptr(accum))
+    a.K4[:] = [float(v) for v in K4]
+    a.P[:] = [float(v) for v in P12]
+    _check(load().nsff_splat_planes(C.byref(a), _stream()), "nsff_splat_planes")
+
+
+def mpi_composite(H, W, S, dt, accum_fw, accum_bw, static_rgb, static_alpha, zs, rgb, depth):
+    a = MpiArgs(H=int(H), W=int(W), n_planes=int(S), dt=float(dt), accum_fw=_ptr(accum_fw), accum_bw=_ptr(accum_bw),
+                static_rgb=_ptr(static_rgb), static_alpha=_ptr(static_alpha), zs=_ptr(zs), rgb=_ptr(rgb),
+                depth=_ptr(depth))
+    _check(load().nsff_mpi_composite(C.byref(a), _stream()), "nsff_mpi_composite")
 
 
 def prof_enable(on):

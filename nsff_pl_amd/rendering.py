@@ -299,3 +299,6 @@ def render_rays(models,
                zs_fine=results['zs_fine'], view_dir=kwargs.get('view_dir', rays[:, 3:6]),
                t_embedded_override=kwargs.get('t_embedded'), a_embedded_override=kwargs.get('a_embedded'))
     return autograd.attach(results, models, embeddings, rays, ts, max_t, rec)
+
+
+from .interpolation import interpolate  # noqa: E402,F401  (`from models.rendering import render_rays, interpolate`, eval.py:11)

@@ -381,6 +381,84 @@ def frame_rays(K, c2w, H, W, near=1.0):
 
 
 # ------------------------------------------------------------------ helpers for callers
+def softsplat_average(inp, flow):
+    """FunctionSoftsplat(..., tenMetric=None, strType='average') for one image (models/softsplat.py:6-44,
+    303-326): forward bilinear splat of `inp` (C,h,w) plus a ones channel along `flow` (2,h,w) [x then y],
+    accumulated with += (atomicAdd there), then divided by the splatted ones (zeros -> 1).
+
+    The reference kernel is CUDA-only (cupy; the CPU branch raises NotImplementedError, softsplat.py:238-239),
+    so this function cannot be checked against a reference run: PARITY UNPINNED for the splat itself
+    (hand-derived known-answer cases in tests/test_interpolate.py)."""
+    C, h, w = inp.shape
+    src = np.concatenate([inp.astype(F), np.ones((1, h, w), F)], 0)
+    out = np.zeros((C + 1, h, w), F)
+    xs, ys = np.meshgrid(np.arange(w, dtype=F), np.arange(h, dtype=F))
+    ox, oy = (xs + flow[0].astype(F)).astype(F), (ys + flow[1].astype(F)).astype(F)
+    with np.errstate(invalid="ignore"):
+        fx, fy = np.floor(ox), np.floor(oy)
+    ok = np.isfinite(fx) & np.isfinite(fy) & (np.abs(fx) < 2 ** 30) & (np.abs(fy) < 2 ** 30)
+    nwx, nwy = np.where(ok, fx, -5).astype(np.int64), np.where(ok, fy, -5).astype(np.int64)
+    sex, sey = (nwx + 1).astype(F), (nwy + 1).astype(F)
+    corners = [(nwx, nwy, (sex - ox) * (sey - oy)), (nwx + 1, nwy, (ox - nwx.astype(F)) * (sey - oy)),
+               (nwx, nwy + 1, (sex - ox) * (oy - nwy.astype(F))), (nwx + 1, nwy + 1, (ox - nwx.astype(F)) * (oy - nwy.astype(F)))]
+    for cx, cy, wgt in corners:
+        m = (cx >= 0) & (cx < w) & (cy >= 0) & (cy < h)
+        for c in range(C + 1):
+            np.add.at(out[c], (cy[m], cx[m]), (src[c][m] * wgt[m].astype(F)).astype(F))
+    norm = out[-1:].copy()
+    norm[norm == 0] = 1
+    return (out[:-1] / norm).astype(F)
+
+
+def interpolate(results_t, results_tp1, dt, K, c2w, img_wh):
+    """models/rendering.py:365-460: time interpolation t -> t+dt by per-plane flow splatting + front-to-back
+    MPI compositing.  results_*: dicts of numpy arrays (test-time render_rays outputs with flows).
+    Returns (h,w,3) rgb and (h,w) NDC depth."""
+    w, h = img_wh
+    dt = F(dt)
+    xyzs = results_t["xyzs_fine"].astype(F)
+    n, S = xyzs.shape[:2]
+    pose = np.eye(4, dtype=F)
+    pose[:3] = c2w
+    w2c = np.linalg.inv(pose)[:3].astype(F)
+    w2c[1:] *= -1
+    P = (np.asarray(K, F) @ w2c).astype(F)
+    gx, gy = np.meshgrid(np.arange(w, dtype=F), np.arange(h, dtype=F))
+
+    def plane_flows(flow, scale):
+        pw = ndc_to_world(xyzs.reshape(-1, 3), K)
+        qw = ndc_to_world((xyzs + flow.astype(F)).reshape(-1, 3), K)
+        qw = (pw + scale * (qw - pw)).astype(F)
+        uvd = (P[:, :3] @ qw.T + P[:, 3:]).astype(F)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            uv = (uvd[:2] / uvd[2]).astype(F).reshape(2, h, w, S)
+        return np.stack([uv[0] - gx[..., None], uv[1] - gy[..., None]], 0)          # (2,h,w,S)
+
+    of_fw = plane_flows(results_t["transient_flows_fw"], dt)
+    of_bw = plane_flows(results_tp1["transient_flows_bw"], F(1) - dt)
+    zs = results_t["zs_fine"].reshape(h, w, S).astype(F)
+    s_rgb = results_t["static_rgbs_fine"].reshape(h, w, S, 3).astype(F)
+    s_a = results_t["static_alphas_fine"].reshape(h, w, S, 1).astype(F)
+
+    def rgba_planes(res):
+        rgb = res["transient_rgbs_fine"].reshape(h, w, S, 3)
+        a = res["transient_alphas_fine"].reshape(h, w, S, 1)
+        return np.concatenate([rgb, a], -1).astype(F).transpose(2, 3, 0, 1)           # (S,4,h,w)
+    src_t, src_tp1 = rgba_planes(results_t), rgba_planes(results_tp1)
+
+    rgba = np.zeros((h, w, 4), F)
+    depth = np.zeros((h, w), F)
+    for s in range(S):
+        fw = softsplat_average(src_t[s], of_fw[..., s]).transpose(1, 2, 0)
+        bw = softsplat_average(src_tp1[s], of_bw[..., s]).transpose(1, 2, 0)
+        c_rgb = fw[..., :3] * fw[..., 3:] * (F(1) - dt) + bw[..., :3] * bw[..., 3:] * dt + s_rgb[:, :, s] * s_a[:, :, s]
+        c_a = F(1) - (F(1) - (fw[..., 3:] * (F(1) - dt) + bw[..., 3:] * dt)) * (F(1) - s_a[:, :, s])
+        rgba[..., :3] += (F(1) - rgba[..., 3:]) * c_rgb
+        depth += (F(1) - rgba[..., 3]) * c_a[..., 0] * zs[..., s]
+        rgba[..., 3:] += (F(1) - rgba[..., 3:]) * c_a
+    return rgba[..., :3].astype(F), depth.astype(F)
+
+
 def field_from_module(module):
     """Describe a NeRF nn.Module (reference's or the build's: same attribute names)."""
     params = {k: v.detach().cpu().numpy().astype(F) for k, v in module.state_dict().items()}

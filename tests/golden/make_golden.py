@@ -32,7 +32,7 @@ def import_reference():
     sys.path.insert(0, REF)
     kornia = types.ModuleType("kornia")
 
-    def create_meshgrid(H, W, normalized_coordinates=False):      # functional stand-in used only for ray-gen goldens
+    def create_meshgrid(H, W, normalized_coordinates=False, device=None):   # functional stand-in (ray-gen / interpolate goldens)
         ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
         return torch.stack([xs, ys], -1)[None]
     kornia.create_meshgrid = create_meshgrid
@@ -247,6 +247,41 @@ def main():
     stage["rays/ndc"] = torch.cat([ro, rd], 1).numpy()
     assert np.abs(orc.frame_rays(K.numpy(), c2w.numpy(), H, W) - stage["rays/ndc"]).max() < 1e-5
     np.savez_compressed(os.path.join(HERE, "g8_stages.npz"), **stage)
+
+    # ---- N2: interpolate (rendering.py:365-460) on that frame.  The reference's splat is a cupy/CUDA kernel that
+    # cannot run here, so FunctionSoftsplat is stood in by the oracle's restatement of it: this golden pins the
+    # projection / optical-flow / MPI-compositing code of the reference, NOT the splat (known-answer tests do). ----
+    import models.rendering as R
+
+    def splat_stub(tenInput, tenFlow, tenMetric, strType):
+        assert tenMetric is None and strType == "average" and tenInput.shape[0] == 1
+        return torch.from_numpy(orc.softsplat_average(tenInput[0].numpy(), tenFlow[0].numpy()))[None]
+    R.FunctionSoftsplat = splat_stub
+    cfg = dict(scenes.INTERP_CFG, n_rays=H * W)
+    models, embeddings = scenes.build_scene(NeRF, PosEmbedding, cfg)
+    frame_rays_ = torch.from_numpy(stage["rays/ndc"])
+    both = []
+    for t in (scenes.INTERP_T, scenes.INTERP_T + 1):
+        both.append(render_rays(models, embeddings, frame_rays_, torch.full((H * W,), t), scenes.N_FRAMES - 1,
+                                cfg["N_samples"], 0, 0, cfg["N_importance"], 1024 * 32, test_time=True,
+                                **scenes.render_kwargs(cfg)))
+    g11 = {"weight_checksum": np.array(scenes.weight_checksum(models, embeddings))}
+    for k in scenes.INTERP_KEYS_T:
+        g11["t/" + k] = both[0][k].numpy()
+    for k in scenes.INTERP_KEYS_TP1:
+        g11["tp1/" + k] = both[1][k].numpy()
+    cuda_orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for dt in scenes.INTERP_DTS:
+            img, dep = R.interpolate(both[0], both[1], dt, K, c2w, (W, H))
+            g11[f"out/rgb_{dt}"], g11[f"out/depth_{dt}"] = img.numpy(), dep.numpy()
+            o_img, o_dep = orc.interpolate(to_np(both[0]), to_np(both[1]), dt, K.numpy(), c2w.numpy(), (W, H))
+            print(f"interpolate dt={dt}: oracle vs reference(+splat stub) rgb {np.abs(o_img - img.numpy()).max():.2e} "
+                  f"depth {np.abs(o_dep - dep.numpy()).max():.2e}; rgb range {img.min():.3f}..{img.max():.3f}")
+    finally:
+        torch.Tensor.cuda = cuda_orig
+    np.savez_compressed(os.path.join(HERE, "g11_interpolate.npz"), **g11)
     print("g8_stages written;", "oracle worst", f"{worst:.2e}")
 
 

@@ -238,3 +238,12 @@ def synthetic_targets(n_rays, ts, seed):
                 ts=ts, cam_ids=torch.zeros(n_rays, dtype=torch.long),
                 uv_fw=torch.rand(n_rays, 2, generator=g) * torch.tensor([512.0, 288.0]),
                 uv_bw=torch.rand(n_rays, 2, generator=g) * torch.tensor([512.0, 288.0]))
+
+
+# ---- N2: time interpolation (reference rendering.py:365-460) on the small N3 frame ----
+INTERP_CFG = dict(N_samples=16, N_importance=16, transient=True, viewdir=False, appearance=False,
+                  test_time=True, flow=['fw', 'bw'], gain=2.5, seed=11)
+INTERP_T, INTERP_DTS = 7, (0.3, 0.75)
+INTERP_KEYS_T = ("xyzs_fine", "zs_fine", "static_rgbs_fine", "static_alphas_fine", "transient_flows_fw",
+                 "transient_rgbs_fine", "transient_alphas_fine")
+INTERP_KEYS_TP1 = ("transient_flows_bw", "transient_rgbs_fine", "transient_alphas_fine")

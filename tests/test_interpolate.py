@@ -1,0 +1,154 @@
+"""Time interpolation: oracle and HIP `interpolate` against the reference's
+rendering.py:365-460 (golden G11) and hand-derived splat cases.
+
+The reference's splat kernel (models/softsplat.py, cupy/CUDA) cannot run in the build container; the golden was
+produced by the reference's `interpolate` with the oracle's splat standing in for it, so G11 pins the projection,
+plane optical flow and MPI compositing; the splat itself is pinned by the known-answer cases below.
+"""
+import numpy as np
+import pytest
+import torch
+
+import common
+import parity
+import scenes
+import nsff_pl_amd as A
+from oracle import nsff_oracle as orc
+
+
+def _golden():
+    z = np.load(common.GOLDEN_DIR + "/g11_interpolate.npz")
+    st = np.load(common.GOLDEN_DIR + "/g8_stages.npz")
+    H, W = [int(v) for v in st["rays/HW"]]
+    res_t = {k[2:]: z[k] for k in z.files if k.startswith("t/")}
+    res_tp1 = {k[4:]: z[k] for k in z.files if k.startswith("tp1/")}
+    outs = {dt: (z[f"out/rgb_{dt}"], z[f"out/depth_{dt}"]) for dt in scenes.INTERP_DTS}
+    return res_t, res_tp1, st["rays/K"], st["rays/c2w"], (W, H), outs, st["rays/ndc"], float(z["weight_checksum"])
+
+
+# ---- known-answer cases of the 'average' forward splat (softsplat.py:12-43, 307-326) ----
+def test_splat_integer_shift_moves_pixels():
+    inp = np.arange(24, dtype=np.float32).reshape(2, 3, 4) + 1
+    flow = np.zeros((2, 3, 4), np.float32)
+    flow[0], flow[1] = 1, -1                                       # one pixel right, one up
+    out = orc.softsplat_average(inp, flow)
+    want = np.zeros_like(inp)
+    want[:, :2, 1:] = inp[:, 1:, :3]
+    assert np.array_equal(out, want)                                # vacated / never-hit pixels stay 0 (norm 0 -> 1)
+
+
+def test_splat_half_pixel_averages_neighbours():
+    inp = np.array([[[2.0, 4.0, 8.0, 16.0]]], np.float32)
+    flow = np.zeros((2, 1, 4), np.float32)
+    flow[0] = 0.5
+    out = orc.softsplat_average(inp, flow)
+    # target x: 0.5*src[x-1] + 0.5*src[x] over weight 1 (interior), 0.5*src[0]/0.5 at x=0; the last source's
+    # east half falls outside and is dropped
+    assert np.allclose(out, [[[2.0, 3.0, 6.0, 12.0]]], rtol=1e-6)
+
+
+def test_splat_collision_is_weighted_average_and_bounds_are_dropped():
+    inp = np.array([[[1.0, 5.0, 9.0]]], np.float32)
+    flow = np.zeros((2, 1, 3), np.float32)
+    flow[0] = [1.0, 0.0, -7.0]                                      # 0 -> 1 (collides with 1), 2 -> outside
+    out = orc.softsplat_average(inp, flow)
+    assert np.allclose(out, [[[0.0, 3.0, 0.0]]])
+    flow[0] = [np.nan, 0.0, 1e30]
+    with np.errstate(all="ignore"):
+        out = orc.softsplat_average(inp, flow)
+    assert np.allclose(out, [[[0.0, 5.0, 0.0]]])
+
+
+def test_splat_bilinear_weights_sum_to_one():
+    rng = np.random.RandomState(0)
+    inp = np.ones((1, 9, 11), np.float32)
+    flow = rng.uniform(-0.9, 0.9, (2, 9, 11)).astype(np.float32)
+    out = orc.softsplat_average(inp, flow)
+    assert np.all((np.abs(out - 1) < 1e-5) | (out == 0))            # average of ones is one wherever anything landed
+
+
+def test_oracle_interpolate_matches_reference_golden():
+    res_t, res_tp1, K, c2w, wh, outs, _, _ = _golden()
+    for dt, (rgb, depth) in outs.items():
+        o_rgb, o_depth = orc.interpolate(res_t, res_tp1, dt, K, c2w, wh)
+        parity.assert_close(f"rgb dt={dt}", o_rgb, rgb, parity.RTOL)
+        parity.assert_close(f"depth dt={dt}", o_depth, depth, parity.RTOL)
+    flow_px = np.abs(res_t["transient_flows_fw"]).max() * wh[0] / 2
+    assert flow_px > 1.0                                            # the case really moves samples across pixels
+
+
+def test_interpolate_needs_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    res_t, res_tp1, K, c2w, wh, *_ = _golden()
+    with pytest.raises(RuntimeError):
+        A.interpolate({k: torch.from_numpy(v) for k, v in res_t.items()},
+                      {k: torch.from_numpy(v) for k, v in res_tp1.items()}, 0.3, K, c2w, wh)
+
+
+# ---- HIP path ----
+@pytest.mark.gpu
+def test_hip_interpolate_matches_reference_golden(hip_lib):
+    res_t, res_tp1, K, c2w, wh, outs, _, _ = _golden()
+    dev = torch.device("cuda:0")
+    rt = {k: torch.from_numpy(v).to(dev) for k, v in res_t.items()}
+    rt1 = {k: torch.from_numpy(v).to(dev) for k, v in res_tp1.items()}
+    for dt, (rgb, depth) in outs.items():
+        g_rgb, g_depth = A.interpolate(rt, rt1, dt, torch.from_numpy(K), torch.from_numpy(c2w), wh)
+        assert g_rgb.shape == (wh[1], wh[0], 3) and g_depth.shape == (wh[1], wh[0])
+        parity.assert_close(f"rgb dt={dt}", g_rgb.cpu().numpy(), rgb, parity.RTOL)
+        parity.assert_close(f"depth dt={dt}", g_depth.cpu().numpy(), depth, parity.RTOL)
+    # CPU tensors (what eval.f of the reference hands over, eval.py:101-104) are accepted and moved
+    c_rgb, _ = A.interpolate({k: torch.from_numpy(v) for k, v in res_t.items()},
+                             {k: torch.from_numpy(v) for k, v in res_tp1.items()}, 0.3, K, c2w, wh)
+    parity.assert_close("rgb from cpu dicts", c_rgb.cpu().numpy(), outs[0.3][0], parity.RTOL)
+
+
+@pytest.mark.gpu
+def test_hip_splat_against_oracle_random_and_degenerate_flows(hip_lib):
+    """nsff_splat_planes + nsff_mpi_composite on crafted inputs: huge / NaN / out-of-frame flows, all-transparent
+    planes, dt at the ends of (0,1)."""
+    res_t, res_tp1, K, c2w, wh, *_ = _golden()
+    rng = np.random.RandomState(5)
+    res_t, res_tp1 = dict(res_t), dict(res_tp1)
+    f = res_t["transient_flows_fw"].copy()
+    # in-plane flows only: scaling the z flow too pushes points through the NDC far plane (z -> 1), where the
+    # projection w = 2/(z-1-eps) is ill-conditioned and 1-ulp differences move samples by pixels
+    f[..., :2] *= rng.choice([0.0, 1.0, 8.0, -30.0], size=f.shape[:2] + (1,)).astype(np.float32)
+    f[3, 5] = np.nan
+    f[10, 2] = 1e30
+    res_t["transient_flows_fw"] = f
+    res_tp1["transient_alphas_fine"] = res_tp1["transient_alphas_fine"] * (rng.rand(*res_tp1["transient_alphas_fine"].shape) > 0.5)
+    res_t["static_alphas_fine"] = np.zeros_like(res_t["static_alphas_fine"])
+    dev = torch.device("cuda:0")
+    for dt in (1e-3, 0.5, 0.999):
+        with np.errstate(all="ignore"):
+            o_rgb, o_depth = orc.interpolate(res_t, res_tp1, dt, K, c2w, wh)
+        g_rgb, g_depth = A.interpolate({k: torch.from_numpy(v).to(dev) for k, v in res_t.items()},
+                                       {k: torch.from_numpy(v).to(dev) for k, v in res_tp1.items()}, dt, K, c2w, wh)
+        parity.assert_close(f"rgb dt={dt}", g_rgb.cpu().numpy(), o_rgb, parity.RTOL)
+        parity.assert_close(f"depth dt={dt}", g_depth.cpu().numpy(), o_depth, parity.RTOL)
+
+
+@pytest.mark.gpu
+def test_hip_render_then_interpolate_end_to_end(hip_lib):
+    """eval.py:199-213 on the device: render t and t+1 with the HIP path, interpolate, compare with the golden
+    (which went reference render -> reference interpolate)."""
+    from test_gpu_parity import _to_dev, DEV
+    res_t, res_tp1, K, c2w, wh, outs, rays, checksum = _golden()
+    cfg = dict(scenes.INTERP_CFG, n_rays=wh[0] * wh[1])
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    assert abs(scenes.weight_checksum(models, emb) - checksum) <= 1e-9 * abs(checksum)
+    _to_dev(models, emb)
+    rays = torch.from_numpy(rays).to(DEV)
+    both = []
+    for t in (scenes.INTERP_T, scenes.INTERP_T + 1):
+        with torch.no_grad():
+            both.append(A.render_rays(models, emb, rays, torch.full((rays.shape[0],), t, device=DEV), scenes.N_FRAMES - 1,
+                                      cfg["N_samples"], 0, 0, cfg["N_importance"], 1024 * 32, test_time=True,
+                                      **scenes.render_kwargs(cfg)))
+    for dt, (rgb, depth) in outs.items():
+        g_rgb, g_depth = A.interpolate(both[0], both[1], dt, K, c2w, wh)
+        # sample_pdf conditioning moves a few fine depths (tests/parity.py), so pixels, not 1e-4: 1e-3 of the range
+        parity.assert_close(f"rgb dt={dt}", g_rgb.cpu().numpy(), rgb, 1e-3)
+        parity.assert_close(f"depth dt={dt}", g_depth.cpu().numpy(), depth, 1e-3)
