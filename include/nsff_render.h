@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      2
+#define NSFF_ABI_VERSION      3
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -109,6 +109,13 @@ typedef struct NsffFieldArgs {
     int32_t ld_emb;
     int32_t off_xyz, off_dir, off_a, off_t;  /* column offsets in x_emb, -1 = absent */
     float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
+    /* training forward (F16X3, input A, models without view directions): also keep what the backward
+     * pass needs, rounded to fp16.  P_pad = P rounded up to a multiple of 128; both may be NULL.
+     *   save_acts: (2*D+2, P_pad, 256) -- slot l = ReLU output of static layer l, slot D = static_xyz_encoding_final,
+     *              slots D+1.. the same for the transient trunk (unused slots are not written);
+     *   save_xin : (P_pad, 128) trunk input [xyz embedding (in_xyz) | 0.. | t embedding at column 64 | 0..]       */
+    void*   save_acts;
+    void*   save_xin;
 } NsffFieldArgs;
 
 int nsff_field_query(const NsffModelDesc* desc, const void* packed,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -43,7 +43,7 @@ class FieldArgs(C.Structure):
                 ("dir_emb", _fp), ("a_emb", _fp), ("t_emb", _fp),
                 ("x_emb", _fp), ("ld_emb", C.c_int32),
                 ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
-                ("off_t", C.c_int32), ("raw", _fp)]
+                ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp)]
 
 
 _COMPOSITE_PTRS_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "xyz_fw", "xyz_bw",
@@ -211,10 +211,10 @@ def posenc(x, freqs, out):
 
 def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
                 xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
-                x_emb=None, emb_offsets=(0, -1, -1, -1)):
+                x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, precision=None):
     from . import config
     desc = model_desc(model)
-    prec = config.precision_code(model)
+    prec = config.precision_code(model) if precision is None else precision
     packed = model.packed(prec)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()
@@ -233,6 +233,8 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     a.ld_emb = int(x_emb.shape[1]) if x_emb is not None else 0
     a.off_xyz, a.off_dir, a.off_a, a.off_t = [int(v) for v in emb_offsets]
     a.raw = _ptr(raw)
+    a.save_acts = None if save_acts is None else save_acts.data_ptr()
+    a.save_xin = None if save_xin is None else save_xin.data_ptr()
     _check(load().nsff_field_query(C.byref(desc), _ptr(packed), C.byref(a), _stream()), "nsff_field_query")
 
 

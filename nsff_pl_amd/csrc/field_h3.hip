@@ -44,7 +44,8 @@ struct H3Step {
     uint8_t pre;         // PRE_*: rebuild the LDS tile before this GEMM
     uint8_t post;        // POST_*: epilogue after this GEMM
     uint8_t head;        // HEAD_*: narrow heads evaluated on the stored activations
-    uint8_t pad[3];
+    uint8_t save;        // training forward: 1 + activation slot this epilogue also writes to HBM, 0 = none
+    uint8_t pad[2];
 };
 enum { PRE_NONE = 0, PRE_INPUT = 1, PRE_INPUT_T = 2, PRE_SIDE = 3 };
 enum { POST_NONE = 0, POST_RELU = 1, POST_LINEAR = 2 };
@@ -63,6 +64,9 @@ struct H3KArgs {
     const float* a_emb;
     const float* t_emb;
     float* raw;
+    _Float16* save_acts;       // training forward: (slots, P_pad, 256) fp16 post-activation values, or null
+    _Float16* save_xin;        // (P_pad, 128) fp16 trunk input [xyz embedding | pad | t | pad], or null
+    long long save_stride;     // halfs per slot = P_pad * 256
     long long n_points;
     int pts_per_ray;
     int static_mode, transient_mode;
@@ -200,8 +204,11 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const BiasRegs& b
         }
 }
 
+// `save` (or null): row p0 of this tile in an HBM activation slot [P_pad][256] fp16; the copy is rounded to
+// nearest (the hi plane in LDS is truncated -- harmless there because lo carries the rest, biased here).
 template <int NT, bool RELU>
-__device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[2][NT], int wave, int nt0, int lane) {
+__device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[2][NT], int wave, int nt0, int lane,
+                                          _Float16* save = nullptr) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -224,32 +231,49 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
                 lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
                 *reinterpret_cast<h4*>(sXh + idx) = hv;
                 *reinterpret_cast<h4*>(sXl + idx) = lv;
+                if (save != nullptr) {
+                    h4 sv;
+                    sv[0] = (_Float16)v[0]; sv[1] = (_Float16)v[1]; sv[2] = (_Float16)v[2]; sv[3] = (_Float16)v[3];
+                    *reinterpret_cast<h4*>(save + (long long)(32 * (nt0 + nt) + (lane & 31)) * NSFF_W
+                                           + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5)) = sv;
+                }
             }
 }
 
+__device__ __forceinline__ void split_store_save(_Float16* xh, _Float16* xl, int idx, float v, _Float16* save, int col) {
+    split_store(xh, xl, idx, v);
+    if (save != nullptr) save[col] = (_Float16)v;
+}
+
 template <int M, int THREADS>
-__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t) {
+__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
+                                            bool save_it = false) {
     constexpr int G = THREADS / M;               // threads per point row
     const int r = threadIdx.x % M, q = threadIdx.x / M;
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
     const int base = r * LDH;
     const int k0s = (int)a.L.k0s;
+    _Float16* sv = (save_it && a.save_xin != nullptr) ? a.save_xin + p * 128 : nullptr;   // rows < P_pad exist
     if (a.xyz != nullptr) {
         float x[3] = {0.f, 0.f, 0.f};
         if (valid) { x[0] = a.xyz[p * 3 + 0]; x[1] = a.xyz[p * 3 + 1]; x[2] = a.xyz[p * 3 + 2]; }
         if (q == 0) {
-            split_store(sXh, sXl, base + 0, x[0]); split_store(sXh, sXl, base + 1, x[1]);
-            split_store(sXh, sXl, base + 2, x[2]);
+            split_store_save(sXh, sXl, base + 0, x[0], sv, 0); split_store_save(sXh, sXl, base + 1, x[1], sv, 1);
+            split_store_save(sXh, sXl, base + 2, x[2], sv, 2);
             for (int c = a.in_xyz; c < k0s; ++c) { sXh[base + c] = (_Float16)0.f; sXl[base + c] = (_Float16)0.f; }
+            if (sv != nullptr) {
+                for (int c = a.in_xyz; c < 64; ++c) sv[c] = (_Float16)0.f;
+                if (!with_t) for (int c = 64; c < 128; ++c) sv[c] = (_Float16)0.f;
+            }
         }
         const int nf3 = 3 * a.n_freqs;
         for (int j = q; j < nf3; j += G) {
             const int f = j / 3, c = j - 3 * f;
             float s, co;
             sincosf(a.freqs[f] * x[c], &s, &co);
-            split_store(sXh, sXl, base + 3 + 6 * f + c, s);
-            split_store(sXh, sXl, base + 3 + 6 * f + 3 + c, co);
+            split_store_save(sXh, sXl, base + 3 + 6 * f + c, s, sv, 3 + 6 * f + c);
+            split_store_save(sXh, sXl, base + 3 + 6 * f + 3 + c, co, sv, 3 + 6 * f + 3 + c);
         }
     } else {
         const float* src = a.x_emb + p * a.ld_emb + a.off_xyz;
@@ -260,7 +284,8 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
         if (valid) src = (a.xyz != nullptr) ? a.t_emb + (p / a.pts_per_ray) * a.in_t
                                             : a.x_emb + p * a.ld_emb + a.off_t;
         const int kt = (int)a.L.kt;
-        for (int c = q; c < kt; c += G) split_store(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f);
+        for (int c = q; c < kt; c += G)
+            split_store_save(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f, sv, 64 + c);
     }
 }
 
@@ -347,7 +372,8 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
 //   <2,1>: 64 points, 2 workgroups per CU;  <4,1>: 128 points, 1 workgroup per CU, 1 wave per SIMD;
 //   <2,2>: 128 points, 8 waves (2 per SIMD): the two wave rows request identical weight lines back to
 //          back, so the L1 merges them and the L2 weight stream per FLOP is halved.
-template <int NT, int WM>
+// SAVE: training forward -- epilogues also write their activations (fp16) to HBM for the backward pass.
+template <int NT, int WM, bool SAVE = false>
 __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
     constexpr int M = 32 * NT * WM;
     constexpr int THREADS = 256 * WM;
@@ -387,7 +413,9 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
             if (st.pre == PRE_SIDE) build_side<M, THREADS>(sXh, sXl, a, p0);
-            else build_input<M, THREADS>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
+            else build_input<M, THREADS>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T,
+                                         SAVE && st.bias_off != NSFF_NONE &&
+                                             (st.pre == PRE_INPUT_T || a.transient_mode == 0));
             __syncthreads();
         }
         if (st.bias_off != NSFF_NONE) acc_init<NT>(acc, br);
@@ -399,8 +427,13 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
         }
         if (st.post != POST_NONE) {
             __syncthreads();
-            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, nt0, lane);
-            else acc_store<NT, false>(sXh, sXl, acc, wave, nt0, lane);
+            _Float16* sv = nullptr;
+            if constexpr (SAVE) {
+                if (st.save && a.save_acts != nullptr)
+                    sv = a.save_acts + (long long)(st.save - 1) * a.save_stride + p0 * NSFF_W;
+            }
+            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, nt0, lane, sv);
+            else acc_store<NT, false>(sXh, sXl, acc, wave, nt0, lane, sv);
             __syncthreads();
             if (st.head != HEAD_NONE) {
                 // static sigma reads the last trunk activation, before *_final (nerf.py:169);
@@ -569,6 +602,10 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.packed = reinterpret_cast<const uint32_t*>(packed);
     k.xyz = g.xyz; k.x_emb = g.x_emb; k.dir_emb = g.dir_emb; k.a_emb = g.a_emb; k.t_emb = g.t_emb;
     k.raw = g.raw; k.n_points = g.n_points; k.pts_per_ray = g.pts_per_ray;
+    k.save_acts = reinterpret_cast<_Float16*>(g.save_acts);
+    k.save_xin = reinterpret_cast<_Float16*>(g.save_xin);
+    k.save_stride = ((g.n_points + 127) / 128) * 128 * NSFF_W;
+    if ((g.save_acts || g.save_xin) && (d.use_viewdir || !g.xyz)) return NSFF_ERR_INVALID;
     k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
     k.D = d.D; k.skip = d.skip;
     k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;
@@ -579,28 +616,30 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
 
     // ---- step program (reference nerf.py:162-208) ----
     int n = 0;
-    auto push = [&](uint32_t w, uint32_t b, uint32_t kcols, int pre, int post, int head) {
+    auto push = [&](uint32_t w, uint32_t b, uint32_t kcols, int pre, int post, int head, int slot = -1) {
         H3Step& s = k.steps[n++];
         s.w_off = w; s.bias_off = b; s.nks = (uint16_t)(kcols / 16);
         s.pre = (uint8_t)pre; s.post = (uint8_t)post; s.head = (uint8_t)head;
+        s.save = (uint8_t)(slot + 1);
     };
-    auto trunk = [&](const NsffTrunkLayoutH3& T, int pre_kind, int last_head) {
+    // activation slots of the training forward: trunk layer l -> slot0 + l, *_final -> slot0 + D
+    auto trunk = [&](const NsffTrunkLayoutH3& T, int pre_kind, int last_head, int slot0) {
         for (int l = 0; l < d.D; ++l) {
             const int head = (l == d.D - 1) ? last_head : HEAD_NONE;
             if (l == 0) {
-                push(T.seg_x[0], T.bias[0], T.k0, pre_kind, POST_RELU, HEAD_NONE);
+                push(T.seg_x[0], T.bias[0], T.k0, pre_kind, POST_RELU, HEAD_NONE, slot0);
             } else if (l == d.skip) {
                 push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
-                push(T.seg_x[l], NSFF_NONE, T.k0, pre_kind, POST_RELU, head);
+                push(T.seg_x[l], NSFF_NONE, T.k0, pre_kind, POST_RELU, head, slot0 + l);
             } else {
-                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_RELU, head);
+                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_RELU, head, slot0 + l);
             }
         }
     };
     if (g.static_mode) {
-        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA);
+        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
         if (g.static_mode == 2) {
-            push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB);
+            push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB, d.D);
             if (d.use_viewdir) {
                 push(k.L.dir_h, k.L.dir_b, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
                 push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB);
@@ -609,13 +648,17 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     }
     k.n_static_steps = n;
     if (g.transient_mode) {
-        trunk(k.L.tr, PRE_INPUT_T, HEAD_NONE);
-        push(k.L.tr.final_w, k.L.tr.final_b, NSFF_W, PRE_NONE, POST_LINEAR, HEAD_T);
+        trunk(k.L.tr, PRE_INPUT_T, HEAD_NONE, d.D + 1);
+        push(k.L.tr.final_w, k.L.tr.final_b, NSFF_W, PRE_NONE, POST_LINEAR, HEAD_T, 2 * d.D + 1);
     }
     if (n > MAX_STEPS) return NSFF_ERR_INVALID;
     k.n_steps = n;
 
-    if (points_per_block == 64) {
+    if (k.save_acts || k.save_xin) {
+        const long long tiles = (g.n_points + 63) / 64;
+        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1, true>), dim3((unsigned)tiles), dim3(256), 0, st, k);
+    } else if (points_per_block == 64) {
         const long long tiles = (g.n_points + 63) / 64;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
         hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1>), dim3((unsigned)tiles), dim3(256), 0, st, k);

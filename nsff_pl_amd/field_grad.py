@@ -1,0 +1,211 @@
+"""Native field node of the backward graph (SURVEY.md 8f, row N1 -- second stage).
+
+``torch_path.render_pass`` expresses compositing / warping with torch ops; the field network inside it
+(PosEmbedding + NeRF.forward, reference models/nerf.py:17-30,118-213) is this ``autograd.Function``:
+
+* forward  = the gfx950 f16x3 field kernel in its *training* variant (``nsff_field_kernel_h3<2,1,true>``),
+  which also keeps every post-activation tensor of the trunks (fp16) and the encoded trunk input in HBM
+  -- 288 GB per GPU make keeping ~4.6 KB per point-trunk cheaper than any recomputation;
+* backward = fp16 tensor-core GEMMs with fp32 accumulation over those saved activations:
+  the data-gradient chain (dX = dY.W, ReLU masks, head derivatives, positional-encoding derivative) and
+  the weight gradients (dW = dY^T.X, K = all points).  Incoming gradients are multiplied by a power of two
+  so that their maximum sits at 2^10 (fp16 range), and divided out of the results.
+
+Only models without view directions take this path (the NSFF configuration, train.py:40-84 defaults);
+others keep the torch expression of :mod:`nsff_pl_amd.torch_path`.
+"""
+import os
+
+import torch
+
+from . import _lib, config
+
+_F16_MAX = 65504.0
+
+
+def enabled():
+    return os.environ.get("NSFF_NATIVE_BACKWARD", "1") != "0"
+
+
+def supported(model, xyz):
+    return enabled() and xyz.is_cuda and xyz.dtype == torch.float32 and not model.use_viewdir
+
+
+def _lin(m):
+    return m[0] if isinstance(m, torch.nn.Sequential) else m
+
+
+def _mm32(a16, b16):
+    """fp16 x fp16 -> fp32 (fp32 accumulate, fp32 result: a weight gradient summed over 1e5 points does not fit fp16)."""
+    try:
+        return torch.mm(a16, b16, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return torch.mm(a16.float(), b16.float())
+
+
+def _h(x):
+    if _MODE == "f32":
+        return x.float()
+    return x.clamp(-_F16_MAX, _F16_MAX).half()
+
+
+_WSPLIT = os.environ.get("NSFF_BWD_WSPLIT", "0") == "1"
+_XIN32 = os.environ.get("NSFF_BWD_XIN32", "0") == "1"
+_MODE = os.environ.get("NSFF_BWD_MODE", "rowscale")      # experiments: f32 | global | rowscale
+
+
+def _bmm(dpre16, w, out32=False):
+    """dX = dY . W with fp16 operands; optionally W = hi + lo (two products) and an fp32 result."""
+    w = w.detach()
+    if _MODE == "f32":
+        return dpre16.float() @ w
+    wh = w.half()
+    mm = _mm32 if out32 else torch.mm
+    out = mm(dpre16, wh)
+    if _WSPLIT:
+        out = out + mm(dpre16, (w - wh.float()).half())
+    return out
+
+
+class _FieldFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, xyz, t_rows, *params):
+        model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
+        static, transient = cfg["static"], cfg["transient"]
+        P, D = xyz.shape[0], model.D
+        p_pad = (P + 127) // 128 * 128
+        raw = torch.zeros(P, _lib.RAW_STRIDE, device=xyz.device)
+        acts = torch.empty(2 * D + 2, p_pad, 256, device=xyz.device, dtype=torch.float16)
+        xin = torch.empty(p_pad, 128, device=xyz.device, dtype=torch.float16)
+        xyz_c = xyz.detach().contiguous()
+        _lib.field_query(model, raw, P, s, 2 if static else 0, 2 if transient else 0,
+                         2 if (transient and model.output_flow) else 0, xyz=xyz_c, freqs=freqs,
+                         t_emb=None if t_rows is None else t_rows.detach().contiguous(),
+                         save_acts=acts, save_xin=xin, precision=config.PRECISIONS["f16x3"])
+        ctx.cfg, ctx.P = cfg, P
+        ctx.save_for_backward(raw, acts, xin, xyz_c, *params)
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        cfg = ctx.cfg
+        model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
+        raw, acts, xin, xyz = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
+        P, D, skip = ctx.P, model.D, model.skips[0]
+        names = [id(p) for p in _lib.param_list(model)]
+        grads = [None] * len(params)
+        slot = {k: i for i, k in enumerate(names)}
+
+        if _MODE == "rowscale":
+            # block floating point per point: every row of d_raw is normalised to max 2^10; the inverse scale is
+            # folded into the activation operand of the weight-gradient GEMMs, centred on the median exponent
+            amax = d_raw.abs().amax(1, keepdim=True).clamp_min(1e-30)
+            scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)))                  # (P,1)
+            ref = torch.median(scale)
+            scale = torch.minimum(scale, ref * 4096.0)                                   # act * ref/scale stays >= 2^-12 act
+            scale = torch.maximum(scale, ref / 1024.0)                                   # ... and <= 2^10 act
+            d = d_raw * scale
+            inv = 1.0 / scale
+            rel = (ref * inv)                                                            # (P,1) exact powers of two
+            inv_ref = 1.0 / ref
+
+            def put(layer, dpre16, inp16):
+                grads[slot[id(layer.weight)]] = _mm32(dpre16.t(), (inp16.float() * rel).half()) * inv_ref
+                grads[slot[id(layer.bias)]] = (dpre16.float() * inv).sum(0)
+        else:
+            amax = d_raw.abs().max().clamp_min(1e-30)
+            scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax))) if _MODE != "f32" else torch.ones_like(amax)
+            d = d_raw * scale
+            inv = 1.0 / scale
+
+            def put(layer, dpre16, inp16):
+                if _MODE == "f32":
+                    grads[slot[id(layer.weight)]] = dpre16.float().t() @ inp16.float() * inv
+                else:
+                    grads[slot[id(layer.weight)]] = _mm32(dpre16.t(), inp16) * inv
+                grads[slot[id(layer.bias)]] = dpre16.sum(0, dtype=torch.float32) * inv
+
+        def trunk(prefix, slot0, dh, in_t):
+            """dh: (P,256) fp16 gradient w.r.t. the last trunk activation.  Returns d(trunk input) (P, 63+in_t) fp32-ish."""
+            x_in = xin[:P, :model.in_channels_xyz] if in_t == 0 else \
+                torch.cat([xin[:P, :model.in_channels_xyz], xin[:P, 64:64 + in_t]], 1)
+            n_in = x_in.shape[1]
+            d_x = None
+            for l in range(D - 1, -1, -1):
+                layer = _lin(getattr(model, f"{prefix}_xyz_encoding_{l + 1}"))
+                dpre = dh * (acts[slot0 + l, :P] > 0).to(dh.dtype)
+                w = layer.weight
+                if l == 0:
+                    put(layer, dpre, x_in)
+                    d0 = _bmm(dpre, w, _XIN32)
+                    d_x = d0 if d_x is None else d_x + d0
+                elif l == skip:
+                    put(layer, dpre, torch.cat([x_in, acts[slot0 + l - 1, :P]], 1))
+                    d_x = _bmm(dpre, w[:, :n_in], _XIN32)
+                    dh = _h(_bmm(dpre, w[:, n_in:]))
+                else:
+                    put(layer, dpre, acts[slot0 + l - 1, :P])
+                    dh = _h(_bmm(dpre, w))
+            return d_x
+
+        d_xin = None
+        if cfg["static"]:
+            y = raw[:, 0:3]
+            dp_rgb = _h(d[:, 0:3] * y * (1 - y))
+            dp_sig = _h(d[:, 3:4])
+            feat, h_last = acts[D, :P], acts[D - 1, :P]
+            rgb, sig, fin = _lin(model.static_rgb), _lin(model.static_sigma), _lin(model.static_xyz_encoding_final)
+            put(rgb, dp_rgb, feat)
+            put(sig, dp_sig, h_last)
+            d_feat = _h(_bmm(dp_rgb, rgb.weight))
+            put(fin, d_feat, h_last)
+            dh = _h(_bmm(d_feat, fin.weight) + _bmm(dp_sig, sig.weight))
+            d_xs = trunk("static", 0, dh, 0)
+            if ctx.needs_input_grad[1]:                                 # (never the case inside render_pass)
+                d_xin = d_xs
+        if cfg["transient"]:
+            fs = getattr(model, "flow_scale", 0.0)
+            y = raw[:, 4:7]
+            heads = [(_lin(model.transient_rgb), _h(d[:, 4:7] * y * (1 - y))),
+                     (_lin(model.transient_sigma), _h(d[:, 7:8]))]
+            if model.output_flow:
+                for name, c0 in (("transient_flow_fw", 8), ("transient_flow_bw", 11)):
+                    yf = raw[:, c0:c0 + 3]
+                    heads.append((_lin(getattr(model, name)), _h(d[:, c0:c0 + 3] * (fs - yf * yf / fs))))
+            feat, h_last = acts[2 * D + 1, :P], acts[2 * D, :P]
+            d_feat = None
+            for layer, dp in heads:
+                put(layer, dp, feat)
+                term = _bmm(dp, layer.weight)
+                d_feat = term if d_feat is None else d_feat + term
+            d_feat = _h(d_feat)
+            fin = _lin(model.transient_xyz_encoding_final)
+            put(fin, d_feat, h_last)
+            dh = _h(_bmm(d_feat, fin.weight))
+            d_xt = trunk("transient", D + 1, dh, model.in_channels_t).float()
+            n_xyz = model.in_channels_xyz
+            if ctx.needs_input_grad[2]:
+                d_t_rows = d_xt[:, n_xyz:] * inv
+            d_xin = d_xt[:, :n_xyz] if d_xin is None else d_xin.float() + d_xt[:, :n_xyz]
+
+        d_xyz = d_t = None
+        if d_xin is not None:
+            d_xin = d_xin.float() * inv
+            n_xyz = model.in_channels_xyz
+            if cfg["transient"] and ctx.needs_input_grad[2]:
+                d_t = d_t_rows.reshape(P // s, s, -1).sum(1)
+            if ctx.needs_input_grad[1]:
+                de = d_xin[:, :n_xyz]
+                d_xyz = de[:, 0:3].clone()
+                for i, f in enumerate(freqs):
+                    ang = f * xyz
+                    d_xyz += f * (torch.cos(ang) * de[:, 3 + 6 * i:6 + 6 * i] - torch.sin(ang) * de[:, 6 + 6 * i:9 + 6 * i])
+        return (None, d_xyz, d_t) + tuple(grads)
+
+
+def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient):
+    """Differentiable field query on raw points: returns the (P,16) raw record (layout of include/nsff_render.h)."""
+    cfg = dict(model=model, freqs=[float(f) for f in freqs], pts_per_ray=int(pts_per_ray), static=bool(static),
+               transient=bool(transient))
+    return _FieldFn.apply(cfg, xyz, t_rows, *_lib.param_list(model))

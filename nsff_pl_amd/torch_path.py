@@ -64,6 +64,27 @@ def field(model, emb_xyz, dir_rows, a_rows, t_rows, static=True, transient=True,
     return out
 
 
+def query(model, xyz, freqs_xyz, dir_embedded, a_embedded, t_embedded, s, static, transient, flows):
+    """Field outputs for (P,3) points, `s` consecutive points per ray.  On the GPU (models without view
+    directions) this is the native node of :mod:`nsff_pl_amd.field_grad`; otherwise the torch expression."""
+    from . import field_grad
+    if field_grad.supported(model, xyz):
+        raw = field_grad.field(model, xyz, freqs_xyz, t_embedded if transient else None, s, static, transient)
+        out = {}
+        if static:
+            out["rgb_s"], out["sigma_s"] = raw[:, 0:3], raw[:, 3]
+        if transient:
+            out["rgb_t"], out["sigma_t"] = raw[:, 4:7], raw[:, 7]
+            if "fw" in flows:
+                out["fw"] = raw[:, 8:11]
+            if "bw" in flows:
+                out["bw"] = raw[:, 11:14]
+        return out
+    rep = lambda e: None if e is None else e.repeat_interleave(s, 0)
+    return field(model, pos_embed(xyz, freqs_xyz), rep(dir_embedded), rep(a_embedded), rep(t_embedded),
+                 static, transient, flows)
+
+
 def _excl_cumprod(x):
     return torch.cumprod(torch.cat([torch.ones_like(x[:, :1]), x], 1)[:, :-1], 1)
 
@@ -82,8 +103,7 @@ def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedd
     n, s = zs.shape
     xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * zs[..., None]
     results[f"zs_{typ}"], results[f"xyzs_{typ}"] = zs, xyz
-    rep = lambda e: None if e is None else e.repeat_interleave(s, 0)
-    f = field(model, pos_embed(xyz.reshape(-1, 3), freqs_xyz), rep(dir_embedded), rep(a_embedded), rep(t_embedded),
+    f = query(model, xyz.reshape(-1, 3), freqs_xyz, dir_embedded, a_embedded, t_embedded, s,
               True, output_transient, flows)
     g = lambda k, c=None: f[k].view(n, s) if c is None else f[k].view(n, s, c)
     s_rgb = results[f"static_rgbs_{typ}"] = g("rgb_s", 3)
@@ -109,8 +129,8 @@ def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedd
 
         if flows and not test_time:
             def warp(xyz_w, t_rows, head, key):
-                fw_ = field(model, pos_embed(xyz_w.reshape(-1, 3), freqs_xyz), rep(dir_embedded), rep(a_embedded),
-                            rep(t_rows), False, True, [head])
+                fw_ = query(model, xyz_w.reshape(-1, 3), freqs_xyz, dir_embedded, a_embedded, t_rows, s,
+                            False, True, [head])
                 rgb_w, sig_w = fw_["rgb_t"].view(n, s, 3), fw_["sigma_t"].view(n, s)
                 flow_w = torch.where(far, torch.zeros_like(rgb_w), fw_[head].view(n, s, 3))
                 al_w = 1 - torch.exp(-d_trans * _softplus(sig_w + nz(key)))

@@ -1,0 +1,78 @@
+"""The native field node of the backward graph (nsff_pl_amd/field_grad.py) against float64 autograd of the
+torch expression of the same network: gradients w.r.t. every parameter, the points and the time codes."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+import nsff_pl_amd as A
+from nsff_pl_amd import field_grad, torch_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_grads(model, xyz, t_rows, s, freqs, cot, static, transient, dt=torch.float64):
+    m64 = copy.deepcopy(model).to(dt)
+    x = xyz.detach().clone().to(dt).requires_grad_(True)
+    t = t_rows.detach().clone().to(dt).requires_grad_(True)
+    out = torch_path.field(m64, torch_path.pos_embed(x, freqs), None, None, t.repeat_interleave(s, 0),
+                           static, transient, ("fw", "bw") if (transient and m64.output_flow) else ())
+    cols = {"rgb_s": slice(0, 3), "sigma_s": 3, "rgb_t": slice(4, 7), "sigma_t": 7, "fw": slice(8, 11), "bw": slice(11, 14)}
+    loss = sum((out[k] * cot[:, c].to(dt)).sum() for k, c in cols.items() if k in out)
+    loss.backward()
+    grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m64.named_parameters()}
+    return grads, x.grad, t.grad
+
+
+@pytest.mark.parametrize("static,transient", [(True, True), (False, True)])
+@pytest.mark.parametrize("spread", [0.0, 6.0])
+def test_field_node_gradients(static, transient, spread, hip_lib):
+    """spread > 0: per-point cotangent magnitudes spanning 10^spread (the dynamic range real losses produce)."""
+    dev = torch.device("cuda:0")
+    cfg = scenes.CASES["g3_nsff_train"]
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    model = models["fine"].to(dev)
+    g = torch.Generator().manual_seed(5)
+    n_rays, s = 48, 40
+    P = n_rays * s
+    xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+    t_rows = torch.randn(n_rays, scenes.N_TAU, generator=g).to(dev)
+    cot = torch.randn(P, 16, generator=g)
+    cot *= 10.0 ** (-spread * torch.rand(P, 1, generator=g))
+    cot = cot.to(dev)
+    freqs = [float(f) for f in emb["xyz"].freqs]
+
+    ref_p, ref_x, ref_t = _reference_grads(model, xyz, t_rows, s, freqs, cot, static, transient)
+    # the same network differentiated by torch in fp32: how far fp32 itself sits from the fp64 gradient
+    f32_p, f32_x, f32_t = _reference_grads(model, xyz, t_rows, s, freqs, cot, static, transient, torch.float32)
+
+    for p in model.parameters():
+        p.grad = None
+    x = xyz.detach().clone().requires_grad_(True)
+    t = t_rows.detach().clone().requires_grad_(True)
+    raw = field_grad.field(model, x, freqs, t, s, static, transient)
+    (raw * cot).sum().backward()
+    torch.cuda.synchronize()
+
+    def rel(a, b, scale=None):
+        return float((a.double() - b).abs().max() / (scale if scale is not None else b.abs().max()).clamp_min(1e-300))
+    worst, base = {}, {}
+    for n, p in model.named_parameters():
+        if ref_p[n].abs().max() == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, n
+            continue
+        # a bias gradient is a plain sum over points that may cancel: measure it on the scale of its layer
+        layer = n.rsplit(".", 1)[0]
+        scale = torch.stack([ref_p[layer + ".weight"].abs().max(), ref_p[layer + ".bias"].abs().max()]).max()
+        worst[n], base[n] = rel(p.grad, ref_p[n], scale), rel(f32_p[n], ref_p[n], scale)
+    worst["xyz"], worst["t"] = rel(x.grad, ref_x), rel(t.grad, ref_t)
+    base["xyz"], base["t"] = rel(f32_x, ref_x), rel(f32_t, ref_t)
+    # fp16 operands: 5e-4 per rounding, a handful of roundings along the chain; with `spread` a few points
+    # dominate every sum, so the rounding noise of single terms is not averaged away
+    tol = 2e-3 if spread == 0 else 6e-3
+    bad = {k: (v, base[k]) for k, v in worst.items() if v > tol + 3 * base[k]}
+    k = max(worst, key=worst.get)
+    print("worst native", worst[k], k, "fp32 torch there", base[k], "| fp32 torch worst", max(base.values()))
+    assert not bad, bad

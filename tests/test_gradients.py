@@ -17,11 +17,13 @@ from nsff_pl_amd import autograd as nauto
 
 GRAD_RTOL = 2e-3
 # Some of these gradients are ill-conditioned in fp32 by construction: the warped re-queries differentiate
-# sin(512 x) at positions that already carry rounding, so the REFERENCE's own fp32 gradient scatters around
-# its fp64 value by up to ~2 % of |g|_1 (flow heads), differently on every machine / BLAS.  The comparison is
+# a ReLU network of sin(512 x) at positions that already carry rounding, so the REFERENCE's own fp32 gradient
+# scatters around its fp64 value by up to ~2 % of |g|_1 (flow heads), differently on every machine / BLAS, and a
+# one-ulp perturbation of the parameters moves those statistics by ~1 % even in float64.  The comparison is
 # therefore made against the float64 gradient -- pinned to the reference run in float64 (stats64 in the
-# golden) -- with tolerance  GRAD_RTOL*|g|_1 + 3 * (observed fp32 scatter), the scatter being the larger of
-# |reference fp32 - fp64| (golden machine) and |torch-path fp32 - fp64| (this machine).
+# golden) -- with tolerance  GRAD_RTOL*|g|_1 + 3 * (observed fp32 scatter), the scatter being the largest
+# deviation from fp64 among: the reference's fp32 run (golden machine), the torch path in fp32 (this machine),
+# and three torch-path fp32 runs with every parameter perturbed by one ulp (6e-8 relative).
 _TRUTH = {}
 
 
@@ -52,8 +54,16 @@ def objective_fn(name, objective, dt=torch.float32, device="cpu"):
     return lambda res: sum(loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw).values())
 
 
-def _torch_path_stats(name, dt, objective="cotangent"):
+def _torch_path_stats(name, dt, objective="cotangent", ulp_seed=0):
+    """ulp_seed > 0: every parameter is multiplied by (1 + 6e-8 * N(0,1)) first -- a one-ulp perturbation of the
+    inputs, i.e. a sample of what ANY fp32 evaluation order may legitimately return."""
     cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+    if ulp_seed:
+        g = torch.Generator().manual_seed(ulp_seed)
+        with torch.no_grad():
+            for m in list(models.values()) + [e for k, e in emb.items() if k in ("t", "a")]:
+                for p in m.parameters():
+                    p.mul_(1 + 6e-8 * torch.randn(p.shape, generator=g))
     draws = scenes.replay_draws(cfg, meta["draw_seed"])
     for m in list(models.values()) + [e for k, e in emb.items() if k in ("t", "a")]:
         m.to(dt)
@@ -75,7 +85,8 @@ def grad_truth(name, objective="cotangent"):
             for k in ref64:
                 for a, b in zip(s64[k], ref64[k]):
                     assert abs(a - b) <= 1e-6 * max(abs(ref64[k][1]), 1e-12), (k, a, b)   # 1e-11 here, 1e-8 across hosts
-        scatter = {k: [max(abs(s32[k][i] - s64[k][i]), abs(ref32[k][i] - s64[k][i])) for i in range(3)] for k in s64}
+        samples = [s32, ref32] + [_torch_path_stats(name, torch.float32, objective, seed)[0] for seed in (1, 2, 3)]
+        scatter = {k: [max(abs(smp[k][i] - s64[k][i]) for smp in samples) for i in range(3)] for k in s64}
         _TRUTH[key] = (s64, full64, scatter)
     return _TRUTH[key]
 
