@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      3
+#define NSFF_ABI_VERSION      4
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -109,17 +109,62 @@ typedef struct NsffFieldArgs {
     int32_t ld_emb;
     int32_t off_xyz, off_dir, off_a, off_t;  /* column offsets in x_emb, -1 = absent */
     float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
-    /* training forward (F16X3, input A, models without view directions): also keep what the backward
-     * pass needs, rounded to fp16.  P_pad = P rounded up to a multiple of 128; both may be NULL.
-     *   save_acts: (2*D+2, P_pad, 256) -- slot l = ReLU output of static layer l, slot D = static_xyz_encoding_final,
-     *              slots D+1.. the same for the transient trunk (unused slots are not written);
-     *   save_xin : (P_pad, 128) trunk input [xyz embedding (in_xyz) | 0.. | t embedding at column 64 | 0..]       */
+    /* training forward (F16X3, input A, models without view directions, in_xyz <= 64, in_t <= 64): also keep
+     * what nsff_field_backward / nsff_weight_grad need.  T = ceil(P/64) point tiles; any of them may be NULL.
+     *   save_acts : fp16 (2*D+2, T, 4, 256, 16): slot l = ReLU output of static layer l, slot D = static_xyz_encoding_final
+     *               output, slots D+1.. the same for the transient trunk (slots of a trunk that is not evaluated stay
+     *               unwritten).  Inside a tile: [16-point group][neuron][point] = the fragment order of the
+     *               weight-gradient GEMM (K = points);
+     *   save_xin  : fp16 (T, 4, 128, 16) trunk input, rows [0,in_xyz) xyz embedding, rows [64, 64+in_t) time code;
+     *   save_masks: uint64 (2*D+2, T, 256) ReLU sign bits of every trunk activation, in accumulator order.        */
     void*   save_acts;
     void*   save_xin;
+    void*   save_masks;
 } NsffFieldArgs;
 
 int nsff_field_query(const NsffModelDesc* desc, const void* packed,
                      const NsffFieldArgs* args, void* stream);
+
+/* ---- N1: backward of the field query (training).  Mixed precision: fp16 MFMA operands, fp32 accumulation;
+ * every point's gradient row is normalised by its own power of two (block floating point), weight-gradient
+ * operands are expressed on one global power-of-two scale G = 2^floor(log2(4096 / *gmax)).
+ *
+ * nsff_bwd_packed_bytes / nsff_pack_weights_bwd: the TRANSPOSED fp16 weight tiles the data-gradient chain
+ * streams (same parameter order as nsff_pack_weights).
+ * nsff_field_backward: d_raw (P,16) -> d(trunk input) and the pre-activation gradients of every layer:
+ *   dpre : fp16 (2*(D+1), T, 4, 256, 16)  slot t*(D+1)+l = trunk t (0 static, 1 transient) layer l, l = D: *_final,
+ *          values = true gradient * G, fragment order as save_acts;
+ *   dhead: fp16 (2, T, 4, 32, 16) head pre-activation gradients * G, rows: static rgb(3) sigma(1);
+ *          transient rgb(3) sigma(1) fw(3) bw(3);
+ *   d_xin: fp32 (P, 128) true gradient w.r.t. the transient trunk input (rows as save_xin), or NULL.            */
+int nsff_bwd_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
+int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params, void* packed, void* stream);
+
+typedef struct NsffFieldBwdArgs {
+    int64_t n_points;
+    int32_t static_mode;        /* 0 skip, 2 rgb+sigma (as in the forward call)            */
+    int32_t transient_mode;     /* 0 skip, 2                                                */
+    const float* d_raw;         /* (P, NSFF_RAW_STRIDE) gradient w.r.t. the raw record      */
+    const float* raw;           /* (P, NSFF_RAW_STRIDE) forward outputs (activation derivatives) */
+    const float* gmax;          /* device scalar: max |d_raw|                                */
+    const void*  masks;         /* save_masks of the forward call                            */
+    void*  dpre;                /* OUT */
+    void*  dhead;               /* OUT */
+    float* d_xin;               /* OUT or NULL                                               */
+} NsffFieldBwdArgs;
+int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
+
+/* Batched weight-gradient GEMMs, K = points:  out[j][s] = sum over the point tiles of split s of  A_j^T . B_j.
+ * A_j: fp16 fragment-major (T,4,a_rows,16), a_rows in {256, 32};  B_j: (T,4,b_rows,16), b_rows in {256, 128}.
+ * out: fp32 (n_jobs, n_splits, a_rows_j x b_rows_j) written at out + out_off[j] + s*a_rows*b_rows (partials, summed
+ * by the caller); bias: fp32 (n_jobs, n_splits, 256) row sums of A_j (the bias gradients).  Host arrays.        */
+typedef struct NsffWgradJob {
+    const void* a;  const void* b;
+    int32_t a_rows, b_rows;
+    int64_t out_off;            /* floats */
+} NsffWgradJob;
+int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
+                     float* out, float* bias, void* stream);
 
 /* ---- a4: coarse sample placement (reference rendering.py:314-324,332) ----
  * zs[n][i] = z_lin[i]                                   (perturb == 0)

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -43,7 +43,7 @@ class FieldArgs(C.Structure):
                 ("dir_emb", _fp), ("a_emb", _fp), ("t_emb", _fp),
                 ("x_emb", _fp), ("ld_emb", C.c_int32),
                 ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
-                ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp)]
+                ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp), ("save_masks", _fp)]
 
 
 _COMPOSITE_PTRS_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "xyz_fw", "xyz_bw",
@@ -64,6 +64,16 @@ class CompositeArgs(C.Structure):
                  ("noise_std", C.c_float), ("z_far", C.c_float)]
                 + [(n, _fp) for n in _COMPOSITE_PTRS_IN]
                 + [(n, _fp) for n in _COMPOSITE_PTRS_OUT])
+
+
+class FieldBwdArgs(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("static_mode", C.c_int32), ("transient_mode", C.c_int32),
+                ("d_raw", _fp), ("raw", _fp), ("gmax", _fp), ("masks", _fp), ("dpre", _fp), ("dhead", _fp),
+                ("d_xin", _fp)]
+
+
+class WgradJob(C.Structure):
+    _fields_ = [("a", _fp), ("b", _fp), ("a_rows", C.c_int32), ("b_rows", C.c_int32), ("out_off", C.c_int64)]
 
 
 class SplatArgs(C.Structure):
@@ -96,6 +106,10 @@ _SIGNATURES = {
     "nsff_composite": (C.c_int, [C.POINTER(CompositeArgs), _fp]),
     "nsff_frame_rays": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float,
                                   C.c_float, C.c_int64, C.c_int64, _fp, _fp]),
+    "nsff_bwd_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
+    "nsff_pack_weights_bwd": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp]),
+    "nsff_field_backward": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldBwdArgs), _fp]),
+    "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp]),
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
     "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
@@ -211,7 +225,7 @@ def posenc(x, freqs, out):
 
 def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
                 xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
-                x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, precision=None):
+                x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, save_masks=None, precision=None):
     from . import config
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
@@ -235,6 +249,7 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     a.raw = _ptr(raw)
     a.save_acts = None if save_acts is None else save_acts.data_ptr()
     a.save_xin = None if save_xin is None else save_xin.data_ptr()
+    a.save_masks = None if save_masks is None else save_masks.data_ptr()
     _check(load().nsff_field_query(C.byref(desc), _ptr(packed), C.byref(a), _stream()), "nsff_field_query")
 
 
@@ -279,6 +294,36 @@ def frame_rays(K4, c2w12, H, W, near, shift_near, first, count, rays):
     m = (C.c_float * 12)(*[float(v) for v in c2w12])
     _check(load().nsff_frame_rays(k, m, int(H), int(W), float(near), float(shift_near), int(first), int(count),
                                   _ptr(rays), _stream()), "nsff_frame_rays")
+
+
+BWD_PACK = 100          # PackCache key of the transposed fp16 weight pack (nsff_pack_weights_bwd)
+
+
+def bwd_packed_bytes(desc):
+    n = C.c_size_t(0)
+    _check(load().nsff_bwd_packed_bytes(C.byref(desc), C.byref(n)), "nsff_bwd_packed_bytes")
+    return n.value
+
+
+def pack_weights_bwd(desc, params, packed):
+    arr = (_fp * len(params))(*[p.data_ptr() for p in params])
+    _check(load().nsff_pack_weights_bwd(C.byref(desc), arr, _ptr(packed), _stream()), "nsff_pack_weights_bwd")
+
+
+def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin):
+    desc = model_desc(model)
+    a = FieldBwdArgs(n_points=int(n_points), static_mode=2 if static else 0, transient_mode=2 if transient else 0,
+                     d_raw=_ptr(d_raw), raw=_ptr(raw), gmax=_ptr(gmax), masks=masks.data_ptr(), dpre=dpre.data_ptr(),
+                     dhead=dhead.data_ptr(), d_xin=_ptr(d_xin))
+    _check(load().nsff_field_backward(C.byref(desc), _ptr(model.packed(BWD_PACK)), C.byref(a), _stream()),
+           "nsff_field_backward")
+
+
+def weight_grad(jobs, n_tiles, n_splits, out, bias):
+    """jobs: list of (a_ptr, b_ptr, a_rows, b_rows, out_off)."""
+    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=j[4]) for j in jobs])
+    _check(load().nsff_weight_grad(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(out), _ptr(bias), _stream()),
+           "nsff_weight_grad")
 
 
 def splat_planes(H, W, S, K4, P12, scale, xyz, flow, rgb, alpha, accum):

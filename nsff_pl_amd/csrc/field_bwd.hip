@@ -1,0 +1,690 @@
+// Backward of the fused NSFF field query for gfx950 (training).
+//
+//   nsff_field_backward  (K1)  data-gradient chain  d_raw -> heads -> *_final -> trunk layers D..1 -> trunk input,
+//                              one workgroup per 64-point tile, the gradient tile lives in LDS as the fp16
+//                              B operand, the TRANSPOSED weights stream from L2 as pre-packed A tiles
+//                              (v_mfma_f32_32x32x16_f16, fp32 accumulate) -- the mirror image of field_h3.hip;
+//   nsff_weight_grad     (K2)  dW = dY^T . X with K = all points: batched split-K GEMMs that stream the
+//                              fragment-major activation / gradient tiles written by the forward (SAVE variant)
+//                              and by K1; partial sums per split, bias gradients as row sums of the same fragments.
+//
+// Mixed precision: fp16 operands, fp32 accumulation.  Each point's gradient row is normalised by its own power of
+// two (block floating point: the chain is linear per point), so fp16's range is spent on the 256 entries of a
+// row, not on the 1e6:1 spread between points; what K2 consumes is re-expressed on one global scale G.
+// Reference semantics: autograd of models/nerf.py:118-213 (+ PosEmbedding :17-30 on the host side).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
+#include "nsff_layout_h3.h"
+#include "nsff_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int LDH = 264;           // halfs per LDS row (528 B: conflict-free ds_read_b128)
+constexpr int NT = 2;              // 32-point column tiles per workgroup (64 points)
+constexpr int MAX_BSTEPS = 24;
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define B_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// ------------------------------------------------------------------------------------------------
+// Layout of the transposed weight pack (offsets in 4-byte words).  A segment holds Wt (256 rows k, K columns n)
+// as A-operand tiles in streaming order  seg[wave][ks][mt][lane][8 halfs]:
+//     value = Wt[64*wave + 32*mt + (lane&31)][16*ks + 8*(lane>>5) + t]
+struct TrunkLayoutB {
+    uint32_t head;                       // rows = *_final outputs, K = head rows (16, padded to 64)
+    uint32_t fin;                        // rows = last trunk activation, K = 256
+    uint32_t layer[NSFF_MAX_LAYERS];     // l = 1..D-1: rows = activation of layer l-1, K = 256 (pre-activations of l)
+    uint32_t x0, xskip;                  // rows = trunk input (128 used), K = 256 (pre-activations of layer 0 / skip)
+};
+struct LayoutB {
+    TrunkLayoutB st, tr;
+    uint32_t s_sigma;                    // 256 fp32: static_sigma.weight (rank-1 term of the static head)
+    uint32_t total;
+};
+
+inline int make_layout_b(const NsffModelDesc& d, LayoutB& L) {
+    NsffLayoutH3 f;
+    const int rc = nsff_make_layout_h3(d, f);
+    if (rc) return rc;
+    if (d.use_viewdir || f.k0s != 64 || f.kt > 64) return NSFF_ERR_INVALID;
+    uint32_t off = 0;
+    auto take = [&](uint32_t halfs) { uint32_t o = off; off += halfs / 2; return o; };
+    auto trunk = [&](TrunkLayoutB& T, bool xparts) {
+        T.head = take(256 * 64);
+        T.fin = take(256 * 256);
+        for (int l = 0; l < NSFF_MAX_LAYERS; ++l) T.layer[l] = NSFF_NONE;
+        for (int l = 1; l < d.D; ++l) T.layer[l] = take(256 * 256);
+        T.x0 = T.xskip = NSFF_NONE;
+        if (xparts) { T.x0 = take(256 * 256); T.xskip = take(256 * 256); }
+    };
+    trunk(L.st, false);
+    L.tr = TrunkLayoutB{};
+    if (d.has_transient) trunk(L.tr, true);
+    L.s_sigma = off; off += 256;
+    L.total = off;
+    return NSFF_OK;
+}
+
+// ---- pack -------------------------------------------------------------------------------------
+struct PackSegB {
+    const float* src[4];     // kind 2: up to four head tensors; otherwise src[0]
+    int32_t r0[4], nr[4];    // kind 2: destination K range of each head tensor
+    uint32_t dst;
+    int32_t kind;            // 0 flat fp32 copy (count = nks), 1 transposed Linear, 2 heads, 3 trunk-input rows
+    int32_t ld, c0;          // kind 1: Wt[k][n] = W[n][c0 + k];  kind 3: W[n][xmap(k)]
+    int32_t nks;
+    int32_t in_xyz, in_t;
+};
+constexpr int PACKB_BATCH = 8;
+struct PackArgsB { PackSegB seg[PACKB_BATCH]; uint32_t* dst; };
+
+__global__ void pack_kernel_b(const PackArgsB a) {
+    const PackSegB& s = a.seg[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s.kind == 0) {
+        if (idx < s.nks) reinterpret_cast<float*>(a.dst + s.dst)[idx] = s.src[0][idx];
+        return;
+    }
+    if (idx >= 4 * s.nks * 2 * 64) return;                 // chunks [wave][ks][mt][lane]
+    const int lane = idx & 63, mt = (idx >> 6) & 1, wk = idx >> 7;
+    const int ks = wk % s.nks, k = 64 * (wk / s.nks) + 32 * mt + (lane & 31);
+    h8 out;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int n = ks * 16 + 8 * (lane >> 5) + t;
+        float v = 0.f;
+        if (s.kind == 1) {
+            v = s.src[0][(long long)n * s.ld + s.c0 + k];
+        } else if (s.kind == 2) {
+            for (int j = 0; j < 4; ++j)
+                if (s.src[j] != nullptr && n >= s.r0[j] && n < s.r0[j] + s.nr[j]) v = s.src[j][(long long)(n - s.r0[j]) * 256 + k];
+        } else {
+            int c = -1;
+            if (k < s.in_xyz) c = k;
+            else if (k >= 64 && k < 64 + s.in_t) c = s.in_xyz + (k - 64);
+            if (c >= 0) v = s.src[0][(long long)n * s.ld + c];
+        }
+        out[t] = (_Float16)v;
+    }
+    reinterpret_cast<h8*>(a.dst + s.dst)[idx] = out;
+}
+
+// ---- K1 ---------------------------------------------------------------------------------------
+enum { EPI_KEEP = 0, EPI_LINEAR = 1, EPI_MASK = 2, EPI_DXIN = 3 };
+enum { F_CONTINUE = 1, F_STASH = 2, F_SIGMA = 4, F_FROM_STASH = 8, F_HALF_ROWS = 16 };
+struct BStep {
+    uint32_t w_off;
+    uint8_t nks, epi, slot, flags;     // slot: dpre slot written (EPI_LINEAR / EPI_MASK); mask slot = slot too
+};
+struct BKArgs {
+    BStep steps[MAX_BSTEPS];
+    int n_steps, n_static_steps;       // [0, n_static_steps) static trunk, rest transient
+    const uint32_t* packed;
+    uint32_t s_sigma;
+    const float* d_raw;
+    const float* raw;
+    const float* gmax;
+    const unsigned long long* masks;
+    _Float16* dpre;
+    _Float16* dhead;
+    float* d_xin;
+    long long n_points, n_tiles;
+    int D;
+    int t_head_rows;                   // 4 or 10
+    float flow_scale;
+};
+
+struct WF1 { h8 w[2]; };
+struct XF1 { h8 x[NT]; };
+struct WRing1 { WF1 r[4]; };
+
+__device__ __forceinline__ void load_w1(WF1& f, const uint4* __restrict__& wp) {
+    const uint4 a0 = wp[0], a1 = wp[64];
+    wp += 128;
+    f.w[0] = __builtin_bit_cast(h8, a0); f.w[1] = __builtin_bit_cast(h8, a1);
+}
+__device__ __forceinline__ void load_x1(XF1& f, const _Float16* sB, int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) f.x[nt] = *reinterpret_cast<const h8*>(sB + nt * 32 * LDH + ks * 16);
+}
+__device__ __forceinline__ void mma1(f32x16 (&acc)[2][NT], const WF1& w, const XF1& x) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.w[mt], x.x[nt], acc[mt][nt]);
+}
+
+// acc += Wt_seg . B^T for this wave's 64 output rows and the 64 points; nks is a multiple of 4.
+__device__ __forceinline__ void gemm1(f32x16 (&acc)[2][NT], const uint4* __restrict__ wp, const _Float16* sB, int nks) {
+    WRing1 ring;
+    load_w1(ring.r[0], wp); load_w1(ring.r[1], wp); load_w1(ring.r[2], wp); load_w1(ring.r[3], wp);
+    XF1 x0, x1;
+    load_x1(x0, sB, 0);
+#pragma unroll 1
+    for (int ks = 4; ks < nks; ks += 4) {
+        load_x1(x1, sB, 1); mma1(acc, ring.r[0], x0); load_w1(ring.r[0], wp); B_PIN();
+        load_x1(x0, sB, 2); mma1(acc, ring.r[1], x1); load_w1(ring.r[1], wp); B_PIN();
+        load_x1(x1, sB, 3); mma1(acc, ring.r[2], x0); load_w1(ring.r[2], wp); B_PIN();
+        load_x1(x0, sB, 4); mma1(acc, ring.r[3], x1); load_w1(ring.r[3], wp); B_PIN();
+        sB += 64;
+    }
+    load_x1(x1, sB, 1); mma1(acc, ring.r[0], x0);
+    load_x1(x0, sB, 2); mma1(acc, ring.r[1], x1);
+    load_x1(x1, sB, 3); mma1(acc, ring.r[2], x0);
+    mma1(acc, ring.r[3], x1);
+}
+
+__device__ __forceinline__ float pow2_scale(float amax) {      // 2^k with amax * 2^k in [1024, 2048); 1 for amax == 0
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    int e;
+    frexpf(amax, &e);
+    return ldexpf(1.0f, 11 - e);
+}
+
+// LDS tile (fp16, [point][LDH]) -> HBM fragments dst[ks][row block][lane][8 pts] (layout of field_h3.hip's
+// tile_to_fragments), every point scaled by rel[p] (a power of two)
+__device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const float* sRel, _Float16* dst, int n_rows) {
+    for (int task = threadIdx.x; task < n_rows * 8; task += 256) {
+        const int row = task % n_rows, pg = task / n_rows;
+        h8 out;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float v = (float)sB[(8 * pg + t) * LDH + row] * sRel[8 * pg + t];
+            out[t] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+        }
+        *reinterpret_cast<h8*>(dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8) = out;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 sB[64 * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 sStash[64 * LDH];
+    __shared__ float sInv[64], sRel[64], sSig[64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long tile = blockIdx.x;
+    const long long p0 = tile * 64;
+    const uint32_t* __restrict__ pk = a.packed;
+    const float G = pow2_scale(*a.gmax);
+    const _Float16* sBw = sB + (lane & 31) * LDH + 8 * (lane >> 5);
+    const _Float16* sSw = sStash + (lane & 31) * LDH + 8 * (lane >> 5);
+    const long long slot_stride = a.n_tiles * (64 * NSFF_W);
+
+    f32x16 acc[2][NT];
+#pragma unroll 1
+    for (int i = 0; i < a.n_steps; ++i) {
+        const BStep st = a.steps[i];
+        const bool is_static = i < a.n_static_steps;
+        if (i == 0 || i == a.n_static_steps) {
+            // ---- head stage of this trunk: activation derivatives, per-point scale, head gradients into the tile ----
+            __syncthreads();
+            const int pt = threadIdx.x & 63, grp = threadIdx.x >> 6;
+            const long long p = p0 + pt;
+            const bool valid = p < a.n_points;
+            float hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] = 0.f;
+            if (valid) {
+                const float4* dr = reinterpret_cast<const float4*>(a.d_raw + p * NSFF_RAW_STRIDE);
+                const float4* yr = reinterpret_cast<const float4*>(a.raw + p * NSFF_RAW_STRIDE);
+                if (is_static) {
+                    const float4 d = dr[0], y = yr[0];
+                    hv[0] = d.x * y.x * (1.f - y.x); hv[1] = d.y * y.y * (1.f - y.y); hv[2] = d.z * y.z * (1.f - y.z);
+                    hv[3] = d.w;
+                } else {
+                    const float4 d = dr[1], y = yr[1];
+                    hv[0] = d.x * y.x * (1.f - y.x); hv[1] = d.y * y.y * (1.f - y.y); hv[2] = d.z * y.z * (1.f - y.z);
+                    hv[3] = d.w;
+                    if (a.t_head_rows > 4) {
+                        const float4 d2 = dr[2], d3 = dr[3], y2 = yr[2], y3 = yr[3];
+                        const float fs = a.flow_scale, ifs = 1.0f / a.flow_scale;
+                        const float df[6] = {d2.x, d2.y, d2.z, d2.w, d3.x, d3.y};
+                        const float yf[6] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y};
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) hv[4 + c] = df[c] * (fs - yf[c] * yf[c] * ifs);
+                    }
+                }
+            }
+            float amax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(hv[r]));
+            const float s = pow2_scale(amax);
+            if (grp == 0) {
+                sInv[pt] = 1.0f / s;
+                sRel[pt] = G / s;
+                sSig[pt] = is_static ? hv[3] * s : 0.f;     // the static sigma head reads the trunk, not *_final
+                h8 lo, hi;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { lo[r] = (_Float16)(hv[r] * s); hi[r] = (_Float16)(hv[8 + r] * s); }
+                if (is_static) lo[3] = (_Float16)0.f;
+                *reinterpret_cast<h8*>(sB + pt * LDH) = lo;
+                *reinterpret_cast<h8*>(sB + pt * LDH + 8) = hi;
+            } else {
+                const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<h8*>(sB + pt * LDH + 16 * grp) = z;
+                *reinterpret_cast<h8*>(sB + pt * LDH + 16 * grp + 8) = z;
+            }
+            // head gradients on the global scale, fragment order [ks][lane = row + 32*(pt/8 & 1)][8 pts]; rows 8*grp .. 8*grp+7
+            _Float16* dh = a.dhead + ((is_static ? 0 : a.n_tiles) + tile) * (64 * 32);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = 8 * grp + r;
+                float v = row < 16 ? hv[row < 16 ? row : 0] * G : 0.f;       // (rows 16..31 are zero)
+                if (grp >= 2) v = 0.f;
+                dh[(((pt >> 4) * 64) + row + 32 * ((pt >> 3) & 1)) * 8 + (pt & 7)] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+            }
+            __syncthreads();
+        }
+
+        unsigned long long mbits = 0ull;
+        if (st.epi == EPI_MASK)
+            mbits = a.masks[((long long)st.slot * a.n_tiles + tile) * 256 + threadIdx.x];
+        if (!(st.flags & F_CONTINUE)) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        }
+        if (!(st.flags & F_HALF_ROWS) || wave < 2) {
+            const uint4* wp = reinterpret_cast<const uint4*>(pk + st.w_off) + (wave * st.nks) * 2 * 64 + lane;
+            gemm1(acc, wp, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks);
+        }
+        if (st.epi == EPI_KEEP) continue;
+        if (st.epi == EPI_DXIN) {
+            if (wave < 2 && a.d_xin != nullptr) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int pt = 32 * nt + (lane & 31);
+                        const float inv = sInv[pt];
+                        if (p0 + pt < a.n_points) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float4 v;
+                                v.x = acc[mt][nt][4 * q + 0] * inv; v.y = acc[mt][nt][4 * q + 1] * inv;
+                                v.z = acc[mt][nt][4 * q + 2] * inv; v.w = acc[mt][nt][4 * q + 3] * inv;
+                                *reinterpret_cast<float4*>(a.d_xin + (p0 + pt) * 128 + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5)) = v;
+                            }
+                        }
+                    }
+            }
+            continue;
+        }
+        // ---- epilogue: (+ rank-1 sigma term) (ReLU mask) -> fp16 tile (B operand of the next step) ----
+        float wsig[2][4][4];
+        if (st.flags & F_SIGMA) {
+            const float* ws = reinterpret_cast<const float*>(pk + a.s_sigma);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(ws + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
+                    wsig[mt][q][0] = w4.x; wsig[mt][q][1] = w4.y; wsig[mt][q][2] = w4.z; wsig[mt][q][3] = w4.w;
+                }
+        }
+        __syncthreads();                                  // every wave is done reading the tile
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pt = 32 * nt + (lane & 31);
+                const float sg = (st.flags & F_SIGMA) ? sSig[pt] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[mt][nt][4 * q + e];
+                        if (st.flags & F_SIGMA) v[e] += wsig[mt][q][e] * sg;
+                        if (st.epi == EPI_MASK && !((mbits >> (((mt * NT + nt) * 4 + q) * 4 + e)) & 1ull)) v[e] = 0.f;
+                        v[e] = fminf(fmaxf(v[e], -65504.f), 65504.f);
+                    }
+                    h4 hv;
+                    hv[0] = (_Float16)v[0]; hv[1] = (_Float16)v[1]; hv[2] = (_Float16)v[2]; hv[3] = (_Float16)v[3];
+                    const int idx = pt * LDH + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5);
+                    *reinterpret_cast<h4*>(sB + idx) = hv;
+                    if (st.flags & F_STASH) *reinterpret_cast<h4*>(sStash + idx) = hv;
+                }
+            }
+        __syncthreads();
+        tile_to_fragments_scaled(sB, sRel, a.dpre + (long long)st.slot * slot_stride + tile * (64 * NSFF_W), NSFF_W);
+    }
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------
+constexpr int MAX_WJOBS = 48;
+struct WJob { const _Float16* a; const _Float16* b; long long out_off; int job_index; int pad; };
+struct WKArgs {
+    WJob jobs[MAX_WJOBS];
+    float* out;
+    float* bias;
+    long long n_tiles;
+    int n_splits;
+    int n_jobs_total;
+};
+
+// direct-to-LDS DMA of 16 bytes per lane: LDS[lds_dst + 16*lane] <- *gsrc  (lds_dst wave-uniform)
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Output block 32*NA*WR x 32*NB*WC per workgroup, waves arranged WR x WC, NA x NB accumulator tiles per wave.
+// Every k-step (16 points) is one stage of (A rows + B rows)/32 one-KiB fragments, DMA'd straight into an
+// 8-stage LDS ring (each wave fetches an equal share, counted vmcnt, one barrier per stage); the waves then read
+// their fragments with conflict-free ds_read_b128 -- each HBM byte is fetched once per workgroup.
+template <int NA, int NB, int WR, int WC>
+__global__ __launch_bounds__(256, 1) void nsff_wgrad_kernel(const WKArgs a) {
+    constexpr int A_BLK = NA * WR, B_BLK = NB * WC, CH = A_BLK + B_BLK, PER_WAVE = CH / 4, RING = 8, STAGE = CH * 1024;
+    constexpr int A_ROWS = 32 * A_BLK, B_ROWS = 32 * B_BLK;
+    static_assert(CH % 4 == 0, "fragments per stage must split evenly over the 4 waves");
+    __shared__ __attribute__((aligned(16))) char ring[RING * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int j = blockIdx.x / a.n_splits, split = blockIdx.x % a.n_splits;
+    const WJob job = a.jobs[j];
+    const long long per = (a.n_tiles + a.n_splits - 1) / a.n_splits;
+    const long long t0 = split * per, t1 = (t0 + per < a.n_tiles) ? t0 + per : a.n_tiles;
+    const long long steps = t1 > t0 ? (t1 - t0) * 4 : 0, s0 = t0 * 4;
+
+    f32x16 acc[NA][NB];
+#pragma unroll
+    for (int na = 0; na < NA; ++na)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[na][nb][r] = 0.f;
+    float bsum[NA];
+#pragma unroll
+    for (int na = 0; na < NA; ++na) bsum[na] = 0.f;
+
+    if (steps > 0) {
+        const char* asrc = reinterpret_cast<const char*>(job.a) + lane * 16;
+        const char* bsrc = reinterpret_cast<const char*>(job.b) + lane * 16;
+        const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);
+        auto issue = [&](long long s) {          // stage s of this split (re-fetches the last one past the end)
+            const long long gs = s0 + (s < steps ? s : steps - 1);
+            const unsigned dst = ring_base + (unsigned)(s % RING) * STAGE;
+#pragma unroll
+            for (int c = 0; c < PER_WAVE; ++c) {
+                const int chunk = wave * PER_WAVE + c;
+                const char* g = chunk < A_BLK ? asrc + (gs * A_BLK + chunk) * 1024 : bsrc + (gs * B_BLK + (chunk - A_BLK)) * 1024;
+                dma16(g, __builtin_amdgcn_readfirstlane(dst + (unsigned)chunk * 1024u));
+            }
+        };
+        for (int s = 0; s < RING - 1; ++s) issue(s);
+        const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll 1
+        for (long long s = 0; s < steps; ++s) {
+            // my share of stage s has landed (RING-2 younger stages may still fly); after the barrier everyone's has,
+            // and everyone is done with stage s-1, whose slot is refilled with stage s+RING-1
+            if constexpr (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if constexpr (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(s + RING - 1);
+            const char* st = ring + (s % RING) * STAGE + lane * 16;
+            h8 af[NA], bf[NB];
+#pragma unroll
+            for (int na = 0; na < NA; ++na) af[na] = *reinterpret_cast<const h8*>(st + (NA * wr + na) * 1024);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const h8*>(st + (A_BLK + NB * wc + nb) * 1024);
+#pragma unroll
+            for (int na = 0; na < NA; ++na) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[na][nb] = MFMA_H(af[na], bf[nb], acc[na][nb]);
+                if (wc == 0) {
+                    const h8 v = af[na];
+                    float t = bsum[na];
+                    t = __builtin_amdgcn_fdot2(h2{v[0], v[1]}, ones, t, false);
+                    t = __builtin_amdgcn_fdot2(h2{v[2], v[3]}, ones, t, false);
+                    t = __builtin_amdgcn_fdot2(h2{v[4], v[5]}, ones, t, false);
+                    t = __builtin_amdgcn_fdot2(h2{v[6], v[7]}, ones, t, false);
+                    bsum[na] = t;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the workgroup's LDS
+    }
+    float* out = a.out + job.out_off + (long long)split * (A_ROWS * B_ROWS);
+#pragma unroll
+    for (int na = 0; na < NA; ++na)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (NA * wr + na) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(long long)row * B_ROWS + 32 * (NB * wc + nb) + (lane & 31)] = acc[na][nb][r];
+            }
+    if (wc == 0) {
+        float* bias = a.bias + ((long long)job.job_index * a.n_splits + split) * 256;
+#pragma unroll
+        for (int na = 0; na < NA; ++na) {
+            const float t = bsum[na] + __shfl_xor(bsum[na], 32);
+            if (lane < 32) bias[32 * (NA * wr + na) + lane] = t;
+        }
+    }
+}
+
+// Head rows (32 x 256 outputs, a handful of jobs): fragments straight from L2, no staging.
+__global__ __launch_bounds__(256, 1) void nsff_wgrad_head_kernel(const WKArgs a) {
+    constexpr int NB = 2, B_ROWS = 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x / a.n_splits, split = blockIdx.x % a.n_splits;
+    const WJob job = a.jobs[j];
+    const long long per = (a.n_tiles + a.n_splits - 1) / a.n_splits;
+    const long long t0 = split * per, t1 = (t0 + per < a.n_tiles) ? t0 + per : a.n_tiles;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    float bsum = 0.f;
+    const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+    const _Float16* ap = job.a + lane * 8;
+    const _Float16* bp = job.b + (NB * wave) * 512 + lane * 8;
+#pragma unroll 2
+    for (long long s = t0 * 4; s < t1 * 4; ++s) {
+        const h8 af = *reinterpret_cast<const h8*>(ap + s * 512);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = MFMA_H(af, *reinterpret_cast<const h8*>(bp + s * (B_ROWS * 16) + nb * 512), acc[nb]);
+        bsum = __builtin_amdgcn_fdot2(h2{af[0], af[1]}, ones, bsum, false);
+        bsum = __builtin_amdgcn_fdot2(h2{af[2], af[3]}, ones, bsum, false);
+        bsum = __builtin_amdgcn_fdot2(h2{af[4], af[5]}, ones, bsum, false);
+        bsum = __builtin_amdgcn_fdot2(h2{af[6], af[7]}, ones, bsum, false);
+    }
+    float* out = a.out + job.out_off + (long long)split * (32 * B_ROWS);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(long long)row * B_ROWS + 32 * (NB * wave + nb) + (lane & 31)] = acc[nb][r];
+        }
+    if (wave == 0) {
+        float* bias = a.bias + ((long long)job.job_index * a.n_splits + split) * 256;
+        const float t = bsum + __shfl_xor(bsum, 32);
+        if (lane < 32) bias[lane] = t;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsff_bwd_packed_bytes(const NsffModelDesc* desc, size_t* bytes) {
+    if (!desc || !bytes) return NSFF_ERR_NULL;
+    LayoutB L;
+    const int rc = make_layout_b(*desc, L);
+    if (rc) return rc;
+    *bytes = (size_t)L.total * 4;
+    return NSFF_OK;
+}
+
+int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params, void* packed, void* stream) {
+    if (!desc || !params || !packed) return NSFF_ERR_NULL;
+    if ((uintptr_t)packed & 15) return NSFF_ERR_ALIGN;
+    const NsffModelDesc& d = *desc;
+    LayoutB L;
+    const int rc = make_layout_b(d, L);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<PackSegB> segs;
+    int pi = 0;
+    auto lin = [&](const float* w, uint32_t dst, int ld, int c0) {
+        PackSegB s{}; s.src[0] = w; s.dst = dst; s.kind = 1; s.ld = ld; s.c0 = c0; s.nks = 16; segs.push_back(s);
+    };
+    auto xrows = [&](const float* w, uint32_t dst, int ld, int in_t) {
+        PackSegB s{}; s.src[0] = w; s.dst = dst; s.kind = 3; s.ld = ld; s.nks = 16; s.in_xyz = d.in_xyz; s.in_t = in_t; segs.push_back(s);
+    };
+    auto trunk = [&](int t, const TrunkLayoutB& T, int in_t) {
+        const int in = d.in_xyz + in_t;
+        for (int l = 0; l < d.D; ++l) {
+            const float* w = params[pi]; pi += 2;
+            if (l == 0) { if (T.x0 != NSFF_NONE) xrows(w, T.x0, in, in_t); }
+            else if (l == d.skip) { lin(w, T.layer[l], in + NSFF_W, in); if (T.xskip != NSFF_NONE) xrows(w, T.xskip, in + NSFF_W, in_t); }
+            else lin(w, T.layer[l], NSFF_W, 0);
+        }
+        const float* wf = params[pi]; pi += 2;
+        lin(wf, T.fin, NSFF_W, 0);
+    };
+    trunk(0, L.st, 0);
+    {
+        const float* wsig = params[pi]; pi += 2;
+        const float* wrgb = params[pi]; pi += 2;
+        PackSegB s{}; s.src[0] = wsig; s.dst = L.s_sigma; s.kind = 0; s.nks = 256; segs.push_back(s);
+        PackSegB h{}; h.src[0] = wrgb; h.r0[0] = 0; h.nr[0] = 3; h.dst = L.st.head; h.kind = 2; h.nks = 4; segs.push_back(h);
+    }
+    if (d.has_transient) {
+        trunk(1, L.tr, d.in_t);
+        const float* ws = params[pi]; pi += 2;
+        const float* wc = params[pi]; pi += 2;
+        PackSegB h{}; h.dst = L.tr.head; h.kind = 2; h.nks = 4;
+        h.src[0] = wc; h.r0[0] = 0; h.nr[0] = 3;
+        h.src[1] = ws; h.r0[1] = 3; h.nr[1] = 1;
+        if (d.has_flow) {
+            h.src[2] = params[pi]; pi += 2; h.r0[2] = 4; h.nr[2] = 3;
+            h.src[3] = params[pi]; pi += 2; h.r0[3] = 7; h.nr[3] = 3;
+        }
+        segs.push_back(h);
+    }
+    for (int i = 0; i < pi; ++i) if (!params[i]) return NSFF_ERR_NULL;
+    for (size_t base = 0; base < segs.size(); base += PACKB_BATCH) {
+        PackArgsB pa{};
+        pa.dst = reinterpret_cast<uint32_t*>(packed);
+        const int n = (int)std::min<size_t>(PACKB_BATCH, segs.size() - base);
+        int max_threads = 0;
+        for (int i = 0; i < n; ++i) {
+            pa.seg[i] = segs[base + i];
+            max_threads = std::max(max_threads, pa.seg[i].kind == 0 ? pa.seg[i].nks : 4 * pa.seg[i].nks * 2 * 64);
+        }
+        hipLaunchKernelGGL(pack_kernel_b, dim3((max_threads + 255) / 256, n), dim3(256), 0, st, pa);
+    }
+    return nsff_launch_status();
+}
+
+int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream) {
+    if (!desc || !packed_bwd || !args) return NSFF_ERR_NULL;
+    const NsffModelDesc& d = *desc;
+    const NsffFieldBwdArgs& g = *args;
+    LayoutB L;
+    const int rc = make_layout_b(d, L);
+    if (rc) return rc;
+    if (g.n_points < 0 || (g.static_mode != 0 && g.static_mode != 2) || (g.transient_mode != 0 && g.transient_mode != 2)) return NSFF_ERR_INVALID;
+    if (!g.static_mode && !g.transient_mode) return NSFF_ERR_INVALID;
+    if (g.transient_mode && !d.has_transient) return NSFF_ERR_INVALID;
+    if (g.n_points == 0) return NSFF_OK;
+    if (!g.d_raw || !g.raw || !g.gmax || !g.masks || !g.dpre || !g.dhead) return NSFF_ERR_NULL;
+    if (((uintptr_t)packed_bwd | (uintptr_t)g.d_raw | (uintptr_t)g.raw | (uintptr_t)g.dpre | (uintptr_t)g.dhead |
+         (uintptr_t)g.d_xin | (uintptr_t)g.masks) & 15) return NSFF_ERR_ALIGN;
+    BKArgs k{};
+    k.packed = reinterpret_cast<const uint32_t*>(packed_bwd);
+    k.s_sigma = L.s_sigma;
+    k.d_raw = g.d_raw; k.raw = g.raw; k.gmax = g.gmax;
+    k.masks = reinterpret_cast<const unsigned long long*>(g.masks);
+    k.dpre = reinterpret_cast<_Float16*>(g.dpre);
+    k.dhead = reinterpret_cast<_Float16*>(g.dhead);
+    k.d_xin = g.d_xin;
+    k.n_points = g.n_points; k.n_tiles = (g.n_points + 63) / 64;
+    k.D = d.D; k.t_head_rows = d.has_flow ? 10 : 4; k.flow_scale = d.flow_scale;
+    if (k.n_tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
+    int n = 0;
+    auto push = [&](uint32_t w, int nks, int epi, int slot, int flags) {
+        BStep& s = k.steps[n++];
+        s.w_off = w; s.nks = (uint8_t)nks; s.epi = (uint8_t)epi; s.slot = (uint8_t)slot; s.flags = (uint8_t)flags;
+    };
+    // slots: trunk t (0 static, 1 transient), layer l -> t*(D+1) + l ; l = D is *_final.  Masks use the forward's
+    // activation slots, which are numbered the same way.
+    auto trunk = [&](const TrunkLayoutB& T, int t, bool want_xin) {
+        const int base = t * (d.D + 1);
+        push(T.head, 4, EPI_LINEAR, base + d.D, 0);
+        push(T.fin, 16, EPI_MASK, base + d.D - 1, (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == d.skip && want_xin) ? F_STASH : 0));
+        for (int l = d.D - 1; l >= 1; --l)
+            push(T.layer[l], 16, EPI_MASK, base + l - 1, (l - 1 == d.skip && want_xin) ? F_STASH : 0);
+        if (want_xin) {
+            push(T.x0, 16, EPI_KEEP, 0, F_HALF_ROWS);
+            push(T.xskip, 16, EPI_DXIN, 0, F_HALF_ROWS | F_CONTINUE | F_FROM_STASH);
+        }
+    };
+    if (g.static_mode) trunk(L.st, 0, false);
+    k.n_static_steps = n;
+    if (g.transient_mode) trunk(L.tr, 1, g.d_xin != nullptr);
+    if (n > MAX_BSTEPS) return NSFF_ERR_INVALID;
+    k.n_steps = n;
+    hipLaunchKernelGGL(nsff_field_bwd_kernel, dim3((unsigned)k.n_tiles), dim3(256), 0, (hipStream_t)stream, k);
+    return nsff_launch_status();
+}
+
+int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
+                     float* out, float* bias, void* stream) {
+    if (!jobs || !out || !bias) return NSFF_ERR_NULL;
+    if (n_jobs < 0 || n_tiles < 0 || n_splits < 1) return NSFF_ERR_INVALID;
+    if (n_jobs == 0 || n_tiles == 0) return NSFF_OK;
+    for (int j = 0; j < n_jobs; ++j) {
+        const bool ok = (jobs[j].a_rows == 256 || jobs[j].a_rows == 32) && (jobs[j].b_rows == 256 || jobs[j].b_rows == 128) &&
+                        !(jobs[j].a_rows == 32 && jobs[j].b_rows == 128);
+        if (!ok) return NSFF_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int cls = 0; cls < 3; ++cls) {
+        const int ar = cls == 2 ? 32 : 256, brw = cls == 1 ? 128 : 256;
+        int done = 0;
+        while (true) {
+            WKArgs k{};
+            k.out = out; k.bias = bias; k.n_tiles = n_tiles; k.n_splits = n_splits; k.n_jobs_total = n_jobs;
+            int m = 0, seen = 0;
+            for (int j = 0; j < n_jobs && m < MAX_WJOBS; ++j) {
+                if (jobs[j].a_rows != ar || jobs[j].b_rows != brw) continue;
+                if (seen++ < done) continue;
+                if (!jobs[j].a || !jobs[j].b) return NSFF_ERR_NULL;
+                k.jobs[m].a = reinterpret_cast<const _Float16*>(jobs[j].a);
+                k.jobs[m].b = reinterpret_cast<const _Float16*>(jobs[j].b);
+                k.jobs[m].out_off = jobs[j].out_off; k.jobs[m].job_index = j;
+                ++m;
+            }
+            if (m == 0) break;
+            const dim3 grid((unsigned)(m * n_splits));
+            if (cls == 0) hipLaunchKernelGGL((nsff_wgrad_kernel<4, 4, 2, 2>), grid, dim3(256), 0, st, k);
+            else if (cls == 1) hipLaunchKernelGGL((nsff_wgrad_kernel<4, 2, 2, 2>), grid, dim3(256), 0, st, k);
+            else hipLaunchKernelGGL(nsff_wgrad_head_kernel, grid, dim3(256), 0, st, k);
+            done += m;
+            if (m < MAX_WJOBS) break;
+        }
+    }
+    return nsff_launch_status();
+}
+
+}  // extern "C"

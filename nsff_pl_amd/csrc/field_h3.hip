@@ -64,9 +64,12 @@ struct H3KArgs {
     const float* a_emb;
     const float* t_emb;
     float* raw;
-    _Float16* save_acts;       // training forward: (slots, P_pad, 256) fp16 post-activation values, or null
-    _Float16* save_xin;        // (P_pad, 128) fp16 trunk input [xyz embedding | pad | t | pad], or null
-    long long save_stride;     // halfs per slot = P_pad * 256
+    // training forward (SAVE variant), all fragment-major so that the weight-gradient GEMM streams them:
+    _Float16* save_acts;       // (slots, tiles, 4 ks, 256 rows, 16 pts) fp16 post-activation values, or null
+    _Float16* save_xin;        // (tiles, 4 ks, 128 rows, 16 pts) fp16 trunk input [xyz emb | pad | t at row 64 | pad], or null
+    unsigned long long* save_masks;   // (slots, tiles, 256 threads) ReLU sign bits in accumulator order, or null
+    long long save_stride;     // halfs per activation slot = tiles * 64 * 256
+    long long n_tiles;
     long long n_points;
     int pts_per_ray;
     int static_mode, transient_mode;
@@ -204,11 +207,11 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const BiasRegs& b
         }
 }
 
-// `save` (or null): row p0 of this tile in an HBM activation slot [P_pad][256] fp16; the copy is rounded to
-// nearest (the hi plane in LDS is truncated -- harmless there because lo carries the rest, biased here).
+// `mask` (or null) receives the ReLU sign bits of this lane's accumulators: bit (mt*NT + nt)*16 + 4q + e.
 template <int NT, bool RELU>
 __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[2][NT], int wave, int nt0, int lane,
-                                          _Float16* save = nullptr) {
+                                          unsigned long long* mask = nullptr) {
+    unsigned long long bits = 0ull;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -231,49 +234,56 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
                 lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
                 *reinterpret_cast<h4*>(sXh + idx) = hv;
                 *reinterpret_cast<h4*>(sXl + idx) = lv;
-                if (save != nullptr) {
-                    h4 sv;
-                    sv[0] = (_Float16)v[0]; sv[1] = (_Float16)v[1]; sv[2] = (_Float16)v[2]; sv[3] = (_Float16)v[3];
-                    *reinterpret_cast<h4*>(save + (long long)(32 * (nt0 + nt) + (lane & 31)) * NSFF_W
-                                           + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5)) = sv;
+                if (mask != nullptr) {
+                    unsigned m = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                    bits |= (unsigned long long)m << (((mt * NT + nt) * 4 + q) * 4);
                 }
             }
+    if (mask != nullptr) *mask = bits;
 }
 
-__device__ __forceinline__ void split_store_save(_Float16* xh, _Float16* xl, int idx, float v, _Float16* save, int col) {
-    split_store(xh, xl, idx, v);
-    if (save != nullptr) save[col] = (_Float16)v;
+// Copy the tile's activations (hi + lo planes, rounded to nearest) to HBM in the fragment order of the
+// weight-gradient GEMM (K = points): dst[ks][row block][lane][8 pts] -- every 1 KiB block is exactly one MFMA
+// operand fragment (32 rows x 16 points) in lane order; rows = neurons (n_rows, a multiple of 32), ks = 4 x 16 points.
+template <int THREADS>
+__device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows,
+                                                  int rows_copied) {
+    for (int task = threadIdx.x; task < rows_copied * 8; task += THREADS) {     // (8-point group, row), row fastest
+        const int row = task % rows_copied, pg = task / rows_copied;
+        h8 out;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int idx = (8 * pg + t) * LDH + row;
+            out[t] = (_Float16)((float)sXh[idx] + (float)sXl[idx]);
+        }
+        // 1 KiB blocks of 32 rows, lane-linear inside: [ks][row/32][(row&31) + 32*(point group&1)][8 points]
+        *reinterpret_cast<h8*>(dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8) = out;
+    }
 }
 
 template <int M, int THREADS>
-__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
-                                            bool save_it = false) {
+__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t) {
     constexpr int G = THREADS / M;               // threads per point row
     const int r = threadIdx.x % M, q = threadIdx.x / M;
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
     const int base = r * LDH;
     const int k0s = (int)a.L.k0s;
-    _Float16* sv = (save_it && a.save_xin != nullptr) ? a.save_xin + p * 128 : nullptr;   // rows < P_pad exist
     if (a.xyz != nullptr) {
         float x[3] = {0.f, 0.f, 0.f};
         if (valid) { x[0] = a.xyz[p * 3 + 0]; x[1] = a.xyz[p * 3 + 1]; x[2] = a.xyz[p * 3 + 2]; }
         if (q == 0) {
-            split_store_save(sXh, sXl, base + 0, x[0], sv, 0); split_store_save(sXh, sXl, base + 1, x[1], sv, 1);
-            split_store_save(sXh, sXl, base + 2, x[2], sv, 2);
+            split_store(sXh, sXl, base + 0, x[0]); split_store(sXh, sXl, base + 1, x[1]);
+            split_store(sXh, sXl, base + 2, x[2]);
             for (int c = a.in_xyz; c < k0s; ++c) { sXh[base + c] = (_Float16)0.f; sXl[base + c] = (_Float16)0.f; }
-            if (sv != nullptr) {
-                for (int c = a.in_xyz; c < 64; ++c) sv[c] = (_Float16)0.f;
-                if (!with_t) for (int c = 64; c < 128; ++c) sv[c] = (_Float16)0.f;
-            }
         }
         const int nf3 = 3 * a.n_freqs;
         for (int j = q; j < nf3; j += G) {
             const int f = j / 3, c = j - 3 * f;
             float s, co;
             sincosf(a.freqs[f] * x[c], &s, &co);
-            split_store_save(sXh, sXl, base + 3 + 6 * f + c, s, sv, 3 + 6 * f + c);
-            split_store_save(sXh, sXl, base + 3 + 6 * f + 3 + c, co, sv, 3 + 6 * f + 3 + c);
+            split_store(sXh, sXl, base + 3 + 6 * f + c, s);
+            split_store(sXh, sXl, base + 3 + 6 * f + 3 + c, co);
         }
     } else {
         const float* src = a.x_emb + p * a.ld_emb + a.off_xyz;
@@ -285,7 +295,7 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
                                             : a.x_emb + p * a.ld_emb + a.off_t;
         const int kt = (int)a.L.kt;
         for (int c = q; c < kt; c += G)
-            split_store_save(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f, sv, 64 + c);
+            split_store(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f);
     }
 }
 
@@ -413,10 +423,15 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
             if (st.pre == PRE_SIDE) build_side<M, THREADS>(sXh, sXl, a, p0);
-            else build_input<M, THREADS>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T,
-                                         SAVE && st.bias_off != NSFF_NONE &&
-                                             (st.pre == PRE_INPUT_T || a.transient_mode == 0));
+            else build_input<M, THREADS>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
             __syncthreads();
+            if constexpr (SAVE) {
+                // trunk input of layer 0: columns [0,64) xyz embedding, [64,128) time code (zero when absent)
+                if (a.save_xin != nullptr && st.bias_off != NSFF_NONE && (st.pre == PRE_INPUT_T || a.transient_mode == 0)) {
+                    tile_to_fragments<THREADS>(sXh, sXl, a.save_xin + (long long)blockIdx.x * (64 * 128), 128,
+                                               st.pre == PRE_INPUT_T ? 128 : 64);     // static only: rows 64.. stay unwritten
+                }
+            }
         }
         if (st.bias_off != NSFF_NONE) acc_init<NT>(acc, br);
         gemm_seg<NT>(acc, ring, wnext, sBh, sBl, st.nks);
@@ -427,14 +442,19 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
         }
         if (st.post != POST_NONE) {
             __syncthreads();
-            _Float16* sv = nullptr;
+            unsigned long long* mk = nullptr;
+            if constexpr (SAVE) {
+                if (st.save && a.save_masks != nullptr && st.post == POST_RELU)
+                    mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + blockIdx.x) * THREADS + threadIdx.x;
+            }
+            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, nt0, lane, mk);
+            else acc_store<NT, false>(sXh, sXl, acc, wave, nt0, lane, mk);
+            __syncthreads();
             if constexpr (SAVE) {
                 if (st.save && a.save_acts != nullptr)
-                    sv = a.save_acts + (long long)(st.save - 1) * a.save_stride + p0 * NSFF_W;
+                    tile_to_fragments<THREADS>(sXh, sXl, a.save_acts + (long long)(st.save - 1) * a.save_stride
+                                                             + (long long)blockIdx.x * (64 * NSFF_W), NSFF_W, NSFF_W);
             }
-            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, nt0, lane, sv);
-            else acc_store<NT, false>(sXh, sXl, acc, wave, nt0, lane, sv);
-            __syncthreads();
             if (st.head != HEAD_NONE) {
                 // static sigma reads the last trunk activation, before *_final (nerf.py:169);
                 // dynamic rows: rgb(3) sigmoid, sigma raw, fw(3)/bw(3) = flow_scale*tanh (nerf.py:197-208)
@@ -604,8 +624,10 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.raw = g.raw; k.n_points = g.n_points; k.pts_per_ray = g.pts_per_ray;
     k.save_acts = reinterpret_cast<_Float16*>(g.save_acts);
     k.save_xin = reinterpret_cast<_Float16*>(g.save_xin);
-    k.save_stride = ((g.n_points + 127) / 128) * 128 * NSFF_W;
-    if ((g.save_acts || g.save_xin) && (d.use_viewdir || !g.xyz)) return NSFF_ERR_INVALID;
+    k.save_masks = reinterpret_cast<unsigned long long*>(g.save_masks);
+    k.n_tiles = (g.n_points + 63) / 64;
+    k.save_stride = k.n_tiles * 64 * NSFF_W;
+    if ((g.save_acts || g.save_xin || g.save_masks) && (d.use_viewdir || !g.xyz || k.L.k0s != 64 || k.L.kt > 64)) return NSFF_ERR_INVALID;
     k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
     k.D = d.D; k.skip = d.skip;
     k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;
@@ -654,7 +676,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     if (n > MAX_STEPS) return NSFF_ERR_INVALID;
     k.n_steps = n;
 
-    if (k.save_acts || k.save_xin) {
+    if (k.save_acts || k.save_xin || k.save_masks) {
         const long long tiles = (g.n_points + 63) / 64;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
         hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1, true>), dim3((unsigned)tiles), dim3(256), 0, st, k);

@@ -6,10 +6,14 @@
 * forward  = the gfx950 f16x3 field kernel in its *training* variant (``nsff_field_kernel_h3<2,1,true>``),
   which also keeps every post-activation tensor of the trunks (fp16) and the encoded trunk input in HBM
   -- 288 GB per GPU make keeping ~4.6 KB per point-trunk cheaper than any recomputation;
-* backward = fp16 tensor-core GEMMs with fp32 accumulation over those saved activations:
-  the data-gradient chain (dX = dY.W, ReLU masks, head derivatives, positional-encoding derivative) and
-  the weight gradients (dW = dY^T.X, K = all points).  Incoming gradients are multiplied by a power of two
-  so that their maximum sits at 2^10 (fp16 range), and divided out of the results.
+* backward = two hand-written gfx950 kernels (csrc/field_bwd.hip), fp16 MFMA operands with fp32 accumulation:
+  ``nsff_field_backward`` runs the whole data-gradient chain of a 64-point tile in one workgroup (head
+  derivatives, dX = dY.W with the transposed weights streamed from L2, ReLU masks from the forward's sign
+  bits) and ``nsff_weight_grad`` the batched split-K weight-gradient GEMMs (dW = dY^T.X, K = all points) over
+  the fragment-major tiles both passes left in HBM.  Every point's gradient row carries its own power-of-two
+  scale (block floating point); the positional-encoding derivative and the per-ray reduction of the time-code
+  gradient are a few torch ops on the (P,128) result.  ``NSFF_BWD_IMPL=torch`` selects an all-torch version of
+  the same arithmetic (debugging).
 
 Only models without view directions take this path (the NSFF configuration, train.py:40-84 defaults);
 others keep the torch expression of :mod:`nsff_pl_amd.torch_path`.
@@ -73,26 +77,136 @@ class _FieldFn(torch.autograd.Function):
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
         static, transient = cfg["static"], cfg["transient"]
         P, D = xyz.shape[0], model.D
-        p_pad = (P + 127) // 128 * 128
-        raw = torch.zeros(P, _lib.RAW_STRIDE, device=xyz.device)
-        acts = torch.empty(2 * D + 2, p_pad, 256, device=xyz.device, dtype=torch.float16)
-        xin = torch.empty(p_pad, 128, device=xyz.device, dtype=torch.float16)
+        tiles = (P + 63) // 64
+        dev = xyz.device
+        raw = torch.zeros(P, _lib.RAW_STRIDE, device=dev)
+        acts = torch.empty(2 * D + 2, tiles, 64 * 256, device=dev, dtype=torch.float16)
+        xin = torch.empty(tiles, 64 * 128, device=dev, dtype=torch.float16)
+        masks = torch.empty(2 * D + 2, tiles, 256, device=dev, dtype=torch.int64)
+        if not transient:
+            xin.zero_()                      # rows 64.. of a static-only launch are never written
         xyz_c = xyz.detach().contiguous()
         _lib.field_query(model, raw, P, s, 2 if static else 0, 2 if transient else 0,
                          2 if (transient and model.output_flow) else 0, xyz=xyz_c, freqs=freqs,
                          t_emb=None if t_rows is None else t_rows.detach().contiguous(),
-                         save_acts=acts, save_xin=xin, precision=config.PRECISIONS["f16x3"])
+                         save_acts=acts, save_xin=xin, save_masks=masks, precision=config.PRECISIONS["f16x3"])
         ctx.cfg, ctx.P = cfg, P
-        ctx.save_for_backward(raw, acts, xin, xyz_c, *params)
+        ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *params)
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
         cfg = ctx.cfg
+        if os.environ.get("NSFF_BWD_IMPL", "hip") == "torch" or (cfg["static"] and ctx.needs_input_grad[1]):
+            return _FieldFn._backward_torch(ctx, d_raw)
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
-        raw, acts, xin, xyz = ctx.saved_tensors[:4]
-        params = ctx.saved_tensors[4:]
+        raw, acts, xin, masks, xyz = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
         P, D, skip = ctx.P, model.D, model.skips[0]
+        tiles, dev = acts.shape[1], d_raw.device
+        static, transient = cfg["static"], cfg["transient"]
+        n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
+        d_raw = d_raw.contiguous()
+        gmax = d_raw.abs().max()
+        dpre = torch.empty(2 * (D + 1), tiles, 64 * 256, device=dev, dtype=torch.float16)
+        dhead = torch.empty(2, tiles, 64 * 32, device=dev, dtype=torch.float16)
+        want_in = transient and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        d_xin = torch.empty(P, 128, device=dev) if want_in else None
+        _lib.field_backward(model, P, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin)
+
+        # ---- weight-gradient GEMMs: one batched launch per output shape ----
+        jobs, sizes, meta = [], [], []            # meta: (kind, trunk, layer)
+
+        def job(a, b, a_rows, b_rows, tag):
+            jobs.append([a.data_ptr(), b.data_ptr(), a_rows, b_rows, 0])
+            sizes.append(a_rows * b_rows)
+            meta.append(tag)
+        for t in ([0] if static else []) + ([1] if transient else []):
+            base = t * (D + 1)
+            for l in range(D):
+                if l == 0:
+                    job(dpre[base], xin, 256, 128, ("x", t, l))
+                else:
+                    job(dpre[base + l], acts[base + l - 1], 256, 256, ("h", t, l))
+                    if l == skip:
+                        job(dpre[base + l], xin, 256, 128, ("x", t, l))
+            job(dpre[base + D], acts[base + D - 1], 256, 256, ("h", t, D))
+            job(dhead[t], acts[base + D], 32, 256, ("head", t, 0))
+            if t == 0:
+                job(dhead[0], acts[base + D - 1], 32, 256, ("head", t, 1))    # static sigma reads the trunk
+        n_splits = max(1, min(32, tiles // 4))
+        off = 0
+        for j, sz in zip(jobs, sizes):
+            j[4] = off
+            off += sz * n_splits
+        out = torch.empty(off, device=dev)
+        bias = torch.empty(len(jobs), n_splits, 256, device=dev)
+        _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias)
+        # G = 2^(11 - exponent(gmax)) exactly as the kernels derive it
+        g_exp = torch.frexp(gmax)[1]
+        inv_g = torch.where(gmax > 0, torch.exp2((g_exp - 11).float()), torch.ones_like(gmax))
+        bias = bias.sum(1) * inv_g
+
+        def result(i):
+            j = jobs[i]
+            return out[j[4]:j[4] + sizes[i] * n_splits].view(n_splits, j[2], j[3]).sum(0) * inv_g
+
+        index = {p_: i for i, p_ in enumerate(id(q) for q in _lib.param_list(model))}
+        grads = [None] * len(params)
+
+        def put(layer, w, b):
+            grads[index[id(layer.weight)]] = w
+            grads[index[id(layer.bias)]] = b
+
+        def xcols(m, in_t):                       # (256,128) in trunk-input rows -> (256, in_dim) in Linear columns
+            return m[:, :n_xyz] if in_t == 0 else torch.cat([m[:, :n_xyz], m[:, 64:64 + in_t]], 1)
+        res = {tag: i for i, tag in enumerate(meta)}
+        for t in ([0] if static else []) + ([1] if transient else []):
+            prefix, in_t = ("static", 0) if t == 0 else ("transient", n_t)
+            for l in range(D):
+                layer = _lin(getattr(model, f"{prefix}_xyz_encoding_{l + 1}"))
+                if l == 0:
+                    i = res[("x", t, 0)]
+                    put(layer, xcols(result(i), in_t), bias[i])
+                elif l == skip:
+                    i = res[("h", t, l)]
+                    put(layer, torch.cat([xcols(result(res[("x", t, l)]), in_t), result(i)], 1), bias[i])
+                else:
+                    i = res[("h", t, l)]
+                    put(layer, result(i), bias[i])
+            i = res[("h", t, D)]
+            put(_lin(getattr(model, f"{prefix}_xyz_encoding_final")), result(i), bias[i])
+            i = res[("head", t, 0)]
+            hw, hb = result(i), bias[i]
+            if t == 0:
+                put(_lin(model.static_rgb), hw[0:3], hb[0:3])
+                i2 = res[("head", 0, 1)]
+                put(_lin(model.static_sigma), result(i2)[3:4], bias[i2][3:4])
+            else:
+                put(_lin(model.transient_rgb), hw[0:3], hb[0:3])
+                put(_lin(model.transient_sigma), hw[3:4], hb[3:4])
+                if model.output_flow:
+                    put(_lin(model.transient_flow_fw), hw[4:7], hb[4:7])
+                    put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
+
+        d_xyz = d_t = None
+        if d_xin is not None:
+            if ctx.needs_input_grad[2]:
+                d_t = d_xin[:, 64:64 + n_t].reshape(P // s, s, -1).sum(1)
+            if ctx.needs_input_grad[1]:
+                d_xyz = _posenc_backward(d_xin, xyz, freqs)
+        return (None, d_xyz, d_t) + tuple(grads)
+
+    @staticmethod
+    def _backward_torch(ctx, d_raw):
+        """The same arithmetic with torch ops (fp16 GEMMs through rocBLAS): debugging aid, and the route for a
+        static trunk whose points require gradients (never the case inside render_pass)."""
+        cfg = ctx.cfg
+        model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
+        raw, acts_f, xin_f, masks, xyz = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        P, D, skip = ctx.P, model.D, model.skips[0]
+        acts, xin = _unfragment(acts_f, 256), _unfragment(xin_f[None], 128)[0]
         names = [id(p) for p in _lib.param_list(model)]
         grads = [None] * len(params)
         slot = {k: i for i, k in enumerate(names)}
@@ -202,6 +316,22 @@ class _FieldFn(torch.autograd.Function):
                     ang = f * xyz
                     d_xyz += f * (torch.cos(ang) * de[:, 3 + 6 * i:6 + 6 * i] - torch.sin(ang) * de[:, 6 + 6 * i:9 + 6 * i])
         return (None, d_xyz, d_t) + tuple(grads)
+
+
+def _posenc_backward(d_xin, xyz, freqs):
+    """d(xyz) from d(embedding) (reference nerf.py:17-30: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...])."""
+    d_xyz = d_xin[:, 0:3].clone()
+    for i, f in enumerate(freqs):
+        ang = f * xyz
+        d_xyz += f * (torch.cos(ang) * d_xin[:, 3 + 6 * i:6 + 6 * i] - torch.sin(ang) * d_xin[:, 6 + 6 * i:9 + 6 * i])
+    return d_xyz
+
+
+def _unfragment(frag, n_rows):
+    """(slots, tiles, 64*n_rows) fragment-major fp16 -> (slots, tiles*64, n_rows) point-major."""
+    slots, tiles = frag.shape[:2]
+    x = frag.view(slots, tiles, 4, n_rows // 32, 2, 32, 8)       # ks, row block, point-group parity, row, 8 points
+    return x.permute(0, 1, 2, 4, 6, 3, 5).reshape(slots, tiles * 64, n_rows)
 
 
 def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient):

@@ -25,11 +25,14 @@ class PackCache:
             dev = params[0].device
             _lib.require_gpu_tensor(params[0], "model parameter")
             desc = _lib.model_desc(model)
-            nbytes = _lib.packed_bytes(desc, precision)
+            nbytes = _lib.bwd_packed_bytes(desc) if precision == _lib.BWD_PACK else _lib.packed_bytes(desc, precision)
             buf = self._buf.get(precision)
             if buf is None or buf.numel() * 4 != nbytes or buf.device != dev:
                 buf = self._buf[precision] = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
-                _lib.pack_weights(desc, params, buf, precision)
+                if precision == _lib.BWD_PACK:
+                    _lib.pack_weights_bwd(desc, params, buf)
+                else:
+                    _lib.pack_weights(desc, params, buf, precision)
             self._key[precision] = key
         return self._buf[precision]

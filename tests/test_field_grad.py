@@ -50,7 +50,9 @@ def test_field_node_gradients(static, transient, spread, hip_lib):
 
     for p in model.parameters():
         p.grad = None
-    x = xyz.detach().clone().requires_grad_(True)
+    # inside render_pass the static trunk only ever sees points without gradient: that is the native route;
+    # static + d(points) takes the torch fallback of field_grad, covered by spread == 0 here
+    x = xyz.detach().clone().requires_grad_(not static or spread == 0.0)
     t = t_rows.detach().clone().requires_grad_(True)
     raw = field_grad.field(model, x, freqs, t, s, static, transient)
     (raw * cot).sum().backward()
@@ -67,12 +69,13 @@ def test_field_node_gradients(static, transient, spread, hip_lib):
         layer = n.rsplit(".", 1)[0]
         scale = torch.stack([ref_p[layer + ".weight"].abs().max(), ref_p[layer + ".bias"].abs().max()]).max()
         worst[n], base[n] = rel(p.grad, ref_p[n], scale), rel(f32_p[n], ref_p[n], scale)
-    worst["xyz"], worst["t"] = rel(x.grad, ref_x), rel(t.grad, ref_t)
-    base["xyz"], base["t"] = rel(f32_x, ref_x), rel(f32_t, ref_t)
+    worst["t"], base["t"] = rel(t.grad, ref_t), rel(f32_t, ref_t)
+    if x.requires_grad:
+        worst["xyz"], base["xyz"] = rel(x.grad, ref_x), rel(f32_x, ref_x)
     # fp16 operands: 5e-4 per rounding, a handful of roundings along the chain; with `spread` a few points
     # dominate every sum, so the rounding noise of single terms is not averaged away
     tol = 2e-3 if spread == 0 else 6e-3
     bad = {k: (v, base[k]) for k, v in worst.items() if v > tol + 3 * base[k]}
     k = max(worst, key=worst.get)
-    print("worst native", worst[k], k, "fp32 torch there", base[k], "| fp32 torch worst", max(base.values()))
+    print("\nworst native", static, spread, worst[k], k, "fp32 torch there", base[k], "| fp32 torch worst", max(base.values()))
     assert not bad, bad
