@@ -121,8 +121,9 @@ def main():
     def step():
         if trainer is not None:
             return trainer.step(batch)
-        out = A.render_rays(models, emb, rays, ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
-                            N_IMPORTANCE, 1024 * 32, test_time=False, **kw)
+        with torch.no_grad():      # the render workload measures the forward path; --workload train the full step
+            out = A.render_rays(models, emb, rays, ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
+                                N_IMPORTANCE, 1024 * 32, test_time=False, **kw)
         if world > 1:
             ndist.all_gather_pixels(out, ("rgb_fine", "depth_fine"))
         return out
