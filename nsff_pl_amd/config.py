@@ -40,7 +40,7 @@ def get_precision():
 def set_tile_points(n):
     """f16x3 only: points per workgroup (0 = library default, 64 or 128)."""
     global _tile_points
-    if n not in (0, 64, 128, 129):
+    if n not in (0, 64, 128, 129, 130):
         raise ValueError("tile_points must be 0, 64 or 128")
     _tile_points = n
 

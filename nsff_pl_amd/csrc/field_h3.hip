@@ -30,6 +30,15 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __fp16 h2 __attribute__((ext_vector_type(2)));
 
+#ifdef H3_TIMING
+// debug build only (make timing): s_memtime stamps of the first 256 workgroups, 6 per step and wave
+__device__ unsigned g_h3_timing[256 * 8 * 32 * 6];
+#define H3_STAMP(k) do { if (lane == 0 && blockIdx.x < 256 && i < 32) \
+    g_h3_timing[((blockIdx.x * 8 + wave_id) * 32 + i) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define H3_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int LDH = 264;          // halfs per LDS row (528 B; 528/16 = 33 odd)
@@ -91,18 +100,26 @@ __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx,
     xl[idx] = (_Float16)(v - (float)hi);
 }
 
-struct WFrag { h8 wh[2], wl[2]; };                 // weights (A operand) of one k-step: 16 VGPRs
+// MTW = 32-neuron tiles per wave: 2 (four waves x 64 neurons) or 1 (eight waves x 32 neurons, kernel variant <4,1,*,1>)
+template <int MTW> struct WFrag { h8 wh[MTW], wl[MTW]; };   // weights (A operand) of one k-step: 8*MTW VGPRs
 template <int NT> struct XFrag { h8 xh[NT], xl[NT]; };  // activations (B operand) of one k-step
-struct WRing { WFrag r[4]; };                       // four k-steps of weights in flight (L2 latency)
-struct BiasRegs { float4 b[2][4]; };
+template <int MTW> struct WRing { WFrag<MTW> r[4]; };       // four k-steps of weights in flight (L2 latency)
+template <int MTW> struct BiasRegs { float4 b[MTW][4]; };
 
 // Weights are read through a bumped pointer so that every load is base + small immediate
 // ([ks][mt][part][lane] 16-byte chunks = 4 KiB per k-step; the lane offset is in the pointer).
-__device__ __forceinline__ void load_w(WFrag& f, const uint4* __restrict__& wp) {
-    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
-    wp += 256;
-    f.wh[0] = __builtin_bit_cast(h8, a0); f.wl[0] = __builtin_bit_cast(h8, a1);
-    f.wh[1] = __builtin_bit_cast(h8, a2); f.wl[1] = __builtin_bit_cast(h8, a3);
+template <int MTW>
+__device__ __forceinline__ void load_w(WFrag<MTW>& f, const uint4* __restrict__& wp) {
+    if constexpr (MTW == 2) {
+        const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
+        wp += 256;
+        f.wh[0] = __builtin_bit_cast(h8, a0); f.wl[0] = __builtin_bit_cast(h8, a1);
+        f.wh[1] = __builtin_bit_cast(h8, a2); f.wl[1] = __builtin_bit_cast(h8, a3);
+    } else {                                   // the wave's pointer already selects its mt half of the k-step
+        const uint4 a0 = wp[0], a1 = wp[64];
+        wp += 256;
+        f.wh[0] = __builtin_bit_cast(h8, a0); f.wl[0] = __builtin_bit_cast(h8, a1);
+    }
 }
 
 template <int NT>
@@ -117,7 +134,8 @@ __device__ __forceinline__ void load_x(XFrag<NT>& f, const _Float16* sBh, const 
 // Issue the weight loads of the first four k-steps of a segment (called BEFORE the barriers /
 // epilogue that precede the segment's GEMM, so the L2 round trip hides behind them).
 // Returns the pointer of k-step 4.
-__device__ __forceinline__ const uint4* prefetch_w(WRing& ring, const uint4* __restrict__ w) {
+template <int MTW>
+__device__ __forceinline__ const uint4* prefetch_w(WRing<MTW>& ring, const uint4* __restrict__ w) {
     const uint4* __restrict__ wp = w;
     load_w(ring.r[0], wp);
     load_w(ring.r[1], wp);
@@ -126,19 +144,19 @@ __device__ __forceinline__ const uint4* prefetch_w(WRing& ring, const uint4* __r
     return wp;
 }
 
-template <int NT>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[2][NT], const WFrag& w, const XFrag<NT>& x) {
+template <int NT, int MTW>
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW>& w, const XFrag<NT>& x) {
     // three passes so that consecutive MFMAs never touch the same accumulator
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wl[mt], x.xh[nt], acc[mt][nt]);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wh[mt], x.xl[nt], acc[mt][nt]);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wh[mt], x.xh[nt], acc[mt][nt]);
 }
@@ -146,8 +164,8 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[2][NT], const WFrag& w, c
 // acc += W_seg . X[:, 0:16*nks]^T  for this wave's 64 neurons and all 32*NT points.
 // `ring` already holds k-steps 0..3 and `wp` points at k-step 4 (prefetch_w); weights run four
 // k-steps ahead of the MFMAs, activations (LDS) one.
-template <int NT>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], WRing& ring, const uint4* __restrict__ wp,
+template <int NT, int MTW>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW>& ring, const uint4* __restrict__ wp,
                                          const _Float16* sBh, const _Float16* sBl, int nks) {
     // nks is a multiple of 4 (every K-segment is zero-padded to 64 columns): no per-step branches.
     XFrag<NT> x0, x1;
@@ -157,45 +175,46 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], WRing& ring, cons
         // sched_barrier pins each refill right behind the MFMAs that free its ring slot: left alone,
         // hipcc sinks all 16 loads to the end of the group and the ring never runs ahead
         load_x<NT>(x1, sBh, sBl, 1);
-        mma_step<NT>(acc, ring.r[0], x0);
+        mma_step<NT, MTW>(acc, ring.r[0], x0);
         load_w(ring.r[0], wp);
         H3_PIN();
         load_x<NT>(x0, sBh, sBl, 2);
-        mma_step<NT>(acc, ring.r[1], x1);
+        mma_step<NT, MTW>(acc, ring.r[1], x1);
         load_w(ring.r[1], wp);
         H3_PIN();
         load_x<NT>(x1, sBh, sBl, 3);
-        mma_step<NT>(acc, ring.r[2], x0);
+        mma_step<NT, MTW>(acc, ring.r[2], x0);
         load_w(ring.r[2], wp);
         H3_PIN();
         load_x<NT>(x0, sBh, sBl, 4);
-        mma_step<NT>(acc, ring.r[3], x1);
+        mma_step<NT, MTW>(acc, ring.r[3], x1);
         load_w(ring.r[3], wp);
         H3_PIN();
         sBh += 64; sBl += 64;                    // four k-steps of 16 halfs
     }
     load_x<NT>(x1, sBh, sBl, 1);
-    mma_step<NT>(acc, ring.r[0], x0);
+    mma_step<NT, MTW>(acc, ring.r[0], x0);
     load_x<NT>(x0, sBh, sBl, 2);
-    mma_step<NT>(acc, ring.r[1], x1);
+    mma_step<NT, MTW>(acc, ring.r[1], x1);
     load_x<NT>(x1, sBh, sBl, 3);
-    mma_step<NT>(acc, ring.r[2], x0);
-    mma_step<NT>(acc, ring.r[3], x1);
+    mma_step<NT, MTW>(acc, ring.r[2], x0);
+    mma_step<NT, MTW>(acc, ring.r[3], x1);
 }
 
 // bias of row (neuron) 64w + 32mt + 8q + 4h + e, e = 0..3 -- loaded early, applied by acc_init
-__device__ __forceinline__ void load_bias(BiasRegs& br, const float* __restrict__ bias, int wave, int lane) {
+template <int MTW>
+__device__ __forceinline__ void load_bias(BiasRegs<MTW>& br, const float* __restrict__ bias, int nb0, int lane) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            br.b[mt][q] = *reinterpret_cast<const float4*>(bias + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
+            br.b[mt][q] = *reinterpret_cast<const float4*>(bias + nb0 + 32 * mt + 8 * q + 4 * (lane >> 5));
 }
 
-template <int NT>
-__device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const BiasRegs& br) {
+template <int NT, int MTW>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[MTW][NT], const BiasRegs<MTW>& br) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 b = br.b[mt][q];
@@ -208,12 +227,12 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[2][NT], const BiasRegs& b
 }
 
 // `mask` (or null) receives the ReLU sign bits of this lane's accumulators: bit (mt*NT + nt)*16 + 4q + e.
-template <int NT, bool RELU>
-__device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[2][NT], int wave, int nt0, int lane,
+template <int NT, bool RELU, int MTW>
+__device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane,
                                           unsigned long long* mask = nullptr) {
     unsigned long long bits = 0ull;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -228,7 +247,7 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
                 const h2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                 const h2 l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
                 const h2 l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
-                const int idx = (32 * (nt0 + nt) + (lane & 31)) * LDH + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5);
+                const int idx = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt + 8 * q + 4 * (lane >> 5);
                 h4 hv, lv;
                 hv[0] = (_Float16)h01[0]; hv[1] = (_Float16)h01[1]; hv[2] = (_Float16)h23[0]; hv[3] = (_Float16)h23[1];
                 lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
@@ -383,27 +402,32 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
 //   <2,2>: 128 points, 8 waves (2 per SIMD): the two wave rows request identical weight lines back to
 //          back, so the L1 merges them and the L2 weight stream per FLOP is halved.
 // SAVE: training forward -- epilogues also write their activations (fp16) to HBM for the backward pass.
-template <int NT, int WM, bool SAVE = false>
-__global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
+//   <4,1,*,1>: 128 points, EIGHT waves of 32 neurons each (MTW = 1): every weight byte is fetched once per 128
+//          points (half the L2 stream of <2,1>) by exactly one wave, and two waves per SIMD hide each other's epilogues.
+template <int NT, int WM, bool SAVE = false, int MTW = 2>
+__global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
     constexpr int M = 32 * NT * WM;
-    constexpr int THREADS = 256 * WM;
+    constexpr int THREADS = 256 * WM * (3 - MTW);
+    static_assert(MTW == 2 || WM == 1, "the 32-neuron-per-wave variant has a single row of point tiles");
     __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
     _Float16* sXh = sX;
     _Float16* sXl = sX + M * LDH;
     const int lane = threadIdx.x & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave = wave_id & 3;                 // neuron block [64*wave, 64*wave+64)
-    const int nt0 = (wave_id >> 2) * NT;          // first point tile of this wave
+    const int wave = MTW == 2 ? (wave_id & 3) : (wave_id >> 1);   // 64-neuron block of the packed weight stream
+    const int mt0 = MTW == 2 ? 0 : (wave_id & 1);                  // this wave's 32-neuron half of it (MTW = 1)
+    const int nb0 = 64 * wave + 32 * mt0;                          // first neuron of this wave
+    const int nt0 = MTW == 2 ? (wave_id >> 2) * NT : 0;            // first point tile of this wave
     const long long p0 = (long long)blockIdx.x * M;
     const uint32_t* __restrict__ pk = a.packed;
     const _Float16* sBh = sXh + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
     const _Float16* sBl = sXl + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
 
-    f32x16 acc[2][NT];
-    WRing ring;
-    BiasRegs br;
+    f32x16 acc[MTW][NT];
+    WRing<MTW> ring;
+    BiasRegs<MTW> br;
     auto seg = [&](uint32_t off, int nks) {
-        return reinterpret_cast<const uint4*>(pk + off) + (wave * nks) * 4 * 64 + lane;
+        return reinterpret_cast<const uint4*>(pk + off) + (wave * nks) * 4 * 64 + mt0 * 128 + lane;
     };
     auto fbias = [&](uint32_t off) { return reinterpret_cast<const float*>(pk + off); };
 
@@ -415,11 +439,12 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
                         ? a.n_static_steps : 0;
     auto step_at = [&](int i) { int j = i + rot; if (j >= a.n_steps) j -= a.n_steps; return a.steps[j]; };
     const H3Step s0 = step_at(0);
-    const uint4* wnext = prefetch_w(ring, seg(s0.w_off, s0.nks));
-    load_bias(br, fbias(s0.bias_off), wave, lane);
+    const uint4* wnext = prefetch_w<MTW>(ring, seg(s0.w_off, s0.nks));
+    load_bias<MTW>(br, fbias(s0.bias_off), nb0, lane);
 #pragma unroll 1
     for (int i = 0; i < a.n_steps; ++i) {
         const H3Step st = step_at(i);
+        H3_STAMP(0);
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
             if (st.pre == PRE_SIDE) build_side<M, THREADS>(sXh, sXl, a, p0);
@@ -433,23 +458,28 @@ __global__ __launch_bounds__(256 * WM, ((NT == 2) ? 2 : 1)) void nsff_field_kern
                 }
             }
         }
-        if (st.bias_off != NSFF_NONE) acc_init<NT>(acc, br);
-        gemm_seg<NT>(acc, ring, wnext, sBh, sBl, st.nks);
+        H3_STAMP(1);
+        if (st.bias_off != NSFF_NONE) acc_init<NT, MTW>(acc, br);
+        gemm_seg<NT, MTW>(acc, ring, wnext, sBh, sBl, st.nks);
+        H3_STAMP(2);
         if (i + 1 < a.n_steps) {                   // next segment's weights + bias fly during the epilogue
             const H3Step nx = step_at(i + 1);
-            wnext = prefetch_w(ring, seg(nx.w_off, nx.nks));
-            if (nx.bias_off != NSFF_NONE) load_bias(br, fbias(nx.bias_off), wave, lane);
+            wnext = prefetch_w<MTW>(ring, seg(nx.w_off, nx.nks));
+            if (nx.bias_off != NSFF_NONE) load_bias<MTW>(br, fbias(nx.bias_off), nb0, lane);
         }
         if (st.post != POST_NONE) {
             __syncthreads();
+            H3_STAMP(3);
             unsigned long long* mk = nullptr;
             if constexpr (SAVE) {
                 if (st.save && a.save_masks != nullptr && st.post == POST_RELU)
                     mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + blockIdx.x) * THREADS + threadIdx.x;
             }
-            if (st.post == POST_RELU) acc_store<NT, true>(sXh, sXl, acc, wave, nt0, lane, mk);
-            else acc_store<NT, false>(sXh, sXl, acc, wave, nt0, lane, mk);
+            if (st.post == POST_RELU) acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk);
+            else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk);
+            H3_STAMP(4);
             __syncthreads();
+            H3_STAMP(5);
             if constexpr (SAVE) {
                 if (st.save && a.save_acts != nullptr)
                     tile_to_fragments<THREADS>(sXh, sXl, a.save_acts + (long long)(st.save - 1) * a.save_stride
@@ -526,6 +556,12 @@ __global__ void nsff_pack_kernel_h3(const PackArgsH3 a) {
 }
 
 }  // namespace
+
+#ifdef H3_TIMING
+extern "C" int nsff_debug_read_timing(unsigned* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_h3_timing), sizeof(unsigned) * n) == hipSuccess ? 0 : -4;
+}
+#endif
 
 int nsff_h3_packed_bytes(const NsffModelDesc* desc, size_t* bytes) {
     NsffLayoutH3 L;
@@ -684,6 +720,10 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         const long long tiles = (g.n_points + 63) / 64;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
         hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1>), dim3((unsigned)tiles), dim3(256), 0, st, k);
+    } else if (points_per_block == 130) {         // 128 points, eight waves of 32 neurons (half the weight stream)
+        const long long tiles = (g.n_points + 127) / 128;
+        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1, false, 1>), dim3((unsigned)tiles), dim3(512), 0, st, k);
     } else if (points_per_block == 129) {         // experiment: 128 points, one wave per SIMD
         const long long tiles = (g.n_points + 127) / 128;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;

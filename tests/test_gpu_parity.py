@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-128", "f16x3_ra"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-128", "f16x3-130", "f16x3_ra"])
 def precision(request):
     """Every test runs on the exact fp32 MFMA path, both tilings of the fp16-split kernel and the
     experimental register-resident fp16-split kernel."""

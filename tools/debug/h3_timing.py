@@ -1,0 +1,44 @@
+"""Debug: per-phase cycle breakdown of the f16x3 field kernel (needs `make -C nsff_pl_amd/csrc timing`).
+Run as  NSFF_LIB=nsff_pl_amd/libnsff_hip_timing.so python tools/debug/h3_timing.py [tile_points]"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import scenes
+import nsff_pl_amd as A
+from nsff_pl_amd import _lib, config
+
+tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+config.set_precision("f16x3"); config.set_tile_points(tile)
+dev = torch.device("cuda:0")
+cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024, seed=0)
+models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+for m in list(models.values()) + [emb["t"]]:
+    m.to(dev)
+model = models["fine"]
+P, S = 1024 * 192, 192
+xyz = (torch.rand(P, 3, device=dev) * 2 - 1)
+t_rows = torch.randn(1024, scenes.N_TAU, device=dev)
+raw = torch.zeros(P, 16, device=dev)
+freqs = [float(f) for f in emb["xyz"].freqs]
+for _ in range(3):
+    _lib.field_query(model, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows)
+torch.cuda.synchronize()
+lib = _lib.load()
+n = 256 * 8 * 32 * 6
+buf = (C.c_uint * n)()
+assert lib.nsff_debug_read_timing(buf, n) == 0
+t = np.frombuffer(buf, dtype=np.uint32).reshape(256, 8, 32, 6).astype(np.int64)
+waves = 8 if tile == 130 else 4
+t = t[:, :waves]
+nsteps = 20
+d = lambda a, b: ((t[:, :, :nsteps, b] - t[:, :, :nsteps, a]) & 0xffffffff).astype(np.float64)
+names = [("pre (barrier+build)", 0, 1), ("gemm issue", 1, 2), ("barrier 1 (gemm drain)", 2, 3), ("acc_store", 3, 4), ("barrier 2", 4, 5)]
+print("s_memtime ticks (100 MHz?) per step, mean over 256 WGs x waves; steps:", nsteps)
+tot = ((t[:, :, nsteps - 1, 5] - t[:, :, 0, 0]) & 0xffffffff).astype(np.float64)
+print("whole tile mean ticks", tot.mean())
+for nm, a_, b_ in names:
+    x = d(a_, b_)
+    print(f"{nm:26s} mean/step {x.mean():9.1f}   share {x.sum() / tot.sum() * 100:5.1f}%   per-step means: " + " ".join(f"{v:6.0f}" for v in x.mean((0, 1))))
+nxt = ((t[:, :, 1:nsteps, 0] - t[:, :, :nsteps - 1, 5]) & 0xffffffff).astype(np.float64)
+print(f"{'after barrier 2 (heads)':26s} mean/step {nxt.mean():9.1f}   share {nxt.sum() / tot.sum() * 100:5.1f}%")
