@@ -40,7 +40,8 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
     if rec["N_importance"] > 0:
         torch_path.render_pass(results, models["coarse"], "coarse", freqs_xyz, rays, rec["zs_coarse"], dir_embedded,
                                None, t_embedded, None, None, out_t, [], rec["noise_std"],
-                               dict(static=rec.get("coarse_static"), transient=rec.get("coarse_transient")), False)
+                               dict(static=rec.get("coarse_static"), transient=rec.get("coarse_transient")), False,
+                               rec.get("saved"))
     fine = models["fine"]
     a_embedded = None
     if fine.encode_appearance:
@@ -54,7 +55,8 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
     torch_path.render_pass(results, fine, "fine", freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded,
                            t_next, t_prev, out_t, flows, rec["noise_std"],
                            dict(static=rec.get("fine_static"), transient=rec.get("fine_transient"),
-                                warp_fw=rec.get("fine_warp_fw"), warp_bw=rec.get("fine_warp_bw")), False)
+                                warp_fw=rec.get("fine_warp_fw"), warp_bw=rec.get("fine_warp_bw")), False,
+                           rec.get("saved"))
     return results
 
 

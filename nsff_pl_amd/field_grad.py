@@ -39,6 +39,24 @@ def _lin(m):
     return m[0] if isinstance(m, torch.nn.Sequential) else m
 
 
+def alloc_saves(model, n_points, device, transient):
+    """Buffers the training forward fills for the backward kernels (layouts: include/nsff_render.h, NsffFieldArgs)."""
+    tiles = (n_points + 63) // 64
+    acts = torch.empty(2 * model.D + 2, tiles, 64 * 256, device=device, dtype=torch.float16)
+    xin = torch.empty(tiles, 64 * 128, device=device, dtype=torch.float16)
+    masks = torch.empty(2 * model.D + 2, tiles, 256, device=device, dtype=torch.int64)
+    if not transient:
+        xin.zero_()                          # rows 64.. of a static-only launch are never written
+    return acts, xin, masks
+
+
+def forward_can_save(model, static_mode, transient_mode):
+    """True when render_rays' own forward launch can already be the training forward (so that backward does not
+    re-run it): f16x3 arithmetic selected, no view directions, full (rgb+sigma) modes."""
+    return (enabled() and not model.use_viewdir and config.precision_code(model) == config.PRECISIONS["f16x3"]
+            and static_mode in (0, 2) and transient_mode in (0, 2) and (static_mode or transient_mode))
+
+
 def _mm32(a16, b16):
     """fp16 x fp16 -> fp32 (fp32 accumulate, fp32 result: a weight gradient summed over 1e5 points does not fit fp16)."""
     try:
@@ -76,15 +94,15 @@ class _FieldFn(torch.autograd.Function):
     def forward(ctx, cfg, xyz, t_rows, *params):
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
         static, transient = cfg["static"], cfg["transient"]
-        P, D = xyz.shape[0], model.D
-        tiles = (P + 63) // 64
+        P = xyz.shape[0]
+        if cfg.get("saved") is not None:         # render_rays' own launch was the training forward: nothing to redo
+            raw, acts, xin, masks, xyz_c = cfg["saved"]
+            ctx.cfg, ctx.P = cfg, P
+            ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *params)
+            return raw.clone()
         dev = xyz.device
         raw = torch.zeros(P, _lib.RAW_STRIDE, device=dev)
-        acts = torch.empty(2 * D + 2, tiles, 64 * 256, device=dev, dtype=torch.float16)
-        xin = torch.empty(tiles, 64 * 128, device=dev, dtype=torch.float16)
-        masks = torch.empty(2 * D + 2, tiles, 256, device=dev, dtype=torch.int64)
-        if not transient:
-            xin.zero_()                      # rows 64.. of a static-only launch are never written
+        acts, xin, masks = alloc_saves(model, P, dev, transient)
         xyz_c = xyz.detach().contiguous()
         _lib.field_query(model, raw, P, s, 2 if static else 0, 2 if transient else 0,
                          2 if (transient and model.output_flow) else 0, xyz=xyz_c, freqs=freqs,
@@ -334,8 +352,9 @@ def _unfragment(frag, n_rows):
     return x.permute(0, 1, 2, 4, 6, 3, 5).reshape(slots, tiles * 64, n_rows)
 
 
-def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient):
-    """Differentiable field query on raw points: returns the (P,16) raw record (layout of include/nsff_render.h)."""
+def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient, saved=None):
+    """Differentiable field query on raw points: returns the (P,16) raw record (layout of include/nsff_render.h).
+    saved: (raw, acts, xin, masks, xyz) of an earlier training-forward launch on exactly these inputs, or None."""
     cfg = dict(model=model, freqs=[float(f) for f in freqs], pts_per_ray=int(pts_per_ray), static=bool(static),
-               transient=bool(transient))
+               transient=bool(transient), saved=saved)
     return _FieldFn.apply(cfg, xyz, t_rows, *_lib.param_list(model))

@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from . import autograd
+from . import field_grad
 from . import ray_geometry
 
 Z_FAR = 0.95  # flows are zeroed beyond this depth (reference rendering.py:316)
@@ -79,12 +80,21 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
     raw = _new(zs, P, _lib.RAW_STRIDE)
     side = dict(dir_emb=ctx.dir_embedded if model.use_viewdir and not sigma_only else None,
                 a_emb=a_embedded if (model.use_viewdir and model.in_channels_a > 0 and not sigma_only) else None)
+
+    def query(tag, raw_out, pts, static_mode, transient_mode, flow_heads, t_rows, **extra):
+        """One field launch.  When gradients will be taken (ctx.rec) and the configuration allows it, this launch
+        already is the training forward: it keeps the activations the backward kernels need."""
+        saves = {}
+        if ctx.rec is not None and field_grad.forward_can_save(model, static_mode, transient_mode):
+            raw_out.zero_()                          # slots of heads this launch does not write read as zeros in backward
+            acts, xin, masks = field_grad.alloc_saves(model, P, zs.device, bool(transient_mode))
+            saves = dict(save_acts=acts, save_xin=xin, save_masks=masks)
+            ctx.rec.setdefault("saved", {})[tag] = (raw_out, acts, xin, masks, pts.view(-1, 3))
+        _lib.field_query(model, raw_out, P, S, static_mode=static_mode, transient_mode=transient_mode,
+                         flow_heads=flow_heads, xyz=pts, freqs=ctx.freqs_xyz, t_emb=t_rows, **saves, **extra)
     if P:
-        _lib.field_query(model, raw, P, S,
-                         static_mode=1 if sigma_only else 2,
-                         transient_mode=0 if not output_transient else (1 if sigma_only else 2),
-                         flow_heads=2 if want_flow else 0,
-                         xyz=xyz, freqs=ctx.freqs_xyz, t_emb=t_embedded if output_transient else None, **side)
+        query(typ, raw, xyz, 1 if sigma_only else 2, 0 if not output_transient else (1 if sigma_only else 2),
+              2 if want_flow else 0, t_embedded if output_transient else None, **side)
 
     visibility = None
     if test_time and output_transient and 'dataset' in ctx.kwargs:
@@ -129,15 +139,13 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         tp1 = _embed_rows(ctx.embeddings, 't', torch.clamp(ts + 1, max=ctx.max_t))
         if P:
             _lib.warp_points(raw, xyz, zs, Z_FAR, xyz_fw, xyz_bw)
-            _lib.field_query(model, raw_fw, P, S, static_mode=0, transient_mode=2, flow_heads=1,
-                             xyz=xyz_fw, freqs=ctx.freqs_xyz, t_emb=tp1)
+            query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1)
         noise_fw = torch.randn(n_rays, S, device=zs.device)
         out('rgb_fw', n_rays, 3)
         results['xyzs_bw'] = xyz_bw
         tm1 = _embed_rows(ctx.embeddings, 't', torch.clamp(ts - 1, min=0))
         if P:
-            _lib.field_query(model, raw_bw, P, S, static_mode=0, transient_mode=2, flow_heads=1,
-                             xyz=xyz_bw, freqs=ctx.freqs_xyz, t_emb=tm1)
+            query(f"{typ}_warp_bw", raw_bw, xyz_bw, 0, 2, 1, tm1)
         noise_bw = torch.randn(n_rays, S, device=zs.device)
         if ctx.rec is not None and nstd != 0:
             ctx.rec[f"{typ}_warp_fw"], ctx.rec[f"{typ}_warp_bw"] = noise_fw, noise_bw

@@ -64,12 +64,12 @@ def field(model, emb_xyz, dir_rows, a_rows, t_rows, static=True, transient=True,
     return out
 
 
-def query(model, xyz, freqs_xyz, dir_embedded, a_embedded, t_embedded, s, static, transient, flows):
+def query(model, xyz, freqs_xyz, dir_embedded, a_embedded, t_embedded, s, static, transient, flows, saved=None):
     """Field outputs for (P,3) points, `s` consecutive points per ray.  On the GPU (models without view
     directions) this is the native node of :mod:`nsff_pl_amd.field_grad`; otherwise the torch expression."""
     from . import field_grad
     if field_grad.supported(model, xyz):
-        raw = field_grad.field(model, xyz, freqs_xyz, t_embedded if transient else None, s, static, transient)
+        raw = field_grad.field(model, xyz, freqs_xyz, t_embedded if transient else None, s, static, transient, saved)
         out = {}
         if static:
             out["rgb_s"], out["sigma_s"] = raw[:, 0:3], raw[:, 3]
@@ -94,7 +94,7 @@ def _softplus(x):
 
 
 def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded, t_next, t_prev,
-                output_transient, flows, noise_std, noise, test_time):
+                output_transient, flows, noise_std, noise, test_time, saved=None):
     """One model pass (reference ``inference``): fills `results` with differentiable tensors.
 
     noise: dict with keys static / transient / warp_fw / warp_bw -> (N,S) standard normal draws (or None).
@@ -103,8 +103,9 @@ def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedd
     n, s = zs.shape
     xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * zs[..., None]
     results[f"zs_{typ}"], results[f"xyzs_{typ}"] = zs, xyz
+    saved = saved or {}
     f = query(model, xyz.reshape(-1, 3), freqs_xyz, dir_embedded, a_embedded, t_embedded, s,
-              True, output_transient, flows)
+              True, output_transient, flows, saved.get(typ))
     g = lambda k, c=None: f[k].view(n, s) if c is None else f[k].view(n, s, c)
     s_rgb = results[f"static_rgbs_{typ}"] = g("rgb_s", 3)
     far = (zs > Z_FAR)[..., None]
@@ -130,7 +131,7 @@ def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedd
         if flows and not test_time:
             def warp(xyz_w, t_rows, head, key):
                 fw_ = query(model, xyz_w.reshape(-1, 3), freqs_xyz, dir_embedded, a_embedded, t_rows, s,
-                            False, True, [head])
+                            False, True, [head], saved.get(f"{typ}_{key}"))
                 rgb_w, sig_w = fw_["rgb_t"].view(n, s, 3), fw_["sigma_t"].view(n, s)
                 flow_w = torch.where(far, torch.zeros_like(rgb_w), fw_[head].view(n, s, 3))
                 al_w = 1 - torch.exp(-d_trans * _softplus(sig_w + nz(key)))
