@@ -80,9 +80,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16x3_ra"],
                     help="arithmetic of the dense layers; both modes pass the same 1e-4 parity tests")
-    ap.add_argument("--workload", default="render", choices=["render", "train"],
+    ap.add_argument("--workload", default="render", choices=["render", "train", "eval", "eval_interp"],
                     help="render = C2 (headline, default); train = C4: the same batch through NSFFTrainer.step "
-                         "(HIP forward, NeRFWLoss, backward, flat RCCL gradient all-reduce, Adam)")
+                         "(HIP forward, NeRFWLoss, backward, flat RCCL gradient all-reduce, Adam); eval = C3: one "
+                         "512x288 test-time frame per step (on-device ray generation, 32768-ray chunks, 128+64 "
+                         "samples), rays sharded over the ranks; eval_interp = C5's inner loop: two frames (t, t+1) "
+                         "+ 9 interpolated frames per step")
     ap.add_argument("--tile-points", type=int, default=int(os.environ.get("NSFF_TILE_POINTS", "0")))
     args = ap.parse_args()
 
@@ -118,7 +121,34 @@ def main():
         batch = {k: v.to(device) for k, v in scenes.synthetic_targets(N_RAYS, ts.cpu(), 100 + rank).items()}
         batch["rays"] = rays
 
+    frame = None
+    if args.workload in ("eval", "eval_interp"):
+        from nsff_pl_amd import evaluate, interpolate
+        H, W = 288, 512
+        K = torch.tensor([[400.0, 0, W / 2], [0, 400.0, H / 2], [0, 0, 1]])
+        c2w = torch.tensor([[1.0, 0, 0, 0.02], [0, 1.0, 0, -0.01], [0, 0, 1.0, 0.0]])
+        lo, hi = ndist.shard_bounds(H * W, world, rank) if args.workload == "eval" else (0, H * W)
+        ekw = dict(output_transient=True, output_transient_flow=['fw', 'bw'] if args.workload == "eval_interp" else [])
+        frame = dict(H=H, W=W, lo=lo, hi=hi)
+
+        def render_t(t, keys):
+            rays_f = evaluate.frame_rays(K, c2w, H, W, device=device, first_pixel=lo, n_pixels=hi - lo)
+            ts_f = torch.full((hi - lo,), t, device=device, dtype=torch.long)
+            return evaluate.render_frame(models, emb, rays_f, ts_f, scenes.N_FRAMES - 1, 128, 64, 1024 * 32,
+                                         keys=keys, **ekw)
+
     def step():
+        if frame is not None:
+            if args.workload == "eval":
+                out = render_t(7, ("rgb_fine", "depth_fine"))
+                if world > 1:
+                    counts = [b - a_ for a_, b in (ndist.shard_bounds(frame["H"] * frame["W"], world, r) for r in range(world))]
+                    ndist.all_gather_pixels(out, ("rgb_fine", "depth_fine"), counts=counts)
+                return out
+            keys_t = ("xyzs_fine", "zs_fine", "static_rgbs_fine", "static_alphas_fine", "transient_flows_fw",
+                      "transient_flows_bw", "transient_rgbs_fine", "transient_alphas_fine", "rgb_fine", "depth_fine")
+            a_, b_ = render_t(7, keys_t), render_t(8, keys_t)
+            return [interpolate(a_, b_, dt / 10, K, c2w, (frame["W"], frame["H"])) for dt in range(1, 10)]
         if trainer is not None:
             return trainer.step(batch)
         with torch.no_grad():      # the render workload measures the forward path; --workload train the full step
@@ -182,6 +212,24 @@ def main():
                          "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
                          "flop_per_launch": kernel_flops / max(launches, 1)},
         }
+        if frame is not None:
+            n_px = frame["H"] * frame["W"]
+            if args.workload == "eval":
+                line["metric"] = "ray-samples/sec (coarse+fine, static+dynamic) -- full-frame EVALUATION"
+                line["value"] = n_px * (128 + 64) * args.steps / elapsed
+                line["config"] = {"workload": "C3 (BASELINE.json configs[2]): 512x288 test-time frame per step, rays generated "
+                                              "on the device, 32768-ray chunks, 128 coarse + 64 importance samples -> 320 fine "
+                                              "points/ray, static+dynamic, rays sharded over the ranks + one pixel all-gather",
+                                  "frames_per_s": args.steps / elapsed, "rays_per_frame": n_px,
+                                  "parallelism": f"ray-shard x{world}" if world > 1 else "single GPU"}
+                line["scaling"] = "strong"
+            else:
+                line["metric"] = "frames/sec -- fixed-view time interpolation x10 (2 rendered + 9 interpolated frames per step)"
+                line["unit"] = "frames/s"
+                line["value"] = world * 10 * args.steps / elapsed
+                line["config"] = {"workload": "C5 inner loop (BASELINE.json configs[4]): render t and t+1 (512x288, 128+64 samples, "
+                                              "flows), 9 x interpolate (plane splat + MPI composite, 320 planes); every rank does "
+                                              "its own frame pair", "parallelism": f"frame-pair per rank x{world}"}
         if trainer is not None:
             line["config"]["workload"] = ("C4 (BASELINE.json configs[3]) per GPU: the C2 batch through one training step = "
                                           "HIP forward + NeRFWLoss (11 terms) + backward (torch/rocBLAS re-evaluation) + "
