@@ -86,6 +86,7 @@ def main():
                          "512x288 test-time frame per step (on-device ray generation, 32768-ray chunks, 128+64 "
                          "samples), rays sharded over the ranks; eval_interp = C5's inner loop: two frames (t, t+1) "
                          "+ 9 interpolated frames per step")
+    ap.add_argument("--graph", action="store_true", help="train workload: replay the step as one captured hipGraph")
     ap.add_argument("--tile-points", type=int, default=int(os.environ.get("NSFF_TILE_POINTS", "0")))
     args = ap.parse_args()
 
@@ -116,7 +117,7 @@ def main():
         from nsff_pl_amd.training import NSFFTrainer
         Ks, Ps, _ = scenes.camera_buffers()
         trainer = NSFFTrainer(models, emb, scenes.N_FRAMES, dict(N_samples=N_SAMPLES, N_importance=N_IMPORTANCE),
-                              Ks, Ps, output_transient_flow=cfg["flow"]).to(device)
+                              Ks, Ps, output_transient_flow=cfg["flow"], graph=args.graph and world == 1).to(device)
         trainer.on_train_epoch_start(0)
         batch = {k: v.to(device) for k, v in scenes.synthetic_targets(N_RAYS, ts.cpu(), 100 + rank).items()}
         batch["rays"] = rays
@@ -235,6 +236,7 @@ def main():
                                           "HIP forward + NeRFWLoss (11 terms) + backward (torch/rocBLAS re-evaluation) + "
                                           "flat RCCL gradient all-reduce + Adam")
             line["config"]["parallelism"] = f"data-parallel x{world}, one flat gradient all-reduce per step"
+            line["config"]["hip_graph"] = bool(trainer.graph)
             line["config"].pop("mlp_tflops_whole_step")
         if cpu is not None:
             line["cpu_baseline"] = cpu

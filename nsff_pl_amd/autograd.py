@@ -1,11 +1,11 @@
 """Gradients for ``render_rays`` (SURVEY.md section 8f, row N1 -- first stage).
 
-Forward values always come from the gfx950 kernels.  When gradients are needed the call is wrapped
-in :class:`_RenderGrad`: ``backward`` re-evaluates the path with the differentiable torch expression of
-:mod:`nsff_pl_amd.torch_path` at the SAME sample depths and random draws (recorded during the HIP
-forward) and back-propagates the incoming gradients to the module parameters -- activation
-checkpointing over one ``render_rays`` call.  ``sample_pdf`` and the disocclusion weights carry no
-gradient in the reference either (``.detach()`` at rendering.py:336,343,290-291).
+Forward values always come from the gfx950 kernels.  When gradients are needed, the same quantities are also
+expressed as a differentiable graph at the SAME sample depths and random draws (recorded during the HIP forward):
+compositing / warping with the torch ops of :mod:`nsff_pl_amd.torch_path`, the field network as the native
+node of :mod:`nsff_pl_amd.field_grad`; every returned tensor keeps the kernel's value and takes its gradient
+route from that graph (:class:`_Graft`).  ``sample_pdf`` and the disocclusion weights carry no gradient in the
+reference either (``.detach()`` at rendering.py:336,343,290-291).
 """
 import torch
 
@@ -60,39 +60,35 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
     return results
 
 
-class _RenderGrad(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, state, *params):
-        ctx.state = state
-        ctx.n_params = len(params)
-        keys, values = state["keys"], state["values"]
-        outs = tuple(values[k] for k in keys)
-        ctx.mark_non_differentiable(*[values[k] for k in keys if k in _NON_DIFF])
-        return outs
+class _Graft(torch.autograd.Function):
+    """value (computed by the HIP render kernels) with the gradient route of `carrier` (the same quantity expressed
+    by the differentiable graph): forward returns the kernel's number untouched, backward hands the incoming gradient
+    to the carrier."""
 
     @staticmethod
-    def backward(ctx, *grads):
-        st = ctx.state
-        params = st["params"]
-        with torch.enable_grad():
-            res = recompute(st["models"], st["embeddings"], st["rays"], st["ts"], st["max_t"], st["rec"])
-            outs, gouts = [], []
-            for k, g in zip(st["keys"], grads):
-                if g is None or k in _NON_DIFF or not res[k].requires_grad:
-                    continue
-                outs.append(res[k])
-                gouts.append(g)
-            pg = torch.autograd.grad(outs, params, gouts, allow_unused=True) if outs else [None] * len(params)
-        return (None,) + tuple(pg)
+    def forward(ctx, value, carrier):
+        return value.detach().view_as(value)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, grad
 
 
 def attach(results, models, embeddings, rays, ts, max_t, rec):
-    """Return `results` with an autograd graph to the parameters (values unchanged)."""
-    params = grad_parameters(models, embeddings)
-    if not params:
+    """Return `results` with an autograd graph to the parameters (values unchanged).
+
+    The graph is built right away: compositing / warping as torch ops on the recorded depths and draws, the
+    field network as the native node of :mod:`nsff_pl_amd.field_grad`, which -- when render_rays' own launches
+    were training forwards (rec['saved']) -- launches nothing here.  No re-entrant backward, no host syncs: the
+    whole step can be captured in a hipGraph."""
+    if not grad_parameters(models, embeddings):
         return results
-    keys = sorted(results)
-    state = dict(keys=keys, values=results, params=params, models=models, embeddings=embeddings,
-                 rays=rays, ts=ts, max_t=max_t, rec=rec)
-    outs = _RenderGrad.apply(state, *params)
-    return dict(zip(keys, outs))
+    with torch.enable_grad():
+        res = recompute(models, embeddings, rays, ts, max_t, rec)
+    out = {}
+    for k, v in results.items():
+        if k in _NON_DIFF or k not in res or not res[k].requires_grad:
+            out[k] = v
+        else:
+            out[k] = _Graft.apply(v, res[k].view_as(v))
+    return out

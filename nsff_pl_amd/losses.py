@@ -38,8 +38,12 @@ class NeRFWLoss(nn.Module):
     """col_l, disp_l, entropy_l, cross_entropy_l, flow_fw_l / flow_bw_l, pho_l, cyc_l, reg_temp_sm_l,
     reg_min_l, reg_sp_sm_l -- each reduced to a scalar mean (after optional per-ray weights / top-k)."""
 
-    def __init__(self, lambda_geo=0.04, lambda_reg=0.1, thickness=1, topk=1.0):
+    def __init__(self, lambda_geo=0.04, lambda_reg=0.1, thickness=1, topk=1.0, static_shapes=False):
+        """static_shapes: evaluate the two masked flow terms as masked means instead of boolean indexing (same value;
+        no data-dependent shapes or host syncs, so the step can be captured in a hipGraph).  Needs topk == 1 and no
+        per-ray `weights`."""
         super().__init__()
+        self.static_shapes = static_shapes
         self.lambda_geo_d = self.lambda_geo_f = lambda_geo
         self.lambda_reg = lambda_reg
         self.lambda_ent = 1e-3
@@ -68,7 +72,7 @@ class NeRFWLoss(nn.Module):
             t_w, s_w = inputs['transient_weights_fine'], inputs['static_weights_fine']
             ret['entropy_l'] = self.lambda_ent * (-t_w * torch.log(t_w + 1e-8)).sum(1)
             # static weights are pushed away from where the (dilated) dynamic weights peak; ramps up over 10 epochs
-            cross_w = self.lambda_ent / 5 * min(kwargs['epoch'] / 10, 1.0)
+            cross_w = self.lambda_ent / 5 * kwargs.get('epoch_ramp', min(kwargs['epoch'] / 10, 1.0))
             dil = t_w.detach()
             if self.thickness > 1:
                 box = torch.ones(1, 1, self.thickness, device=dil.device, dtype=dil.dtype)
@@ -84,9 +88,15 @@ class NeRFWLoss(nn.Module):
             uv_bw, d_bw = self._project(inputs['xyz_bw'], Ks, cam_ids, torch.clamp(ts - 1, min=0))
             ok_fw = (d_fw > 0) & (ts < self.max_t)
             ok_bw = (d_bw > 0) & (ts > 0)
-            if ok_fw.any():
+            scalars = {}
+            if self.static_shapes:
+                assert self.topk >= 1 and 'weights' not in kwargs, "static_shapes needs topk == 1 and no ray weights"
+                for key, ok, uv, tgt in (('flow_fw_l', ok_fw, uv_fw, targets['uv_fw']), ('flow_bw_l', ok_bw, uv_bw, targets['uv_bw'])):
+                    err = torch.where(ok[:, None], torch.abs(uv - tgt), torch.zeros_like(uv))
+                    scalars[key] = self.lambda_geo_f / 2 * err.sum() / (2 * ok.sum().clamp_min(1))
+            elif ok_fw.any():
                 ret['flow_fw_l'] = (self.lambda_geo_f / 2 * torch.abs(uv_fw[ok_fw] - targets['uv_fw'][ok_fw])).mean(1)
-            if ok_bw.any():
+            if not self.static_shapes and ok_bw.any():
                 ret['flow_bw_l'] = (self.lambda_geo_f / 2 * torch.abs(uv_bw[ok_bw] - targets['uv_bw'][ok_bw])).mean(1)
 
             # photometric + cycle consistency of the warped renders, weighted by disocclusion
@@ -109,6 +119,8 @@ class NeRFWLoss(nn.Module):
             ret['reg_sp_sm_l'] = (self.lambda_reg * (torch.abs(sf_f[:, 1:] - sf_f[:, :-1]) * near +
                                                      torch.abs(sf_b[:, 1:] - sf_b[:, :-1]) * near)).mean((1, 2))
 
+        if kwargs['output_transient_flow'] and self.static_shapes:
+            ret.update(scalars)             # already reduced (mean of a 0-d tensor is itself)
         for k, loss in ret.items():
             if 'weights' in kwargs:
                 loss = loss * kwargs['weights']

@@ -85,8 +85,38 @@ def query(model, xyz, freqs_xyz, dir_embedded, a_embedded, t_embedded, s, static
                  static, transient, flows)
 
 
-def _excl_cumprod(x):
+def _excl_cumprod_raw(x):
     return torch.cumprod(torch.cat([torch.ones_like(x[:, :1]), x], 1)[:, :-1], 1)
+
+
+def _rev_excl_cumsum(v):
+    return torch.flip(torch.cumsum(torch.flip(v, [1]), 1), [1]) - v
+
+
+class _ExclCumprod(torch.autograd.Function):
+    """T_i = prod_{j<i} x_j along dim 1 (rendering.py:226-229).  torch.cumprod's own backward asks the host whether
+    the input holds zeros (a device sync, which also forbids hipGraph capture); this backward is the same
+    mathematics without the question: sum_{i>j} g_i T_i / x_j where x_j != 0, and for the first zero of a row the
+    products are re-formed with that factor left out (entries behind a zero get exactly 0, as they must)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        T = _excl_cumprod_raw(x)
+        ctx.save_for_backward(x, T)
+        return T
+
+    @staticmethod
+    def backward(ctx, g):
+        x, T = ctx.saved_tensors
+        zero = x == 0
+        first = zero & (torch.cumsum(zero.to(torch.int32), 1) == 1)
+        T1 = _excl_cumprod_raw(torch.where(first, torch.ones_like(x), x))
+        plain = _rev_excl_cumsum(g * T) / torch.where(zero, torch.ones_like(x), x)
+        return torch.where(first, _rev_excl_cumsum(g * T1), torch.where(zero, torch.zeros_like(x), plain))
+
+
+def _excl_cumprod(x):
+    return _ExclCumprod.apply(x)
 
 
 def _softplus(x):

@@ -57,7 +57,10 @@ class NSFFTrainer:
                     decay_step=[20], decay_gamma=0.1)
 
     def __init__(self, models, embeddings, n_frames, hparams=None, Ks=None, Ps=None,
-                 output_transient=True, output_transient_flow=("fw", "bw", "disocc")):
+                 output_transient=True, output_transient_flow=("fw", "bw", "disocc"), graph=False):
+        """graph=True: the whole step (forward kernels, loss, backward kernels, Adam) is captured once into a
+        hipGraph (``torch.cuda.CUDAGraph``) and replayed -- the step is ~1100 small launches and otherwise
+        launch-bound.  Needs fixed batch shapes, topk == 1, a single process (no collective inside the graph)."""
         hp = dict(self.DEFAULTS)
         if hparams is not None:
             given = hparams if isinstance(hparams, dict) else vars(hparams)
@@ -66,16 +69,28 @@ class NSFFTrainer:
         self.models, self.embeddings, self.n_frames = models, embeddings, n_frames
         self.output_transient = output_transient
         self.output_transient_flow = list(output_transient_flow) if output_transient else []
-        self.loss = NeRFWLoss(lambda_geo=hp["lambda_geo_init"], thickness=hp["thickness"], topk=hp["topk"])
+        self.graph = bool(graph)
+        self.loss = NeRFWLoss(lambda_geo=hp["lambda_geo_init"], thickness=hp["thickness"], topk=hp["topk"],
+                              static_shapes=self.graph)
         if self.output_transient_flow:                                   # train.py:136-138
             self.loss.register_buffer("Ks", Ks)
             self.loss.register_buffer("Ps", Ps)
             self.loss.max_t = n_frames - 1
         self.params = grad_parameters(models, embeddings)
-        self.optimizer = torch.optim.Adam(self.params, lr=hp["lr"], eps=1e-8, weight_decay=hp["weight_decay"])
-        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(hp["decay_step"]),
-                                                              gamma=hp["decay_gamma"])
+        self.optimizer = self.scheduler = None
         self.current_epoch = 0
+        self._graph = self._static_batch = self._static_log = None
+        self._geo = None                     # device scalars the captured loss reads (lambda_geo, epoch ramp)
+
+    def _make_optimizer(self):
+        hp = self.hp
+        if self.graph:                        # capturable Adam: step counter and lr live on the device
+            lr = torch.tensor(float(hp["lr"]), device=self.params[0].device)
+            self.optimizer = torch.optim.Adam(self.params, lr=lr, eps=1e-8, weight_decay=hp["weight_decay"], capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(self.params, lr=hp["lr"], eps=1e-8, weight_decay=hp["weight_decay"])
+            self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(hp["decay_step"]),
+                                                                  gamma=hp["decay_gamma"])
 
     def to(self, device):
         for m in self.models.values():
@@ -84,6 +99,7 @@ class NSFFTrainer:
             if k in self.embeddings:
                 self.embeddings[k].to(device)
         self.loss.to(device)
+        self._make_optimizer()               # after the move: optimizer state must live where the parameters do
         return self
 
     # train.py:99-123
@@ -102,12 +118,24 @@ class NSFFTrainer:
     # train.py:174-176
     def on_train_epoch_start(self, epoch):
         self.current_epoch = epoch
-        self.loss.lambda_geo_d = self.loss.lambda_geo_f = self.hp["lambda_geo_init"] * 0.1 ** (epoch // 10)
+        geo = self.hp["lambda_geo_init"] * 0.1 ** (epoch // 10)
+        if self.graph:                        # the captured graph reads these from device scalars
+            dev = self.params[0].device
+            if self._geo is None:
+                self._geo = torch.zeros((), device=dev)
+                self._ramp = torch.zeros((), device=dev)
+            self._geo.fill_(geo)
+            self._ramp.fill_(min(epoch / 10, 1.0))
+            self.loss.lambda_geo_d = self.loss.lambda_geo_f = self._geo
+        else:
+            self.loss.lambda_geo_d = self.loss.lambda_geo_f = geo
 
     # train.py:178-198
     def training_step(self, batch):
         kwargs = dict(output_transient=self.output_transient, output_transient_flow=self.output_transient_flow)
         results = self.forward(batch["rays"], batch.get("ts"), **kwargs)
+        if self.graph:
+            kwargs["epoch_ramp"] = self._ramp
         loss_d = self.loss(results, batch, epoch=self.current_epoch, **kwargs)
         loss = sum(loss_d.values())
         with torch.no_grad():
@@ -119,6 +147,10 @@ class NSFFTrainer:
 
     def step(self, batch):
         """zero_grad -> training_step -> backward -> gradient all-reduce -> Adam; returns the log dict."""
+        if self.optimizer is None:
+            self._make_optimizer()
+        if self.graph:
+            return self._graph_step(batch)
         self.optimizer.zero_grad(set_to_none=True)
         loss, log = self.training_step(batch)
         loss.backward()
@@ -126,5 +158,49 @@ class NSFFTrainer:
         self.optimizer.step()
         return log
 
+    def _eager_graph_body(self):
+        self.optimizer.zero_grad(set_to_none=False)
+        loss, log = self.training_step(self._static_batch)
+        loss.backward()
+        self.optimizer.step()
+        return log
+
+    def _graph_step(self, batch):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("graph=True captures a single-process step (no collective inside the graph)")
+        if self._graph is None:
+            if self._geo is None:
+                self.on_train_epoch_start(self.current_epoch)
+            self._static_batch = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+            for p in self.params:
+                p.grad = torch.zeros_like(p)
+            keep = [p.detach().clone() for p in self.params]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):              # warm-up off the capture stream (allocator, pack caches, Adam state)
+                for _ in range(3):
+                    self._eager_graph_body()
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static_log = self._eager_graph_body()
+            # the warm-up steps were not part of the schedule: undo them (parameters and Adam moments / step count)
+            with torch.no_grad():
+                for p, k in zip(self.params, keep):
+                    p.copy_(k)
+                for st in self.optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+        for k, v in self._static_batch.items():
+            v.copy_(batch[k])
+        self._graph.replay()
+        for m in self.models.values():          # replays change the weights without bumping tensor versions
+            m._pack_cache.invalidate()
+        return self._static_log
+
     def on_train_epoch_end(self):
-        self.scheduler.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        elif self.optimizer is not None and (self.current_epoch + 1) in list(self.hp["decay_step"]):
+            self.optimizer.param_groups[0]["lr"].mul_(self.hp["decay_gamma"])

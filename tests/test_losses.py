@@ -131,6 +131,25 @@ def test_loss_options():
     assert sorted(static) == ["col_l", "disp_l"]
 
 
+def test_static_shape_loss_equals_indexed_loss():
+    """The graph-capturable form of the masked flow terms gives the same eleven values."""
+    name = "g3_nsff_train"
+    cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+    res = {k: torch.from_numpy(v) for k, v in want.items()}
+    kw = scenes.render_kwargs(cfg)
+    loss_fn, targets = _loss_module(name)
+    base = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+    loss_fn.static_shapes = True
+    ramp = torch.tensor(min(scenes.LOSS_EPOCH / 10, 1.0))
+    stat = loss_fn(res, targets, epoch=0, epoch_ramp=ramp, **kw)
+    assert sorted(stat) == sorted(base)
+    for k in base:
+        assert abs(float(stat[k]) - float(base[k])) <= 1e-6 * abs(float(base[k])) + 1e-12, k
+    targets["ts"] = torch.zeros_like(targets["ts"])              # no ray has a previous frame: the term is dropped / zero
+    gone = loss_fn(res, targets, epoch=0, epoch_ramp=ramp, **kw)
+    assert float(gone["flow_bw_l"]) == 0.0
+
+
 def test_depth_loss_and_ndc2world_properties():
     g = torch.Generator().manual_seed(3)
     d, disp = torch.rand(64, generator=g), torch.rand(64, generator=g) + 0.1
@@ -204,5 +223,17 @@ def test_trainer_steps_reduce_the_loss(hip_lib):
         assert all(np.isfinite(float(l["train/loss"])) and np.isfinite(float(l["train/psnr"])) for l in logs)
         assert any(not torch.equal(before[k], p.detach()) for k, p in enumerate(tr.params))
         assert logs[0]["lr"] == 5e-4
+        # the same schedule replayed as one captured hipGraph: identical first-step terms, loss goes down as well
+        cfg, meta, rays, ts, models2, emb2, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+        tg = NSFFTrainer(models2, emb2, scenes.N_FRAMES, hp, Ks, Ps, output_transient_flow=cfg["flow"], graph=True).to(DEV)
+        tg.on_train_epoch_start(scenes.LOSS_EPOCH)
+        glogs = []
+        for _ in range(8):
+            lg = tg.step(batch)
+            glogs.append({k: float(v) for k, v in lg.items()})
+        for k, v in gold.items():
+            assert abs(glogs[0][f"train/{k}"] - v) <= 2e-3 * max(abs(v), 1e-6), (k, glogs[0][f"train/{k}"], v)
+        assert glogs[-1]["train/loss"] < glogs[0]["train/loss"]
+        assert abs(glogs[-1]["train/loss"] - float(logs[-1]["train/loss"])) <= 0.05 * abs(float(logs[-1]["train/loss"]))
     finally:
         A.set_precision("f32")
