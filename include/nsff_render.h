@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      4
+#define NSFF_ABI_VERSION      5
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -154,17 +154,20 @@ typedef struct NsffFieldBwdArgs {
 } NsffFieldBwdArgs;
 int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
 
-/* Batched weight-gradient GEMMs, K = points:  out[j][s] = sum over the point tiles of split s of  A_j^T . B_j.
+/* Batched weight-gradient GEMMs, K = points:  out_j = (1/G) * A_j^T . B_j over all point tiles, G as above.
  * A_j: fp16 fragment-major (T,4,a_rows,16), a_rows in {256, 32};  B_j: (T,4,b_rows,16), b_rows in {256, 128}.
- * out: fp32 (n_jobs, n_splits, a_rows_j x b_rows_j) written at out + out_off[j] + s*a_rows*b_rows (partials, summed
- * by the caller); bias: fp32 (n_jobs, n_splits, 256) row sums of A_j (the bias gradients).  Host arrays.        */
+ * Split-K: every job is cut into n_splits tile ranges (heads: 8x as many) whose partial sums go to `scratch`
+ * (nsff_weight_grad_scratch floats) and are summed, scaled and written by a second launch to
+ *   out + out_off[j]  : fp32 a_rows_j x b_rows_j (row-major),     bias + 256*j : fp32 row sums of A_j (bias gradients).
+ * `jobs` is a HOST array.                                                                                      */
 typedef struct NsffWgradJob {
     const void* a;  const void* b;
     int32_t a_rows, b_rows;
     int64_t out_off;            /* floats */
 } NsffWgradJob;
+int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits);
 int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
-                     float* out, float* bias, void* stream);
+                     float* scratch, float* out, float* bias, const float* gmax, void* stream);
 
 /* ---- a4: coarse sample placement (reference rendering.py:314-324,332) ----
  * zs[n][i] = z_lin[i]                                   (perturb == 0)

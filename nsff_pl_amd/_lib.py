@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -109,7 +109,8 @@ _SIGNATURES = {
     "nsff_bwd_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
     "nsff_pack_weights_bwd": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp]),
     "nsff_field_backward": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldBwdArgs), _fp]),
-    "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp]),
+    "nsff_weight_grad_scratch": (C.c_int64, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32]),
+    "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
     "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
@@ -319,11 +320,15 @@ def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, 
            "nsff_field_backward")
 
 
-def weight_grad(jobs, n_tiles, n_splits, out, bias):
-    """jobs: list of (a_ptr, b_ptr, a_rows, b_rows, out_off)."""
+def weight_grad(jobs, n_tiles, n_splits, out, bias, gmax):
+    """jobs: list of (a_ptr, b_ptr, a_rows, b_rows, out_off); out / bias receive the final (summed, unscaled) gradients."""
     arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=j[4]) for j in jobs])
-    _check(load().nsff_weight_grad(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(out), _ptr(bias), _stream()),
-           "nsff_weight_grad")
+    n = load().nsff_weight_grad_scratch(arr, len(jobs), int(n_tiles), int(n_splits))
+    if n < 0:
+        raise RuntimeError("nsff_weight_grad_scratch failed")
+    scratch = torch.empty(n, device=out.device)
+    _check(load().nsff_weight_grad(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(scratch), _ptr(out), _ptr(bias),
+                                   _ptr(gmax), _stream()), "nsff_weight_grad")
 
 
 def splat_planes(H, W, S, K4, P12, scale, xyz, flow, rgb, alpha, accum):

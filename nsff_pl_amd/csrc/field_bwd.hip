@@ -361,14 +361,21 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
 
 // ---- K2 ---------------------------------------------------------------------------------------
 constexpr int MAX_WJOBS = 48;
-struct WJob { const _Float16* a; const _Float16* b; long long out_off; int job_index; int pad; };
+struct WJob { const _Float16* a; const _Float16* b; long long out_off; long long bias_off; };   // offsets into the scratch
 struct WKArgs {
     WJob jobs[MAX_WJOBS];
-    float* out;
-    float* bias;
+    float* out;          // scratch partial sums
+    float* bias;         // scratch partial row sums
     long long n_tiles;
     int n_splits;
     int n_jobs_total;
+};
+struct RJob { long long part_off, bias_part_off, out_off; int size, n_splits, job_index, pad; };
+struct RKArgs {
+    RJob jobs[MAX_WJOBS];
+    const float* part; const float* bias_part; const float* gmax;
+    float* out; float* bias;
+    int n_jobs;
 };
 
 // direct-to-LDS DMA of 16 bytes per lane: LDS[lds_dst + 16*lane] <- *gsrc  (lds_dst wave-uniform)
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void nsff_wgrad_kernel(const WKArgs a) {
                 out[(long long)row * B_ROWS + 32 * (NB * wc + nb) + (lane & 31)] = acc[na][nb][r];
             }
     if (wc == 0) {
-        float* bias = a.bias + ((long long)job.job_index * a.n_splits + split) * 256;
+        float* bias = a.bias + job.bias_off + (long long)split * 256;
 #pragma unroll
         for (int na = 0; na < NA; ++na) {
             const float t = bsum[na] + __shfl_xor(bsum[na], 32);
@@ -515,9 +522,29 @@ __global__ __launch_bounds__(256, 1) void nsff_wgrad_head_kernel(const WKArgs a)
             out[(long long)row * B_ROWS + 32 * (NB * wave + nb) + (lane & 31)] = acc[nb][r];
         }
     if (wave == 0) {
-        float* bias = a.bias + ((long long)job.job_index * a.n_splits + split) * 256;
+        float* bias = a.bias + job.bias_off + (long long)split * 256;
         const float t = bsum + __shfl_xor(bsum, 32);
         if (lane < 32) bias[lane] = t;
+    }
+}
+
+// Sum the split-K partials, undo the global scale G and write the final gradients (one launch for every job).
+__global__ __launch_bounds__(256) void nsff_wgrad_reduce_kernel(const RKArgs a) {
+    const RJob job = a.jobs[blockIdx.y];
+    const float inv_g = 1.0f / pow2_scale(*a.gmax);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < job.size + 256; e += gridDim.x * 256) {
+        if (e < job.size) {
+            const float* p = a.part + job.part_off + e;
+            float t = 0.f;
+            for (int s = 0; s < job.n_splits; ++s) t += p[(long long)s * job.size];
+            a.out[job.out_off + e] = t * inv_g;
+        } else {
+            const int r = e - job.size;
+            const float* p = a.bias_part + job.bias_part_off + r;
+            float t = 0.f;
+            for (int s = 0; s < job.n_splits; ++s) t += p[(long long)s * 256];
+            a.bias[(long long)job.job_index * 256 + r] = t * inv_g;
+        }
     }
 }
 
@@ -648,42 +675,65 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     return nsff_launch_status();
 }
 
+static inline int wgrad_splits(const NsffWgradJob& j, int64_t n_tiles, int32_t n_splits) {
+    long long s = j.a_rows == 32 ? 8LL * n_splits : n_splits;       // the head jobs are tiny: cut them finer
+    if (s > n_tiles) s = n_tiles;
+    return (int)(s < 1 ? 1 : s);
+}
+
+int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits) {
+    if (!jobs || n_jobs < 0 || n_splits < 1) return -1;
+    int64_t total = 0;
+    for (int j = 0; j < n_jobs; ++j)
+        total += (int64_t)wgrad_splits(jobs[j], n_tiles, n_splits) * ((int64_t)jobs[j].a_rows * jobs[j].b_rows + 256);
+    return total;
+}
+
 int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
-                     float* out, float* bias, void* stream) {
-    if (!jobs || !out || !bias) return NSFF_ERR_NULL;
-    if (n_jobs < 0 || n_tiles < 0 || n_splits < 1) return NSFF_ERR_INVALID;
+                     float* scratch, float* out, float* bias, const float* gmax, void* stream) {
+    if (!jobs || !scratch || !out || !bias || !gmax) return NSFF_ERR_NULL;
+    if (n_jobs < 0 || n_jobs > MAX_WJOBS || n_tiles < 0 || n_splits < 1) return NSFF_ERR_INVALID;
     if (n_jobs == 0 || n_tiles == 0) return NSFF_OK;
     for (int j = 0; j < n_jobs; ++j) {
         const bool ok = (jobs[j].a_rows == 256 || jobs[j].a_rows == 32) && (jobs[j].b_rows == 256 || jobs[j].b_rows == 128) &&
                         !(jobs[j].a_rows == 32 && jobs[j].b_rows == 128);
         if (!ok) return NSFF_ERR_INVALID;
+        if (!jobs[j].a || !jobs[j].b) return NSFF_ERR_NULL;
     }
     hipStream_t st = (hipStream_t)stream;
+    RKArgs r{};
+    r.part = scratch; r.bias_part = scratch; r.gmax = gmax; r.out = out; r.bias = bias; r.n_jobs = n_jobs;
+    long long off = 0;
+    int max_size = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int sp = wgrad_splits(jobs[j], n_tiles, n_splits);
+        const int size = jobs[j].a_rows * jobs[j].b_rows;
+        r.jobs[j].part_off = off; off += (long long)sp * size;
+        r.jobs[j].bias_part_off = off; off += (long long)sp * 256;
+        r.jobs[j].out_off = jobs[j].out_off; r.jobs[j].size = size; r.jobs[j].n_splits = sp; r.jobs[j].job_index = j;
+        max_size = std::max(max_size, size);
+    }
     for (int cls = 0; cls < 3; ++cls) {
         const int ar = cls == 2 ? 32 : 256, brw = cls == 1 ? 128 : 256;
-        int done = 0;
-        while (true) {
-            WKArgs k{};
-            k.out = out; k.bias = bias; k.n_tiles = n_tiles; k.n_splits = n_splits; k.n_jobs_total = n_jobs;
-            int m = 0, seen = 0;
-            for (int j = 0; j < n_jobs && m < MAX_WJOBS; ++j) {
-                if (jobs[j].a_rows != ar || jobs[j].b_rows != brw) continue;
-                if (seen++ < done) continue;
-                if (!jobs[j].a || !jobs[j].b) return NSFF_ERR_NULL;
-                k.jobs[m].a = reinterpret_cast<const _Float16*>(jobs[j].a);
-                k.jobs[m].b = reinterpret_cast<const _Float16*>(jobs[j].b);
-                k.jobs[m].out_off = jobs[j].out_off; k.jobs[m].job_index = j;
-                ++m;
-            }
-            if (m == 0) break;
-            const dim3 grid((unsigned)(m * n_splits));
-            if (cls == 0) hipLaunchKernelGGL((nsff_wgrad_kernel<4, 4, 2, 2>), grid, dim3(256), 0, st, k);
-            else if (cls == 1) hipLaunchKernelGGL((nsff_wgrad_kernel<4, 2, 2, 2>), grid, dim3(256), 0, st, k);
-            else hipLaunchKernelGGL(nsff_wgrad_head_kernel, grid, dim3(256), 0, st, k);
-            done += m;
-            if (m < MAX_WJOBS) break;
+        WKArgs k{};
+        k.out = scratch; k.bias = scratch; k.n_tiles = n_tiles; k.n_jobs_total = n_jobs;
+        int m = 0;
+        for (int j = 0; j < n_jobs; ++j) {
+            if (jobs[j].a_rows != ar || jobs[j].b_rows != brw) continue;
+            k.jobs[m].a = reinterpret_cast<const _Float16*>(jobs[j].a);
+            k.jobs[m].b = reinterpret_cast<const _Float16*>(jobs[j].b);
+            k.jobs[m].out_off = r.jobs[j].part_off; k.jobs[m].bias_off = r.jobs[j].bias_part_off;
+            k.n_splits = r.jobs[j].n_splits;                 // equal within a class
+            ++m;
         }
+        if (m == 0) continue;
+        const dim3 grid((unsigned)(m * k.n_splits));
+        if (cls == 0) hipLaunchKernelGGL((nsff_wgrad_kernel<4, 4, 2, 2>), grid, dim3(256), 0, st, k);
+        else if (cls == 1) hipLaunchKernelGGL((nsff_wgrad_kernel<4, 2, 2, 2>), grid, dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(nsff_wgrad_head_kernel, grid, dim3(256), 0, st, k);
     }
+    hipLaunchKernelGGL(nsff_wgrad_reduce_kernel, dim3((unsigned)std::min((max_size + 256 + 255) / 256, 64), (unsigned)n_jobs),
+                       dim3(256), 0, st, r);
     return nsff_launch_status();
 }
 

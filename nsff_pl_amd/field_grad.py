@@ -156,18 +156,14 @@ class _FieldFn(torch.autograd.Function):
         off = 0
         for j, sz in zip(jobs, sizes):
             j[4] = off
-            off += sz * n_splits
+            off += sz
         out = torch.empty(off, device=dev)
-        bias = torch.empty(len(jobs), n_splits, 256, device=dev)
-        _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias)
-        # G = 2^(11 - exponent(gmax)) exactly as the kernels derive it
-        g_exp = torch.frexp(gmax)[1]
-        inv_g = torch.where(gmax > 0, torch.exp2((g_exp - 11).float()), torch.ones_like(gmax))
-        bias = bias.sum(1) * inv_g
+        bias = torch.empty(len(jobs), 256, device=dev)
+        _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias, gmax)      # summed and unscaled in there
 
         def result(i):
             j = jobs[i]
-            return out[j[4]:j[4] + sizes[i] * n_splits].view(n_splits, j[2], j[3]).sum(0) * inv_g
+            return out[j[4]:j[4] + sizes[i]].view(j[2], j[3])
 
         index = {p_: i for i, p_ in enumerate(id(q) for q in _lib.param_list(model))}
         grads = [None] * len(params)
