@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      5
+#define NSFF_ABI_VERSION      6
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -276,6 +276,32 @@ typedef struct NsffMpiArgs {
     float* depth;               /* (H*W)    OUT (NDC)                                                        */
 } NsffMpiArgs;
 int nsff_mpi_composite(const NsffMpiArgs* args, void* stream);
+
+/* ---- N1: backward of nsff_composite for the training configurations (has_rgb = 1, flow_mode 0 or 2): gradients
+ * w.r.t. the raw records of the main pass and of the two warped re-queries, and w.r.t. the (far-masked) per-sample
+ * flows that enter the per-ray flow expectations.  g_* = gradient of the output of that name (NULL = zero):
+ * per sample (n_rays, S): static_sigmas, transient_sigmas, static_weights, transient_weights, weights;
+ * per ray: depth (n), rgb (n,3), transient_alpha (n), transient_rgb (n,3), so_rgb = _static_rgb (n,3), so_depth =
+ * _static_depth (n), xyz_exp = xyz_fine (n,3), flow_fw_exp / flow_bw_exp = transient_flow_fw / _bw (n,3), rgb_fw, rgb_bw.
+ * The per-sample passthrough outputs (rgbs, flows, warped points) are plain views of the inputs and stay with the
+ * caller.  scratch: (n_rays, S, 4) floats.  d_raw* : (P, NSFF_RAW_STRIDE), slots 0-7 written, the rest zeroed. ---- */
+typedef struct NsffCompositeBwdArgs {
+    int64_t n_rays;
+    int32_t n_samples, has_transient, flow_mode;
+    float   noise_std;
+    const float* raw;  const float* raw_fw;  const float* raw_bw;
+    const float* zs;   const float* xyz;     const float* f_fw;  const float* f_bw;
+    const float* noise_static;  const float* noise_transient;  const float* noise_fw;  const float* noise_bw;
+    const float* g_static_sigmas;  const float* g_transient_sigmas;
+    const float* g_static_weights; const float* g_transient_weights;  const float* g_weights;
+    const float* g_depth;  const float* g_rgb;  const float* g_transient_alpha;  const float* g_transient_rgb;
+    const float* g_so_rgb; const float* g_so_depth;
+    const float* g_xyz_exp;  const float* g_flow_fw_exp;  const float* g_flow_bw_exp;
+    const float* g_rgb_fw;   const float* g_rgb_bw;
+    float* scratch;
+    float* d_raw;  float* d_raw_fw;  float* d_raw_bw;  float* d_f_fw;  float* d_f_bw;
+} NsffCompositeBwdArgs;
+int nsff_composite_backward(const NsffCompositeBwdArgs* args, void* stream);
 
 /* ---- profiling hooks used by bench.py (HIP events around field-query launches) ---- */
 int nsff_prof_enable(int on);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -66,6 +66,18 @@ class CompositeArgs(C.Structure):
                 + [(n, _fp) for n in _COMPOSITE_PTRS_OUT])
 
 
+_CBWD_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "f_fw", "f_bw", "noise_static", "noise_transient", "noise_fw", "noise_bw"]
+_CBWD_G = ["g_static_sigmas", "g_transient_sigmas", "g_static_weights", "g_transient_weights", "g_weights", "g_depth",
+           "g_rgb", "g_transient_alpha", "g_transient_rgb", "g_so_rgb", "g_so_depth", "g_xyz_exp", "g_flow_fw_exp",
+           "g_flow_bw_exp", "g_rgb_fw", "g_rgb_bw"]
+_CBWD_OUT = ["scratch", "d_raw", "d_raw_fw", "d_raw_bw", "d_f_fw", "d_f_bw"]
+
+
+class CompositeBwdArgs(C.Structure):
+    _fields_ = ([("n_rays", C.c_int64), ("n_samples", C.c_int32), ("has_transient", C.c_int32), ("flow_mode", C.c_int32),
+                 ("noise_std", C.c_float)] + [(n, _fp) for n in _CBWD_IN + _CBWD_G + _CBWD_OUT])
+
+
 class FieldBwdArgs(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("static_mode", C.c_int32), ("transient_mode", C.c_int32),
                 ("d_raw", _fp), ("raw", _fp), ("gmax", _fp), ("masks", _fp), ("dpre", _fp), ("dhead", _fp),
@@ -111,6 +123,7 @@ _SIGNATURES = {
     "nsff_field_backward": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldBwdArgs), _fp]),
     "nsff_weight_grad_scratch": (C.c_int64, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32]),
     "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
+    "nsff_composite_backward": (C.c_int, [C.POINTER(CompositeBwdArgs), _fp]),
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
     "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
@@ -329,6 +342,14 @@ def weight_grad(jobs, n_tiles, n_splits, out, bias, gmax):
     scratch = torch.empty(n, device=out.device)
     _check(load().nsff_weight_grad(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(scratch), _ptr(out), _ptr(bias),
                                    _ptr(gmax), _stream()), "nsff_weight_grad")
+
+
+def composite_backward(n_rays, n_samples, has_transient, flow_mode, noise_std, **tensors):
+    a = CompositeBwdArgs(n_rays=int(n_rays), n_samples=int(n_samples), has_transient=int(has_transient),
+                         flow_mode=int(flow_mode), noise_std=float(noise_std))
+    for k, v in tensors.items():
+        setattr(a, k, _ptr(v))
+    _check(load().nsff_composite_backward(C.byref(a), _stream()), "nsff_composite_backward")
 
 
 def splat_planes(H, W, S, K4, P12, scale, xyz, flow, rgb, alpha, accum):

@@ -41,7 +41,7 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
         torch_path.render_pass(results, models["coarse"], "coarse", freqs_xyz, rays, rec["zs_coarse"], dir_embedded,
                                None, t_embedded, None, None, out_t, [], rec["noise_std"],
                                dict(static=rec.get("coarse_static"), transient=rec.get("coarse_transient")), False,
-                               rec.get("saved"))
+                               rec.get("saved"), rec.get("values"))
     fine = models["fine"]
     a_embedded = None
     if fine.encode_appearance:
@@ -56,7 +56,7 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
                            t_next, t_prev, out_t, flows, rec["noise_std"],
                            dict(static=rec.get("fine_static"), transient=rec.get("fine_transient"),
                                 warp_fw=rec.get("fine_warp_fw"), warp_bw=rec.get("fine_warp_bw")), False,
-                           rec.get("saved"))
+                           rec.get("saved"), rec.get("values"))
     return results
 
 
@@ -83,6 +83,7 @@ def attach(results, models, embeddings, rays, ts, max_t, rec):
     whole step can be captured in a hipGraph."""
     if not grad_parameters(models, embeddings):
         return results
+    rec = dict(rec, values=results)          # the compositing node hands these numbers out again
     with torch.enable_grad():
         res = recompute(models, embeddings, rays, ts, max_t, rec)
     out = {}

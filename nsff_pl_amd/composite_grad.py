@@ -1,0 +1,86 @@
+"""Native compositing node of the backward graph.
+
+One ``autograd.Function`` per render pass: forward hands out the values the compositing kernel of ``render_rays``
+already produced (nothing is launched), backward is ``nsff_composite_backward`` (csrc/rays_bwd.hip) -- one launch
+instead of the ~250 small torch kernels the elementwise expression of the same mathematics needs
+(reference models/rendering.py:122-140,200-298).
+"""
+import os
+
+import torch
+
+from . import _lib
+
+# (result-key template, per-sample?, gradient argument of nsff_composite_backward)
+_OUTS_STATIC = [("static_sigmas_{t}", "g_static_sigmas"), ("static_weights_{t}", "g_static_weights"),
+                ("depth_{t}", "g_depth"), ("rgb_{t}", "g_rgb")]
+_OUTS_TRANSIENT = [("static_sigmas_{t}", "g_static_sigmas"), ("transient_sigmas_{t}", "g_transient_sigmas"),
+                   ("static_weights_{t}", "g_static_weights"), ("transient_weights_{t}", "g_transient_weights"),
+                   ("weights_{t}", "g_weights"), ("depth_{t}", "g_depth"), ("rgb_{t}", "g_rgb"),
+                   ("transient_alpha_{t}", "g_transient_alpha"), ("transient_rgb_{t}", "g_transient_rgb"),
+                   ("_static_rgb_{t}", "g_so_rgb"), ("_static_depth_{t}", "g_so_depth")]
+_OUTS_FLOW = [("xyz_fine", "g_xyz_exp"), ("transient_flow_fw", "g_flow_fw_exp"), ("transient_flow_bw", "g_flow_bw_exp")]
+_OUTS_WARP = [("rgb_fw", "g_rgb_fw"), ("rgb_bw", "g_rgb_bw")]
+
+
+def enabled():
+    return os.environ.get("NSFF_NATIVE_COMPOSITE_BWD", "1") != "0"
+
+
+def output_spec(typ, transient, flows, warps):
+    spec = list(_OUTS_TRANSIENT if transient else _OUTS_STATIC)
+    if transient and flows:
+        spec += _OUTS_FLOW
+        if warps:
+            spec += _OUTS_WARP
+    return [(k.format(t=typ), g) for k, g in spec]
+
+
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, raw, raw_fw, raw_bw, f_fw, f_bw):
+        values = cfg["values"]
+        ctx.cfg = cfg
+        ctx.save_for_backward(*[t for t in (raw, raw_fw, raw_bw, f_fw, f_bw) if t is not None])
+        ctx.present = [t is not None for t in (raw, raw_fw, raw_bw, f_fw, f_bw)]
+        return tuple(values[k].detach().clone() for k, _ in cfg["spec"])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cfg = ctx.cfg
+        it = iter(ctx.saved_tensors)
+        raw, raw_fw, raw_bw, f_fw, f_bw = [next(it) if p else None for p in ctx.present]
+        n, s = cfg["zs"].shape
+        dev = raw.device
+        tens = dict(raw=raw, raw_fw=raw_fw, raw_bw=raw_bw, zs=cfg["zs"], noise_static=cfg["noise"].get("static"),
+                    noise_transient=cfg["noise"].get("transient"), noise_fw=cfg["noise"].get("warp_fw"),
+                    noise_bw=cfg["noise"].get("warp_bw"))
+        if cfg["noise_std"] == 0:
+            for k in ("noise_static", "noise_transient", "noise_fw", "noise_bw"):
+                tens[k] = None
+        if f_fw is not None:
+            tens.update(xyz=cfg["xyz"], f_fw=f_fw.contiguous(), f_bw=f_bw.contiguous())
+        for (_, gname), g in zip(cfg["spec"], grads):
+            tens[gname] = None if g is None else g.contiguous()
+        tens["scratch"] = torch.empty(n, s, 4, device=dev)
+        d_raw = torch.empty_like(raw)
+        tens["d_raw"] = d_raw
+        d_raw_fw = d_raw_bw = d_f_fw = d_f_bw = None
+        if raw_fw is not None:
+            d_raw_fw, d_raw_bw = torch.empty_like(raw_fw), torch.empty_like(raw_bw)
+            tens.update(d_raw_fw=d_raw_fw, d_raw_bw=d_raw_bw)
+        if f_fw is not None:
+            d_f_fw, d_f_bw = torch.empty_like(f_fw), torch.empty_like(f_bw)
+            tens.update(d_f_fw=d_f_fw, d_f_bw=d_f_bw)
+        flow_mode = 0 if f_fw is None else (2 if raw_fw is not None else 1)
+        _lib.composite_backward(n, s, cfg["transient"], flow_mode, cfg["noise_std"], **tens)
+        return None, d_raw, d_raw_fw, d_raw_bw, d_f_fw, d_f_bw
+
+
+def composite(values, typ, raw, raw_fw, raw_bw, f_fw, f_bw, zs, xyz, transient, noise_std, noise):
+    """Differentiable per-ray / per-sample compositing outputs of one pass, as a dict keyed like render_rays."""
+    spec = output_spec(typ, transient, f_fw is not None, raw_fw is not None)
+    cfg = dict(values=values, spec=spec, zs=zs.contiguous(), xyz=None if xyz is None else xyz.contiguous(),
+               transient=bool(transient), noise_std=float(noise_std), noise=noise)
+    outs = _CompositeFn.apply(cfg, raw, raw_fw, raw_bw, f_fw, f_bw)
+    return {k: o for (k, _), o in zip(spec, outs)}

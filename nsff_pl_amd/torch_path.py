@@ -123,8 +123,50 @@ def _softplus(x):
     return F.softplus(x)          # beta = 1, threshold = 20 like torch.nn.Softplus()
 
 
+def render_pass_native(results, model, typ, freqs_xyz, rays, zs, t_embedded, t_next, t_prev, output_transient, flows,
+                       noise_std, noise, saved, values):
+    """render_pass with the field AND the compositing as native nodes (GPU, models without view directions, train
+    mode).  `values`: the result dict the HIP forward of render_rays produced (the compositing node hands those
+    numbers out instead of recomputing them).  What stays in torch is the glue between the nodes: far-masking of the
+    flows, the warped query points, and sums of node outputs."""
+    from . import composite_grad, field_grad
+    n, s = zs.shape
+    saved = saved or {}
+    xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * zs[..., None]
+    results[f"zs_{typ}"], results[f"xyzs_{typ}"] = zs, xyz
+    raw = field_grad.field(model, xyz.reshape(-1, 3), freqs_xyz, t_embedded if output_transient else None, s,
+                           True, output_transient, saved.get(typ))
+    results[f"static_rgbs_{typ}"] = raw[:, 0:3].view(n, s, 3)
+    raw_fw = raw_bw = f_fw = f_bw = None
+    if output_transient:
+        results[f"transient_rgbs_{typ}"] = raw[:, 4:7].view(n, s, 3)
+        if flows:
+            far = (zs > Z_FAR)[..., None]
+            zero = torch.zeros((), device=zs.device)
+            f_fw = results["transient_flows_fw"] = torch.where(far, zero, raw[:, 8:11].view(n, s, 3))
+            f_bw = results["transient_flows_bw"] = torch.where(far, zero, raw[:, 11:14].view(n, s, 3))
+            xyz_fw = results["xyzs_fw"] = xyz + f_fw
+            xyz_bw = results["xyzs_bw"] = xyz + f_bw
+            raw_fw = field_grad.field(model, xyz_fw.reshape(-1, 3), freqs_xyz, t_next, s, False, True,
+                                      saved.get(f"{typ}_warp_fw"))
+            raw_bw = field_grad.field(model, xyz_bw.reshape(-1, 3), freqs_xyz, t_prev, s, False, True,
+                                      saved.get(f"{typ}_warp_bw"))
+            results["xyzs_fw_bw"] = xyz_fw + torch.where(far, zero, raw_fw[:, 11:14].view(n, s, 3))
+            results["xyzs_bw_fw"] = xyz_bw + torch.where(far, zero, raw_bw[:, 8:11].view(n, s, 3))
+    results.update(composite_grad.composite(values, typ, raw, raw_fw, raw_bw, f_fw, f_bw, zs, xyz if flows else None,
+                                            output_transient, noise_std, noise))
+    if output_transient and flows:
+        results["xyz_fw"] = results["xyz_fine"] + results["transient_flow_fw"]
+        results["xyz_bw"] = results["xyz_fine"] + results["transient_flow_bw"]
+
+
 def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded, t_next, t_prev,
-                output_transient, flows, noise_std, noise, test_time, saved=None):
+                output_transient, flows, noise_std, noise, test_time, saved=None, values=None):
+    from . import composite_grad, field_grad
+    if (values is not None and not test_time and composite_grad.enabled() and field_grad.supported(model, zs)
+            and (not flows or "fw" in flows and "bw" in flows)):
+        return render_pass_native(results, model, typ, freqs_xyz, rays, zs, t_embedded, t_next, t_prev,
+                                  output_transient, flows, noise_std, noise, saved, values)
     """One model pass (reference ``inference``): fills `results` with differentiable tensors.
 
     noise: dict with keys static / transient / warp_fw / warp_bw -> (N,S) standard normal draws (or None).

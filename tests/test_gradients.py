@@ -171,3 +171,37 @@ def test_render_rays_backward_matches_reference(name, precision, hip_lib, monkey
         assert not out["rgb_fine"].requires_grad
     finally:
         A.set_precision("f32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g7_nsff_train_noise", "g2_static_c2f"])
+def test_native_compositing_backward_equals_torch_expression(name, hip_lib, monkeypatch):
+    """nsff_composite_backward against autograd of the elementwise torch expression of the same compositing
+    (same field nodes, same forward values): both fp32, so they agree far below the fp64-truth tolerance."""
+    from test_gpu_parity import _Replay, _to_dev, DEV
+    import nsff_pl_amd.rendering as R
+    A.set_precision("f16x3")
+    grads = {}
+    try:
+        for native in ("1", "0"):
+            monkeypatch.setenv("NSFF_NATIVE_COMPOSITE_BWD", native)
+            cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+            _to_dev(models, emb)
+            draws = scenes.replay_draws(cfg, meta["draw_seed"])
+            kw = scenes.render_kwargs(cfg)
+            kw["_zs_fine"] = torch.from_numpy(want["zs_fine"])
+            if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
+                replay = _Replay(cfg, draws)
+                monkeypatch.setattr(R.torch, "rand", replay.rand)
+                monkeypatch.setattr(R.torch, "randn", replay.randn)
+            res = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
+                                cfg["N_samples"], cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"],
+                                1024 * 32, test_time=False, **kw)
+            monkeypatch.undo()
+            scenes.cotangent_loss(res).backward()
+            grads[native] = {n: p.grad.detach().clone() for n, p in scenes.named_grad_params(models, emb) if p.grad is not None}
+        assert sorted(grads["0"]) == sorted(grads["1"])
+        for n, g in grads["0"].items():
+            parity.assert_close("grad " + n, grads["1"][n].cpu().numpy(), g.cpu().numpy(), 2e-3)
+    finally:
+        A.set_precision("f32")
