@@ -43,7 +43,7 @@ class _CompositeFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.save_for_backward(*[t for t in (raw, raw_fw, raw_bw, f_fw, f_bw) if t is not None])
         ctx.present = [t is not None for t in (raw, raw_fw, raw_bw, f_fw, f_bw)]
-        return tuple(values[k].detach().clone() for k, _ in cfg["spec"])
+        return tuple(values[k].detach().view_as(values[k]) for k, _ in cfg["spec"])
 
     @staticmethod
     def backward(ctx, *grads):

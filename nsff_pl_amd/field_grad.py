@@ -99,7 +99,7 @@ class _FieldFn(torch.autograd.Function):
             raw, acts, xin, masks, xyz_c = cfg["saved"]
             ctx.cfg, ctx.P = cfg, P
             ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *params)
-            return raw.clone()
+            return raw.detach().view_as(raw)
         dev = xyz.device
         raw = torch.zeros(P, _lib.RAW_STRIDE, device=dev)
         acts, xin, masks = alloc_saves(model, P, dev, transient)
@@ -332,13 +332,19 @@ class _FieldFn(torch.autograd.Function):
         return (None, d_xyz, d_t) + tuple(grads)
 
 
+_FREQ_CACHE = {}
+
+
 def _posenc_backward(d_xin, xyz, freqs):
     """d(xyz) from d(embedding) (reference nerf.py:17-30: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...])."""
-    d_xyz = d_xin[:, 0:3].clone()
-    for i, f in enumerate(freqs):
-        ang = f * xyz
-        d_xyz += f * (torch.cos(ang) * d_xin[:, 3 + 6 * i:6 + 6 * i] - torch.sin(ang) * d_xin[:, 6 + 6 * i:9 + 6 * i])
-    return d_xyz
+    nf = len(freqs)
+    key = (xyz.device, tuple(freqs))
+    if key not in _FREQ_CACHE:               # built once, outside any graph capture (the eager warm-up comes first)
+        _FREQ_CACHE[key] = torch.tensor(freqs, device=xyz.device, dtype=torch.float32).view(1, nf, 1)
+    fr = _FREQ_CACHE[key]
+    ang = xyz[:, None, :] * fr                                         # (P, nf, 3)
+    de = d_xin[:, 3:3 + 6 * nf].reshape(-1, nf, 2, 3)                   # [.., 0, :] = d sin, [.., 1, :] = d cos
+    return d_xin[:, 0:3] + (fr * (torch.cos(ang) * de[:, :, 0] - torch.sin(ang) * de[:, :, 1])).sum(1)
 
 
 def _unfragment(frag, n_rows):
