@@ -122,6 +122,8 @@ class _FieldFn(torch.autograd.Function):
         params = ctx.saved_tensors[5:]
         P, D, skip = ctx.P, model.D, model.skips[0]
         tiles, dev = acts.shape[1], d_raw.device
+        if P == 0:                               # an empty batch contributes nothing
+            return (None, None if not ctx.needs_input_grad[1] else torch.zeros_like(xyz), None) + (None,) * len(params)
         static, transient = cfg["static"], cfg["transient"]
         n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
         d_raw = d_raw.contiguous()
