@@ -189,15 +189,20 @@ __device__ __forceinline__ float pow2_scale(float amax) {      // 2^k with amax 
 // LDS tile (fp16, [point][LDH]) -> HBM fragments dst[ks][row block][lane][8 pts] (layout of field_h3.hip's
 // tile_to_fragments), every point scaled by rel[p] (a power of two)
 __device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const float* sRel, _Float16* dst, int n_rows) {
-    for (int task = threadIdx.x; task < n_rows * 8; task += 256) {
-        const int row = task % n_rows, pg = task / n_rows;
-        h8 out;
+    const int pairs = n_rows >> 1;                                         // two neurons per 4-byte LDS read
+    for (int task = threadIdx.x; task < pairs * 8; task += 256) {
+        const int row = 2 * (task % pairs), pg = task / pairs;
+        h8 out0, out1;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const float v = (float)sB[(8 * pg + t) * LDH + row] * sRel[8 * pg + t];
-            out[t] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+            const h2 v = *reinterpret_cast<const h2*>(sB + (8 * pg + t) * LDH + row);
+            const float r = sRel[8 * pg + t];
+            out0[t] = (_Float16)fminf(fmaxf((float)v[0] * r, -65504.f), 65504.f);
+            out1[t] = (_Float16)fminf(fmaxf((float)v[1] * r, -65504.f), 65504.f);
         }
-        *reinterpret_cast<h8*>(dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8) = out;
+        _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
+        *reinterpret_cast<h8*>(d) = out0;
+        *reinterpret_cast<h8*>(d + 8) = out1;
     }
 }
 

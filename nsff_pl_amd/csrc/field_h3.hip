@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2f __attribute__((ext_vector_type(2)));
 
 #ifdef H3_TIMING
 // debug build only (make timing): s_memtime stamps of the first 256 workgroups, 6 per step and wave
@@ -267,16 +268,21 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
 template <int THREADS>
 __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows,
                                                   int rows_copied) {
-    for (int task = threadIdx.x; task < rows_copied * 8; task += THREADS) {     // (8-point group, row), row fastest
-        const int row = task % rows_copied, pg = task / rows_copied;
-        h8 out;
+    const int pairs = rows_copied >> 1;                                    // two neurons per 4-byte LDS read
+    for (int task = threadIdx.x; task < pairs * 8; task += THREADS) {      // (8-point group, row pair), pair fastest
+        const int row = 2 * (task % pairs), pg = task / pairs;
+        h8 out0, out1;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int idx = (8 * pg + t) * LDH + row;
-            out[t] = (_Float16)((float)sXh[idx] + (float)sXl[idx]);
+            const h2f hi = *reinterpret_cast<const h2f*>(sXh + idx), lo = *reinterpret_cast<const h2f*>(sXl + idx);
+            out0[t] = (_Float16)((float)hi[0] + (float)lo[0]);
+            out1[t] = (_Float16)((float)hi[1] + (float)lo[1]);
         }
         // 1 KiB blocks of 32 rows, lane-linear inside: [ks][row/32][(row&31) + 32*(point group&1)][8 points]
-        *reinterpret_cast<h8*>(dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8) = out;
+        _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
+        *reinterpret_cast<h8*>(d) = out0;
+        *reinterpret_cast<h8*>(d + 8) = out1;
     }
 }
 
