@@ -37,6 +37,10 @@ CASES = {
     "g7_nsff_train_noise": dict(n_rays=16, N_samples=64, N_importance=64, transient=True, viewdir=False,
                                 appearance=False, test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5,
                                 seed=7, perturb=1.0, noise_std=1.0),
+    # a different architecture: 6 layers, skip at 2, 16-wide time code, 8 / 3 embedding frequencies (in_xyz = 51)
+    "g12_other_arch": dict(n_rays=12, N_samples=32, N_importance=24, transient=True, viewdir=False,
+                           appearance=False, test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=12,
+                           D=6, skips=[2], n_tau=16, xyz_emb=(7, 8), dir_emb=(2, 3)),
     "g7b_static_noise_odd": dict(n_rays=9, N_samples=48, N_importance=40, transient=False, viewdir=True,
                                  appearance=False, test_time=False, flow=[], gain=2.5, seed=8,
                                  perturb=0.5, noise_std=0.7),
@@ -54,19 +58,23 @@ def synthetic_rays(n_rays, seed):
 def build_scene(nerf_cls, posemb_cls, cfg):
     """Construct embeddings + models in a fixed order under cfg['seed'] and apply the gain."""
     torch.manual_seed(cfg["seed"])
-    embeddings = {"xyz": posemb_cls(9, 10), "dir": posemb_cls(3, 4)}
+    xyz_emb, dir_emb = cfg.get("xyz_emb", (9, 10)), cfg.get("dir_emb", (3, 4))
+    n_tau = cfg.get("n_tau", N_TAU)
+    embeddings = {"xyz": posemb_cls(*xyz_emb), "dir": posemb_cls(*dir_emb)}
     if cfg["transient"]:
-        embeddings["t"] = torch.nn.Embedding(N_FRAMES, N_TAU)
+        embeddings["t"] = torch.nn.Embedding(N_FRAMES, n_tau)
     if cfg["appearance"]:
         embeddings["a"] = torch.nn.Embedding(N_FRAMES, N_A)
     flow = bool(cfg["flow"])
+    arch = dict(D=cfg.get("D", 8), skips=cfg.get("skips", [4]), in_channels_xyz=3 + 6 * xyz_emb[1],
+                in_channels_dir=3 + 6 * dir_emb[1])
     models = {"fine": nerf_cls("fine", use_viewdir=cfg["viewdir"],
                                encode_appearance=cfg["appearance"], in_channels_a=N_A,
-                               encode_transient=cfg["transient"], in_channels_t=N_TAU,
-                               output_flow=flow)}
+                               encode_transient=cfg["transient"], in_channels_t=n_tau,
+                               output_flow=flow, **arch)}
     if cfg["N_importance"] > 0:
         models["coarse"] = nerf_cls("coarse", use_viewdir=cfg["viewdir"],
-                                    encode_transient=cfg["transient"], in_channels_t=N_TAU)
+                                    encode_transient=cfg["transient"], in_channels_t=n_tau, **arch)
     with torch.no_grad():
         for m in models.values():
             for name, p in m.named_parameters():

@@ -175,7 +175,7 @@ def test_render_rays_backward_matches_reference(name, precision, hip_lib, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g7_nsff_train_noise", "g2_static_c2f"])
+@pytest.mark.parametrize("name", ["g7_nsff_train_noise", "g2_static_c2f", "g12_other_arch"])
 def test_native_compositing_backward_equals_torch_expression(name, hip_lib, monkeypatch):
     """nsff_composite_backward against autograd of the elementwise torch expression of the same compositing
     (same field nodes, same forward values): both fp32, so they agree far below the fp64-truth tolerance."""
