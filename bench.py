@@ -219,7 +219,7 @@ def main():
                 line["metric"] = "ray-samples/sec (coarse+fine, static+dynamic) -- full-frame EVALUATION"
                 line["value"] = n_px * (128 + 64) * args.steps / elapsed
                 line["config"] = {"workload": "C3 (BASELINE.json configs[2]): 512x288 test-time frame per step, rays generated "
-                                              "on the device, 32768-ray chunks, 128 coarse + 64 importance samples -> 320 fine "
+                                              "on the device, 32768-ray chunks, 128 coarse + 64 importance samples -> 256 fine "
                                               "points/ray, static+dynamic, rays sharded over the ranks + one pixel all-gather",
                                   "frames_per_s": args.steps / elapsed, "rays_per_frame": n_px,
                                   "parallelism": f"ray-shard x{world}" if world > 1 else "single GPU"}
@@ -229,7 +229,7 @@ def main():
                 line["unit"] = "frames/s"
                 line["value"] = world * 10 * args.steps / elapsed
                 line["config"] = {"workload": "C5 inner loop (BASELINE.json configs[4]): render t and t+1 (512x288, 128+64 samples, "
-                                              "flows), 9 x interpolate (plane splat + MPI composite, 320 planes); every rank does "
+                                              "flows), 9 x interpolate (plane splat + MPI composite, 256 planes); every rank does "
                                               "its own frame pair", "parallelism": f"frame-pair per rank x{world}"}
         if trainer is not None:
             line["config"]["workload"] = ("C4 (BASELINE.json configs[3]) per GPU: the C2 batch through one training step = "
