@@ -159,10 +159,15 @@ __device__ __forceinline__ void mma1(f32x16 (&acc)[2][NT], const WF1& w, const X
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.w[mt], x.x[nt], acc[mt][nt]);
 }
 
-// acc += Wt_seg . B^T for this wave's 64 output rows and the 64 points; nks is a multiple of 4.
-__device__ __forceinline__ void gemm1(f32x16 (&acc)[2][NT], const uint4* __restrict__ wp, const _Float16* sB, int nks) {
-    WRing1 ring;
+// first four k-steps of a segment; issued before the epilogue that precedes the segment's GEMM (L2 latency hidden)
+__device__ __forceinline__ const uint4* prefetch_w1(WRing1& ring, const uint4* __restrict__ wp) {
     load_w1(ring.r[0], wp); load_w1(ring.r[1], wp); load_w1(ring.r[2], wp); load_w1(ring.r[3], wp);
+    return wp;
+}
+
+// acc += Wt_seg . B^T for this wave's 64 output rows and the 64 points; nks is a multiple of 4; `ring` holds
+// k-steps 0..3 and wp points at k-step 4.
+__device__ __forceinline__ void gemm1(f32x16 (&acc)[2][NT], WRing1& ring, const uint4* __restrict__ wp, const _Float16* sB, int nks) {
     XF1 x0, x1;
     load_x1(x0, sB, 0);
 #pragma unroll 1
@@ -196,9 +201,9 @@ __device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, con
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const h2 v = *reinterpret_cast<const h2*>(sB + (8 * pg + t) * LDH + row);
-            const float r = sRel[8 * pg + t];
-            out0[t] = (_Float16)fminf(fmaxf((float)v[0] * r, -65504.f), 65504.f);
-            out1[t] = (_Float16)fminf(fmaxf((float)v[1] * r, -65504.f), 65504.f);
+            const float r = sRel[8 * pg + t];          // fp32 on purpose: G/s reaches down to 2^-40, the PRODUCT is what must fit fp16
+            out0[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[0] * r, -65504.f, 65504.f);
+            out1[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[1] * r, -65504.f, 65504.f);
         }
         _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
         *reinterpret_cast<h8*>(d) = out0;
@@ -221,6 +226,11 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
     const long long slot_stride = a.n_tiles * (64 * NSFF_W);
 
     f32x16 acc[2][NT];
+    WRing1 ring;
+    auto seg = [&](const BStep& s_) {
+        return reinterpret_cast<const uint4*>(pk + s_.w_off) + (wave * s_.nks) * 2 * 64 + lane;
+    };
+    const uint4* wnext = prefetch_w1(ring, seg(a.steps[0]));
 #pragma unroll 1
     for (int i = 0; i < a.n_steps; ++i) {
         const BStep st = a.steps[i];
@@ -297,10 +307,9 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
-        if (!(st.flags & F_HALF_ROWS) || wave < 2) {
-            const uint4* wp = reinterpret_cast<const uint4*>(pk + st.w_off) + (wave * st.nks) * 2 * 64 + lane;
-            gemm1(acc, wp, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks);
-        }
+        if (!(st.flags & F_HALF_ROWS) || wave < 2)
+            gemm1(acc, ring, wnext, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks);
+        if (i + 1 < a.n_steps) wnext = prefetch_w1(ring, seg(a.steps[i + 1]));    // flies during the epilogue
         if (st.epi == EPI_KEEP) continue;
         if (st.epi == EPI_DXIN) {
             if (wave < 2 && a.d_xin != nullptr) {
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                         v[e] = acc[mt][nt][4 * q + e];
                         if (st.flags & F_SIGMA) v[e] += wsig[mt][q][e] * sg;
                         if (st.epi == EPI_MASK && !((mbits >> (((mt * NT + nt) * 4 + q) * 4 + e)) & 1ull)) v[e] = 0.f;
-                        v[e] = fminf(fmaxf(v[e], -65504.f), 65504.f);
+                        v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
                     }
                     h4 hv;
                     hv[0] = (_Float16)v[0]; hv[1] = (_Float16)v[1]; hv[2] = (_Float16)v[2]; hv[3] = (_Float16)v[3];
