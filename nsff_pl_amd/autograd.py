@@ -1,4 +1,4 @@
-"""Gradients for ``render_rays`` (SURVEY.md section 8f, row N1 -- first stage).
+"""Gradients for ``render_rays``.
 
 Forward values always come from the gfx950 kernels.  When gradients are needed, the same quantities are also
 expressed as a differentiable graph at the SAME sample depths and random draws (recorded during the HIP forward):

@@ -66,27 +66,12 @@ def _mm32(a16, b16):
 
 
 def _h(x):
-    if _MODE == "f32":
-        return x.float()
     return x.clamp(-_F16_MAX, _F16_MAX).half()
 
 
-_WSPLIT = os.environ.get("NSFF_BWD_WSPLIT", "0") == "1"
-_XIN32 = os.environ.get("NSFF_BWD_XIN32", "0") == "1"
-_MODE = os.environ.get("NSFF_BWD_MODE", "rowscale")      # experiments: f32 | global | rowscale
-
-
 def _bmm(dpre16, w, out32=False):
-    """dX = dY . W with fp16 operands; optionally W = hi + lo (two products) and an fp32 result."""
-    w = w.detach()
-    if _MODE == "f32":
-        return dpre16.float() @ w
-    wh = w.half()
-    mm = _mm32 if out32 else torch.mm
-    out = mm(dpre16, wh)
-    if _WSPLIT:
-        out = out + mm(dpre16, (w - wh.float()).half())
-    return out
+    """dX = dY . W with fp16 operands (fp32 accumulate), fp16 or fp32 result."""
+    return (_mm32 if out32 else torch.mm)(dpre16, w.detach().half())
 
 
 class _FieldFn(torch.autograd.Function):
@@ -227,34 +212,21 @@ class _FieldFn(torch.autograd.Function):
         grads = [None] * len(params)
         slot = {k: i for i, k in enumerate(names)}
 
-        if _MODE == "rowscale":
-            # block floating point per point: every row of d_raw is normalised to max 2^10; the inverse scale is
-            # folded into the activation operand of the weight-gradient GEMMs, centred on the median exponent
-            amax = d_raw.abs().amax(1, keepdim=True).clamp_min(1e-30)
-            scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)))                  # (P,1)
-            ref = torch.median(scale)
-            scale = torch.minimum(scale, ref * 4096.0)                                   # act * ref/scale stays >= 2^-12 act
-            scale = torch.maximum(scale, ref / 1024.0)                                   # ... and <= 2^10 act
-            d = d_raw * scale
-            inv = 1.0 / scale
-            rel = (ref * inv)                                                            # (P,1) exact powers of two
-            inv_ref = 1.0 / ref
+        # block floating point per point: every row of d_raw is normalised to max 2^10; the inverse scale is
+        # folded into the activation operand of the weight-gradient GEMMs, centred on the median exponent
+        amax = d_raw.abs().amax(1, keepdim=True).clamp_min(1e-30)
+        scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)))                  # (P,1)
+        ref = torch.median(scale)
+        scale = torch.minimum(scale, ref * 4096.0)
+        scale = torch.maximum(scale, ref / 1024.0)
+        d = d_raw * scale
+        inv = 1.0 / scale
+        rel = (ref * inv)                                                            # (P,1) exact powers of two
+        inv_ref = 1.0 / ref
 
-            def put(layer, dpre16, inp16):
-                grads[slot[id(layer.weight)]] = _mm32(dpre16.t(), (inp16.float() * rel).half()) * inv_ref
-                grads[slot[id(layer.bias)]] = (dpre16.float() * inv).sum(0)
-        else:
-            amax = d_raw.abs().max().clamp_min(1e-30)
-            scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax))) if _MODE != "f32" else torch.ones_like(amax)
-            d = d_raw * scale
-            inv = 1.0 / scale
-
-            def put(layer, dpre16, inp16):
-                if _MODE == "f32":
-                    grads[slot[id(layer.weight)]] = dpre16.float().t() @ inp16.float() * inv
-                else:
-                    grads[slot[id(layer.weight)]] = _mm32(dpre16.t(), inp16) * inv
-                grads[slot[id(layer.bias)]] = dpre16.sum(0, dtype=torch.float32) * inv
+        def put(layer, dpre16, inp16):
+            grads[slot[id(layer.weight)]] = _mm32(dpre16.t(), (inp16.float() * rel).half()) * inv_ref
+            grads[slot[id(layer.bias)]] = (dpre16.float() * inv).sum(0)
 
         def trunk(prefix, slot0, dh, in_t):
             """dh: (P,256) fp16 gradient w.r.t. the last trunk activation.  Returns d(trunk input) (P, 63+in_t) fp32-ish."""
@@ -268,11 +240,11 @@ class _FieldFn(torch.autograd.Function):
                 w = layer.weight
                 if l == 0:
                     put(layer, dpre, x_in)
-                    d0 = _bmm(dpre, w, _XIN32)
+                    d0 = _bmm(dpre, w, True)
                     d_x = d0 if d_x is None else d_x + d0
                 elif l == skip:
                     put(layer, dpre, torch.cat([x_in, acts[slot0 + l - 1, :P]], 1))
-                    d_x = _bmm(dpre, w[:, :n_in], _XIN32)
+                    d_x = _bmm(dpre, w[:, :n_in], True)
                     dh = _h(_bmm(dpre, w[:, n_in:]))
                 else:
                     put(layer, dpre, acts[slot0 + l - 1, :P])
