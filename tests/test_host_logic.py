@@ -132,3 +132,20 @@ def test_shard_bounds_cover_everything_once():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_compositing_node_outputs_are_result_keys_of_the_reference():
+    """Every tensor the native compositing node hands out is a key the reference's render_rays returns in that mode
+    (golden key sets), and the node covers every differentiable per-ray key."""
+    import common
+    from nsff_pl_amd import composite_grad
+    for name, typ_flags in (("g3_nsff_train", dict(coarse=(True, False, False), fine=(True, True, True))),
+                            ("g2_static_c2f", dict(coarse=(False, False, False), fine=(False, False, False)))):
+        want = common.load_golden(name)[-1] if hasattr(common, "load_golden") else common.build_case(name, A.NeRF, A.PosEmbedding)[-1]
+        for typ, (tr, fl, wp) in typ_flags.items():
+            keys = [k for k, _ in composite_grad.output_spec(typ, tr, fl, wp)]
+            assert len(keys) == len(set(keys))
+            assert all(k in want for k in keys), [k for k in keys if k not in want]
+    per_ray = {"rgb_fine", "depth_fine", "transient_alpha_fine", "transient_rgb_fine", "_static_rgb_fine",
+               "_static_depth_fine", "xyz_fine", "transient_flow_fw", "transient_flow_bw", "rgb_fw", "rgb_bw"}
+    assert per_ray <= {k for k, _ in composite_grad.output_spec("fine", True, True, True)}
