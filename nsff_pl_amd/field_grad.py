@@ -144,51 +144,63 @@ class _FieldFn(torch.autograd.Function):
         for j, sz in zip(jobs, sizes):
             j[4] = off
             off += sz
-        out = torch.empty(off, device=dev)
-        bias = torch.empty(len(jobs), 256, device=dev)
-        _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias, gmax)      # summed and unscaled in there
+        # The weight-gradient GEMMs depend only on this node's K1 output and nothing downstream needs them before the
+        # optimizer: they run on a side stream (HBM-bound, they overlap with the next node's store-bound K1 and the
+        # small torch kernels) and a callback at the end of the backward pass adds them to .grad.
+        overlap = _overlap_enabled()
+        main = torch.cuda.current_stream()
+        # inside a hipGraph capture the fork / join costs more than the concurrency returns (13.98 vs 12.56 ms per
+        # step): there only the accumulation is deferred and fused, on the capture stream itself
+        side = _side_stream(dev) if (overlap and not torch.cuda.is_current_stream_capturing()) else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = torch.empty(off, device=dev)
+            bias = torch.empty(len(jobs), 256, device=dev)
+            _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias, gmax)  # summed and unscaled in there
 
-        def result(i):
-            j = jobs[i]
-            return out[j[4]:j[4] + sizes[i]].view(j[2], j[3])
+        with torch.cuda.stream(side):
+            def result(i):
+                j = jobs[i]
+                return out[j[4]:j[4] + sizes[i]].view(j[2], j[3])
 
-        index = {p_: i for i, p_ in enumerate(id(q) for q in _lib.param_list(model))}
-        grads = [None] * len(params)
+            index = {p_: i for i, p_ in enumerate(id(q) for q in _lib.param_list(model))}
+            grads = [None] * len(params)
 
-        def put(layer, w, b):
-            grads[index[id(layer.weight)]] = w
-            grads[index[id(layer.bias)]] = b
+            def put(layer, w, b):
+                grads[index[id(layer.weight)]] = w
+                grads[index[id(layer.bias)]] = b
 
-        def xcols(m, in_t):                       # (256,128) in trunk-input rows -> (256, in_dim) in Linear columns
-            return m[:, :n_xyz] if in_t == 0 else torch.cat([m[:, :n_xyz], m[:, 64:64 + in_t]], 1)
-        res = {tag: i for i, tag in enumerate(meta)}
-        for t in ([0] if static else []) + ([1] if transient else []):
-            prefix, in_t = ("static", 0) if t == 0 else ("transient", n_t)
-            for l in range(D):
-                layer = _lin(getattr(model, f"{prefix}_xyz_encoding_{l + 1}"))
-                if l == 0:
-                    i = res[("x", t, 0)]
-                    put(layer, xcols(result(i), in_t), bias[i])
-                elif l == skip:
-                    i = res[("h", t, l)]
-                    put(layer, torch.cat([xcols(result(res[("x", t, l)]), in_t), result(i)], 1), bias[i])
+            def xcols(m, in_t):                       # (256,128) in trunk-input rows -> (256, in_dim) in Linear columns
+                return m[:, :n_xyz] if in_t == 0 else torch.cat([m[:, :n_xyz], m[:, 64:64 + in_t]], 1)
+            res = {tag: i for i, tag in enumerate(meta)}
+            for t in ([0] if static else []) + ([1] if transient else []):
+                prefix, in_t = ("static", 0) if t == 0 else ("transient", n_t)
+                for l in range(D):
+                    layer = _lin(getattr(model, f"{prefix}_xyz_encoding_{l + 1}"))
+                    if l == 0:
+                        i = res[("x", t, 0)]
+                        put(layer, xcols(result(i), in_t), bias[i])
+                    elif l == skip:
+                        i = res[("h", t, l)]
+                        put(layer, torch.cat([xcols(result(res[("x", t, l)]), in_t), result(i)], 1), bias[i])
+                    else:
+                        i = res[("h", t, l)]
+                        put(layer, result(i), bias[i])
+                i = res[("h", t, D)]
+                put(_lin(getattr(model, f"{prefix}_xyz_encoding_final")), result(i), bias[i])
+                i = res[("head", t, 0)]
+                hw, hb = result(i), bias[i]
+                if t == 0:
+                    put(_lin(model.static_rgb), hw[0:3], hb[0:3])
+                    i2 = res[("head", 0, 1)]
+                    put(_lin(model.static_sigma), result(i2)[3:4], bias[i2][3:4])
                 else:
-                    i = res[("h", t, l)]
-                    put(layer, result(i), bias[i])
-            i = res[("h", t, D)]
-            put(_lin(getattr(model, f"{prefix}_xyz_encoding_final")), result(i), bias[i])
-            i = res[("head", t, 0)]
-            hw, hb = result(i), bias[i]
-            if t == 0:
-                put(_lin(model.static_rgb), hw[0:3], hb[0:3])
-                i2 = res[("head", 0, 1)]
-                put(_lin(model.static_sigma), result(i2)[3:4], bias[i2][3:4])
-            else:
-                put(_lin(model.transient_rgb), hw[0:3], hb[0:3])
-                put(_lin(model.transient_sigma), hw[3:4], hb[3:4])
-                if model.output_flow:
-                    put(_lin(model.transient_flow_fw), hw[4:7], hb[4:7])
-                    put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
+                    put(_lin(model.transient_rgb), hw[0:3], hb[0:3])
+                    put(_lin(model.transient_sigma), hw[3:4], hb[3:4])
+                    if model.output_flow:
+                        put(_lin(model.transient_flow_fw), hw[4:7], hb[4:7])
+                        put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
 
         d_xyz = d_t = None
         if d_xin is not None:
@@ -196,6 +208,13 @@ class _FieldFn(torch.autograd.Function):
                 d_t = d_xin[:, 64:64 + n_t].reshape(P // s, s, -1).sum(1)
             if ctx.needs_input_grad[1]:
                 d_xyz = _posenc_backward(d_xin, xyz, freqs)
+        if overlap:
+            # keep what the side stream still reads alive until the join, then hand the gradients over there
+            _PENDING["items"].append((list(_lib.param_list(model)), grads, (dpre, dhead, acts, xin, out, bias, gmax)))
+            if not _PENDING["queued"]:
+                _PENDING["queued"] = True
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
+            return (None, d_xyz, d_t) + (None,) * len(params)
         return (None, d_xyz, d_t) + tuple(grads)
 
     @staticmethod
@@ -307,6 +326,42 @@ class _FieldFn(torch.autograd.Function):
 
 
 _FREQ_CACHE = {}
+_PENDING = {"items": [], "queued": False}
+_SIDE = {}
+
+
+def _overlap_enabled():
+    return os.environ.get("NSFF_WGRAD_OVERLAP", "1") != "0"
+
+
+def _side_stream(device):
+    if device not in _SIDE:                  # created by the first (eager) backward, i.e. before any graph capture
+        _SIDE[device] = torch.cuda.Stream(device=device)
+    return _SIDE[device]
+
+
+def _flush_weight_grads():
+    """End-of-backward callback: join the side stream and add the weight gradients of every field node to .grad
+    (one fused add per node instead of one per parameter).  Gradients therefore reach the parameters through
+    ``loss.backward()``; ``torch.autograd.grad(..., parameters)`` needs NSFF_WGRAD_OVERLAP=0."""
+    items, _PENDING["items"], _PENDING["queued"] = _PENDING["items"], [], False
+    if not items:
+        return
+    for dev, side in _SIDE.items():
+        torch.cuda.current_stream(dev).wait_stream(side)
+    with torch.no_grad():
+        for plist, grads, _keep in items:
+            have, new = [], []
+            for p, g in zip(plist, grads):
+                if g is None or not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    have.append(p.grad)
+                    new.append(g)
+            if have:
+                torch._foreach_add_(have, new)
 
 
 def _posenc_backward(d_xin, xyz, freqs):
