@@ -139,7 +139,7 @@ class _FieldFn(torch.autograd.Function):
             job(dhead[t], acts[base + D], 32, 256, ("head", t, 0))
             if t == 0:
                 job(dhead[0], acts[base + D - 1], 32, 256, ("head", t, 1))    # static sigma reads the trunk
-        n_splits = max(1, min(32, tiles // 4))
+        n_splits = max(1, min(int(os.environ.get("NSFF_WGRAD_SPLITS", "32")), tiles // 4))
         off = 0
         for j, sz in zip(jobs, sizes):
             j[4] = off
