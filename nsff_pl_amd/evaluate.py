@@ -70,6 +70,43 @@ def render_frame_sharded(models, embeddings, rays, ts, max_t, N_samples, N_impor
     return merged
 
 
+def render_sequence(models, embeddings, samples, max_t, N_samples, N_importance, img_wh, chunk=1024 * 32, interp=0,
+                    K=None, **kwargs):
+    """The frame loop of the reference's ``eval.py`` (:171-222) as a generator of ``(name, rgb (h,w,3), depth (h,w))``
+    GPU tensors, values clipped like there.
+
+    samples: sequence of dicts ``{'rays': (h*w,6) [, 'ts': (h*w,) long] [, 'c2w': (3,4)]}`` (what the dataset yields).
+    interp == 0: one image per sample (splits ``test`` / ``test_spiral``), named ``'{i:03d}'``.
+    interp  > 0: the fixed-view time interpolation of split ``test_fixview*_interp{N}`` (:176-213): frame i is rendered
+    once, re-used as the left end of the next pair (``last_results``), frame i+1 is rendered at ``ts + 1`` and
+    ``interp - 1`` in-between images come from :func:`nsff_pl_amd.interpolate`; names ``'{i:03d}_{int(dt*100):03d}'``;
+    the last sample only closes the sequence.  ``kwargs`` must then ask for ``output_transient_flow=['fw','bw']``."""
+    from .interpolation import interpolate
+    w, h = img_wh
+    n = len(samples)
+    last = None
+    for i, sample in enumerate(samples):
+        rays = sample['rays']
+        ts = sample.get('ts')
+        if interp > 0 and i == n - 1:                                   # eval.py:172-180: last frame closes the sequence
+            yield f"{i:03d}_000", torch.clip(last['rgb_fine'].view(h, w, 3), 0, 1), last['depth_fine'].view(h, w)
+            return
+        res = last if last is not None else render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance,
+                                                         chunk, **kwargs)
+        if interp > 0:
+            nxt = render_frame(models, embeddings, rays, ts + 1, max_t, N_samples, N_importance, chunk, **kwargs)
+            for j in range(interp):
+                dt = j / interp
+                if j == 0:
+                    img, depth = res['rgb_fine'].view(h, w, 3), res['depth_fine'].view(h, w)
+                else:
+                    img, depth = interpolate(res, nxt, dt, K, sample['c2w'], (w, h))
+                yield f"{i:03d}_{int(dt * 100):03d}", torch.clip(img, 0, 1), depth
+            last = nxt
+        else:
+            yield f"{i:03d}", torch.clip(res['rgb_fine'].view(h, w, 3), 0, 1), res['depth_fine'].view(h, w)
+
+
 def psnr(image_pred, image_gt, valid_mask=None):
     """-10 log10(mean squared error) (reference metrics.py:6-16)."""
     err = (image_pred - image_gt) ** 2

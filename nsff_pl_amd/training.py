@@ -145,6 +145,14 @@ class NSFFTrainer:
             log["lr"] = self.optimizer.param_groups[0]["lr"]
         return loss, log
 
+    # train.py:200-214 (the metric part; image grids / SSIM maps of the reference are logging)
+    @torch.no_grad()
+    def validation_step(self, batch):
+        """batch: {'rays': (H*W,6), 'rgbs': (H*W,3) [, 'ts']} of one full frame -> {'val_psnr'}."""
+        kwargs = dict(output_transient=self.output_transient, output_transient_flow=[])
+        results = self.forward(batch["rays"], batch.get("ts"), test_time=True, **kwargs)
+        return {"val_psnr": psnr(results["rgb_fine"], batch["rgbs"])}
+
     def step(self, batch):
         """zero_grad -> training_step -> backward -> gradient all-reduce -> Adam; returns the log dict."""
         if self.optimizer is None:

@@ -152,3 +152,31 @@ def test_hip_render_then_interpolate_end_to_end(hip_lib):
         # sample_pdf conditioning moves a few fine depths (tests/parity.py), so pixels, not 1e-4: 1e-3 of the range
         parity.assert_close(f"rgb dt={dt}", g_rgb.cpu().numpy(), rgb, 1e-3)
         parity.assert_close(f"depth dt={dt}", g_depth.cpu().numpy(), depth, 1e-3)
+
+
+@pytest.mark.gpu
+def test_render_sequence_mirrors_the_eval_loop(hip_lib):
+    """eval.py:171-222 with split test_fixview*_interp3 on three samples: names, frame reuse and in-between frames."""
+    from test_gpu_parity import _to_dev, DEV
+    from nsff_pl_amd import evaluate
+    res_t, res_tp1, K, c2w, wh, outs, rays, checksum = _golden()
+    cfg = dict(scenes.INTERP_CFG, n_rays=wh[0] * wh[1])
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    rays = torch.from_numpy(rays).to(DEV)
+    ts = torch.full((rays.shape[0],), scenes.INTERP_T, device=DEV)
+    samples = [dict(rays=rays, ts=ts + k, c2w=torch.from_numpy(c2w)) for k in range(3)]
+    kw = scenes.render_kwargs(cfg)
+    frames = list(evaluate.render_sequence(models, emb, samples, scenes.N_FRAMES - 1, cfg["N_samples"], cfg["N_importance"],
+                                           wh, interp=3, K=torch.from_numpy(K), **kw))
+    assert [f[0] for f in frames] == ["000_000", "000_033", "000_066", "001_000", "001_033", "001_066", "002_000"]
+    a = evaluate.render_frame(models, emb, rays, ts, scenes.N_FRAMES - 1, cfg["N_samples"], cfg["N_importance"], **kw)
+    b = evaluate.render_frame(models, emb, rays, ts + 1, scenes.N_FRAMES - 1, cfg["N_samples"], cfg["N_importance"], **kw)
+    assert torch.equal(frames[0][1], torch.clip(a["rgb_fine"].view(wh[1], wh[0], 3), 0, 1))
+    assert torch.equal(frames[3][1], torch.clip(b["rgb_fine"].view(wh[1], wh[0], 3), 0, 1))     # reused as left end
+    img, dep = A.interpolate(a, b, 1 / 3, K, c2w, wh)
+    parity.assert_close("in-between", frames[1][1].cpu().numpy(), torch.clip(img, 0, 1).cpu().numpy(), 1e-5)
+    # plain split: one image per sample
+    plain = list(evaluate.render_sequence(models, emb, samples[:2], scenes.N_FRAMES - 1, cfg["N_samples"],
+                                          cfg["N_importance"], wh, **dict(kw, output_transient_flow=[])))
+    assert [f[0] for f in plain] == ["000", "001"] and plain[0][1].shape == (wh[1], wh[0], 3)
