@@ -98,3 +98,49 @@ def test_flat_gradient_allreduce():
     ctx = mp.spawn(_grad_worker, args=(world, _free_port(), ret), nprocs=world, join=False)
     ctx.join(timeout=300)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _trainer_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import nsff_pl_amd as A
+    from nsff_pl_amd import dist as ndist, training
+    ndist.init_from_env("gloo")
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    models = {"fine": A.NeRF("fine", use_viewdir=False)}
+    emb = {"xyz": A.PosEmbedding(9, 10), "dir": A.PosEmbedding(3, 4)}
+
+    def cpu_render(models_, embeddings_, rays, ts, max_t, N_samples, *a, **kw):
+        """Stand-in with the signature of render_rays: a differentiable function of the fine model's parameters
+        (the HIP kernels cannot run here; what is under test is the data-parallel step around the renderer)."""
+        m = models_["fine"]
+        h = torch.sigmoid(rays[:, :3] @ m.static_xyz_encoding_1[0].weight[:3, :3] + m.static_rgb[0].bias)
+        return {"rgb_fine": h, "depth_fine": (rays[:, 3:] ** 2).sum(1) * m.static_sigma.bias.abs().sum()}
+    training.render_rays = cpu_render
+    tr = training.NSFFTrainer(models, emb, 30, dict(N_samples=8, perturb=0, noise_std=0), output_transient=False)
+    tr.on_train_epoch_start(0)
+    g = torch.Generator().manual_seed(100 + rank)          # every rank trains on its own batch
+    for _ in range(3):
+        batch = dict(rays=torch.randn(16, 6, generator=g), rgbs=torch.rand(16, 3, generator=g),
+                     disps=torch.rand(16, generator=g) + 0.1)
+        log = tr.step(batch)
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    moved = float((models["fine"].static_rgb[0].bias.detach() - 0).abs().sum()) > 0
+    ret[rank] = bool(torch.equal(gathered[0], gathered[1])) and moved and bool(torch.isfinite(log["train/loss"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_trainer_keeps_replicas_in_sync():
+    """NSFFTrainer.step on two ranks with different batches: after the flat gradient all-reduce and Adam the
+    parameter replicas are bit-identical (what PL's DDP guarantees for the reference, train.py:294-301)."""
+    world = 2
+    ret = mp.Manager().dict()
+    ctx = mp.spawn(_trainer_worker, args=(world, _free_port(), ret), nprocs=world, join=False)
+    ctx.join(timeout=300)
+    assert dict(ret) == {0: True, 1: True}
