@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      6
+#define NSFF_ABI_VERSION      7
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -56,15 +56,18 @@ typedef struct NsffModelDesc {
     float   flow_scale;     /* 0.2                                                 */
 } NsffModelDesc;
 
-/* Arithmetic of the field kernel's dense layers (results agree to fp32 rounding level):
+/* Arithmetic of the field kernel's dense layers:
  *   NSFF_PREC_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   NSFF_PREC_F16X3 fp32 operands split into two halfs, three f16 MFMAs per product,
- *                   fp32 accumulate (v_mfma_f32_32x32x16_f16), activations staged in LDS
- *   NSFF_PREC_F16X3_RA same arithmetic, register-resident activations + LDS weight ring (D = 8 only)
+ *                   fp32 accumulate (v_mfma_f32_32x32x16_f16), activations staged in LDS;
+ *                   agrees with F32 to fp32 rounding level (same 1e-4 parity tests)
+ *   NSFF_PREC_F16   FAST MODE, not parity-grade: operands rounded once to fp16, one f16 MFMA per product,
+ *                   fp32 accumulate (~5e-3 max-norm on rendered values).  Reads the F16X3 packed buffer
+ *                   (hi halfs only); inference only (the save_* outputs are refused).
  */
 #define NSFF_PREC_F32        0
 #define NSFF_PREC_F16X3      1
-#define NSFF_PREC_F16X3_RA   2
+#define NSFF_PREC_F16        3
 
 /* Size in bytes of the packed-weight buffer for `desc` at `precision`. */
 int nsff_packed_bytes(const NsffModelDesc* desc, int precision, size_t* bytes);

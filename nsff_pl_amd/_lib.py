@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -179,8 +179,18 @@ def _stream():
 
 # ----------------------------------------------------------------------------------
 def model_desc(model):
+    """NsffModelDesc of a NeRF module.  The reference constructor (models/nerf.py:34-40) takes any width W and a
+    list of skip layers; the gfx950 kernels are built for W = 256 trunks with exactly one skip connection (every
+    configuration the reference's train.py / eval.py create) -- anything else is refused here, by name."""
+    if model.W != 256:
+        raise RuntimeError(f"unsupported NeRF architecture: W={model.W} (the gfx950 field kernels tile W=256 trunks "
+                           "into 4 x 64-neuron wave blocks; other widths are not built)")
     if len(model.skips) != 1:
-        raise RuntimeError("the gfx950 field kernel supports exactly one skip layer")
+        raise RuntimeError(f"unsupported NeRF architecture: skips={list(model.skips)} (the kernels' layer program "
+                           "has exactly one skip connection; pass a single layer index)")
+    if not 1 <= model.skips[0] < model.D or not 2 <= model.D <= 8:
+        raise RuntimeError(f"unsupported NeRF architecture: D={model.D}, skips={list(model.skips)} (need 2 <= D <= 8 "
+                           "and 1 <= skip < D)")
     return ModelDesc(D=model.D, W=model.W, skip=model.skips[0], in_xyz=model.in_channels_xyz,
                      in_dir=model.in_channels_dir,
                      in_a=model.in_channels_a if model.use_viewdir else 0,
@@ -243,7 +253,7 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     from . import config
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
-    packed = model.packed(prec)
+    packed = model.packed(1 if prec == 3 else prec)      # the "f16" fast mode reads the f16x3 pack (hi halfs only)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()
     a.n_points, a.pts_per_ray = int(n_points), int(pts_per_ray)

@@ -1,26 +1,27 @@
 """Execution options of the field kernel (not part of the reference's interface).
 
 precision
+    "f16x3" -- (default) every fp32 operand split into two halfs, three f16 MFMAs per product, fp32
+               accumulation; agrees with "f32" to fp32-rounding level and passes the same 1e-4 parity tests,
+               ~2.7x faster.
     "f32"   -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
-    "f16x3" -- every fp32 operand split into two halfs, three f16 MFMAs per product, fp32
-               accumulation; agrees with "f32" to fp32-rounding level and passes the same
-               1e-4 parity tests, ~2.7x faster.
-    "f16x3_ra" -- same arithmetic, register-resident activations + LDS weight ring (experimental).
+    "f16"   -- FAST MODE, not parity-grade: operands rounded once to fp16, ONE f16 MFMA per product, fp32
+               accumulation.  ~5e-3 max-norm error on rendered values (measured per key in
+               tests/test_fast_mode.py, PSNR delta in DESIGN.md section 8); inference only -- gradients are always
+               taken through the f16x3 training forward.
 Select with ``set_precision`` or the environment variable ``NSFF_PRECISION``.
 """
 import os
 
-# "f16x3" = LDS-activation kernel (fastest so far); "f16x3_ra" = register-resident-activation
-# kernel (experimental, reference depth D = 8 only; falls back to "f16x3" for other models).
-PRECISIONS = {"f32": 0, "f16x3": 1, "f16x3_ra": 2}
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 3}
+DEFAULT_PRECISION = "f16x3"
 
 
 def precision_code(model):
-    code = PRECISIONS[_precision]
-    if code == 2 and (model.D != 8 or model.in_channels_xyz > 63 or model.in_channels_t > 64):
-        code = 1
-    return code
-_precision = os.environ.get("NSFF_PRECISION", "f32")
+    return PRECISIONS[_precision]
+
+
+_precision = os.environ.get("NSFF_PRECISION", DEFAULT_PRECISION)
 _tile_points = int(os.environ.get("NSFF_TILE_POINTS", "0"))
 if _precision not in PRECISIONS:
     raise RuntimeError(f"NSFF_PRECISION must be one of {sorted(PRECISIONS)}")
@@ -38,10 +39,11 @@ def get_precision():
 
 
 def set_tile_points(n):
-    """f16x3 only: points per workgroup (0 = library default, 64 or 128)."""
+    """f16x3 only: points per workgroup (0 = library default = 64; the others are slower experiments kept selectable)."""
     global _tile_points
     if n not in (0, 64, 128, 129, 130):
-        raise ValueError("tile_points must be 0, 64 or 128")
+        raise ValueError("tile_points must be 0 (library default), 64, 128 (8 waves, two wave rows), "
+                         "129 (128 points, 4 waves) or 130 (128 points, 8 waves x 32 neurons)")
     _tile_points = n
 
 

@@ -389,8 +389,7 @@ const char* nsff_last_hip_error(void) { return hipGetErrorString(g_nsff_last_err
 
 int nsff_packed_bytes(const NsffModelDesc* desc, int precision, size_t* bytes) {
     if (!desc || !bytes) return NSFF_ERR_NULL;
-    if (precision == NSFF_PREC_F16X3) return nsff_h3_packed_bytes(desc, bytes);
-    if (precision == NSFF_PREC_F16X3_RA) return nsff_ra_packed_bytes(desc, bytes);
+    if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16) return nsff_h3_packed_bytes(desc, bytes);
     if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
     NsffLayout L;
     const int rc = nsff_make_layout(*desc, L);
@@ -410,8 +409,8 @@ int nsff_pack_weights(const NsffModelDesc* desc, int precision, const float* con
                       void* stream) {
     if (!desc || !params || !packed_v) return NSFF_ERR_NULL;
     if ((uintptr_t)packed_v & 15) return NSFF_ERR_ALIGN;
-    if (precision == NSFF_PREC_F16X3) return nsff_h3_pack_weights(desc, params, packed_v, (hipStream_t)stream);
-    if (precision == NSFF_PREC_F16X3_RA) return nsff_ra_pack_weights(desc, params, packed_v, (hipStream_t)stream);
+    if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16)      // one packed layout serves both
+        return nsff_h3_pack_weights(desc, params, packed_v, (hipStream_t)stream);
     if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
     float* packed = reinterpret_cast<float*>(packed_v);
     NsffLayout L;
@@ -513,7 +512,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     if (g.static_mode < 0 || g.static_mode > 2 || g.transient_mode < 0 || g.transient_mode > 2) return NSFF_ERR_INVALID;
     if (g.static_mode == 0 && g.transient_mode == 0) return NSFF_ERR_INVALID;
     if (g.flow_heads < 0 || g.flow_heads > 2 || (g.flow_heads && !d.has_flow)) return NSFF_ERR_INVALID;
-    if (g.precision < NSFF_PREC_F32 || g.precision > NSFF_PREC_F16X3_RA) return NSFF_ERR_INVALID;
+    if (g.precision != NSFF_PREC_F32 && g.precision != NSFF_PREC_F16X3 && g.precision != NSFF_PREC_F16) return NSFF_ERR_INVALID;
     if (g.tile_points != 0 && g.tile_points != 64 && g.tile_points != 128 && g.tile_points != 129 && g.tile_points != 130) return NSFF_ERR_INVALID;
     if (g.transient_mode && !d.has_transient) return NSFF_ERR_INVALID;
     if (g.n_points == 0) return NSFF_OK;
@@ -562,8 +561,8 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     if (g.precision == NSFF_PREC_F16X3) {
         const int rc3 = nsff_h3_field_query(desc, packed_v, args, g.tile_points ? g.tile_points : 64, st);
         if (rc3 != NSFF_OK) return rc3;
-    } else if (g.precision == NSFF_PREC_F16X3_RA) {
-        const int rc3 = nsff_ra_field_query(desc, packed_v, args, st);
+    } else if (g.precision == NSFF_PREC_F16) {
+        const int rc3 = nsff_h3_field_query(desc, packed_v, args, NSFF_H3_FAST, st);
         if (rc3 != NSFF_OK) return rc3;
     } else {
         hipLaunchKernelGGL(nsff_field_kernel, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);

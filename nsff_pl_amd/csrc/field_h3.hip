@@ -15,6 +15,10 @@
 //     conflict-free ds_read_b128);
 //   * the 32x32 accumulator then holds 4 consecutive neurons of one point per register quad, so
 //     the epilogue packs them to 8-byte hi / lo stores (ds_write_b64).
+// SPLIT = false is the FAST MODE ("f16", not parity-grade): the same kernel with every operand rounded once to
+// fp16 (round-to-nearest-even, clamped to the fp16 range) and ONE MFMA per product -- only the hi halfs of the
+// packed weights are fetched, the LDS tile is a single fp16 plane (so a 128-point workgroup needs 67.6 KB and two
+// of them share a CU) and the epilogue is one v_med3 + half a v_cvt_pk_f16_f32 per value.
 // Wave w owns neurons [64w, 64w+64) for all points of the tile: 2 x NT accumulator tiles.
 // NT = 4 (128 points, one workgroup per CU) halves the weight stream per FLOP; NT = 2
 // (64 points, two workgroups per CU) hides epilogues behind the other workgroup's MFMAs.
@@ -95,22 +99,34 @@ struct H3KArgs {
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H3_PIN() __builtin_amdgcn_sched_barrier(0)
 
+template <bool SPLIT = true>
 __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx, float v) {
     const _Float16 hi = (_Float16)v;
     xh[idx] = hi;
-    xl[idx] = (_Float16)(v - (float)hi);
+    if constexpr (SPLIT) xl[idx] = (_Float16)(v - (float)hi);
 }
 
 // MTW = 32-neuron tiles per wave: 2 (four waves x 64 neurons) or 1 (eight waves x 32 neurons, kernel variant <4,1,*,1>)
-template <int MTW> struct WFrag { h8 wh[MTW], wl[MTW]; };   // weights (A operand) of one k-step: 8*MTW VGPRs
-template <int NT> struct XFrag { h8 xh[NT], xl[NT]; };  // activations (B operand) of one k-step
-template <int MTW> struct WRing { WFrag<MTW> r[4]; };       // four k-steps of weights in flight (L2 latency)
+template <int MTW, bool SPLIT = true> struct WFrag { h8 wh[MTW], wl[MTW]; };   // weights (A operand) of one k-step: 8*MTW VGPRs
+template <int MTW> struct WFrag<MTW, false> { h8 wh[MTW]; };
+template <int NT, bool SPLIT = true> struct XFrag { h8 xh[NT], xl[NT]; };  // activations (B operand) of one k-step
+template <int NT> struct XFrag<NT, false> { h8 xh[NT]; };
+template <int MTW, bool SPLIT = true> struct WRing { WFrag<MTW, SPLIT> r[4]; };       // four k-steps of weights in flight (L2 latency)
 template <int MTW> struct BiasRegs { float4 b[MTW][4]; };
 
 // Weights are read through a bumped pointer so that every load is base + small immediate
 // ([ks][mt][part][lane] 16-byte chunks = 4 KiB per k-step; the lane offset is in the pointer).
 template <int MTW>
-__device__ __forceinline__ void load_w(WFrag<MTW>& f, const uint4* __restrict__& wp) {
+__device__ __forceinline__ void load_w(WFrag<MTW, false>& f, const uint4* __restrict__& wp) {
+    // fast mode: only the hi halfs ([part 0] chunks) of the same packed stream are touched
+    static_assert(MTW == 2, "fast mode runs the 64-neuron-per-wave tiling");
+    const uint4 a0 = wp[0], a2 = wp[128];
+    wp += 256;
+    f.wh[0] = __builtin_bit_cast(h8, a0); f.wh[1] = __builtin_bit_cast(h8, a2);
+}
+
+template <int MTW>
+__device__ __forceinline__ void load_w(WFrag<MTW, true>& f, const uint4* __restrict__& wp) {
     if constexpr (MTW == 2) {
         const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
         wp += 256;
@@ -123,20 +139,20 @@ __device__ __forceinline__ void load_w(WFrag<MTW>& f, const uint4* __restrict__&
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void load_x(XFrag<NT>& f, const _Float16* sBh, const _Float16* sBl, int ks) {
+template <int NT, bool SPLIT>
+__device__ __forceinline__ void load_x(XFrag<NT, SPLIT>& f, const _Float16* sBh, const _Float16* sBl, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f.xh[nt] = *reinterpret_cast<const h8*>(sBh + nt * 32 * LDH + ks * 16);
-        f.xl[nt] = *reinterpret_cast<const h8*>(sBl + nt * 32 * LDH + ks * 16);
+        if constexpr (SPLIT) f.xl[nt] = *reinterpret_cast<const h8*>(sBl + nt * 32 * LDH + ks * 16);
     }
 }
 
 // Issue the weight loads of the first four k-steps of a segment (called BEFORE the barriers /
 // epilogue that precede the segment's GEMM, so the L2 round trip hides behind them).
 // Returns the pointer of k-step 4.
-template <int MTW>
-__device__ __forceinline__ const uint4* prefetch_w(WRing<MTW>& ring, const uint4* __restrict__ w) {
+template <int MTW, bool SPLIT>
+__device__ __forceinline__ const uint4* prefetch_w(WRing<MTW, SPLIT>& ring, const uint4* __restrict__ w) {
     const uint4* __restrict__ wp = w;
     load_w(ring.r[0], wp);
     load_w(ring.r[1], wp);
@@ -146,7 +162,15 @@ __device__ __forceinline__ const uint4* prefetch_w(WRing<MTW>& ring, const uint4
 }
 
 template <int NT, int MTW>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW>& w, const XFrag<NT>& x) {
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW, false>& w, const XFrag<NT, false>& x) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wh[mt], x.xh[nt], acc[mt][nt]);
+}
+
+template <int NT, int MTW>
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW, true>& w, const XFrag<NT, true>& x) {
     // three passes so that consecutive MFMAs never touch the same accumulator
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -165,11 +189,11 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW
 // acc += W_seg . X[:, 0:16*nks]^T  for this wave's 64 neurons and all 32*NT points.
 // `ring` already holds k-steps 0..3 and `wp` points at k-step 4 (prefetch_w); weights run four
 // k-steps ahead of the MFMAs, activations (LDS) one.
-template <int NT, int MTW>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW>& ring, const uint4* __restrict__ wp,
+template <int NT, int MTW, bool SPLIT>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLIT>& ring, const uint4* __restrict__ wp,
                                          const _Float16* sBh, const _Float16* sBl, int nks) {
     // nks is a multiple of 4 (every K-segment is zero-padded to 64 columns): no per-step branches.
-    XFrag<NT> x0, x1;
+    XFrag<NT, SPLIT> x0, x1;
     load_x<NT>(x0, sBh, sBl, 0);
 #pragma unroll 1
     for (int ks = 4; ks < nks; ks += 4) {        // every group but the last: refill the ring
@@ -228,6 +252,29 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[MTW][NT], const BiasRegs<
 }
 
 // `mask` (or null) receives the ReLU sign bits of this lane's accumulators: bit (mt*NT + nt)*16 + 4q + e.
+// fast mode: clamp to the fp16 range (one v_med3 that is also the ReLU), round to nearest, one 8-byte store
+template <int NT, bool RELU, int MTW>
+__device__ __forceinline__ void acc_store_f16(_Float16* sXh, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f2 a, b;
+                a[0] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 0], RELU ? 0.0f : -65504.0f, 65504.0f);
+                a[1] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 1], RELU ? 0.0f : -65504.0f, 65504.0f);
+                b[0] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 2], RELU ? 0.0f : -65504.0f, 65504.0f);
+                b[1] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 3], RELU ? 0.0f : -65504.0f, 65504.0f);
+                const h2f h01 = __builtin_convertvector(a, h2f), h23 = __builtin_convertvector(b, h2f);
+                h4 hv;
+                hv[0] = h01[0]; hv[1] = h01[1]; hv[2] = h23[0]; hv[3] = h23[1];
+                const int idx = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt + 8 * q + 4 * (lane >> 5);
+                *reinterpret_cast<h4*>(sXh + idx) = hv;
+            }
+}
+
 template <int NT, bool RELU, int MTW>
 __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane,
                                           unsigned long long* mask = nullptr) {
@@ -286,7 +333,7 @@ __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Fl
     }
 }
 
-template <int M, int THREADS>
+template <int M, int THREADS, bool SPLIT>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t) {
     constexpr int G = THREADS / M;               // threads per point row
     const int r = threadIdx.x % M, q = threadIdx.x / M;
@@ -298,21 +345,21 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
         float x[3] = {0.f, 0.f, 0.f};
         if (valid) { x[0] = a.xyz[p * 3 + 0]; x[1] = a.xyz[p * 3 + 1]; x[2] = a.xyz[p * 3 + 2]; }
         if (q == 0) {
-            split_store(sXh, sXl, base + 0, x[0]); split_store(sXh, sXl, base + 1, x[1]);
-            split_store(sXh, sXl, base + 2, x[2]);
-            for (int c = a.in_xyz; c < k0s; ++c) { sXh[base + c] = (_Float16)0.f; sXl[base + c] = (_Float16)0.f; }
+            split_store<SPLIT>(sXh, sXl, base + 0, x[0]); split_store<SPLIT>(sXh, sXl, base + 1, x[1]);
+            split_store<SPLIT>(sXh, sXl, base + 2, x[2]);
+            for (int c = a.in_xyz; c < k0s; ++c) split_store<SPLIT>(sXh, sXl, base + c, 0.f);
         }
         const int nf3 = 3 * a.n_freqs;
         for (int j = q; j < nf3; j += G) {
             const int f = j / 3, c = j - 3 * f;
             float s, co;
             sincosf(a.freqs[f] * x[c], &s, &co);
-            split_store(sXh, sXl, base + 3 + 6 * f + c, s);
-            split_store(sXh, sXl, base + 3 + 6 * f + 3 + c, co);
+            split_store<SPLIT>(sXh, sXl, base + 3 + 6 * f + c, s);
+            split_store<SPLIT>(sXh, sXl, base + 3 + 6 * f + 3 + c, co);
         }
     } else {
         const float* src = a.x_emb + p * a.ld_emb + a.off_xyz;
-        for (int c = q; c < k0s; c += G) split_store(sXh, sXl, base + c, (valid && c < a.in_xyz) ? src[c] : 0.f);
+        for (int c = q; c < k0s; c += G) split_store<SPLIT>(sXh, sXl, base + c, (valid && c < a.in_xyz) ? src[c] : 0.f);
     }
     if (with_t) {
         const float* src = nullptr;
@@ -320,11 +367,11 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
                                             : a.x_emb + p * a.ld_emb + a.off_t;
         const int kt = (int)a.L.kt;
         for (int c = q; c < kt; c += G)
-            split_store(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f);
+            split_store<SPLIT>(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f);
     }
 }
 
-template <int M, int THREADS>
+template <int M, int THREADS, bool SPLIT>
 __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0) {
     constexpr int G = THREADS / M;
     const int r = threadIdx.x % M, q = threadIdx.x / M;
@@ -348,7 +395,7 @@ __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H
             if (c < a.in_dir) v = sd[c];
             else if (c < a.in_dir + a.in_a) v = sa[c - a.in_dir];
         }
-        split_store(sXh, sXl, r * LDH + c, v);
+        split_store<SPLIT>(sXh, sXl, r * LDH + c, v);
     }
 }
 
@@ -356,7 +403,7 @@ enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
 
 // Narrow heads as one zero-padded 32-row MFMA tile; wave w evaluates the 32 points of tile w (w < NT).
 // out row = (r&3) + 8*(r>>2) + 4*(lane>>5); only r < 8 (rows < 16) can be live.
-template <int NT>
+template <int NT, bool SPLIT>
 __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, const uint32_t* __restrict__ pk,
                                       uint32_t w_off, uint32_t b_off, int n_rows, unsigned kinds, float flow_scale,
                                       float* raw, long long p0, long long n_points, int slot0, int wave, int lane) {
@@ -382,9 +429,11 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
             const h8 wh = __builtin_bit_cast(h8, wr[j][0]);
             const h8 wl = __builtin_bit_cast(h8, wr[j][1]);
             const h8 xh = *reinterpret_cast<const h8*>(bh + ks * 16);
-            const h8 xl = *reinterpret_cast<const h8*>(bl + ks * 16);
-            acc = MFMA_H(wl, xh, acc);
-            acc = MFMA_H(wh, xl, acc);
+            acc = MFMA_H(wl, xh, acc);                 // the narrow heads keep the weights' lo halfs in both modes
+            if constexpr (SPLIT) {
+                const h8 xl = *reinterpret_cast<const h8*>(bl + ks * 16);
+                acc = MFMA_H(wh, xl, acc);
+            }
             acc = MFMA_H(wh, xh, acc);
         }
     }
@@ -410,14 +459,17 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
 // SAVE: training forward -- epilogues also write their activations (fp16) to HBM for the backward pass.
 //   <4,1,*,1>: 128 points, EIGHT waves of 32 neurons each (MTW = 1): every weight byte is fetched once per 128
 //          points (half the L2 stream of <2,1>) by exactly one wave, and two waves per SIMD hide each other's epilogues.
-template <int NT, int WM, bool SAVE = false, int MTW = 2>
-__global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
+//   <4,1,false,2,false>: FAST MODE -- 128 points, four waves of 64 neurons x 128 points, single fp16 plane (67.6 KB), two
+//          workgroups per CU, one MFMA per product.
+template <int NT, int WM, bool SAVE = false, int MTW = 2, bool SPLIT = true>
+__global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
     constexpr int M = 32 * NT * WM;
     constexpr int THREADS = 256 * WM * (3 - MTW);
     static_assert(MTW == 2 || WM == 1, "the 32-neuron-per-wave variant has a single row of point tiles");
-    __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
+    static_assert(SPLIT || !SAVE, "the training forward keeps fp32-grade activations: f16x3 only");
+    __shared__ __attribute__((aligned(16))) _Float16 sX[(SPLIT ? 2 : 1) * M * LDH];
     _Float16* sXh = sX;
-    _Float16* sXl = sX + M * LDH;
+    _Float16* sXl = SPLIT ? sX + M * LDH : sX;        // (never dereferenced when !SPLIT)
     const int lane = threadIdx.x & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = MTW == 2 ? (wave_id & 3) : (wave_id >> 1);   // 64-neuron block of the packed weight stream
@@ -430,7 +482,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsf
     const _Float16* sBl = sXl + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
 
     f32x16 acc[MTW][NT];
-    WRing<MTW> ring;
+    WRing<MTW, SPLIT> ring;
     BiasRegs<MTW> br;
     auto seg = [&](uint32_t off, int nks) {
         return reinterpret_cast<const uint4*>(pk + off) + (wave * nks) * 4 * 64 + mt0 * 128 + lane;
@@ -445,7 +497,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsf
                         ? a.n_static_steps : 0;
     auto step_at = [&](int i) { int j = i + rot; if (j >= a.n_steps) j -= a.n_steps; return a.steps[j]; };
     const H3Step s0 = step_at(0);
-    const uint4* wnext = prefetch_w<MTW>(ring, seg(s0.w_off, s0.nks));
+    const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
     load_bias<MTW>(br, fbias(s0.bias_off), nb0, lane);
 #pragma unroll 1
     for (int i = 0; i < a.n_steps; ++i) {
@@ -453,8 +505,8 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsf
         H3_STAMP(0);
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
-            if (st.pre == PRE_SIDE) build_side<M, THREADS>(sXh, sXl, a, p0);
-            else build_input<M, THREADS>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
+            if (st.pre == PRE_SIDE) build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0);
+            else build_input<M, THREADS, SPLIT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
             __syncthreads();
             if constexpr (SAVE) {
                 // trunk input of layer 0: columns [0,64) xyz embedding, [64,128) time code (zero when absent)
@@ -466,11 +518,11 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsf
         }
         H3_STAMP(1);
         if (st.bias_off != NSFF_NONE) acc_init<NT, MTW>(acc, br);
-        gemm_seg<NT, MTW>(acc, ring, wnext, sBh, sBl, st.nks);
+        gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, sBh, sBl, st.nks);
         H3_STAMP(2);
         if (i + 1 < a.n_steps) {                   // next segment's weights + bias fly during the epilogue
             const H3Step nx = step_at(i + 1);
-            wnext = prefetch_w<MTW>(ring, seg(nx.w_off, nx.nks));
+            wnext = prefetch_w<MTW, SPLIT>(ring, seg(nx.w_off, nx.nks));
             if (nx.bias_off != NSFF_NONE) load_bias<MTW>(br, fbias(nx.bias_off), nb0, lane);
         }
         if (st.post != POST_NONE) {
@@ -481,7 +533,10 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsf
                 if (st.save && a.save_masks != nullptr && st.post == POST_RELU)
                     mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + blockIdx.x) * THREADS + threadIdx.x;
             }
-            if (st.post == POST_RELU) acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk);
+            if constexpr (!SPLIT) {
+                if (st.post == POST_RELU) acc_store_f16<NT, true, MTW>(sXh, acc, nb0, nt0, lane);
+                else acc_store_f16<NT, false, MTW>(sXh, acc, nb0, nt0, lane);
+            } else if (st.post == POST_RELU) acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk);
             else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk);
             H3_STAMP(4);
             __syncthreads();
@@ -502,8 +557,8 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2) ? 2 : 1)) void nsf
                     w_off = a.L.t_head_w; b_off = a.L.t_head_b; n_rows = (int)a.L.t_head_rows; slot0 = 4;
                     kinds = 0x15u | (0xAAAu << 8);
                 }
-                heads<NT * WM>(sXh, sXl, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points, slot0,
-                              wave_id, lane);
+                heads<NT * WM, SPLIT>(sXh, sXl, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points, slot0,
+                                     wave_id, lane);
             }
         }
     }
@@ -718,7 +773,12 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     if (n > MAX_STEPS) return NSFF_ERR_INVALID;
     k.n_steps = n;
 
-    if (k.save_acts || k.save_xin || k.save_masks) {
+    if (points_per_block == NSFF_H3_FAST) {       // "f16": one product per MAC, 128-point tiles, two workgroups per CU
+        if (k.save_acts || k.save_xin || k.save_masks) return NSFF_ERR_INVALID;
+        const long long tiles = (g.n_points + 127) / 128;
+        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1, false, 2, false>), dim3((unsigned)tiles), dim3(256), 0, st, k);
+    } else if (k.save_acts || k.save_xin || k.save_masks) {
         const long long tiles = (g.n_points + 63) / 64;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
         hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1, true>), dim3((unsigned)tiles), dim3(256), 0, st, k);

@@ -6,11 +6,9 @@
 
 int nsff_h3_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
 int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st);
-// args already validated by nsff_field_query; points_per_block is 64 or 128
+// args already validated by nsff_field_query; points_per_block is 64 / 128 / 129 / 130 (f16x3 tilings) or
+// NSFF_H3_FAST (the single-product "f16" fast mode on the same packed weights)
+#define NSFF_H3_FAST 1
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
                         int points_per_block, hipStream_t st);
 
-// register-resident f16x3 kernel (field_ra.hip)
-int nsff_ra_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
-int nsff_ra_pack_weights(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st);
-int nsff_ra_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args, hipStream_t st);

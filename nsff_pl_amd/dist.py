@@ -39,6 +39,53 @@ def init_from_env(backend=None):
     return rank, world, device
 
 
+def launch_local(n_procs, argv, master_port=None, env=None, timeout=None):
+    """Start `argv` (a command line, e.g. [sys.executable, "bench.py", ...]) as `n_procs` ranks on this node, the
+    way ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` would: RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment, one process per GPU (``init_from_env`` picks
+    ``cuda:LOCAL_RANK``).  stdout / stderr are inherited, so rank 0's single JSON line reaches the caller's stdout.
+    Returns the worst exit code; if one rank fails the others are terminated."""
+    import socket
+    import subprocess
+    import time
+    if master_port is None:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            master_port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n_procs):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_procs), LOCAL_WORLD_SIZE=str(n_procs),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+        procs.append(subprocess.Popen(list(argv), env=e))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:                         # a dead rank would leave the others in a collective
+                        q.terminate()
+            if deadline is not None and time.monotonic() > deadline:
+                worst = worst or 124
+                for q in pending:
+                    q.terminate()
+                deadline = None
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
+
+
 def shard_bounds(n_items, world, rank):
     """Contiguous, balanced block [lo, hi) of rank `rank`; blocks differ by at most one item."""
     base, rem = divmod(n_items, world)

@@ -31,8 +31,14 @@ def enabled():
     return os.environ.get("NSFF_NATIVE_BACKWARD", "1") != "0"
 
 
+def _kernel_handles(model):
+    """What csrc/field_bwd.hip and the SAVE variant of csrc/field_h3.hip are built for."""
+    return (not model.use_viewdir and model.W == 256 and len(model.skips) == 1
+            and model.in_channels_xyz <= 64 and (not model.encode_transient or model.in_channels_t <= 64))
+
+
 def supported(model, xyz):
-    return enabled() and xyz.is_cuda and xyz.dtype == torch.float32 and not model.use_viewdir
+    return enabled() and xyz.is_cuda and xyz.dtype == torch.float32 and _kernel_handles(model)
 
 
 def _lin(m):
@@ -53,7 +59,7 @@ def alloc_saves(model, n_points, device, transient):
 def forward_can_save(model, static_mode, transient_mode):
     """True when render_rays' own forward launch can already be the training forward (so that backward does not
     re-run it): f16x3 arithmetic selected, no view directions, full (rgb+sigma) modes."""
-    return (enabled() and not model.use_viewdir and config.precision_code(model) == config.PRECISIONS["f16x3"]
+    return (enabled() and _kernel_handles(model) and config.precision_code(model) == config.PRECISIONS["f16x3"]
             and static_mode in (0, 2) and transient_mode in (0, 2) and (static_mode or transient_mode))
 
 
@@ -80,6 +86,7 @@ class _FieldFn(torch.autograd.Function):
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
         static, transient = cfg["static"], cfg["transient"]
         P = xyz.shape[0]
+        drop_stale_pending()
         if cfg.get("saved") is not None:         # render_rays' own launch was the training forward: nothing to redo
             raw, acts, xin, masks, xyz_c = cfg["saved"]
             ctx.cfg, ctx.P = cfg, P
@@ -209,11 +216,11 @@ class _FieldFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 d_xyz = _posenc_backward(d_xin, xyz, freqs)
         if overlap:
-            # keep what the side stream still reads alive until the join, then hand the gradients over there
-            _PENDING["items"].append((list(_lib.param_list(model)), grads, (dpre, dhead, acts, xin, out, bias, gmax)))
-            if not _PENDING["queued"]:
-                _PENDING["queued"] = True
-                torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
+            # keep what the side stream still reads alive until the join, then hand the gradients over there.
+            # Every node queues the (idempotent) flush: a callback queued by an earlier backward pass that died
+            # half-way is dropped by the engine, so "already queued" cannot be remembered across passes.
+            _PENDING.append((list(_lib.param_list(model)), grads, (dpre, dhead, acts, xin, out, bias, gmax)))
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
             return (None, d_xyz, d_t) + (None,) * len(params)
         return (None, d_xyz, d_t) + tuple(grads)
 
@@ -326,12 +333,35 @@ class _FieldFn(torch.autograd.Function):
 
 
 _FREQ_CACHE = {}
-_PENDING = {"items": [], "queued": False}
+_PENDING = []            # (parameters, gradients, buffers to keep alive) of the field nodes of the running backward pass
 _SIDE = {}
+_DEFER = [False]
+
+
+class deferred_weight_grads:
+    """Context manager (used by ``NSFFTrainer.step``): inside it the weight-gradient GEMMs of every field node run
+    on a side stream and are ADDED TO ``.grad`` by an end-of-backward callback instead of being returned through
+    autograd -- so ``torch.autograd.grad(loss, params)`` and post-accumulate hooks do not see them.  Outside (the
+    default) the node returns its gradients like any other autograd function.  ``NSFF_WGRAD_OVERLAP=1`` / ``0``
+    forces the behaviour on / off everywhere."""
+
+    def __enter__(self):
+        self.old, _DEFER[0] = _DEFER[0], True
+
+    def __exit__(self, *exc):
+        _DEFER[0] = self.old
+        return False
 
 
 def _overlap_enabled():
-    return os.environ.get("NSFF_WGRAD_OVERLAP", "1") != "0"
+    env = os.environ.get("NSFF_WGRAD_OVERLAP")
+    return _DEFER[0] if env is None else env != "0"
+
+
+def drop_stale_pending():
+    """Called when a new forward starts: anything still pending belongs to a backward pass that raised before its
+    end-of-pass callback ran (the engine drops queued callbacks then); release it."""
+    del _PENDING[:]
 
 
 def _side_stream(device):
@@ -344,7 +374,8 @@ def _flush_weight_grads():
     """End-of-backward callback: join the side stream and add the weight gradients of every field node to .grad
     (one fused add per node instead of one per parameter).  Gradients therefore reach the parameters through
     ``loss.backward()``; ``torch.autograd.grad(..., parameters)`` needs NSFF_WGRAD_OVERLAP=0."""
-    items, _PENDING["items"], _PENDING["queued"] = _PENDING["items"], [], False
+    items = list(_PENDING)
+    del _PENDING[:]
     if not items:
         return
     for dev, side in _SIDE.items():

@@ -17,10 +17,15 @@ import torch
 
 from . import _lib
 from . import autograd
+from . import config
 from . import field_grad
 from . import ray_geometry
 
 Z_FAR = 0.95  # flows are zeroed beyond this depth (reference rendering.py:316)
+
+# Not part of the interface: tests/common.py::fine_depths patches this to evaluate the fine pass at given
+# (N_rays, S_fine) depths, because the inverse-CDF draw is ill-conditioned in near-empty bins (tests/parity.py).
+_FINE_DEPTHS_OVERRIDE = None
 
 
 def _new(ref, *shape):
@@ -209,8 +214,7 @@ def render_rays(models,
     rays: (N_rays, 6) origins+directions (NDC); ts: (N_rays,) int64 or None; max_t: int.
     Recognised kwargs: output_transient, output_transient_flow, view_dir, t_embedded,
     a_embedded, dataset (eval visibility); others (epoch, K, ...) are ignored like the
-    reference does.  ``_zs_fine`` (N_rays, S_fine) is a test hook that overrides the merged
-    fine depths.  ``chunk`` is accepted and ignored: the fused field kernel tiles the
+    reference does.  ``chunk`` is accepted and ignored: the fused field kernel tiles the
     points itself, so there is no inner point-chunk loop to size.
     Results are fresh contiguous fp32 GPU tensors computed by the HIP kernels.  With autograd enabled,
     ``test_time=False`` and parameters that require grad, the results carry a graph to the model /
@@ -223,6 +227,15 @@ def render_rays(models,
     want_grad = (torch.is_grad_enabled() and not test_time and
                  bool(autograd.grad_parameters(models, embeddings)))
     rec = {} if want_grad else None
+    if want_grad and config.get_precision() == "f16":
+        # the single-product fast mode is inference only: a call that will be differentiated runs (and saves its
+        # activations) in the parity-grade f16x3 arithmetic
+        config.set_precision("f16x3")
+        try:
+            return render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_std, N_importance, chunk,
+                               test_time, **kwargs)
+        finally:
+            config.set_precision("f16")
     with torch.cuda.device(rays.device), torch.no_grad():
         results = {}
         rays = rays.contiguous().float()
@@ -278,10 +291,8 @@ def render_rays(models,
                 results['static_zs_fine'] = zs_static
                 if output_transient:
                     results['transient_zs_fine'] = zs_transient
-            if kwargs.get('_zs_fine') is not None:
-                # test hook: evaluate the fine pass at caller-supplied depths (the inverse-CDF
-                # draw is ill-conditioned in near-empty bins, see tests/parity.py)
-                zs_fine = kwargs['_zs_fine'].to(rays.device).contiguous().float()
+            if _FINE_DEPTHS_OVERRIDE is not None:
+                zs_fine = _FINE_DEPTHS_OVERRIDE.to(rays.device).contiguous().float()
                 xyz_fine = (rays[:, None, 0:3] + rays[:, None, 3:6] * zs_fine[..., None]).contiguous()
             zs, xyz = zs_fine, xyz_fine
         else:

@@ -16,6 +16,7 @@ from collections import defaultdict
 import torch
 import torch.distributed as dist
 
+from . import field_grad
 from .autograd import grad_parameters
 from .losses import NeRFWLoss
 from .rendering import render_rays
@@ -161,7 +162,8 @@ class NSFFTrainer:
             return self._graph_step(batch)
         self.optimizer.zero_grad(set_to_none=True)
         loss, log = self.training_step(batch)
-        loss.backward()
+        with field_grad.deferred_weight_grads():
+            loss.backward()
         allreduce_gradients(self.params)
         self.optimizer.step()
         return log
@@ -169,7 +171,8 @@ class NSFFTrainer:
     def _eager_graph_body(self):
         self.optimizer.zero_grad(set_to_none=False)
         loss, log = self.training_step(self._static_batch)
-        loss.backward()
+        with field_grad.deferred_weight_grads():
+            loss.backward()
         self.optimizer.step()
         return log
 

@@ -42,7 +42,22 @@ def pos_embedding(x, freqs):
     return np.concatenate(out, -1).astype(F)
 
 
+_TORCH_DENSE = False
+
+
+def use_torch_dense(on):
+    """Timing aid for bench.py's cpu_baseline: evaluate the dense layers with torch's CPU BLAS / threaded elementwise
+    ops (what the reference's own ``nn.Linear`` + ReLU run on) instead of numpy's.  Same fp32 arithmetic up to
+    summation order; the parity tests always run the numpy form."""
+    global _TORCH_DENSE
+    _TORCH_DENSE = bool(on)
+
+
 def _lin(p, name, x):
+    if _TORCH_DENSE:
+        import torch
+        return torch.addmm(torch.from_numpy(p[name + ".bias"]), torch.from_numpy(np.ascontiguousarray(x, F)),
+                           torch.from_numpy(p[name + ".weight"]).t()).numpy()
     return x @ p[name + ".weight"].T + p[name + ".bias"]
 
 
@@ -51,6 +66,16 @@ def _sigmoid(x):
 
 
 def _trunk(p, prefix, x_in, D, skips):
+    if _TORCH_DENSE:
+        import torch
+        x_t = torch.from_numpy(np.ascontiguousarray(x_in, F))
+        h = x_t
+        for i in range(D):
+            if i in skips:
+                h = torch.cat([x_t, h], 1)
+            name = f"{prefix}_xyz_encoding_{i + 1}.0"
+            h = torch.relu_(torch.addmm(torch.from_numpy(p[name + ".bias"]), h, torch.from_numpy(p[name + ".weight"]).t()))
+        return h.numpy()
     h = x_in
     for i in range(D):
         if i in skips:

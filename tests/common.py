@@ -1,4 +1,5 @@
 """Fixture loading and oracle invocation shared by CPU and GPU tests."""
+import contextlib
 import json
 import os
 
@@ -9,12 +10,27 @@ import scenes
 from oracle import nsff_oracle as orc
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # keys produced by a second, chained field query at positions that already carry fp32
 # rounding (x + flow, then sin(512 x)): two correct fp32 paths differ more there.
 CHAINED_KEYS = ("xyzs_fw_bw", "xyzs_bw_fw", "rgb_fw", "rgb_bw", "disocc_fw", "disocc_bw",
                 "disoccs_fw", "disoccs_bw")
 SAMPLE_KEYS = ("static_zs_fine", "transient_zs_fine", "zs_fine", "xyzs_fine")
+
+
+@contextlib.contextmanager
+def fine_depths(zs_fine):
+    """Evaluate the fine pass of nsff_pl_amd.render_rays at the given (N_rays, S_fine) depths (numpy / tensor /
+    None = free-running).  sample_pdf is ill-conditioned in near-empty bins (tests/parity.py), so per-sample fine
+    keys of two correct fp32 implementations are only comparable at identical depths."""
+    import nsff_pl_amd.rendering as R
+    old = R._FINE_DEPTHS_OVERRIDE
+    R._FINE_DEPTHS_OVERRIDE = None if zs_fine is None else torch.as_tensor(zs_fine)
+    try:
+        yield
+    finally:
+        R._FINE_DEPTHS_OVERRIDE = old
 
 
 def load_golden(name):

@@ -123,15 +123,27 @@ def _trainer_worker(rank, world, port, ret):
     tr = training.NSFFTrainer(models, emb, 30, dict(N_samples=8, perturb=0, noise_std=0), output_transient=False)
     tr.on_train_epoch_start(0)
     g = torch.Generator().manual_seed(100 + rank)          # every rank trains on its own batch
-    for _ in range(3):
-        batch = dict(rays=torch.randn(16, 6, generator=g), rgbs=torch.rand(16, 3, generator=g),
-                     disps=torch.rand(16, generator=g) + 0.1)
-        log = tr.step(batch)
-    flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
-    gathered = [torch.zeros_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
-    moved = float((models["fine"].static_rgb[0].bias.detach() - 0).abs().sum()) > 0
-    ret[rank] = bool(torch.equal(gathered[0], gathered[1])) and moved and bool(torch.isfinite(log["train/loss"]))
+    before = {n: p.detach().clone() for n, p in models["fine"].named_parameters()}
+
+    def three_steps():
+        for _ in range(3):
+            batch = dict(rays=torch.randn(16, 6, generator=g), rgbs=torch.rand(16, 3, generator=g),
+                         disps=torch.rand(16, generator=g) + 0.1)
+            log = tr.step(batch)
+        flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        return log, gathered
+    log, gathered = three_steps()
+    after = dict(models["fine"].named_parameters())
+    moved = all(not torch.equal(after[n].detach(), before[n]) for n in
+                ("static_rgb.0.bias", "static_xyz_encoding_1.0.weight", "static_sigma.bias"))
+    in_sync = bool(torch.equal(gathered[0], gathered[1]))
+    # control: without the gradient all-reduce the replicas (different batches) must drift apart
+    training.allreduce_gradients = lambda params, group=None: None
+    _, gathered = three_steps()
+    drifted = not torch.equal(gathered[0], gathered[1])
+    ret[rank] = in_sync and moved and drifted and bool(torch.isfinite(log["train/loss"]))
     dist.barrier()
     dist.destroy_process_group()
 

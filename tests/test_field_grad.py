@@ -79,3 +79,52 @@ def test_field_node_gradients(static, transient, spread, hip_lib):
     k = max(worst, key=worst.get)
     print("\nworst native", static, spread, worst[k], k, "fp32 torch there", base[k], "| fp32 torch worst", max(base.values()))
     assert not bad, bad
+
+
+def test_failed_backward_does_not_lose_later_weight_gradients(hip_lib):
+    """A backward pass that raises after a field node ran leaves deferred weight gradients behind (the engine drops
+    the queued end-of-pass callbacks); the next pass must still deliver every trunk gradient, and the default
+    (non-deferred) node must hand its gradients to torch.autograd.grad."""
+    dev = torch.device("cuda:0")
+    cfg = scenes.CASES["g3_nsff_train"]
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    model = models["fine"].to(dev)
+    freqs = [float(f) for f in emb["xyz"].freqs]
+    g = torch.Generator().manual_seed(9)
+    xyz = (torch.rand(256, 3, generator=g) * 2 - 1).to(dev)
+    t_rows = torch.randn(4, scenes.N_TAU, generator=g).to(dev)
+    trunk = model.transient_xyz_encoding_3[0].weight
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError("boom")
+
+    t_leaf = t_rows.clone().requires_grad_(True)
+
+    def loss(with_failure):
+        # the time codes pass through a node whose backward raises: it runs AFTER the field node (it is upstream of it)
+        t_in = Boom.apply(t_leaf) if with_failure else t_rows
+        return field_grad.field(model, xyz, freqs, t_in, 64, True, True).sum()
+
+    # default: gradients come back through autograd itself
+    got = torch.autograd.grad(loss(False), [trunk])[0]
+    assert got is not None and float(got.abs().sum()) > 0
+    with field_grad.deferred_weight_grads():
+        for p in model.parameters():
+            p.grad = None
+        try:
+            loss(True).backward()
+        except RuntimeError as e:
+            assert "boom" in str(e)
+        for p in model.parameters():
+            p.grad = None
+        loss(False).backward()
+        torch.cuda.synchronize()
+        assert trunk.grad is not None
+        assert torch.allclose(trunk.grad, got, rtol=1e-5, atol=1e-6 * float(got.abs().max()))
+        assert not field_grad._PENDING

@@ -22,16 +22,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-128", "f16x3-130", "f16x3_ra"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3"])
 def precision(request):
-    """Every test runs on the exact fp32 MFMA path, both tilings of the fp16-split kernel and the
-    experimental register-resident fp16-split kernel."""
+    """Every test runs on the two parity-grade arithmetics: exact fp32 MFMA and the fp16-split kernel (default
+    64-point tile).  The alternative tilings have one smoke test each (test_alternative_tilings_smoke); the
+    single-product "f16" fast mode has its own error-reporting test (tests/test_fast_mode.py)."""
     from nsff_pl_amd import config
     name, _, tile = request.param.partition("-")
     config.set_precision(name)
     config.set_tile_points(int(tile) if tile else 0)
     yield name if not tile else request.param
-    config.set_precision("f32")
+    config.set_precision(config.DEFAULT_PRECISION)
     config.set_tile_points(0)
 
 
@@ -68,8 +69,6 @@ class _Replay:
 
 def _render(cfg, models, emb, rays, ts, dataset, monkeypatch, draws=None, zs_fine=None):
     kw = scenes.render_kwargs(cfg, dataset)
-    if zs_fine is not None:
-        kw["_zs_fine"] = torch.from_numpy(zs_fine)
     replay = None
     if draws is not None:
         replay = _Replay(cfg, draws)
@@ -77,10 +76,11 @@ def _render(cfg, models, emb, rays, ts, dataset, monkeypatch, draws=None, zs_fin
         monkeypatch.setattr(R.torch, "rand", replay.rand)
         monkeypatch.setattr(R.torch, "randn", replay.randn)
     try:
-        out = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV),
-                            scenes.N_FRAMES - 1, cfg["N_samples"], cfg.get("perturb", 0),
-                            cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
-                            test_time=cfg["test_time"], **kw)
+        with common.fine_depths(zs_fine):
+            out = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV),
+                                scenes.N_FRAMES - 1, cfg["N_samples"], cfg.get("perturb", 0),
+                                cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
+                                test_time=cfg["test_time"], **kw)
     finally:
         monkeypatch.undo()
     if replay is not None:
@@ -123,6 +123,59 @@ def test_render_rays_matches_reference_goldens(name, hip_lib, monkeypatch):
             if k in ("static_zs_fine", "transient_zs_fine"):
                 continue
             parity.assert_close(k, got[k], want[k], common.key_rtol(k, cfg))
+
+
+# Per-ray keys north_star names, FREE-RUNNING (no fine-depth override): the whole chain coarse field ->
+# compositing -> inverse-CDF sampling -> merge/sort -> fine field -> compositing against the reference's own
+# outputs (models/rendering.py:335-362).  On the well-conditioned scenes a 1e-6 depth shift stays small in the
+# per-ray expectations; g3b (gain 3) and g5 (visibility-masked, near-empty rays) are reported, not asserted at 1e-4.
+FREE_RUN_KEYS = ("rgb_fine", "depth_fine", "transient_flow_fw", "transient_flow_bw", "xyz_fw", "xyz_bw",
+                 "_static_rgb_fine", "rgb_coarse", "depth_coarse")
+FREE_RUN_STRICT = ("g2_static_c2f", "g3_nsff_train", "g4_nsff_test", "g7_nsff_train_noise", "g7b_static_noise_odd",
+                   "g12_other_arch")
+FREE_RUN_REPORTED = {"g3b_nsff_train_gain3": 5e-2, "g5_nsff_test_vis": 5e-2}
+
+
+@pytest.mark.parametrize("name", FREE_RUN_STRICT + tuple(FREE_RUN_REPORTED))
+def test_free_running_per_ray_keys_match_reference(name, hip_lib, monkeypatch, precision, record_property):
+    cfg, meta, rays, ts, models, emb, dataset, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+    _to_dev(models, emb)
+    draws = scenes.replay_draws(cfg, meta["draw_seed"])
+    use_draws = draws if (cfg.get("perturb", 0) or cfg.get("noise_std", 0)) else None
+    got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, use_draws)      # zs_fine=None: nothing overridden
+    import nsff_pl_amd.rendering as R
+    assert R._FINE_DEPTHS_OVERRIDE is None
+    rtol = parity.RTOL if name in FREE_RUN_STRICT else FREE_RUN_REPORTED[name]
+    errs = {}
+    for k in FREE_RUN_KEYS:
+        if k in want:
+            errs[k] = parity.max_rel_err(got[k], want[k])
+    worst = max(errs, key=errs.get)
+    print(f"free-run {name} [{precision}]: worst {worst} {errs[worst]:.2e}  " +
+          " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    record_property("free_run_worst", f"{worst}={errs[worst]:.3e}")
+    os.makedirs(os.path.join(common.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(common.ROOT, "gpurun_out", "free_run_errors.txt"), "a") as f:
+        f.write(f"{name} {precision} " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + "\n")
+    for k, e in errs.items():
+        assert np.isfinite(got[k]).all() and e <= rtol, f"{name} {k}: free-running max-norm rel err {e:.3e} > {rtol:g}"
+
+
+@pytest.mark.parametrize("variant", ["f16x3-128", "f16x3-129", "f16x3-130"])
+def test_alternative_tilings_smoke(variant, hip_lib, monkeypatch):
+    """The slower f16x3 tilings stay selectable; one golden scene each keeps them honest."""
+    from nsff_pl_amd import config
+    name, _, tile = variant.partition("-")
+    config.set_precision(name)
+    config.set_tile_points(int(tile) if tile else 0)
+    try:
+        cfg, meta, rays, ts, models, emb, dataset, want = common.build_case("g3_nsff_train", A.NeRF, A.PosEmbedding)
+        _to_dev(models, emb)
+        got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, None, zs_fine=want["zs_fine"])
+        for k in want:
+            parity.assert_close(k, got[k], want[k], common.key_rtol(k, cfg))
+    finally:
+        config.set_tile_points(0)
 
 
 @pytest.fixture(scope="module")

@@ -147,15 +147,15 @@ def test_render_rays_backward_matches_reference(name, precision, hip_lib, monkey
         _to_dev(models, emb)
         draws = scenes.replay_draws(cfg, meta["draw_seed"])
         kw = scenes.render_kwargs(cfg)
-        kw["_zs_fine"] = torch.from_numpy(want["zs_fine"])          # same depths as the reference run
         if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
             replay = _Replay(cfg, draws)
             import nsff_pl_amd.rendering as R
             monkeypatch.setattr(R.torch, "rand", replay.rand)
             monkeypatch.setattr(R.torch, "randn", replay.randn)
-        res = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
-                            cfg["N_samples"], cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"],
-                            1024 * 32, test_time=False, **kw)
+        with common.fine_depths(want["zs_fine"]):                   # same depths as the reference run
+            res = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
+                                cfg["N_samples"], cfg.get("perturb", 0), cfg.get("noise_std", 0),
+                                cfg["N_importance"], 1024 * 32, test_time=False, **kw)
         monkeypatch.undo()
         assert res["rgb_fine"].requires_grad and not res["zs_fine"].requires_grad
         for k in want:                                # values still come from the HIP kernels
@@ -171,7 +171,7 @@ def test_render_rays_backward_matches_reference(name, precision, hip_lib, monkey
                                 **scenes.render_kwargs(cfg))
         assert not out["rgb_fine"].requires_grad
     finally:
-        A.set_precision("f32")
+        A.set_precision(A.config.DEFAULT_PRECISION)
 
 
 @pytest.mark.gpu
@@ -190,14 +190,14 @@ def test_native_compositing_backward_equals_torch_expression(name, hip_lib, monk
             _to_dev(models, emb)
             draws = scenes.replay_draws(cfg, meta["draw_seed"])
             kw = scenes.render_kwargs(cfg)
-            kw["_zs_fine"] = torch.from_numpy(want["zs_fine"])
             if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
                 replay = _Replay(cfg, draws)
                 monkeypatch.setattr(R.torch, "rand", replay.rand)
                 monkeypatch.setattr(R.torch, "randn", replay.randn)
-            res = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
-                                cfg["N_samples"], cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"],
-                                1024 * 32, test_time=False, **kw)
+            with common.fine_depths(want["zs_fine"]):
+                res = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
+                                    cfg["N_samples"], cfg.get("perturb", 0), cfg.get("noise_std", 0),
+                                    cfg["N_importance"], 1024 * 32, test_time=False, **kw)
             monkeypatch.undo()
             scenes.cotangent_loss(res).backward()
             grads[native] = {n: p.grad.detach().clone() for n, p in scenes.named_grad_params(models, emb) if p.grad is not None}
@@ -205,7 +205,7 @@ def test_native_compositing_backward_equals_torch_expression(name, hip_lib, monk
         for n, g in grads["0"].items():
             parity.assert_close("grad " + n, grads["1"][n].cpu().numpy(), g.cpu().numpy(), 2e-3)
     finally:
-        A.set_precision("f32")
+        A.set_precision(A.config.DEFAULT_PRECISION)
 
 
 @pytest.mark.gpu
@@ -238,4 +238,4 @@ def test_backward_on_ragged_batches(n_rays, hip_lib):
     finally:
         os.environ.pop("NSFF_NATIVE_BACKWARD", None)
         os.environ.pop("NSFF_NATIVE_COMPOSITE_BWD", None)
-        A.set_precision("f32")
+        A.set_precision(A.config.DEFAULT_PRECISION)

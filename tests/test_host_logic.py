@@ -55,7 +55,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_layouts_match_the_header_sizes():
@@ -149,3 +149,13 @@ def test_compositing_node_outputs_are_result_keys_of_the_reference():
     per_ray = {"rgb_fine", "depth_fine", "transient_alpha_fine", "transient_rgb_fine", "_static_rgb_fine",
                "_static_depth_fine", "xyz_fine", "transient_flow_fw", "transient_flow_bw", "rgb_fw", "rgb_bw"}
     assert per_ray <= {k for k, _ in composite_grad.output_spec("fine", True, True, True)}
+
+
+def test_unsupported_architectures_are_refused_by_name():
+    """models/nerf.py:34-40 accepts any W and a list of skips; the kernels do not -- the error must say which field."""
+    for kw, needle in ((dict(W=128), "W=128"), (dict(skips=[2, 5]), r"skips=\[2, 5\]"), (dict(skips=[]), r"skips=\[\]"),
+                       (dict(D=8, skips=[8]), "skips="), (dict(D=1, skips=[0]), "D=1")):
+        m = A.NeRF('fine', use_viewdir=False, **kw)
+        with pytest.raises(RuntimeError, match="unsupported NeRF architecture.*" + needle):
+            _lib.model_desc(m)
+    _lib.model_desc(A.NeRF('fine', D=6, skips=[2], use_viewdir=False))       # fine

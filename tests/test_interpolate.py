@@ -180,3 +180,98 @@ def test_render_sequence_mirrors_the_eval_loop(hip_lib):
     plain = list(evaluate.render_sequence(models, emb, samples[:2], scenes.N_FRAMES - 1, cfg["N_samples"],
                                           cfg["N_importance"], wh, **dict(kw, output_transient_flow=[])))
     assert [f[0] for f in plain] == ["000", "001"] and plain[0][1].shape == (wh[1], wh[0], 3)
+
+
+# ---- multi-tile frame: the splat's tile ownership, halo and far path (csrc/interp.hip: TILE 32x8, HALO 4, 8 planes
+# per workgroup) against the oracle's scatter-add restatement of softsplat.py:6-44 / :303-326 ----
+SPLAT_TILE_X, SPLAT_TILE_Y, SPLAT_HALO, SPLAT_PLANES = 32, 8, 4, 8
+# landing-cell offsets (pixels, after the dt scaling): inside the halo, on its last cell (3.75 -> +3, -3.75 -> -4),
+# first cell beyond it (4.25 -> +4, -4.25 -> -5), far, several tiles away, out of the frame.  No value is near an
+# integer: a cell that only receives an epsilon weight is normalised to a full value ('average'), i.e. the floor of a
+# near-integer landing would be a legitimate one-ulp discontinuity, not what this test is about.
+SPLAT_SHIFTS = (0.25, -0.5, 2.3, -2.3, 3.75, -3.75, 4.25, -4.25, 7.6, -7.6, 33.5, -33.5, 150.0)
+
+
+def multi_tile_case(W=96, H=40, S=24, seed=3):
+    """Crafted test-time dicts on a (W,H) frame with identity pose: sample (px,py,s) projects onto its own pixel, and
+    its scene flow moves it by a chosen number of pixels at dt=0.4 (forward) / 0.6 (backward)."""
+    rng = np.random.RandomState(seed)
+    f = 80.0
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], np.float32)
+    c2w = np.eye(4, dtype=np.float32)[:3]
+    dt = 0.4
+    n = H * W
+    px, py = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    x_ndc = (px / (W / 2) - 1).reshape(n, 1)
+    y_ndc = (1 - py / (H / 2)).reshape(n, 1)
+    zs = np.sort(rng.uniform(-0.9, 0.8, (n, S)), 1)
+    xyz = np.stack([np.broadcast_to(x_ndc, (n, S)), np.broadcast_to(y_ndc, (n, S)), zs], -1).astype(np.float32)
+
+    def flows(scale):
+        sx = rng.choice(SPLAT_SHIFTS, size=(n, S))
+        sy = rng.choice(SPLAT_SHIFTS, size=(n, S))
+        fl = np.zeros((n, S, 3), np.float32)
+        fl[..., 0] = sx / scale / (W / 2)                      # pixel shift -> NDC, undone by the dt scaling
+        fl[..., 1] = -sy / scale / (H / 2)
+        return fl, sx, sy
+    f_fw, sx, sy = flows(dt)
+    f_bw, _, _ = flows(1 - dt)
+    u = lambda *s: rng.uniform(0.05, 0.95, s).astype(np.float32)
+    res_t = dict(xyzs_fine=xyz, zs_fine=zs.astype(np.float32), static_rgbs_fine=u(n, S, 3),
+                 static_alphas_fine=u(n, S) * 0.2, transient_flows_fw=f_fw, transient_rgbs_fine=u(n, S, 3),
+                 transient_alphas_fine=u(n, S) * 0.3)
+    res_tp1 = dict(transient_flows_bw=f_bw, transient_rgbs_fine=u(n, S, 3), transient_alphas_fine=u(n, S) * 0.3)
+    return res_t, res_tp1, dt, K, c2w, (W, H), (sx, sy)
+
+
+def test_multi_tile_case_exercises_every_splat_path():
+    """The crafted flows really land where intended (checked with the oracle's projection) and cover: near samples
+    that cross tile boundaries in x and y, the last halo cell, the first far cell, far moves and out-of-frame."""
+    res_t, res_tp1, dt, K, c2w, (W, H), (sx, sy) = multi_tile_case()
+    n, S = sx.shape
+    xyz = res_t["xyzs_fine"].reshape(-1, 3)
+    pw = orc.ndc_to_world(xyz, K)
+    qw = orc.ndc_to_world(xyz + res_t["transient_flows_fw"].reshape(-1, 3), K)
+    qw = pw + np.float32(dt) * (qw - pw)
+    w2c = np.eye(4, dtype=np.float32)[:3].copy()
+    w2c[1:] *= -1
+    uvd = (K @ w2c)[:, :3] @ qw.T
+    u, v = (uvd[0] / uvd[2]).reshape(n, S), (uvd[1] / uvd[2]).reshape(n, S)
+    px, py = np.meshgrid(np.arange(W), np.arange(H))
+    px, py = px.reshape(n, 1), py.reshape(n, 1)
+    assert np.abs(u - (px + sx)).max() < 1e-3 and np.abs(v - (py + sy)).max() < 1e-3
+    dx, dy = np.floor(u).astype(int) - px, np.floor(v).astype(int) - py
+    near = (dx >= -SPLAT_HALO) & (dx < SPLAT_HALO) & (dy >= -SPLAT_HALO) & (dy < SPLAT_HALO)
+    inside = (px + dx >= 0) & (px + dx + 1 < W) & (py + dy >= 0) & (py + dy + 1 < H)
+    cross_x = (px // SPLAT_TILE_X) != ((px + dx + 1) // SPLAT_TILE_X)
+    cross_y = (py // SPLAT_TILE_Y) != ((py + dy + 1) // SPLAT_TILE_Y)
+    assert W // SPLAT_TILE_X >= 3 and H // SPLAT_TILE_Y >= 5 and S // SPLAT_PLANES >= 3
+    for what, m in {"near, crosses a tile boundary in x": near & cross_x & inside,
+                    "near, crosses a tile boundary in y": near & cross_y & inside,
+                    "near, crosses both": near & cross_x & cross_y & inside,
+                    "last halo cell (+3 / -4) across a boundary": near & ((dx == 3) | (dx == -4)) & cross_x & inside,
+                    "last halo row (+3 / -4) across a boundary": near & ((dy == 3) | (dy == -4)) & cross_y & inside,
+                    "first cell beyond the halo (+4 / -5)": ((dx == 4) | (dx == -5)) & inside,
+                    "first row beyond the halo (+4 / -5)": ((dy == 4) | (dy == -5)) & inside,
+                    "far in x only": (np.abs(dx) > 5) & (np.abs(dy) < 4) & inside,
+                    "several tiles away": (np.abs(dx) > 32) & inside,
+                    "out of the frame": ~inside}.items():
+        assert m.sum() > 50, f"crafted case has only {m.sum()} samples for: {what}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(96, 40, 24), (70, 19, 11)])        # whole tiles / ragged tiles and plane groups
+def test_hip_interpolate_multi_tile_matches_oracle(shape, hip_lib):
+    W, H, S = shape
+    res_t, res_tp1, dt, K, c2w, wh, _ = multi_tile_case(W, H, S)
+    dev = torch.device("cuda:0")
+    with np.errstate(all="ignore"):
+        o_rgb, o_depth = orc.interpolate(res_t, res_tp1, dt, K, c2w, wh)
+    g_rgb, g_depth = A.interpolate({k: torch.from_numpy(v).to(dev) for k, v in res_t.items()},
+                                   {k: torch.from_numpy(v).to(dev) for k, v in res_tp1.items()}, dt, K, c2w, wh)
+    assert np.abs(o_rgb).max() > 0.3
+    parity.assert_close(f"rgb {shape}", g_rgb.cpu().numpy(), o_rgb, parity.RTOL)
+    parity.assert_close(f"depth {shape}", g_depth.cpu().numpy(), o_depth, parity.RTOL)
+    # per-pixel, not only max-norm: count pixels off by more than 1e-4 of the range
+    bad = (np.abs(g_rgb.cpu().numpy() - o_rgb).max(-1) > 1e-4 * np.abs(o_rgb).max()).sum()
+    assert bad == 0, f"{bad} pixels differ"

@@ -183,9 +183,10 @@ def test_training_step_matches_reference(name, precision, hip_lib, monkeypatch):
             import nsff_pl_amd.rendering as R
             monkeypatch.setattr(R.torch, "rand", replay.rand)
             monkeypatch.setattr(R.torch, "randn", replay.randn)
-        res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
-                            cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
-                            test_time=False, _zs_fine=torch.from_numpy(want["zs_fine"]), **kw)
+        with common.fine_depths(want["zs_fine"]):
+            res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
+                                cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
+                                test_time=False, **kw)
         monkeypatch.undo()
         loss_fn, targets = _loss_module(name, DEV)
         terms = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
@@ -194,7 +195,7 @@ def test_training_step_matches_reference(name, precision, hip_lib, monkeypatch):
         torch.cuda.synchronize()
         _check_grads(models, emb, name, "nsff_loss")
     finally:
-        A.set_precision("f32")
+        A.set_precision(A.config.DEFAULT_PRECISION)
 
 
 @pytest.mark.gpu
@@ -236,4 +237,4 @@ def test_trainer_steps_reduce_the_loss(hip_lib):
         assert glogs[-1]["train/loss"] < glogs[0]["train/loss"]
         assert abs(glogs[-1]["train/loss"] - float(logs[-1]["train/loss"])) <= 0.05 * abs(float(logs[-1]["train/loss"]))
     finally:
-        A.set_precision("f32")
+        A.set_precision(A.config.DEFAULT_PRECISION)

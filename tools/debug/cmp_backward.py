@@ -17,7 +17,7 @@ for native in ("0", "1"):
     _to_dev(models, emb)
     draws = scenes.replay_draws(cfg, meta["draw_seed"])
     kw = scenes.render_kwargs(cfg)
-    kw["_zs_fine"] = torch.from_numpy(want["zs_fine"])
+    R._FINE_DEPTHS_OVERRIDE = torch.from_numpy(want["zs_fine"])
     orig = (R.torch.rand, R.torch.randn)
     if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
         rp = _Replay(cfg, draws)
