@@ -38,10 +38,14 @@ typedef _Float16 h2f __attribute__((ext_vector_type(2)));
 #ifdef H3_TIMING
 // debug build only (make timing): s_memtime stamps of the first 256 workgroups, 6 per step and wave
 __device__ unsigned g_h3_timing[256 * 8 * 32 * 6];
+__device__ unsigned long long g_h3_span[2] = {~0ull, 0ull};     // first / last s_memtime of the launch (tick calibration)
+#define H3_SPAN(k) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if (k) atomicMax(&g_h3_span[1], t_); else atomicMin(&g_h3_span[0], t_); } } while (0)
 #define H3_STAMP(k) do { if (lane == 0 && blockIdx.x < 256 && i < 32) \
     g_h3_timing[((blockIdx.x * 8 + wave_id) * 32 + i) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define H3_STAMP(k) do {} while (0)
+#define H3_SPAN(k) do {} while (0)
 #endif
 
 namespace {
@@ -98,6 +102,11 @@ struct H3KArgs {
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H3_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef H3_LDS_AHEAD      // experiment: also pin every activation read one k-step ahead of its MFMAs
+#define H3_PIN_X() __builtin_amdgcn_sched_barrier(0)
+#else
+#define H3_PIN_X() do {} while (0)
+#endif
 
 template <bool SPLIT = true>
 __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx, float v) {
@@ -197,31 +206,40 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLI
     load_x<NT>(x0, sBh, sBl, 0);
 #pragma unroll 1
     for (int ks = 4; ks < nks; ks += 4) {        // every group but the last: refill the ring
-        // sched_barrier pins each refill right behind the MFMAs that free its ring slot: left alone,
-        // hipcc sinks all 16 loads to the end of the group and the ring never runs ahead
+        // sched_barrier pins (a) each activation read one k-step AHEAD of the MFMAs that consume it (left alone hipcc
+        // sinks the ds_reads behind the previous k-step's MFMAs, merges x0/x1 and exposes the LDS latency every k-step)
+        // and (b) each weight refill right behind the MFMAs that free its ring slot (left alone hipcc sinks all 16
+        // loads to the end of the group and the ring never runs ahead)
         load_x<NT>(x1, sBh, sBl, 1);
+        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[0], x0);
         load_w(ring.r[0], wp);
         H3_PIN();
         load_x<NT>(x0, sBh, sBl, 2);
+        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[1], x1);
         load_w(ring.r[1], wp);
         H3_PIN();
         load_x<NT>(x1, sBh, sBl, 3);
+        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[2], x0);
         load_w(ring.r[2], wp);
         H3_PIN();
         load_x<NT>(x0, sBh, sBl, 4);
+        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[3], x1);
         load_w(ring.r[3], wp);
         H3_PIN();
         sBh += 64; sBl += 64;                    // four k-steps of 16 halfs
     }
     load_x<NT>(x1, sBh, sBl, 1);
+    H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[0], x0);
     load_x<NT>(x0, sBh, sBl, 2);
+    H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[1], x1);
     load_x<NT>(x1, sBh, sBl, 3);
+    H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[2], x0);
     mma_step<NT, MTW>(acc, ring.r[3], x1);
 }
@@ -275,6 +293,25 @@ __device__ __forceinline__ void acc_store_f16(_Float16* sXh, const f32x16 (&acc)
             }
 }
 
+// v - (float)h[0] / v - (float)h[1] in one instruction each (v_fma_mix_f32 converts the f16 source on the fly)
+__device__ __forceinline__ float minus_lo_half(h2 h, float v) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+__device__ __forceinline__ float minus_hi_half(h2 h, float v) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+__device__ __forceinline__ float relu1(float v) {      // one v_max (fmaxf would also canonicalise: two)
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// Epilogue: [ReLU ->] hi/lo split -> LDS.  3 VALU per value: v_max, half a v_cvt_pkrtz (hi), v_fma_mix (v - hi),
+// half a v_cvt_pkrtz (lo).
 template <int NT, bool RELU, int MTW>
 __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane,
                                           unsigned long long* mask = nullptr) {
@@ -289,12 +326,12 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = acc[mt][nt][4 * q + e];
-                    if (RELU) v[e] = fmaxf(v[e], 0.0f);
+                    if (RELU) v[e] = relu1(v[e]);
                 }
                 const h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
                 const h2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                const h2 l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
-                const h2 l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+                const h2 l01 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h01, v[0]), minus_hi_half(h01, v[1]));
+                const h2 l23 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h23, v[2]), minus_hi_half(h23, v[3]));
                 const int idx = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt + 8 * q + 4 * (lane >> 5);
                 h4 hv, lv;
                 hv[0] = (_Float16)h01[0]; hv[1] = (_Float16)h01[1]; hv[2] = (_Float16)h23[0]; hv[3] = (_Float16)h23[1];
@@ -333,17 +370,48 @@ __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Fl
     }
 }
 
+// four consecutive columns of one row -> one 8-byte store per plane
+template <bool SPLIT>
+__device__ __forceinline__ void split_store4(_Float16* xh, _Float16* xl, int idx, const float4 v) {
+    h4 hv, lv;
+    hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+    *reinterpret_cast<h4*>(xh + idx) = hv;
+    if constexpr (SPLIT) {
+        lv[0] = (_Float16)(v.x - (float)hv[0]); lv[1] = (_Float16)(v.y - (float)hv[1]);
+        lv[2] = (_Float16)(v.z - (float)hv[2]); lv[3] = (_Float16)(v.w - (float)hv[3]);
+        *reinterpret_cast<h4*>(xl + idx) = lv;
+    }
+}
+
+// (Re)build the trunk input tile [xyz embedding | zero pad to k0s | time code | zero pad to kt] of this workgroup's
+// points.  `x` = the point of row threadIdx % M, read once at kernel start (raw-position mode).  The time-code
+// loads are issued first (16-byte loads when the rows allow it) so that their L2 latency hides behind the sincos work.
 template <int M, int THREADS, bool SPLIT>
-__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t) {
+__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
+                                            const float (&x)[3]) {
     constexpr int G = THREADS / M;               // threads per point row
+    constexpr int CH = 16 / G;                   // float4 chunks of a 64-column time-code segment per thread
     const int r = threadIdx.x % M, q = threadIdx.x / M;
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
     const int base = r * LDH;
-    const int k0s = (int)a.L.k0s;
+    const int k0s = (int)a.L.k0s, kt = (int)a.L.kt;
+    const float* tsrc = nullptr;
+    if (with_t && valid) tsrc = (a.xyz != nullptr) ? a.t_emb + (p / a.pts_per_ray) * a.in_t
+                                                  : a.x_emb + p * a.ld_emb + a.off_t;
+    // rows of 16-byte-aligned float4s: per-ray time codes with in_t % 4 == 0 (the pointer itself is checked on the host)
+    const bool vec_t = with_t && a.xyz != nullptr && kt == 64 && (a.in_t & 3) == 0;
+    // the first (up to) four chunks are requested before the sincos work, so that their L2 latency hides behind it
+    constexpr int CH0 = CH < 4 ? CH : 4;
+    float4 tv[CH0];
+    if (vec_t) {
+#pragma unroll
+        for (int j = 0; j < CH0; ++j) {
+            const int c = 4 * (q + j * G);
+            tv[j] = (valid && c < a.in_t) ? *reinterpret_cast<const float4*>(tsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     if (a.xyz != nullptr) {
-        float x[3] = {0.f, 0.f, 0.f};
-        if (valid) { x[0] = a.xyz[p * 3 + 0]; x[1] = a.xyz[p * 3 + 1]; x[2] = a.xyz[p * 3 + 2]; }
         if (q == 0) {
             split_store<SPLIT>(sXh, sXl, base + 0, x[0]); split_store<SPLIT>(sXh, sXl, base + 1, x[1]);
             split_store<SPLIT>(sXh, sXl, base + 2, x[2]);
@@ -361,13 +429,21 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
         const float* src = a.x_emb + p * a.ld_emb + a.off_xyz;
         for (int c = q; c < k0s; c += G) split_store<SPLIT>(sXh, sXl, base + c, (valid && c < a.in_xyz) ? src[c] : 0.f);
     }
-    if (with_t) {
-        const float* src = nullptr;
-        if (valid) src = (a.xyz != nullptr) ? a.t_emb + (p / a.pts_per_ray) * a.in_t
-                                            : a.x_emb + p * a.ld_emb + a.off_t;
-        const int kt = (int)a.L.kt;
+    if (vec_t) {
+#pragma unroll
+        for (int j = 0; j < CH0; ++j) split_store4<SPLIT>(sXh, sXl, base + k0s + 4 * (q + j * G), tv[j]);
+        if constexpr (CH > CH0) {                     // two threads per row: the second half of the 16 chunks
+#pragma unroll
+            for (int j = CH0; j < CH; ++j) {
+                const int c = 4 * (q + j * G);
+                tv[j - CH0] = (valid && c < a.in_t) ? *reinterpret_cast<const float4*>(tsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = CH0; j < CH; ++j) split_store4<SPLIT>(sXh, sXl, base + k0s + 4 * (q + j * G), tv[j - CH0]);
+        }
+    } else if (with_t) {
         for (int c = q; c < kt; c += G)
-            split_store<SPLIT>(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? src[c] : 0.f);
+            split_store<SPLIT>(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? tsrc[c] : 0.f);
     }
 }
 
@@ -401,22 +477,28 @@ __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H
 
 enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
 
-// Narrow heads as one zero-padded 32-row MFMA tile; wave w evaluates the 32 points of tile w (w < NT).
+// Narrow heads as one zero-padded 32-row MFMA tile per 32 points.  The workgroup's NW waves split the NPT point
+// tiles AND (when NW > NPT) the K range: wave w takes point tile w % NPT and k-steps [16/KS * (w / NPT), ...), the
+// partial sums of the upper k ranges travel through `sRed` (one barrier).  Every product term has its own
+// accumulator chain (a 32x32x16 MFMA on the same accumulator can only issue every 64 cycles).
 // out row = (r&3) + 8*(r>>2) + 4*(lane>>5); only r < 8 (rows < 16) can be live.
-template <int NT, bool SPLIT>
-__device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, const uint32_t* __restrict__ pk,
+template <int NPT, int NW, bool SPLIT>
+__device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, float* sRed, const uint32_t* __restrict__ pk,
                                       uint32_t w_off, uint32_t b_off, int n_rows, unsigned kinds, float flow_scale,
                                       float* raw, long long p0, long long n_points, int slot0, int wave, int lane) {
-    if (wave >= NT) return;
-    f32x16 acc;
+    constexpr int KS = NW / NPT;                 // k-splits
+    constexpr int NK = 16 / KS;                  // k-steps per wave
+    static_assert(NW % NPT == 0 && (KS == 1 || KS == 2), "heads: 1 or 2 waves per point tile");
+    const int pt = wave % NPT, kh = wave / NPT;
+    f32x16 acc0, acc1, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane;
-    const _Float16* bh = sXh + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
-    const _Float16* bl = sXl + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane + kh * NK * 2 * 64;
+    const _Float16* bh = sXh + (32 * pt + (lane & 31)) * LDH + 8 * (lane >> 5) + kh * NK * 16;
+    const _Float16* bl = sXl + (32 * pt + (lane & 31)) * LDH + 8 * (lane >> 5) + kh * NK * 16;
     // weights are requested eight k-steps (8 KiB per wave) at a time, ahead of their MFMAs
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < NK / 8; ++half) {
         uint4 wr[8][2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -429,21 +511,36 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
             const h8 wh = __builtin_bit_cast(h8, wr[j][0]);
             const h8 wl = __builtin_bit_cast(h8, wr[j][1]);
             const h8 xh = *reinterpret_cast<const h8*>(bh + ks * 16);
-            acc = MFMA_H(wl, xh, acc);                 // the narrow heads keep the weights' lo halfs in both modes
+            acc0 = MFMA_H(wl, xh, acc0);               // the narrow heads keep the weights' lo halfs in both modes
             if constexpr (SPLIT) {
                 const h8 xl = *reinterpret_cast<const h8*>(bl + ks * 16);
-                acc = MFMA_H(wh, xl, acc);
+                acc1 = MFMA_H(wh, xl, acc1);
+                acc2 = MFMA_H(wh, xh, acc2);
+            } else {
+                acc0 = MFMA_H(wh, xh, acc0);
             }
-            acc = MFMA_H(wh, xh, acc);
         }
     }
-    const long long p = p0 + 32 * wave + (lane & 31);
+    float part[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) part[r] = SPLIT ? (acc0[r] + acc1[r]) + acc2[r] : acc0[r];
+    if constexpr (KS == 2) {
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sRed[(pt * 8 + r) * 64 + lane] = part[r];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part[r] += sRed[(pt * 8 + r) * 64 + lane];
+    }
+    const long long p = p0 + 32 * pt + (lane & 31);
     const float* bias = reinterpret_cast<const float*>(pk + b_off);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < n_rows) {
-            float v = acc[r] + bias[row];
+            float v = part[r] + bias[row];
             const unsigned kind = (kinds >> (2 * row)) & 3u;
             if (kind == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
             else if (kind == ACT_FLOW) v = flow_scale * tanhf(v);
@@ -468,6 +565,8 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     static_assert(MTW == 2 || WM == 1, "the 32-neuron-per-wave variant has a single row of point tiles");
     static_assert(SPLIT || !SAVE, "the training forward keeps fp32-grade activations: f16x3 only");
     __shared__ __attribute__((aligned(16))) _Float16 sX[(SPLIT ? 2 : 1) * M * LDH];
+    constexpr int NPT = M / 32, NW = THREADS / 64;                       // heads: point tiles, waves
+    __shared__ float sRed[NW > NPT ? NPT * 8 * 64 : 1];                  // k-split partial sums of the heads
     _Float16* sXh = sX;
     _Float16* sXl = SPLIT ? sX + M * LDH : sX;        // (never dereferenced when !SPLIT)
     const int lane = threadIdx.x & 63;
@@ -489,6 +588,16 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     };
     auto fbias = [&](uint32_t off) { return reinterpret_cast<const float*>(pk + off); };
 
+    // raw-position mode: this thread's point, read once (it is re-encoded up to four times: both trunks, layer 0 + skip)
+    // (the 128-point fast kernel has no registers to spare for it and re-reads the point in every build instead)
+    constexpr bool KEEP_POINT = SPLIT;
+    float px[3] = {0.f, 0.f, 0.f};
+    auto read_point = [&]() {
+        const long long bp = p0 + threadIdx.x % M;
+        if (a.xyz != nullptr && bp < a.n_points) { px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2]; }
+    };
+    if constexpr (KEEP_POINT) read_point();
+
     // weights of step 0 start their L2 round trip before the tile's input is even encoded
     // Every workgroup streams the same weights; if all of them walk the program in the same order
     // they hit the same few L2 channels at the same instant.  Half of the workgroups therefore run
@@ -496,6 +605,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     const int rot = (a.n_static_steps > 0 && a.n_static_steps < a.n_steps && ((blockIdx.x >> 3) & 1))
                         ? a.n_static_steps : 0;
     auto step_at = [&](int i) { int j = i + rot; if (j >= a.n_steps) j -= a.n_steps; return a.steps[j]; };
+    H3_SPAN(0);
     const H3Step s0 = step_at(0);
     const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
     load_bias<MTW>(br, fbias(s0.bias_off), nb0, lane);
@@ -506,7 +616,10 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
             if (st.pre == PRE_SIDE) build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0);
-            else build_input<M, THREADS, SPLIT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T);
+            else {
+                if constexpr (!KEEP_POINT) read_point();
+                build_input<M, THREADS, SPLIT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px);
+            }
             __syncthreads();
             if constexpr (SAVE) {
                 // trunk input of layer 0: columns [0,64) xyz embedding, [64,128) time code (zero when absent)
@@ -557,11 +670,12 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                     w_off = a.L.t_head_w; b_off = a.L.t_head_b; n_rows = (int)a.L.t_head_rows; slot0 = 4;
                     kinds = 0x15u | (0xAAAu << 8);
                 }
-                heads<NT * WM, SPLIT>(sXh, sXl, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points, slot0,
-                                     wave_id, lane);
+                heads<NPT, NW, SPLIT>(sXh, sXl, sRed, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points,
+                                      slot0, wave_id, lane);
             }
         }
     }
+    H3_SPAN(1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -621,6 +735,11 @@ __global__ void nsff_pack_kernel_h3(const PackArgsH3 a) {
 #ifdef H3_TIMING
 extern "C" int nsff_debug_read_timing(unsigned* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_h3_timing), sizeof(unsigned) * n) == hipSuccess ? 0 : -4;
+}
+extern "C" int nsff_debug_span(unsigned long long* host, int reset) {       // host[2] = {first, last} tick of the launches since reset
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_h3_span), 16) != hipSuccess) return -4;
+    if (reset) { const unsigned long long init[2] = {~0ull, 0ull}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_h3_span), init, 16) != hipSuccess) return -4; }
+    return 0;
 }
 #endif
 

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD=${PMC_CMD:-"python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"}
+CMD=${PMC_CMD:-"python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aux"}
 run() { # name, counters...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $name -- $CMD > $OUT/$name.log 2>&1

@@ -41,8 +41,9 @@ def test_fast_mode_error_per_key_against_reference_goldens(name, hip_lib, monkey
     from test_gpu_parity import _render, _to_dev
     cfg, meta, rays, ts, models, emb, dataset, want = common.build_case(name, A.NeRF, A.PosEmbedding)
     _to_dev(models, emb)
-    got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, None,
-                  zs_fine=want.get("zs_fine") if cfg["N_importance"] > 0 else None)
+    with torch.no_grad():          # (with gradients enabled a train-mode call runs in f16x3: the fast mode is inference only)
+        got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, None,
+                      zs_fine=want.get("zs_fine") if cfg["N_importance"] > 0 else None)
     assert sorted(got) == sorted(want)
     errs = {k: parity.max_rel_err(got[k], want[k]) for k in want if k not in common.SAMPLE_KEYS}
     per_ray = ("rgb_fine", "depth_fine", "transient_flow_fw", "transient_flow_bw", "_static_rgb_fine", "rgb_coarse")

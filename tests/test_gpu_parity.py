@@ -128,12 +128,14 @@ def test_render_rays_matches_reference_goldens(name, hip_lib, monkeypatch):
 # Per-ray keys north_star names, FREE-RUNNING (no fine-depth override): the whole chain coarse field ->
 # compositing -> inverse-CDF sampling -> merge/sort -> fine field -> compositing against the reference's own
 # outputs (models/rendering.py:335-362).  On the well-conditioned scenes a 1e-6 depth shift stays small in the
-# per-ray expectations; g3b (gain 3) and g5 (visibility-masked, near-empty rays) are reported, not asserted at 1e-4.
+# per-ray expectations; the gain-3 stress scene is reported and bounded at 1e-2, not asserted at 1e-4.
 FREE_RUN_KEYS = ("rgb_fine", "depth_fine", "transient_flow_fw", "transient_flow_bw", "xyz_fw", "xyz_bw",
                  "_static_rgb_fine", "rgb_coarse", "depth_coarse")
-FREE_RUN_STRICT = ("g2_static_c2f", "g3_nsff_train", "g4_nsff_test", "g7_nsff_train_noise", "g7b_static_noise_odd",
-                   "g12_other_arch")
-FREE_RUN_REPORTED = {"g3b_nsff_train_gain3": 5e-2, "g5_nsff_test_vis": 5e-2}
+FREE_RUN_STRICT = ("g2_static_c2f", "g3_nsff_train", "g4_nsff_test", "g5_nsff_test_vis", "g7_nsff_train_noise",
+                   "g7b_static_noise_odd", "g12_other_arch")
+# gain 3: sigma up to 33, weights near 0/1 -- a 1e-6 depth shift moves per-ray values by 1e-3 (the numpy oracle itself
+# sits 3e-4..1.5e-3 from the reference there); measured 1.6e-3 on the MI355X, bounded at 1e-2
+FREE_RUN_REPORTED = {"g3b_nsff_train_gain3": 1e-2}
 
 
 @pytest.mark.parametrize("name", FREE_RUN_STRICT + tuple(FREE_RUN_REPORTED))

@@ -24,7 +24,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16"])
+    ap.add_argument("--tile-points", type=int, default=0)
     args = ap.parse_args()
+    from nsff_pl_amd import config
+    config.set_precision(args.precision)
+    config.set_tile_points(args.tile_points)
+    peak = {"f32": 157.3e12, "f16x3": 2500e12, "f16": 2500e12}[args.precision]
     dev = "cuda:0"
     cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=args.rays, seed=0)
     models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
@@ -55,7 +61,8 @@ def main():
         print(f"{name:14s} P={P:7d}  {ms / k:8.3f} ms  {fl / (ms * 1e-3) / 1e12:7.2f} TFLOP/s")
     ms = res["coarse_s+t"][0] + res["fine_s+t+flow"][0] + 2 * res["warp_t"][0]
     fl = res["coarse_s+t"][1] + res["fine_s+t+flow"][1] + 2 * res["warp_t"][1]
-    print(f"C2 mix         {ms:8.3f} ms  {fl / (ms * 1e-3) / 1e12:7.2f} TFLOP/s  ({fl / (ms * 1e-3) / 157.3e12:.3f} of fp32 MFMA peak)")
+    print(f"C2 mix [{args.precision}] {ms:8.3f} ms  {fl / (ms * 1e-3) / 1e12:7.2f} TFLOP/s  ({fl / (ms * 1e-3) / peak:.3f} of the dense MFMA peak "
+          f"of the dtype, avg launch {ms / 4:.4f} ms)")
 
 
 if __name__ == "__main__":

@@ -9,7 +9,8 @@ import nsff_pl_amd as A
 from nsff_pl_amd import _lib, config
 
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-config.set_precision("f16x3"); config.set_tile_points(tile)
+prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
+config.set_precision(prec); config.set_tile_points(tile)
 dev = torch.device("cuda:0")
 cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024, seed=0)
 models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
@@ -25,6 +26,18 @@ for _ in range(3):
     _lib.field_query(model, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows)
 torch.cuda.synchronize()
 lib = _lib.load()
+# tick calibration: one launch bracketed by events vs first/last s_memtime stamp inside it
+span = (C.c_ulonglong * 2)()
+lib.nsff_debug_span.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+lib.nsff_debug_span(span, 1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+_lib.field_query(model, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows)
+e1.record()
+torch.cuda.synchronize()
+lib.nsff_debug_span(span, 0)
+ms = e0.elapsed_time(e1)
+print(f"launch {ms:.4f} ms by events, {span[1] - span[0]} ticks first->last stamp  =>  {(span[1] - span[0]) / ms / 1e6:.4f} GHz tick rate (lower bound)")
 n = 256 * 8 * 32 * 6
 buf = (C.c_uint * n)()
 assert lib.nsff_debug_read_timing(buf, n) == 0
