@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      7
+#define NSFF_ABI_VERSION      8
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -112,17 +112,21 @@ typedef struct NsffFieldArgs {
     int32_t ld_emb;
     int32_t off_xyz, off_dir, off_a, off_t;  /* column offsets in x_emb, -1 = absent */
     float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
-    /* training forward (F16X3, input A, models without view directions, in_xyz <= 64, in_t <= 64): also keep
-     * what nsff_field_backward / nsff_weight_grad need.  T = ceil(P/64) point tiles; any of them may be NULL.
-     *   save_acts : fp16 (2*D+2, T, 4, 256, 16): slot l = ReLU output of static layer l, slot D = static_xyz_encoding_final
-     *               output, slots D+1.. the same for the transient trunk (slots of a trunk that is not evaluated stay
-     *               unwritten).  Inside a tile: [16-point group][neuron][point] = the fragment order of the
-     *               weight-gradient GEMM (K = points);
+    /* training forward (F16X3, input A, in_xyz <= 64, in_t <= 64, in_dir + in_a <= 128): also keep what
+     * nsff_field_backward / nsff_weight_grad need.  T = ceil(P/64) point tiles; any of them may be NULL.
+     * NS = 2*D+2 activation slots (+1 when use_viewdir):
+     *   save_acts : fp16 (NS, T, 4, 256, 16): slot l = ReLU output of static layer l, slot D = static_xyz_encoding_final
+     *               output, slots D+1.. the same for the transient trunk, slot 2*D+2 = static_dir_encoding output (slots
+     *               of a trunk that is not evaluated stay unwritten).  Inside a tile: [16-point group][neuron][point] =
+     *               the fragment order of the weight-gradient GEMM (K = points);
      *   save_xin  : fp16 (T, 4, 128, 16) trunk input, rows [0,in_xyz) xyz embedding, rows [64, 64+in_t) time code;
-     *   save_masks: uint64 (2*D+2, T, 256) ReLU sign bits of every trunk activation, in accumulator order.        */
+     *   save_masks: uint64 (NS, T, 256) ReLU sign bits of every trunk activation, in accumulator order;
+     *   save_side : fp16 (T, 4, 128, 16) [dir | a] input of static_dir_encoding (use_viewdir, static_mode 2), rows
+     *               [0, in_dir + in_a); rows from ceil64(in_dir + in_a) up stay unwritten.                         */
     void*   save_acts;
     void*   save_xin;
     void*   save_masks;
+    void*   save_side;
 } NsffFieldArgs;
 
 int nsff_field_query(const NsffModelDesc* desc, const void* packed,
@@ -135,11 +139,13 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed,
  * nsff_bwd_packed_bytes / nsff_pack_weights_bwd: the TRANSPOSED fp16 weight tiles the data-gradient chain
  * streams (same parameter order as nsff_pack_weights).
  * nsff_field_backward: d_raw (P,16) -> d(trunk input) and the pre-activation gradients of every layer:
- *   dpre : fp16 (2*(D+1), T, 4, 256, 16)  slot t*(D+1)+l = trunk t (0 static, 1 transient) layer l, l = D: *_final,
- *          values = true gradient * G, fragment order as save_acts;
- *   dhead: fp16 (2, T, 4, 32, 16) head pre-activation gradients * G, rows: static rgb(3) sigma(1);
- *          transient rgb(3) sigma(1) fw(3) bw(3);
- *   d_xin: fp32 (P, 128) true gradient w.r.t. the transient trunk input (rows as save_xin), or NULL.            */
+ *   dpre : fp16 (NS, T, 4, 256, 16)  slot t*(D+1)+l = trunk t (0 static, 1 transient) layer l, l = D: *_final,
+ *          slot 2*D+2 = static_dir_encoding (use_viewdir); values = true gradient * G, fragment order as save_acts;
+ *   dhead: fp16 (2, T, 4, 32, 16) head pre-activation gradients * G, rows 0..15: static rgb(3) sigma(1);
+ *          transient rgb(3) sigma(1) fw(3) bw(3); rows 16..31: the fp16 rounding remainder of rows 0..15 (the head
+ *          weight / bias gradients are the sum of both halves);
+ *   d_xin: fp32 (P, 128) true gradient w.r.t. the transient trunk input (rows as save_xin), or NULL;
+ *   d_side: fp32 (P, 128) true gradient w.r.t. the [dir | a] input of static_dir_encoding (rows as save_side), or NULL. */
 int nsff_bwd_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
 int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params, void* packed, void* stream);
 
@@ -154,6 +160,7 @@ typedef struct NsffFieldBwdArgs {
     void*  dpre;                /* OUT */
     void*  dhead;               /* OUT */
     float* d_xin;               /* OUT or NULL                                               */
+    float* d_side;              /* OUT or NULL (use_viewdir models, static_mode 2)           */
 } NsffFieldBwdArgs;
 int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
 

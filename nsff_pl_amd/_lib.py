@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -43,7 +43,8 @@ class FieldArgs(C.Structure):
                 ("dir_emb", _fp), ("a_emb", _fp), ("t_emb", _fp),
                 ("x_emb", _fp), ("ld_emb", C.c_int32),
                 ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
-                ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp), ("save_masks", _fp)]
+                ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp), ("save_masks", _fp),
+                ("save_side", _fp)]
 
 
 _COMPOSITE_PTRS_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "xyz_fw", "xyz_bw",
@@ -81,7 +82,7 @@ class CompositeBwdArgs(C.Structure):
 class FieldBwdArgs(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("static_mode", C.c_int32), ("transient_mode", C.c_int32),
                 ("d_raw", _fp), ("raw", _fp), ("gmax", _fp), ("masks", _fp), ("dpre", _fp), ("dhead", _fp),
-                ("d_xin", _fp)]
+                ("d_xin", _fp), ("d_side", _fp)]
 
 
 class WgradJob(C.Structure):
@@ -249,7 +250,8 @@ def posenc(x, freqs, out):
 
 def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
                 xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
-                x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, save_masks=None, precision=None):
+                x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, save_masks=None, save_side=None,
+                precision=None):
     from . import config
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
@@ -274,6 +276,7 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     a.save_acts = None if save_acts is None else save_acts.data_ptr()
     a.save_xin = None if save_xin is None else save_xin.data_ptr()
     a.save_masks = None if save_masks is None else save_masks.data_ptr()
+    a.save_side = None if save_side is None else save_side.data_ptr()
     _check(load().nsff_field_query(C.byref(desc), _ptr(packed), C.byref(a), _stream()), "nsff_field_query")
 
 
@@ -334,11 +337,11 @@ def pack_weights_bwd(desc, params, packed):
     _check(load().nsff_pack_weights_bwd(C.byref(desc), arr, _ptr(packed), _stream()), "nsff_pack_weights_bwd")
 
 
-def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin):
+def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side=None):
     desc = model_desc(model)
     a = FieldBwdArgs(n_points=int(n_points), static_mode=2 if static else 0, transient_mode=2 if transient else 0,
                      d_raw=_ptr(d_raw), raw=_ptr(raw), gmax=_ptr(gmax), masks=masks.data_ptr(), dpre=dpre.data_ptr(),
-                     dhead=dhead.data_ptr(), d_xin=_ptr(d_xin))
+                     dhead=dhead.data_ptr(), d_xin=_ptr(d_xin), d_side=_ptr(d_side))
     _check(load().nsff_field_backward(C.byref(desc), _ptr(model.packed(BWD_PACK)), C.byref(a), _stream()),
            "nsff_field_backward")
 

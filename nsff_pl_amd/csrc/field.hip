@@ -518,8 +518,8 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     if (g.n_points == 0) return NSFF_OK;
     if (!g.raw) return NSFF_ERR_NULL;
     if ((uintptr_t)packed & 15) return NSFF_ERR_ALIGN;
-    if ((g.save_acts || g.save_xin) && (g.precision != NSFF_PREC_F16X3 || d.use_viewdir || !g.xyz)) return NSFF_ERR_INVALID;
-    if (((uintptr_t)g.save_acts | (uintptr_t)g.save_xin) & 15) return NSFF_ERR_ALIGN;
+    if ((g.save_acts || g.save_xin || g.save_side) && (g.precision != NSFF_PREC_F16X3 || !g.xyz)) return NSFF_ERR_INVALID;
+    if (((uintptr_t)g.save_acts | (uintptr_t)g.save_xin | (uintptr_t)g.save_side) & 15) return NSFF_ERR_ALIGN;
     const bool need_side = g.static_mode == 2 && d.use_viewdir;
     if (g.xyz) {
         if (g.x_emb) return NSFF_ERR_INVALID;

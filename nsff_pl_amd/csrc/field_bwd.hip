@@ -44,6 +44,8 @@ struct TrunkLayoutB {
 struct LayoutB {
     TrunkLayoutB st, tr;
     uint32_t s_sigma;                    // 256 fp32: static_sigma.weight (rank-1 term of the static head)
+    uint32_t dir_h, dir_side;            // use_viewdir: static_dir_encoding transposed -- rows = *_final outputs (256) /
+                                         // rows = [dir | a] inputs (128 used), K = 256 (its pre-activations)
     uint32_t total;
 };
 
@@ -51,7 +53,7 @@ inline int make_layout_b(const NsffModelDesc& d, LayoutB& L) {
     NsffLayoutH3 f;
     const int rc = nsff_make_layout_h3(d, f);
     if (rc) return rc;
-    if (d.use_viewdir || f.k0s != 64 || f.kt > 64) return NSFF_ERR_INVALID;
+    if (f.k0s != 64 || f.kt > 64 || f.side_k > 128) return NSFF_ERR_INVALID;
     uint32_t off = 0;
     auto take = [&](uint32_t halfs) { uint32_t o = off; off += halfs / 2; return o; };
     auto trunk = [&](TrunkLayoutB& T, bool xparts) {
@@ -66,6 +68,8 @@ inline int make_layout_b(const NsffModelDesc& d, LayoutB& L) {
     L.tr = TrunkLayoutB{};
     if (d.has_transient) trunk(L.tr, true);
     L.s_sigma = off; off += 256;
+    L.dir_h = L.dir_side = NSFF_NONE;
+    if (d.use_viewdir) { L.dir_h = take(256 * 256); L.dir_side = take(256 * 256); }
     L.total = off;
     return NSFF_OK;
 }
@@ -75,7 +79,7 @@ struct PackSegB {
     const float* src[4];     // kind 2: up to four head tensors; otherwise src[0]
     int32_t r0[4], nr[4];    // kind 2: destination K range of each head tensor
     uint32_t dst;
-    int32_t kind;            // 0 flat fp32 copy (count = nks), 1 transposed Linear, 2 heads, 3 trunk-input rows
+    int32_t kind;            // 0 flat fp32 copy (count = nks), 1 transposed Linear, 2 heads, 3 trunk-input rows, 4 side-input rows
     int32_t ld, c0;          // kind 1: Wt[k][n] = W[n][c0 + k];  kind 3: W[n][xmap(k)]
     int32_t nks;
     int32_t in_xyz, in_t;
@@ -103,6 +107,8 @@ __global__ void pack_kernel_b(const PackArgsB a) {
         } else if (s.kind == 2) {
             for (int j = 0; j < 4; ++j)
                 if (s.src[j] != nullptr && n >= s.r0[j] && n < s.r0[j] + s.nr[j]) v = s.src[j][(long long)(n - s.r0[j]) * 256 + k];
+        } else if (s.kind == 4) {                          // Wt[k][n] = W_dir[n][256 + k], k < in_dir + in_a (passed in in_xyz)
+            if (k < s.in_xyz) v = s.src[0][(long long)n * s.ld + 256 + k];
         } else {
             int c = -1;
             if (k < s.in_xyz) c = k;
@@ -116,7 +122,7 @@ __global__ void pack_kernel_b(const PackArgsB a) {
 
 // ---- K1 ---------------------------------------------------------------------------------------
 enum { EPI_KEEP = 0, EPI_LINEAR = 1, EPI_MASK = 2, EPI_DXIN = 3 };
-enum { F_CONTINUE = 1, F_STASH = 2, F_SIGMA = 4, F_FROM_STASH = 8, F_HALF_ROWS = 16 };
+enum { F_CONTINUE = 1, F_STASH = 2, F_SIGMA = 4, F_FROM_STASH = 8, F_HALF_ROWS = 16, F_TO_SIDE = 32 };
 struct BStep {
     uint32_t w_off;
     uint8_t nks, epi, slot, flags;     // slot: dpre slot written (EPI_LINEAR / EPI_MASK); mask slot = slot too
@@ -133,6 +139,7 @@ struct BKArgs {
     _Float16* dpre;
     _Float16* dhead;
     float* d_xin;
+    float* d_side;
     long long n_points, n_tiles;
     int D;
     int t_head_rows;                   // 4 or 10
@@ -284,14 +291,17 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                 *reinterpret_cast<h8*>(sB + pt * LDH + 16 * grp) = z;
                 *reinterpret_cast<h8*>(sB + pt * LDH + 16 * grp + 8) = z;
             }
-            // head gradients on the global scale, fragment order [ks][lane = row + 32*(pt/8 & 1)][8 pts]; rows 8*grp .. 8*grp+7
+            // head gradients on the global scale, fragment order [ks][lane = row + 32*(pt/8 & 1)][8 pts]; rows 8*grp .. 8*grp+7.
+            // Rows 0..15 carry fp16(g * G), rows 16..31 the rounding remainder g * G - fp16(g * G): the head weight / bias
+            // gradients are the sum of both halves (a bias gradient is a plain sum over points that may cancel heavily).
             _Float16* dh = a.dhead + ((is_static ? 0 : a.n_tiles) + tile) * (64 * 32);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int row = 8 * grp + r;
-                float v = row < 16 ? hv[row < 16 ? row : 0] * G : 0.f;       // (rows 16..31 are zero)
-                if (grp >= 2) v = 0.f;
-                dh[(((pt >> 4) * 64) + row + 32 * ((pt >> 3) & 1)) * 8 + (pt & 7)] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+                const float v = fminf(fmaxf(hv[row & 15] * G, -65504.f), 65504.f);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 o = row < 16 ? hi : (_Float16)(v - (float)hi);
+                dh[(((pt >> 4) * 64) + row + 32 * ((pt >> 3) & 1)) * 8 + (pt & 7)] = o;
             }
             __syncthreads();
         }
@@ -312,7 +322,8 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
         if (i + 1 < a.n_steps) wnext = prefetch_w1(ring, seg(a.steps[i + 1]));    // flies during the epilogue
         if (st.epi == EPI_KEEP) continue;
         if (st.epi == EPI_DXIN) {
-            if (wave < 2 && a.d_xin != nullptr) {
+            float* dst_in = (st.flags & F_TO_SIDE) ? a.d_side : a.d_xin;
+            if (wave < 2 && dst_in != nullptr) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                                 float4 v;
                                 v.x = acc[mt][nt][4 * q + 0] * inv; v.y = acc[mt][nt][4 * q + 1] * inv;
                                 v.z = acc[mt][nt][4 * q + 2] * inv; v.w = acc[mt][nt][4 * q + 3] * inv;
-                                *reinterpret_cast<float4*>(a.d_xin + (p0 + pt) * 128 + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5)) = v;
+                                *reinterpret_cast<float4*>(dst_in + (p0 + pt) * 128 + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5)) = v;
                             }
                         }
                     }
@@ -603,6 +614,12 @@ int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params,
         lin(wf, T.fin, NSFF_W, 0);
     };
     trunk(0, L.st, 0);
+    if (d.use_viewdir) {
+        const float* wdir = params[pi]; pi += 2;
+        const int ld = NSFF_W + d.in_dir + d.in_a;
+        lin(wdir, L.dir_h, ld, 0);
+        PackSegB s{}; s.src[0] = wdir; s.dst = L.dir_side; s.kind = 4; s.ld = ld; s.nks = 16; s.in_xyz = d.in_dir + d.in_a; segs.push_back(s);
+    }
     {
         const float* wsig = params[pi]; pi += 2;
         const float* wrgb = params[pi]; pi += 2;
@@ -650,7 +667,7 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     if (g.n_points == 0) return NSFF_OK;
     if (!g.d_raw || !g.raw || !g.gmax || !g.masks || !g.dpre || !g.dhead) return NSFF_ERR_NULL;
     if (((uintptr_t)packed_bwd | (uintptr_t)g.d_raw | (uintptr_t)g.raw | (uintptr_t)g.dpre | (uintptr_t)g.dhead |
-         (uintptr_t)g.d_xin | (uintptr_t)g.masks) & 15) return NSFF_ERR_ALIGN;
+         (uintptr_t)g.d_xin | (uintptr_t)g.d_side | (uintptr_t)g.masks) & 15) return NSFF_ERR_ALIGN;
     BKArgs k{};
     k.packed = reinterpret_cast<const uint32_t*>(packed_bwd);
     k.s_sigma = L.s_sigma;
@@ -659,6 +676,7 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     k.dpre = reinterpret_cast<_Float16*>(g.dpre);
     k.dhead = reinterpret_cast<_Float16*>(g.dhead);
     k.d_xin = g.d_xin;
+    k.d_side = d.use_viewdir ? g.d_side : nullptr;
     k.n_points = g.n_points; k.n_tiles = (g.n_points + 63) / 64;
     k.D = d.D; k.t_head_rows = d.has_flow ? 10 : 4; k.flow_scale = d.flow_scale;
     if (k.n_tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
@@ -671,7 +689,14 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     // activation slots, which are numbered the same way.
     auto trunk = [&](const TrunkLayoutB& T, int t, bool want_xin) {
         const int base = t * (d.D + 1);
-        push(T.head, 4, EPI_LINEAR, base + d.D, 0);
+        if (t == 0 && d.use_viewdir) {
+            // static_rgb reads static_dir_encoding = relu(W_dir . [*_final | dir | a]) (nerf.py:183-186)
+            push(T.head, 4, EPI_MASK, 2 * d.D + 2, 0);
+            if (k.d_side != nullptr) push(L.dir_side, 16, EPI_DXIN, 0, F_HALF_ROWS | F_TO_SIDE);
+            push(L.dir_h, 16, EPI_LINEAR, base + d.D, 0);
+        } else {
+            push(T.head, 4, EPI_LINEAR, base + d.D, 0);
+        }
         push(T.fin, 16, EPI_MASK, base + d.D - 1, (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == d.skip && want_xin) ? F_STASH : 0));
         for (int l = d.D - 1; l >= 1; --l)
             push(T.layer[l], 16, EPI_MASK, base + l - 1, (l - 1 == d.skip && want_xin) ? F_STASH : 0);

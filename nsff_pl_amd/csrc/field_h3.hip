@@ -51,7 +51,6 @@ __device__ unsigned long long g_h3_span[2] = {~0ull, 0ull};     // first / last 
 namespace {
 
 constexpr int LDH = 264;          // halfs per LDS row (528 B; 528/16 = 33 odd)
-constexpr int NTHREADS = 256;
 
 // The network is executed as a short program of GEMM steps (built on the host), so that the
 // kernel holds exactly one copy of the GEMM loop, the epilogue, the input builders and the heads.
@@ -86,6 +85,7 @@ struct H3KArgs {
     _Float16* save_acts;       // (slots, tiles, 4 ks, 256 rows, 16 pts) fp16 post-activation values, or null
     _Float16* save_xin;        // (tiles, 4 ks, 128 rows, 16 pts) fp16 trunk input [xyz emb | pad | t at row 64 | pad], or null
     unsigned long long* save_masks;   // (slots, tiles, 256 threads) ReLU sign bits in accumulator order, or null
+    _Float16* save_side;       // (tiles, 4 ks, 128 rows, 16 pts) fp16 [dir | a] input of static_dir_encoding, or null
     long long save_stride;     // halfs per activation slot = tiles * 64 * 256
     long long n_tiles;
     long long n_points;
@@ -615,8 +615,15 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         H3_STAMP(0);
         if (st.pre != PRE_NONE) {
             __syncthreads();                       // everyone is done reading the previous tile
-            if (st.pre == PRE_SIDE) build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0);
-            else {
+            if (st.pre == PRE_SIDE) {
+                build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0);
+                if constexpr (SAVE) {
+                    if (a.save_side != nullptr) {
+                        __syncthreads();
+                        tile_to_fragments<THREADS>(sXh, sXl, a.save_side + (long long)blockIdx.x * (64 * 128), 128, (int)a.L.side_k);
+                    }
+                }
+            } else {
                 if constexpr (!KEEP_POINT) read_point();
                 build_input<M, THREADS, SPLIT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px);
             }
@@ -841,9 +848,11 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.save_acts = reinterpret_cast<_Float16*>(g.save_acts);
     k.save_xin = reinterpret_cast<_Float16*>(g.save_xin);
     k.save_masks = reinterpret_cast<unsigned long long*>(g.save_masks);
+    k.save_side = reinterpret_cast<_Float16*>(g.save_side);
     k.n_tiles = (g.n_points + 63) / 64;
     k.save_stride = k.n_tiles * 64 * NSFF_W;
-    if ((g.save_acts || g.save_xin || g.save_masks) && (d.use_viewdir || !g.xyz || k.L.k0s != 64 || k.L.kt > 64)) return NSFF_ERR_INVALID;
+    if ((g.save_acts || g.save_xin || g.save_masks || g.save_side) && (!g.xyz || k.L.k0s != 64 || k.L.kt > 64 || k.L.side_k > 128))
+        return NSFF_ERR_INVALID;
     k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
     k.D = d.D; k.skip = d.skip;
     k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;
@@ -880,7 +889,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB, d.D);
             if (d.use_viewdir) {
                 push(k.L.dir_h, k.L.dir_b, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
-                push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB);
+                push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
             }
         }
     }
@@ -893,7 +902,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.n_steps = n;
 
     if (points_per_block == NSFF_H3_FAST) {       // "f16": one product per MAC, 128-point tiles, two workgroups per CU
-        if (k.save_acts || k.save_xin || k.save_masks) return NSFF_ERR_INVALID;
+        if (k.save_acts || k.save_xin || k.save_masks || k.save_side) return NSFF_ERR_INVALID;
         const long long tiles = (g.n_points + 127) / 128;
         if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
         hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1, false, 2, false>), dim3((unsigned)tiles), dim3(256), 0, st, k);

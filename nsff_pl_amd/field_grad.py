@@ -1,7 +1,7 @@
 """Native field node of the backward graph (SURVEY.md 8f, row N1 -- second stage).
 
-``torch_path.render_pass`` expresses compositing / warping with torch ops; the field network inside it
-(PosEmbedding + NeRF.forward, reference models/nerf.py:17-30,118-213) is this ``autograd.Function``:
+The field network (PosEmbedding + NeRF.forward, reference models/nerf.py:17-30,118-213) inside the backward graph of
+:mod:`nsff_pl_amd.autograd` is this ``autograd.Function``:
 
 * forward  = the gfx950 f16x3 field kernel in its *training* variant (``nsff_field_kernel_h3<2,1,true>``),
   which also keeps every post-activation tensor of the trunks (fp16) and the encoded trunk input in HBM
@@ -15,8 +15,10 @@
   gradient are a few torch ops on the (P,128) result.  ``NSFF_BWD_IMPL=torch`` selects an all-torch version of
   the same arithmetic (debugging).
 
-Only models without view directions take this path (the NSFF configuration, train.py:40-84 defaults);
-others keep the torch expression of :mod:`nsff_pl_amd.torch_path`.
+View-direction / appearance models (``static_dir_encoding``, reference nerf.py:83-91,183-185) are covered: the
+training forward also keeps that layer's input rows and activation, K1 differentiates it and returns the
+gradient of the per-ray appearance code.  Architectures the kernels are not built for (``why_unsupported``) are
+refused by name -- there is no torch fallback in the product.
 """
 import os
 
@@ -31,29 +33,51 @@ def enabled():
     return os.environ.get("NSFF_NATIVE_BACKWARD", "1") != "0"
 
 
+def why_unsupported(model):
+    """None, or what csrc/field_bwd.hip and the SAVE variant of csrc/field_h3.hip are not built for."""
+    if model.W != 256 or len(model.skips) != 1:
+        return f"W={model.W}, skips={list(model.skips)} (the kernels need W=256 and one skip layer)"
+    if model.in_channels_xyz > 64:
+        return f"in_channels_xyz={model.in_channels_xyz} > 64 (the saved trunk input has 64 position columns)"
+    if model.encode_transient and model.in_channels_t > 64:
+        return f"in_channels_t={model.in_channels_t} > 64 (the saved trunk input has 64 time-code columns)"
+    if model.use_viewdir and model.in_channels_dir + model.in_channels_a > 128:
+        return f"in_channels_dir + in_channels_a = {model.in_channels_dir + model.in_channels_a} > 128"
+    return None
+
+
 def _kernel_handles(model):
-    """What csrc/field_bwd.hip and the SAVE variant of csrc/field_h3.hip are built for."""
-    return (not model.use_viewdir and model.W == 256 and len(model.skips) == 1
-            and model.in_channels_xyz <= 64 and (not model.encode_transient or model.in_channels_t <= 64))
+    return why_unsupported(model) is None
 
 
 def supported(model, xyz):
     return enabled() and xyz.is_cuda and xyz.dtype == torch.float32 and _kernel_handles(model)
 
 
+def n_slots(model):
+    """Activation / pre-activation-gradient slots: trunk t layer l -> t*(D+1)+l (l = D: *_final), 2D+2: static_dir_encoding."""
+    return 2 * model.D + 2 + (1 if model.use_viewdir else 0)
+
+
 def _lin(m):
     return m[0] if isinstance(m, torch.nn.Sequential) else m
 
 
-def alloc_saves(model, n_points, device, transient):
-    """Buffers the training forward fills for the backward kernels (layouts: include/nsff_render.h, NsffFieldArgs)."""
+def alloc_saves(model, n_points, device, transient, static=True):
+    """Buffers the training forward fills for the backward kernels (layouts: include/nsff_render.h, NsffFieldArgs):
+    (acts, xin, masks, side) -- side is None unless the launch evaluates static_dir_encoding."""
     tiles = (n_points + 63) // 64
-    acts = torch.empty(2 * model.D + 2, tiles, 64 * 256, device=device, dtype=torch.float16)
+    acts = torch.empty(n_slots(model), tiles, 64 * 256, device=device, dtype=torch.float16)
     xin = torch.empty(tiles, 64 * 128, device=device, dtype=torch.float16)
-    masks = torch.empty(2 * model.D + 2, tiles, 256, device=device, dtype=torch.int64)
+    masks = torch.empty(n_slots(model), tiles, 256, device=device, dtype=torch.int64)
     if not transient:
         xin.zero_()                          # rows 64.. of a static-only launch are never written
-    return acts, xin, masks
+    side = None
+    if model.use_viewdir and static:
+        side = torch.empty(tiles, 64 * 128, device=device, dtype=torch.float16)
+        if model.in_channels_dir + model.in_channels_a <= 64:
+            side.zero_()                     # rows 64.. are never written
+    return acts, xin, masks, side
 
 
 def forward_can_save(model, static_mode, transient_mode):
@@ -82,49 +106,62 @@ def _bmm(dpre16, w, out32=False):
 
 class _FieldFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg, xyz, t_rows, *params):
+    def forward(ctx, cfg, xyz, t_rows, dir_rows, a_rows, *params):
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
         static, transient = cfg["static"], cfg["transient"]
         P = xyz.shape[0]
         drop_stale_pending()
+        ctx.cfg, ctx.P = cfg, P
         if cfg.get("saved") is not None:         # render_rays' own launch was the training forward: nothing to redo
-            raw, acts, xin, masks, xyz_c = cfg["saved"]
-            ctx.cfg, ctx.P = cfg, P
-            ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *params)
+            raw, acts, xin, masks, xyz_c, side = cfg["saved"]
+            ctx.has_side = side is not None
+            ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *([side] if side is not None else []), *params)
             return raw.detach().view_as(raw)
         dev = xyz.device
         raw = torch.zeros(P, _lib.RAW_STRIDE, device=dev)
-        acts, xin, masks = alloc_saves(model, P, dev, transient)
+        acts, xin, masks, side = alloc_saves(model, P, dev, transient, static)
         xyz_c = xyz.detach().contiguous()
+        use_side = model.use_viewdir and static
         _lib.field_query(model, raw, P, s, 2 if static else 0, 2 if transient else 0,
                          2 if (transient and model.output_flow) else 0, xyz=xyz_c, freqs=freqs,
                          t_emb=None if t_rows is None else t_rows.detach().contiguous(),
-                         save_acts=acts, save_xin=xin, save_masks=masks, precision=config.PRECISIONS["f16x3"])
-        ctx.cfg, ctx.P = cfg, P
-        ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *params)
+                         dir_emb=dir_rows.detach().contiguous() if use_side else None,
+                         a_emb=a_rows.detach().contiguous() if (use_side and model.in_channels_a > 0) else None,
+                         save_acts=acts, save_xin=xin, save_masks=masks, save_side=side,
+                         precision=config.PRECISIONS["f16x3"])
+        ctx.has_side = side is not None
+        ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *([side] if side is not None else []), *params)
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
         cfg = ctx.cfg
         if os.environ.get("NSFF_BWD_IMPL", "hip") == "torch" or (cfg["static"] and ctx.needs_input_grad[1]):
+            if cfg["model"].use_viewdir and cfg["static"]:
+                raise NotImplementedError("gradient w.r.t. the points of a view-direction static trunk / NSFF_BWD_IMPL=torch: "
+                                          "only the HIP backward covers static_dir_encoding")
             return _FieldFn._backward_torch(ctx, d_raw)
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
         raw, acts, xin, masks, xyz = ctx.saved_tensors[:5]
-        params = ctx.saved_tensors[5:]
+        side = ctx.saved_tensors[5] if ctx.has_side else None
+        params = ctx.saved_tensors[6 if ctx.has_side else 5:]
         P, D, skip = ctx.P, model.D, model.skips[0]
         tiles, dev = acts.shape[1], d_raw.device
         if P == 0:                               # an empty batch contributes nothing
-            return (None, None if not ctx.needs_input_grad[1] else torch.zeros_like(xyz), None) + (None,) * len(params)
+            return (None, None if not ctx.needs_input_grad[1] else torch.zeros_like(xyz), None, None, None) + (None,) * len(params)
         static, transient = cfg["static"], cfg["transient"]
+        viewdir = bool(model.use_viewdir and static)
+        S_DIR = 2 * D + 2
         n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
         d_raw = d_raw.contiguous()
         gmax = d_raw.abs().max()
-        dpre = torch.empty(2 * (D + 1), tiles, 64 * 256, device=dev, dtype=torch.float16)
+        dpre = torch.empty(n_slots(model), tiles, 64 * 256, device=dev, dtype=torch.float16)
         dhead = torch.empty(2, tiles, 64 * 32, device=dev, dtype=torch.float16)
         want_in = transient and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         d_xin = torch.empty(P, 128, device=dev) if want_in else None
-        _lib.field_backward(model, P, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin)
+        want_a = viewdir and model.in_channels_a > 0 and ctx.needs_input_grad[4]
+        d_side = torch.empty(P, 128, device=dev) if want_a else None
+        _lib.field_backward(model, P, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side)
 
         # ---- weight-gradient GEMMs: one batched launch per output shape ----
         jobs, sizes, meta = [], [], []            # meta: (kind, trunk, layer)
@@ -143,7 +180,12 @@ class _FieldFn(torch.autograd.Function):
                     if l == skip:
                         job(dpre[base + l], xin, 256, 128, ("x", t, l))
             job(dpre[base + D], acts[base + D - 1], 256, 256, ("h", t, D))
-            job(dhead[t], acts[base + D], 32, 256, ("head", t, 0))
+            if t == 0 and viewdir:            # static_dir_encoding: [*_final | dir | a] -> 256, static_rgb reads it
+                job(dpre[S_DIR], acts[D], 256, 256, ("dir_h", 0, 0))
+                job(dpre[S_DIR], side, 256, 128, ("dir_x", 0, 0))
+                job(dhead[0], acts[S_DIR], 32, 256, ("head", 0, 0))
+            else:
+                job(dhead[t], acts[base + D], 32, 256, ("head", t, 0))
             if t == 0:
                 job(dhead[0], acts[base + D - 1], 32, 256, ("head", t, 1))    # static sigma reads the trunk
         n_splits = max(1, min(int(os.environ.get("NSFF_WGRAD_SPLITS", "32")), tiles // 4))
@@ -198,10 +240,15 @@ class _FieldFn(torch.autograd.Function):
                 put(_lin(getattr(model, f"{prefix}_xyz_encoding_final")), result(i), bias[i])
                 i = res[("head", t, 0)]
                 hw, hb = result(i), bias[i]
+                hw, hb = hw[0:16] + hw[16:32], hb[0:16] + hb[16:32]      # fp16 value + rounding remainder rows
+                if t == 0 and viewdir:
+                    ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
+                    n_side = model.in_channels_dir + model.in_channels_a
+                    put(_lin(model.static_dir_encoding), torch.cat([result(ih), result(ix)[:, :n_side]], 1), bias[ih])
                 if t == 0:
                     put(_lin(model.static_rgb), hw[0:3], hb[0:3])
                     i2 = res[("head", 0, 1)]
-                    put(_lin(model.static_sigma), result(i2)[3:4], bias[i2][3:4])
+                    put(_lin(model.static_sigma), result(i2)[3:4] + result(i2)[19:20], bias[i2][3:4] + bias[i2][19:20])
                 else:
                     put(_lin(model.transient_rgb), hw[0:3], hb[0:3])
                     put(_lin(model.transient_sigma), hw[3:4], hb[3:4])
@@ -209,20 +256,23 @@ class _FieldFn(torch.autograd.Function):
                         put(_lin(model.transient_flow_fw), hw[4:7], hb[4:7])
                         put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
 
-        d_xyz = d_t = None
+        d_xyz = d_t = d_a = None
         if d_xin is not None:
             if ctx.needs_input_grad[2]:
                 d_t = d_xin[:, 64:64 + n_t].reshape(P // s, s, -1).sum(1)
             if ctx.needs_input_grad[1]:
                 d_xyz = _posenc_backward(d_xin, xyz, freqs)
+        if d_side is not None:               # per-ray appearance code: sum over the ray's points (rendering.py:168,172)
+            c0 = model.in_channels_dir
+            d_a = d_side[:, c0:c0 + model.in_channels_a].reshape(P // s, s, -1).sum(1)
         if overlap:
             # keep what the side stream still reads alive until the join, then hand the gradients over there.
             # Every node queues the (idempotent) flush: a callback queued by an earlier backward pass that died
             # half-way is dropped by the engine, so "already queued" cannot be remembered across passes.
-            _PENDING.append((list(_lib.param_list(model)), grads, (dpre, dhead, acts, xin, out, bias, gmax)))
+            _PENDING.append((list(_lib.param_list(model)), grads, (dpre, dhead, acts, xin, side, out, bias, gmax)))
             torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
-            return (None, d_xyz, d_t) + (None,) * len(params)
-        return (None, d_xyz, d_t) + tuple(grads)
+            return (None, d_xyz, d_t, None, d_a) + (None,) * len(params)
+        return (None, d_xyz, d_t, None, d_a) + tuple(grads)
 
     @staticmethod
     def _backward_torch(ctx, d_raw):
@@ -329,7 +379,7 @@ class _FieldFn(torch.autograd.Function):
                 for i, f in enumerate(freqs):
                     ang = f * xyz
                     d_xyz += f * (torch.cos(ang) * de[:, 3 + 6 * i:6 + 6 * i] - torch.sin(ang) * de[:, 6 + 6 * i:9 + 6 * i])
-        return (None, d_xyz, d_t) + tuple(grads)
+        return (None, d_xyz, d_t, None, None) + tuple(grads)
 
 
 _FREQ_CACHE = {}
@@ -414,9 +464,10 @@ def _unfragment(frag, n_rows):
     return x.permute(0, 1, 2, 4, 6, 3, 5).reshape(slots, tiles * 64, n_rows)
 
 
-def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient, saved=None):
+def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient, saved=None, dir_rows=None, a_rows=None):
     """Differentiable field query on raw points: returns the (P,16) raw record (layout of include/nsff_render.h).
-    saved: (raw, acts, xin, masks, xyz) of an earlier training-forward launch on exactly these inputs, or None."""
+    dir_rows / a_rows: per-ray view-direction embedding and appearance code (use_viewdir models, static pass).
+    saved: (raw, acts, xin, masks, xyz, side) of an earlier training-forward launch on exactly these inputs, or None."""
     cfg = dict(model=model, freqs=[float(f) for f in freqs], pts_per_ray=int(pts_per_ray), static=bool(static),
                transient=bool(transient), saved=saved)
-    return _FieldFn.apply(cfg, xyz, t_rows, *_lib.param_list(model))
+    return _FieldFn.apply(cfg, xyz, t_rows, dir_rows, a_rows, *_lib.param_list(model))

@@ -92,9 +92,9 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         saves = {}
         if ctx.rec is not None and field_grad.forward_can_save(model, static_mode, transient_mode):
             raw_out.zero_()                          # slots of heads this launch does not write read as zeros in backward
-            acts, xin, masks = field_grad.alloc_saves(model, P, zs.device, bool(transient_mode))
-            saves = dict(save_acts=acts, save_xin=xin, save_masks=masks)
-            ctx.rec.setdefault("saved", {})[tag] = (raw_out, acts, xin, masks, pts.view(-1, 3))
+            acts, xin, masks, side_rows = field_grad.alloc_saves(model, P, zs.device, bool(transient_mode), bool(static_mode))
+            saves = dict(save_acts=acts, save_xin=xin, save_masks=masks, save_side=side_rows)
+            ctx.rec.setdefault("saved", {})[tag] = (raw_out, acts, xin, masks, pts.view(-1, 3), side_rows)
         _lib.field_query(model, raw_out, P, S, static_mode=static_mode, transient_mode=transient_mode,
                          flow_heads=flow_heads, xyz=pts, freqs=ctx.freqs_xyz, t_emb=t_rows, **saves, **extra)
     if P:
@@ -222,8 +222,8 @@ def render_rays(models,
     """
     _lib.require_gpu_tensor(rays, "rays")
     _lib.load()
-    # Gradients (training): forward values still come from the kernels below; the autograd graph is
-    # attached afterwards and differentiates a torch re-evaluation at the recorded depths / draws.
+    # Gradients (training): forward values still come from the kernels below; the autograd graph of native
+    # backward nodes is attached afterwards at the recorded depths / draws (nsff_pl_amd.autograd).
     want_grad = (torch.is_grad_enabled() and not test_time and
                  bool(autograd.grad_parameters(models, embeddings)))
     rec = {} if want_grad else None
@@ -315,7 +315,7 @@ def render_rays(models,
         return results
     rec.update(N_importance=N_importance, noise_std=float(noise_std), output_transient=output_transient,
                flows=list(output_transient_flow), zs_coarse=results.get('zs_coarse', results.get('zs_fine')),
-               zs_fine=results['zs_fine'], view_dir=kwargs.get('view_dir', rays[:, 3:6]),
+               zs_fine=results['zs_fine'], view_dir=kwargs.get('view_dir', rays[:, 3:6]), dir_embedded=ctx.dir_embedded,
                t_embedded_override=kwargs.get('t_embedded'), a_embedded_override=kwargs.get('a_embedded'))
     return autograd.attach(results, models, embeddings, rays, ts, max_t, rec)
 

@@ -41,6 +41,9 @@ CASES = {
     "g12_other_arch": dict(n_rays=12, N_samples=32, N_importance=24, transient=True, viewdir=False,
                            appearance=False, test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=12,
                            D=6, skips=[2], n_tau=16, xyz_emb=(7, 8), dir_emb=(2, 3)),
+    # view directions + appearance code in TRAIN mode (static_dir_encoding on the gradient path; ctor default use_viewdir=True)
+    "g13_viewdir_train": dict(n_rays=16, N_samples=64, N_importance=64, transient=True, viewdir=True, appearance=True,
+                              test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=13),
     "g7b_static_noise_odd": dict(n_rays=9, N_samples=48, N_importance=40, transient=False, viewdir=True,
                                  appearance=False, test_time=False, flow=[], gain=2.5, seed=8,
                                  perturb=0.5, noise_std=0.7),
@@ -179,10 +182,11 @@ def replay_draws(cfg, seed):
 
 
 # ---- gradient goldens (G9): a fixed random cotangent per differentiable output key ----
-GRAD_CASES = ("g3_nsff_train", "g7_nsff_train_noise", "g2_static_c2f")
+GRAD_CASES = ("g3_nsff_train", "g7_nsff_train_noise", "g2_static_c2f", "g13_viewdir_train")
 NON_DIFF_KEYS = ("zs_coarse", "xyzs_coarse", "zs_fine", "xyzs_fine")
 FULL_GRAD_PARAMS = ("t.weight", "fine.transient_flow_fw.0.weight", "fine.static_sigma.weight",
-                    "fine.static_xyz_encoding_5.0.bias", "coarse.transient_rgb.0.bias", "coarse.static_rgb.0.weight")
+                    "fine.static_xyz_encoding_5.0.bias", "coarse.transient_rgb.0.bias", "coarse.static_rgb.0.weight",
+                    "a.weight", "fine.static_dir_encoding.0.weight", "coarse.static_dir_encoding.0.bias")
 
 
 def cotangent_loss(results):

@@ -8,7 +8,8 @@ import torch
 
 import scenes
 import nsff_pl_amd as A
-from nsff_pl_amd import field_grad, torch_path
+import torch_path
+from nsff_pl_amd import field_grad
 
 pytestmark = pytest.mark.gpu
 

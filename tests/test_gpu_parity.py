@@ -131,7 +131,7 @@ def test_render_rays_matches_reference_goldens(name, hip_lib, monkeypatch):
 # per-ray expectations; the gain-3 stress scene is reported and bounded at 1e-2, not asserted at 1e-4.
 FREE_RUN_KEYS = ("rgb_fine", "depth_fine", "transient_flow_fw", "transient_flow_bw", "xyz_fw", "xyz_bw",
                  "_static_rgb_fine", "rgb_coarse", "depth_coarse")
-FREE_RUN_STRICT = ("g2_static_c2f", "g3_nsff_train", "g4_nsff_test", "g5_nsff_test_vis", "g7_nsff_train_noise",
+FREE_RUN_STRICT = ("g2_static_c2f", "g3_nsff_train", "g4_nsff_test", "g5_nsff_test_vis", "g7_nsff_train_noise", "g13_viewdir_train",
                    "g7b_static_noise_odd", "g12_other_arch")
 # gain 3: sigma up to 33, weights near 0/1 -- a 1e-6 depth shift moves per-ray values by 1e-3 (the numpy oracle itself
 # sits 3e-4..1.5e-3 from the reference there); measured 1.6e-3 on the MI355X, bounded at 1e-2

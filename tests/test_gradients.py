@@ -1,7 +1,8 @@
 """Gradient parity: d<outputs, fixed cotangents>/d(parameters) against the reference.
 
-CPU part: the differentiable torch path of nsff_pl_amd (used only by backward) evaluated at the golden
-depths / replayed draws.  GPU part: the real thing -- render_rays (HIP forward) + loss.backward().
+CPU part: tests/torch_path.py (the all-torch expression of the path, test infrastructure) evaluated at the golden
+depths / replayed draws -- it pins the float64 truth and the fp32 scatter the GPU results are judged against.
+GPU part: the real thing -- render_rays (HIP forward) + loss.backward() through the native backward kernels.
 """
 import json
 import os
@@ -14,7 +15,7 @@ import common
 import parity
 import scenes
 import nsff_pl_amd as A
-from nsff_pl_amd import autograd as nauto
+import torch_path
 
 GRAD_RTOL = 2e-3
 # Some of these gradients are ill-conditioned in fp32 by construction: the warped re-queries differentiate
@@ -70,7 +71,7 @@ def _torch_path_stats(name, dt, objective="cotangent", ulp_seed=0):
         m.to(dt)
     rec = _record(cfg, want, draws, rays.to(dt))
     rec = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in rec.items()}
-    res = nauto.recompute(models, emb, rays.to(dt), ts, scenes.N_FRAMES - 1, rec)
+    res = torch_path.recompute(models, emb, rays.to(dt), ts, scenes.N_FRAMES - 1, rec)
     objective_fn(name, objective, dt)(res).backward()
     return scenes.grad_stats(models, emb)
 
@@ -126,7 +127,7 @@ def _record(cfg, want, draws, rays):
 def test_torch_backward_path_matches_reference(name):
     cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
     draws = scenes.replay_draws(cfg, meta["draw_seed"])
-    res = nauto.recompute(models, emb, rays, ts, scenes.N_FRAMES - 1, _record(cfg, want, draws, rays))
+    res = torch_path.recompute(models, emb, rays, ts, scenes.N_FRAMES - 1, _record(cfg, want, draws, rays))
     assert sorted(res) == sorted(want)
     for k in want:                                   # forward values of the backward path
         parity.assert_close(k, res[k].detach().numpy(), want[k], common.key_rtol(k, cfg))
@@ -174,36 +175,46 @@ def test_render_rays_backward_matches_reference(name, precision, hip_lib, monkey
         A.set_precision(A.config.DEFAULT_PRECISION)
 
 
+def _native_field_fn(model, xyz, freqs, t_rows, s, static, transient, dir_rows, a_rows):
+    from nsff_pl_amd import field_grad
+    side = dict(dir_rows=dir_rows, a_rows=a_rows) if (model.use_viewdir and static) else {}
+    return field_grad.field(model, xyz, freqs, t_rows, s, static, transient, **side)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g7_nsff_train_noise", "g2_static_c2f", "g12_other_arch"])
+@pytest.mark.parametrize("name", ["g7_nsff_train_noise", "g2_static_c2f", "g12_other_arch", "g13_viewdir_train"])
 def test_native_compositing_backward_equals_torch_expression(name, hip_lib, monkeypatch):
     """nsff_composite_backward against autograd of the elementwise torch expression of the same compositing
-    (same field nodes, same forward values): both fp32, so they agree far below the fp64-truth tolerance."""
+    (tests/torch_path.py with the SAME native field nodes, same depths and draws): both fp32, so they agree far
+    below the fp64-truth tolerance."""
     from test_gpu_parity import _Replay, _to_dev, DEV
     import nsff_pl_amd.rendering as R
     A.set_precision("f16x3")
     grads = {}
     try:
-        for native in ("1", "0"):
-            monkeypatch.setenv("NSFF_NATIVE_COMPOSITE_BWD", native)
+        for native in (True, False):
             cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
             _to_dev(models, emb)
             draws = scenes.replay_draws(cfg, meta["draw_seed"])
             kw = scenes.render_kwargs(cfg)
-            if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
-                replay = _Replay(cfg, draws)
-                monkeypatch.setattr(R.torch, "rand", replay.rand)
-                monkeypatch.setattr(R.torch, "randn", replay.randn)
-            with common.fine_depths(want["zs_fine"]):
-                res = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
-                                    cfg["N_samples"], cfg.get("perturb", 0), cfg.get("noise_std", 0),
-                                    cfg["N_importance"], 1024 * 32, test_time=False, **kw)
-            monkeypatch.undo()
+            rd, td = rays.to(DEV), None if ts is None else ts.to(DEV)
+            if native:
+                if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
+                    replay = _Replay(cfg, draws)
+                    monkeypatch.setattr(R.torch, "rand", replay.rand)
+                    monkeypatch.setattr(R.torch, "randn", replay.randn)
+                with common.fine_depths(want["zs_fine"]):
+                    res = A.render_rays(models, emb, rd, td, scenes.N_FRAMES - 1, cfg["N_samples"], cfg.get("perturb", 0),
+                                        cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32, test_time=False, **kw)
+                monkeypatch.undo()
+            else:
+                rec = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _record(cfg, want, draws, rays).items()}
+                res = torch_path.recompute(models, emb, rd, td, scenes.N_FRAMES - 1, rec, field_fn=_native_field_fn)
             scenes.cotangent_loss(res).backward()
             grads[native] = {n: p.grad.detach().clone() for n, p in scenes.named_grad_params(models, emb) if p.grad is not None}
-        assert sorted(grads["0"]) == sorted(grads["1"])
-        for n, g in grads["0"].items():
-            parity.assert_close("grad " + n, grads["1"][n].cpu().numpy(), g.cpu().numpy(), 2e-3)
+        assert sorted(grads[False]) == sorted(grads[True])
+        for n, g in grads[False].items():
+            parity.assert_close("grad " + n, grads[True][n].cpu().numpy(), g.cpu().numpy(), 2e-3)
     finally:
         A.set_precision(A.config.DEFAULT_PRECISION)
 
@@ -211,31 +222,47 @@ def test_native_compositing_backward_equals_torch_expression(name, hip_lib, monk
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_rays", [1, 3, 37])
 def test_backward_on_ragged_batches(n_rays, hip_lib):
-    """Tiles, splits and wave chunks that are not full: native backward vs the torch expression on the same rays."""
+    """Tiles, splits and wave chunks that are not full: native backward vs the all-torch expression on the same rays
+    and depths."""
     from test_gpu_parity import _to_dev, DEV
     A.set_precision("f16x3")
     try:
         cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=n_rays, N_samples=24, N_importance=9)
         rays, ts = scenes.synthetic_rays(n_rays, 77)
-        grads = {}
-        for native in ("1", "0"):
-            os.environ["NSFF_NATIVE_BACKWARD"] = native
-            os.environ["NSFF_NATIVE_COMPOSITE_BWD"] = native
+        grads, zs = {}, None
+        for native in (True, False):
             models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
             _to_dev(models, emb)
-            torch.manual_seed(5)
-            res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0,
-                                cfg["N_importance"], 1024 * 32, test_time=False, **scenes.render_kwargs(cfg))
+            if native:
+                res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0,
+                                    cfg["N_importance"], 1024 * 32, test_time=False, **scenes.render_kwargs(cfg))
+                zs = {k: res[k].detach().cpu().numpy() for k in ("zs_coarse", "zs_fine")}
+            else:
+                rec = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _record(cfg, zs, {}, rays).items()}
+                res = torch_path.recompute(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, rec)
             loss = sum((v * v).sum() for k, v in res.items() if v.requires_grad)
             loss.backward()
             grads[native] = {n: p.grad.detach().cpu().numpy() for n, p in scenes.named_grad_params(models, emb) if p.grad is not None}
-        assert sorted(grads["0"]) == sorted(grads["1"])
-        for n, g in grads["0"].items():
-            assert np.isfinite(grads["1"][n]).all(), n
+        assert sorted(grads[False]) == sorted(grads[True])
+        for n, g in grads[False].items():
+            assert np.isfinite(grads[True][n]).all(), n
             # a handful of points: nothing averages the fp16 rounding of single terms or the fp32 scatter of the
             # sin(512 x) chain (see the header), so this only separates "right" from "wrong tile / chunk handling"
-            parity.assert_close("grad " + n, grads["1"][n], g, 5e-2)
+            parity.assert_close("grad " + n, grads[True][n], g, 5e-2)
     finally:
-        os.environ.pop("NSFF_NATIVE_BACKWARD", None)
-        os.environ.pop("NSFF_NATIVE_COMPOSITE_BWD", None)
         A.set_precision(A.config.DEFAULT_PRECISION)
+
+
+@pytest.mark.gpu
+def test_unsupported_models_are_refused_not_routed_elsewhere(hip_lib):
+    """No torch fallback in the product: a call the native backward nodes do not cover raises, naming the reason."""
+    from test_gpu_parity import _to_dev, DEV
+    cfg = dict(scenes.CASES["g12_other_arch"], xyz_emb=(10, 11), n_rays=4)          # in_channels_xyz = 69 > 64
+    rays, ts = scenes.synthetic_rays(4, 1)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    kw = scenes.render_kwargs(cfg)
+    with torch.no_grad():                                                            # inference is fine
+        A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 16, 0, 0, 8, 32768, test_time=False, **kw)
+    with pytest.raises(RuntimeError, match="cannot be differentiated.*in_channels_xyz=69"):
+        A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 16, 0, 0, 8, 32768, test_time=False, **kw)

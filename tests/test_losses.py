@@ -13,7 +13,7 @@ import torch
 import common
 import scenes
 import nsff_pl_amd as A
-from nsff_pl_amd import autograd as nauto
+import torch_path
 from nsff_pl_amd.losses import NeRFWLoss, ndc2world, shiftscale_invariant_depthloss
 from test_gradients import _check_grads, _record
 
@@ -45,7 +45,7 @@ def _torch_path_terms(name, dt):
     rec = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v)
            for k, v in _record(cfg, want, draws, rays.to(dt)).items()}
     with torch.no_grad():
-        res = nauto.recompute(models, emb, rays.to(dt), ts, scenes.N_FRAMES - 1, rec)
+        res = torch_path.recompute(models, emb, rays.to(dt), ts, scenes.N_FRAMES - 1, rec)
         loss_fn, targets = _loss_module(name)
         loss_fn.to(dt)
         targets = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in targets.items()}
@@ -96,7 +96,7 @@ def test_loss_terms_on_golden_render(name):
 def test_loss_and_gradients_torch_path(name):
     cfg, meta, rays, ts, models, emb, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
     draws = scenes.replay_draws(cfg, meta["draw_seed"])
-    res = nauto.recompute(models, emb, rays, ts, scenes.N_FRAMES - 1, _record(cfg, want, draws, rays))
+    res = torch_path.recompute(models, emb, rays, ts, scenes.N_FRAMES - 1, _record(cfg, want, draws, rays))
     loss_fn, targets = _loss_module(name)
     terms = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **scenes.render_kwargs(cfg))
     _check_terms(terms, name)

@@ -1,14 +1,10 @@
-"""Differentiable torch expression of the render path, used ONLY to obtain gradients.
+"""TEST INFRASTRUCTURE, NOT THE PRODUCT: a differentiable torch expression of the render path.
 
-``render_rays`` computes its outputs with the gfx950 kernels (no autograd graph).  When the
-caller needs gradients (training, reference ``train.py:178-198``), :mod:`nsff_pl_amd.autograd`
-re-evaluates the same mathematics here with ordinary torch ops on the GPU -- same sample depths,
-same random draws -- and lets autograd differentiate it (activation checkpointing at the granularity
-of one ``render_rays`` call).  Nothing in this module is on the forward / inference path.
-
-The dense layers of this backward path run on rocBLAS through ``torch.nn.functional.linear``
-(plain library GEMMs); replacing them by native MFMA backward kernels is the planned next step
- and only needs :func:`field` to become an ``autograd.Function``.
+The product (``nsff_pl_amd``) takes gradients only through its HIP nodes (``field_grad``, ``composite_grad``) and
+refuses what they do not cover.  This module re-expresses the same mathematics with ordinary torch ops so that
+tests can (a) check the autograd graph of the product against float64 autograd on the CPU (``recompute``, used by
+tests/test_gradients.py with the reference's gradient goldens) and (b) A/B the native compositing backward against
+autograd of the elementwise expression on the GPU (``field_fn`` = the native field node).
 
 Algorithm references: models/nerf.py:118-213 (field), models/rendering.py:98-140, 187-188,
 202-298 (compositing / warping / disocclusion).
@@ -64,12 +60,12 @@ def field(model, emb_xyz, dir_rows, a_rows, t_rows, static=True, transient=True,
     return out
 
 
-def query(model, xyz, freqs_xyz, dir_embedded, a_embedded, t_embedded, s, static, transient, flows, saved=None):
-    """Field outputs for (P,3) points, `s` consecutive points per ray.  On the GPU (models without view
-    directions) this is the native node of :mod:`nsff_pl_amd.field_grad`; otherwise the torch expression."""
-    from . import field_grad
-    if field_grad.supported(model, xyz):
-        raw = field_grad.field(model, xyz, freqs_xyz, t_embedded if transient else None, s, static, transient, saved)
+def query(model, xyz, freqs_xyz, dir_embedded, a_embedded, t_embedded, s, static, transient, flows, field_fn=None):
+    """Field outputs for (P,3) points, `s` consecutive points per ray.  field_fn (optional): a replacement returning
+    the (P,16) raw record -- tests pass the product's native node to isolate the compositing."""
+    if field_fn is not None:
+        raw = field_fn(model, xyz, freqs_xyz, t_embedded if transient else None, s, static, transient,
+                       dir_embedded, a_embedded)
         out = {}
         if static:
             out["rgb_s"], out["sigma_s"] = raw[:, 0:3], raw[:, 3]
@@ -123,50 +119,8 @@ def _softplus(x):
     return F.softplus(x)          # beta = 1, threshold = 20 like torch.nn.Softplus()
 
 
-def render_pass_native(results, model, typ, freqs_xyz, rays, zs, t_embedded, t_next, t_prev, output_transient, flows,
-                       noise_std, noise, saved, values):
-    """render_pass with the field AND the compositing as native nodes (GPU, models without view directions, train
-    mode).  `values`: the result dict the HIP forward of render_rays produced (the compositing node hands those
-    numbers out instead of recomputing them).  What stays in torch is the glue between the nodes: far-masking of the
-    flows, the warped query points, and sums of node outputs."""
-    from . import composite_grad, field_grad
-    n, s = zs.shape
-    saved = saved or {}
-    xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * zs[..., None]
-    results[f"zs_{typ}"], results[f"xyzs_{typ}"] = zs, xyz
-    raw = field_grad.field(model, xyz.reshape(-1, 3), freqs_xyz, t_embedded if output_transient else None, s,
-                           True, output_transient, saved.get(typ))
-    results[f"static_rgbs_{typ}"] = raw[:, 0:3].view(n, s, 3)
-    raw_fw = raw_bw = f_fw = f_bw = None
-    if output_transient:
-        results[f"transient_rgbs_{typ}"] = raw[:, 4:7].view(n, s, 3)
-        if flows:
-            far = (zs > Z_FAR)[..., None]
-            zero = torch.zeros((), device=zs.device)
-            f_fw = results["transient_flows_fw"] = torch.where(far, zero, raw[:, 8:11].view(n, s, 3))
-            f_bw = results["transient_flows_bw"] = torch.where(far, zero, raw[:, 11:14].view(n, s, 3))
-            xyz_fw = results["xyzs_fw"] = xyz + f_fw
-            xyz_bw = results["xyzs_bw"] = xyz + f_bw
-            raw_fw = field_grad.field(model, xyz_fw.reshape(-1, 3), freqs_xyz, t_next, s, False, True,
-                                      saved.get(f"{typ}_warp_fw"))
-            raw_bw = field_grad.field(model, xyz_bw.reshape(-1, 3), freqs_xyz, t_prev, s, False, True,
-                                      saved.get(f"{typ}_warp_bw"))
-            results["xyzs_fw_bw"] = xyz_fw + torch.where(far, zero, raw_fw[:, 11:14].view(n, s, 3))
-            results["xyzs_bw_fw"] = xyz_bw + torch.where(far, zero, raw_bw[:, 8:11].view(n, s, 3))
-    results.update(composite_grad.composite(values, typ, raw, raw_fw, raw_bw, f_fw, f_bw, zs, xyz if flows else None,
-                                            output_transient, noise_std, noise))
-    if output_transient and flows:
-        results["xyz_fw"] = results["xyz_fine"] + results["transient_flow_fw"]
-        results["xyz_bw"] = results["xyz_fine"] + results["transient_flow_bw"]
-
-
 def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded, t_next, t_prev,
-                output_transient, flows, noise_std, noise, test_time, saved=None, values=None):
-    from . import composite_grad, field_grad
-    if (values is not None and not test_time and composite_grad.enabled() and field_grad.supported(model, zs)
-            and (not flows or "fw" in flows and "bw" in flows)):
-        return render_pass_native(results, model, typ, freqs_xyz, rays, zs, t_embedded, t_next, t_prev,
-                                  output_transient, flows, noise_std, noise, saved, values)
+                output_transient, flows, noise_std, noise, test_time, field_fn=None):
     """One model pass (reference ``inference``): fills `results` with differentiable tensors.
 
     noise: dict with keys static / transient / warp_fw / warp_bw -> (N,S) standard normal draws (or None).
@@ -175,9 +129,8 @@ def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedd
     n, s = zs.shape
     xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * zs[..., None]
     results[f"zs_{typ}"], results[f"xyzs_{typ}"] = zs, xyz
-    saved = saved or {}
     f = query(model, xyz.reshape(-1, 3), freqs_xyz, dir_embedded, a_embedded, t_embedded, s,
-              True, output_transient, flows, saved.get(typ))
+              True, output_transient, flows, field_fn)
     g = lambda k, c=None: f[k].view(n, s) if c is None else f[k].view(n, s, c)
     s_rgb = results[f"static_rgbs_{typ}"] = g("rgb_s", 3)
     far = (zs > Z_FAR)[..., None]
@@ -203,7 +156,7 @@ def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedd
         if flows and not test_time:
             def warp(xyz_w, t_rows, head, key):
                 fw_ = query(model, xyz_w.reshape(-1, 3), freqs_xyz, dir_embedded, a_embedded, t_rows, s,
-                            False, True, [head], saved.get(f"{typ}_{key}"))
+                            False, True, [head], field_fn)
                 rgb_w, sig_w = fw_["rgb_t"].view(n, s, 3), fw_["sigma_t"].view(n, s)
                 flow_w = torch.where(far, torch.zeros_like(rgb_w), fw_[head].view(n, s, 3))
                 al_w = 1 - torch.exp(-d_trans * _softplus(sig_w + nz(key)))
@@ -250,3 +203,36 @@ def render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedd
             results["disoccs_fw"] = (1 - torch.abs(occ_fw))[..., None]
             results["disocc_bw"] = 1 - torch.abs(occ_bw.sum(1, keepdim=True))
             results["disoccs_bw"] = (1 - torch.abs(occ_bw))[..., None]
+
+
+def recompute(models, embeddings, rays, ts, max_t, rec, field_fn=None):
+    """Differentiable torch evaluation of a recorded train-time call (same record as nsff_pl_amd.autograd.recompute:
+    depths, draws, flags); returns the result dict."""
+    results = {}
+    freqs_xyz = [float(f) for f in embeddings["xyz"].freqs]
+    dir_embedded = None
+    if any(m.use_viewdir for m in models.values()):
+        dir_embedded = pos_embed(rec["view_dir"], [float(f) for f in embeddings["dir"].freqs])
+    t_embedded = None
+    out_t = rec["output_transient"]
+    if out_t:
+        t_embedded = rec["t_embedded_override"] if rec["t_embedded_override"] is not None else embeddings["t"](ts)
+    if rec["N_importance"] > 0:
+        render_pass(results, models["coarse"], "coarse", freqs_xyz, rays, rec["zs_coarse"], dir_embedded,
+                    None, t_embedded, None, None, out_t, [], rec["noise_std"],
+                    dict(static=rec.get("coarse_static"), transient=rec.get("coarse_transient")), False, field_fn)
+    fine = models["fine"]
+    a_embedded = None
+    if fine.encode_appearance:
+        a_embedded = rec["a_embedded_override"] if rec["a_embedded_override"] is not None else embeddings["a"](ts)
+    flows = rec["flows"]
+    t_next = t_prev = None
+    if out_t and flows:
+        t_next = embeddings["t"](torch.clamp(ts + 1, max=max_t))
+        t_prev = embeddings["t"](torch.clamp(ts - 1, min=0))
+    zs = rec["zs_fine"] if rec["N_importance"] > 0 else rec["zs_coarse"]
+    render_pass(results, fine, "fine", freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded,
+                t_next, t_prev, out_t, flows, rec["noise_std"],
+                dict(static=rec.get("fine_static"), transient=rec.get("fine_transient"),
+                     warp_fw=rec.get("fine_warp_fw"), warp_bw=rec.get("fine_warp_bw")), False, field_fn)
+    return results
