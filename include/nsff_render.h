@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      8
+#define NSFF_ABI_VERSION      9
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -178,6 +178,41 @@ typedef struct NsffWgradJob {
 int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits);
 int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
                      float* scratch, float* out, float* bias, const float* gmax, void* stream);
+
+/* ---- N1: the training objective NeRFWLoss (reference losses.py:8-28, 31-171) on the render dict, NSFF train-mode
+ * configuration (flows + disocclusion present, topk == 1, no per-ray weights, thickness == 1), every term reduced to
+ * its scalar mean.  mode 1: terms[11] = col_l, disp_l, entropy_l, cross_entropy_l, flow_fw_l, flow_bw_l, pho_l, cyc_l,
+ * reg_temp_sm_l, reg_min_l, reg_sp_sm_l (three launches; `stats` receives the batch statistics mode 2 re-uses).
+ * mode 2: g_* = gradient of sum_k term_w[k] * term_k w.r.t. the tensor of the same name (one launch).
+ * The two flow terms are masked means over the rays whose projection is valid (0 when there is none).
+ * n_rays <= 4096.  hyper (device): lambda_geo_d, lambda_geo_f, cross-entropy weight, lambda_reg, lambda_ent.      */
+typedef struct NsffLossArgs {
+    int64_t n_rays; int32_t n_samples; int32_t n_keep;   /* n_keep = int(n_samples * z_far): samples the regularisers see */
+    int32_t n_frames; int32_t max_t;
+    /* render dict */
+    const float* rgb_fine; const float* rgb_coarse;      /* (N,3); coarse pair may be NULL                         */
+    const float* depth_fine; const float* depth_coarse;  /* (N)                                                    */
+    const float* t_weights; const float* s_weights;      /* (N,S) transient_weights_fine, static_weights_fine      */
+    const float* xyz_fw; const float* xyz_bw;            /* (N,3)                                                  */
+    const float* rgb_fw; const float* rgb_bw;            /* (N,3)                                                  */
+    const float* disocc_fw; const float* disocc_bw;      /* (N)                                                    */
+    const float* disoccs_fw; const float* disoccs_bw;    /* (N,S)                                                  */
+    const float* xyzs_fw_bw; const float* xyzs_bw_fw;    /* (N,S,3)                                                */
+    const float* xyzs_fine; const float* xyzs_fw; const float* xyzs_bw;   /* (N,S,3)                               */
+    /* targets / camera buffers (train.py:136-138) */
+    const float* rgbs; const float* disps;               /* (N,3), (N)                                             */
+    const int64_t* ts; const int64_t* cam_ids;           /* (N); cam_ids may be NULL (= 0)                         */
+    const float* uv_fw; const float* uv_bw;              /* (N,2)                                                  */
+    const float* Ks; const float* Ps;                    /* (n_cam,3,3), (n_cam,n_frames,3,4)                      */
+    const float* hyper;                                  /* device, 5 floats                                       */
+    float* stats;                                        /* device, 24 floats: written by mode 1, read by mode 2   */
+    float* terms;                                        /* OUT mode 1: 11 floats                                  */
+    const float* term_w;                                 /* mode 2: 11 upstream scalars (device)                   */
+    float* g_rgb_fine; float* g_rgb_coarse; float* g_depth_fine; float* g_depth_coarse;
+    float* g_t_weights; float* g_s_weights; float* g_xyz_fw; float* g_xyz_bw; float* g_rgb_fw; float* g_rgb_bw;
+    float* g_xyzs_fw_bw; float* g_xyzs_bw_fw; float* g_xyzs_fw; float* g_xyzs_bw;
+} NsffLossArgs;
+int nsff_nerfw_loss(const NsffLossArgs* args, int mode, void* stream);
 
 /* ---- a4: coarse sample placement (reference rendering.py:314-324,332) ----
  * zs[n][i] = z_lin[i]                                   (perturb == 0)

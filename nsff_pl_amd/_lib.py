@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -101,6 +101,19 @@ class MpiArgs(C.Structure):
                 ("rgb", _fp), ("depth", _fp)]
 
 
+_LOSS_IN = ["rgb_fine", "rgb_coarse", "depth_fine", "depth_coarse", "t_weights", "s_weights", "xyz_fw", "xyz_bw", "rgb_fw",
+            "rgb_bw", "disocc_fw", "disocc_bw", "disoccs_fw", "disoccs_bw", "xyzs_fw_bw", "xyzs_bw_fw", "xyzs_fine",
+            "xyzs_fw", "xyzs_bw", "rgbs", "disps", "ts", "cam_ids", "uv_fw", "uv_bw", "Ks", "Ps", "hyper", "stats", "terms",
+            "term_w"]
+LOSS_GRADS = ["g_rgb_fine", "g_rgb_coarse", "g_depth_fine", "g_depth_coarse", "g_t_weights", "g_s_weights", "g_xyz_fw",
+              "g_xyz_bw", "g_rgb_fw", "g_rgb_bw", "g_xyzs_fw_bw", "g_xyzs_bw_fw", "g_xyzs_fw", "g_xyzs_bw"]
+
+
+class LossArgs(C.Structure):
+    _fields_ = ([("n_rays", C.c_int64), ("n_samples", C.c_int32), ("n_keep", C.c_int32), ("n_frames", C.c_int32),
+                 ("max_t", C.c_int32)] + [(n, _fp) for n in _LOSS_IN + LOSS_GRADS])
+
+
 # name -> (restype, argtypes); also the list of symbols the header declares
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
@@ -125,6 +138,7 @@ _SIGNATURES = {
     "nsff_weight_grad_scratch": (C.c_int64, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32]),
     "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "nsff_composite_backward": (C.c_int, [C.POINTER(CompositeBwdArgs), _fp]),
+    "nsff_nerfw_loss": (C.c_int, [C.POINTER(LossArgs), C.c_int, _fp]),
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
     "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
@@ -363,6 +377,20 @@ def composite_backward(n_rays, n_samples, has_transient, flow_mode, noise_std, *
     for k, v in tensors.items():
         setattr(a, k, _ptr(v))
     _check(load().nsff_composite_backward(C.byref(a), _stream()), "nsff_composite_backward")
+
+
+def nerfw_loss(mode, n_rays, n_samples, n_keep, n_frames, max_t, **tensors):
+    """mode 1: term sums into tensors['terms']; mode 2: gradients into tensors['g_*'] (include/nsff_render.h)."""
+    a = LossArgs(n_rays=int(n_rays), n_samples=int(n_samples), n_keep=int(n_keep), n_frames=int(n_frames), max_t=int(max_t))
+    for k, v in tensors.items():
+        if v is None:
+            continue
+        if v.dtype == torch.int64:
+            assert v.is_cuda and v.is_contiguous()
+            setattr(a, k, v.data_ptr())
+        else:
+            setattr(a, k, _ptr(v))
+    _check(load().nsff_nerfw_loss(C.byref(a), int(mode), _stream()), "nsff_nerfw_loss")
 
 
 def splat_planes(H, W, S, K4, P12, scale, xyz, flow, rgb, alpha, accum):

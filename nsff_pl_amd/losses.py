@@ -1,9 +1,10 @@
 """Objective of the NSFF trainer, consuming the ``render_rays`` result dict.
 
 A restatement of the reference's ``losses.py`` (``shiftscale_invariant_depthloss`` :8-28, ``NeRFWLoss``
-:31-171) with the same constructor, term names, weights and reductions; plain torch ops with autograd
-(the terms are a few elementwise passes over the per-ray / per-sample tensors -- HBM-trivial next to the
-field kernels).  ``kornia.filter2d`` (1 x thickness box filter, zero padded) is replaced by ``conv1d``.
+:31-171) with the same constructor, term names, weights and reductions.  On the GPU the NSFF train configuration
+is evaluated -- forward and backward -- by the fused kernels of ``csrc/loss.hip`` (:mod:`nsff_pl_amd.fused_loss`);
+the torch expression below is the general form (top-k mining, per-ray weights, dilated cross entropy, static-only
+models, CPU tensors) and what the kernels are tested against.  ``kornia.filter2d`` (1 x thickness box filter, zero padded) is replaced by ``conv1d``.
 ``Ks`` (n_cam,3,3), ``Ps`` (n_cam,N_frames,3,4) and ``max_t`` are attached by the trainer exactly like
 ``train.py:136-138`` does.
 """
@@ -58,6 +59,9 @@ class NeRFWLoss(nn.Module):
         return uvd[:, :2] / (torch.abs(uvd[:, 2:]) + 1e-8), uvd[:, 2]
 
     def forward(self, inputs, targets, **kwargs):
+        from . import fused_loss
+        if fused_loss.applicable(self, inputs, targets, kwargs):      # NSFF train configuration on the GPU: csrc/loss.hip
+            return fused_loss.nerfw_loss(self, inputs, targets, kwargs)
         ret = {}
         rgbs = targets['rgbs']
         ret['col_l'] = ((inputs['rgb_fine'] - rgbs) ** 2).mean(1)

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import common
+import parity
 import scenes
 import nsff_pl_amd as A
 import torch_path
@@ -238,3 +239,49 @@ def test_trainer_steps_reduce_the_loss(hip_lib):
         assert abs(glogs[-1]["train/loss"] - float(logs[-1]["train/loss"])) <= 0.05 * abs(float(logs[-1]["train/loss"]))
     finally:
         A.set_precision(A.config.DEFAULT_PRECISION)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rays,coarse", [(64, True), (333, True), (1024, False)])
+def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, hip_lib, monkeypatch):
+    """csrc/loss.hip (terms + gradients w.r.t. every consumed render tensor, arbitrary upstream weights per term)
+    against autograd of the torch NeRFWLoss on the same render dict."""
+    from test_gpu_parity import _to_dev, DEV
+    from nsff_pl_amd import fused_loss
+    cfg = dict(scenes.CASES["g7_nsff_train_noise"], n_rays=n_rays)
+    rays, ts = scenes.synthetic_rays(n_rays, 21)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    kw = scenes.render_kwargs(cfg)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, 64, 1.0, 1.0, 64, 32768,
+                            test_time=False, **kw)
+    if not coarse:
+        res = {k: v for k, v in res.items() if not k.endswith("_coarse")}
+    loss_fn = NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0, static_shapes=True)
+    Ks, Ps, max_t = scenes.camera_buffers()
+    loss_fn.register_buffer("Ks", Ks); loss_fn.register_buffer("Ps", Ps); loss_fn.max_t = max_t
+    loss_fn.to(DEV)
+    targets = {k: v.to(DEV) for k, v in scenes.synthetic_targets(n_rays, ts, 5).items()}
+    g = torch.Generator().manual_seed(11)
+    upstream = {k: float(torch.rand(1, generator=g)) + 0.5 for k in fused_loss.TERMS}
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NSFF_FUSED_LOSS", fused)
+        leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.startswith(("zs_", "disocc")) and k != "xyzs_fine")
+                  for k, v in res.items()}
+        terms = loss_fn(leaves, targets, epoch=3, **kw)
+        assert fused_loss.applicable(loss_fn, leaves, targets, dict(kw, epoch=3)) == (fused == "1")
+        sum(upstream[k] * v for k, v in terms.items()).backward()
+        torch.cuda.synchronize()
+        out[fused] = ({k: float(v.detach()) for k, v in terms.items()},
+                      {k: v.grad.detach().cpu().numpy() for k, v in leaves.items() if v.grad is not None})
+    t1, g1 = out["1"]
+    t0, g0 = out["0"]
+    assert sorted(t1) == sorted(t0) == sorted(fused_loss.TERMS)
+    for k in t0:
+        assert abs(t1[k] - t0[k]) <= 2e-5 * max(abs(t0[k]), 1e-6), (k, t1[k], t0[k])
+    assert sorted(g1) == sorted(g0), sorted(set(g1) ^ set(g0))
+    for k in g0:
+        parity.assert_close("d loss / d " + k, g1[k], g0[k], 2e-4)
