@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      9
+#define NSFF_ABI_VERSION      10
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -163,6 +163,12 @@ typedef struct NsffFieldBwdArgs {
     float* d_side;              /* OUT or NULL (use_viewdir models, static_mode 2)           */
 } NsffFieldBwdArgs;
 int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
+
+/* d_xin (P,128) of nsff_field_backward -> gradient w.r.t. the points (derivative of PosEmbedding, reference
+ * nerf.py:17-30) and w.r.t. the per-ray time codes (sum over the ray's pts_per_ray consecutive points, the repeat of
+ * rendering.py:168).  d_xyz (P,3) / d_t (n_rays, in_t): either may be NULL.  freqs_host: HOST array.                */
+int nsff_field_input_backward(const float* d_xin, const float* xyz, int64_t n_rays, int32_t pts_per_ray,
+                              const float* freqs_host, int32_t n_freqs, int32_t in_t, float* d_xyz, float* d_t, void* stream);
 
 /* Batched weight-gradient GEMMs, K = points:  out_j = (1/G) * A_j^T . B_j over all point tiles, G as above.
  * A_j: fp16 fragment-major (T,4,a_rows,16), a_rows in {256, 32};  B_j: (T,4,b_rows,16), b_rows in {256, 128}.

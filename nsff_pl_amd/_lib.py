@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -135,6 +135,8 @@ _SIGNATURES = {
     "nsff_bwd_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
     "nsff_pack_weights_bwd": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp]),
     "nsff_field_backward": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldBwdArgs), _fp]),
+    "nsff_field_input_backward": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_int32, _fp,
+                                            _fp, _fp]),
     "nsff_weight_grad_scratch": (C.c_int64, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32]),
     "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "nsff_composite_backward": (C.c_int, [C.POINTER(CompositeBwdArgs), _fp]),
@@ -358,6 +360,19 @@ def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, 
                      dhead=dhead.data_ptr(), d_xin=_ptr(d_xin), d_side=_ptr(d_side))
     _check(load().nsff_field_backward(C.byref(desc), _ptr(model.packed(BWD_PACK)), C.byref(a), _stream()),
            "nsff_field_backward")
+
+
+def field_input_backward(d_xin, xyz, pts_per_ray, freqs, in_t, want_xyz, want_t):
+    """(d_xyz (P,3) or None, d_t (n_rays, in_t) or None) from the (P,128) trunk-input gradient."""
+    P = d_xin.shape[0]
+    n_rays = P // pts_per_ray
+    d_xyz = torch.empty(P, 3, device=d_xin.device) if want_xyz else None
+    d_t = torch.empty(n_rays, in_t, device=d_xin.device) if want_t else None
+    f = [float(v) for v in freqs]
+    arr = (C.c_float * max(len(f), 1))(*f)
+    _check(load().nsff_field_input_backward(_ptr(d_xin), _ptr(xyz), n_rays, int(pts_per_ray), arr, len(f), int(in_t),
+                                            _ptr(d_xyz), _ptr(d_t), _stream()), "nsff_field_input_backward")
+    return d_xyz, d_t
 
 
 def weight_grad(jobs, n_tiles, n_splits, out, bias, gmax):

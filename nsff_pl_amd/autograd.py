@@ -37,6 +37,32 @@ def grad_parameters(models, embeddings):
     return params
 
 
+class _EmbedRows(torch.autograd.Function):
+    """weight[idx] with a dense backward: one_hot(idx)^T . grad as a small GEMM.  torch's embedding backward takes
+    ~200 us for 1024 rows that hit only 30 distinct codes (atomics on a handful of rows); the render graph needs it
+    three times per step (t, t+1, t-1)."""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = weight.shape[0]
+        return weight.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        onehot = (idx[None, :] == torch.arange(ctx.n, device=idx.device)[:, None]).to(grad.dtype)      # (rows, N)
+        return onehot @ grad, None
+
+
+def embed_rows(module, idx):
+    """module(idx) -- through the dense-backward gather when `module` is a plain nn.Embedding on the GPU."""
+    if (isinstance(module, torch.nn.Embedding) and module.padding_idx is None and module.max_norm is None
+            and not module.sparse and module.weight.is_cuda and idx.dim() == 1 and module.weight.shape[0] <= 4096):
+        return _EmbedRows.apply(module.weight, idx)
+    return module(idx)
+
+
 def why_not_differentiable(models, rays, flows):
     """None, or the reason the native backward cannot serve this call."""
     if not rays.is_cuda:
@@ -100,7 +126,7 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
     t_embedded = None
     out_t = rec["output_transient"]
     if out_t:
-        t_embedded = rec["t_embedded_override"] if rec["t_embedded_override"] is not None else embeddings["t"](ts)
+        t_embedded = rec["t_embedded_override"] if rec["t_embedded_override"] is not None else embed_rows(embeddings["t"], ts)
     if rec["N_importance"] > 0:
         _render_pass(results, models["coarse"], "coarse", freqs_xyz, rays, rec["zs_coarse"], dir_embedded,
                      None, t_embedded, None, None, out_t, [], rec["noise_std"],
@@ -109,12 +135,12 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
     fine = models["fine"]
     a_embedded = None
     if fine.encode_appearance:
-        a_embedded = rec["a_embedded_override"] if rec["a_embedded_override"] is not None else embeddings["a"](ts)
+        a_embedded = rec["a_embedded_override"] if rec["a_embedded_override"] is not None else embed_rows(embeddings["a"], ts)
     flows = rec["flows"]
     t_next = t_prev = None
     if out_t and flows:
-        t_next = embeddings["t"](torch.clamp(ts + 1, max=max_t))
-        t_prev = embeddings["t"](torch.clamp(ts - 1, min=0))
+        t_next = embed_rows(embeddings["t"], torch.clamp(ts + 1, max=max_t))
+        t_prev = embed_rows(embeddings["t"], torch.clamp(ts - 1, min=0))
     zs = rec["zs_fine"] if rec["N_importance"] > 0 else rec["zs_coarse"]
     _render_pass(results, fine, "fine", freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded,
                  t_next, t_prev, out_t, flows, rec["noise_std"],

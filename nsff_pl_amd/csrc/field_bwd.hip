@@ -384,6 +384,54 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
     }
 }
 
+
+// ---- d(trunk input) -> d(points), d(per-ray time codes) -------------------------------------------------------
+// One workgroup per ray: the ray's d_xin rows (fp32 [point][128]: columns [0,in_xyz) position embedding, [64,64+in_t)
+// time code) pass through LDS in 64-point chunks; d_xyz = derivative of PosEmbedding (reference nerf.py:17-30:
+// [x, sin(f0 x), cos(f0 x), ...]), d_t = sum over the ray's points (the code is repeated per sample, rendering.py:168).
+struct InArgs {
+    const float* d_xin; const float* xyz; float* d_xyz; float* d_t;
+    long long n_rays; int pts_per_ray, n_freqs, in_t;
+    float freqs[NSFF_MAX_FREQS];
+};
+__global__ __launch_bounds__(256) void field_input_bwd_kernel(const InArgs a) {
+    constexpr int LDI = 132;                               // floats per LDS row (128 + 4: rows 16 B aligned, stride odd in 16-B units)
+    __shared__ __attribute__((aligned(16))) float sD[64 * LDI];
+    const long long ray = blockIdx.x;
+    const int S = a.pts_per_ray, tid = threadIdx.x;
+    const long long p_ray = ray * S;
+    float tsum = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int cnt = S - s0 < 64 ? S - s0 : 64;
+        __syncthreads();
+        for (int i = tid; i < cnt * 32; i += 256) {         // float4 chunks, coalesced
+            const int r = i >> 5, c4 = i & 31;
+            *reinterpret_cast<float4*>(sD + r * LDI + 4 * c4) =
+                *reinterpret_cast<const float4*>(a.d_xin + (p_ray + s0 + r) * 128 + 4 * c4);
+        }
+        __syncthreads();
+        if (a.d_xyz != nullptr && tid < 192) {
+            const int r = tid & 63, c = tid >> 6;           // point of the chunk, component
+            if (r < cnt) {
+                const long long p = p_ray + s0 + r;
+                const float x = a.xyz[p * 3 + c];
+                const float* d = sD + r * LDI;
+                float g = d[c];
+                for (int f = 0; f < a.n_freqs; ++f) {
+                    float sn, cs;
+                    sincosf(a.freqs[f] * x, &sn, &cs);
+                    g += a.freqs[f] * (cs * d[3 + 6 * f + c] - sn * d[3 + 6 * f + 3 + c]);
+                }
+                a.d_xyz[p * 3 + c] = g;
+            }
+        }
+        if (a.d_t != nullptr && tid < a.in_t) {
+            for (int r = 0; r < cnt; ++r) tsum += sD[r * LDI + 64 + tid];
+        }
+    }
+    if (a.d_t != nullptr && tid < a.in_t) a.d_t[ray * a.in_t + tid] = tsum;
+}
+
 // ---- K2 ---------------------------------------------------------------------------------------
 constexpr int MAX_WJOBS = 48;
 struct WJob { const _Float16* a; const _Float16* b; long long out_off; long long bias_off; };   // offsets into the scratch
@@ -711,6 +759,21 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     if (n > MAX_BSTEPS) return NSFF_ERR_INVALID;
     k.n_steps = n;
     hipLaunchKernelGGL(nsff_field_bwd_kernel, dim3((unsigned)k.n_tiles), dim3(256), 0, (hipStream_t)stream, k);
+    return nsff_launch_status();
+}
+
+int nsff_field_input_backward(const float* d_xin, const float* xyz, int64_t n_rays, int32_t pts_per_ray,
+                              const float* freqs_host, int32_t n_freqs, int32_t in_t, float* d_xyz, float* d_t, void* stream) {
+    if (n_rays < 0 || pts_per_ray < 1 || n_freqs < 0 || n_freqs > NSFF_MAX_FREQS || in_t < 0 || in_t > 64) return NSFF_ERR_INVALID;
+    if (n_rays == 0 || (!d_xyz && !d_t)) return NSFF_OK;
+    if (!d_xin || (d_xyz && (!xyz || !freqs_host))) return NSFF_ERR_NULL;
+    if ((uintptr_t)d_xin & 15) return NSFF_ERR_ALIGN;
+    if (n_rays > 0x7fffffffLL) return NSFF_ERR_INVALID;
+    InArgs a{};
+    a.d_xin = d_xin; a.xyz = xyz; a.d_xyz = d_xyz; a.d_t = d_t;
+    a.n_rays = n_rays; a.pts_per_ray = pts_per_ray; a.n_freqs = n_freqs; a.in_t = in_t;
+    for (int i = 0; i < n_freqs; ++i) a.freqs[i] = freqs_host[i];
+    hipLaunchKernelGGL(field_input_bwd_kernel, dim3((unsigned)n_rays), dim3(256), 0, (hipStream_t)stream, a);
     return nsff_launch_status();
 }
 

@@ -1,12 +1,12 @@
-// N1: the NSFF training objective as three launches (reference losses.py:8-28 shiftscale_invariant_depthloss,
+// N1: the NSFF training objective as four small launches forward + one backward (reference losses.py:8-28 shiftscale_invariant_depthloss,
 // :31-171 NeRFWLoss) instead of the ~580 elementwise / reduction kernels the torch expression of its forward and
 // backward needs.  All eleven terms, train-mode NSFF configuration (flows + disocclusion present, topk == 1, no
 // per-ray weights, thickness == 1); every term is reduced to its scalar mean like the reference does.
 //
 //   loss_sums_kernel   grid-stride sums of the per-sample disocclusion weights (their means normalise cyc_l)
-//   loss_stats_kernel  ONE workgroup: medians (rank counting in LDS, torch.median = lower median) and mean absolute
-//                      deviations of depth_fine / depth_coarse / -disp, the second-level sums their gradients need,
-//                      means of the per-ray disocclusion weights, counts of valid flow projections
+//   loss_median_kernel medians of depth_fine / depth_coarse / -disp by rank counting in LDS (torch.median = lower median)
+//   loss_stats_kernel  ONE workgroup: mean absolute deviations around them, the second-level sums their gradients
+//                      need, means of the per-ray disocclusion weights, counts of valid flow projections
 //   loss_rays_kernel   one wavefront per ray, lane = sample: term sums (mode 1) or the gradient of
 //                      sum_k w_k * term_k w.r.t. every consumed render tensor (mode 2, w = upstream scalars)
 // Bound: HBM (reads ~70 B/sample, writes ~50 B/sample in mode 2); a few microseconds per launch at 1024 x 192.
@@ -102,30 +102,41 @@ __device__ __forceinline__ void block_sum4(float (&v)[4], float* sRed) {
     }
 }
 
-__global__ __launch_bounds__(1024) void loss_stats_kernel(const NsffLossArgs a) {
+// medians by rank counting (rank = # smaller, ties broken by index): block (b, v) ranks 256 elements of vector v
+__global__ __launch_bounds__(256) void loss_median_kernel(const NsffLossArgs a) {
     __shared__ float sX[MAXN];
+    const int N = (int)a.n_rays, v = blockIdx.y;
+    const float* src = v == 0 ? a.depth_fine : (v == 1 ? a.depth_coarse : a.disps);
+    if (src == nullptr) return;
+    for (int i = threadIdx.x; i < N; i += 256) sX[i] = v == 2 ? -src[i] : src[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float x = sX[i];
+    int rank = 0;
+    for (int j = 0; j < N; ++j) { const float y = sX[j]; rank += (y < x || (y == x && j < i)) ? 1 : 0; }
+    if (rank == (N - 1) / 2) {                              // torch.median: the lower of the two middle elements
+        a.stats[ST_MED + v] = x; a.stats[ST_IDX + v] = __int_as_float(i);
+    }
+}
+
+__global__ __launch_bounds__(1024) void loss_stats_kernel(const NsffLossArgs a) {
     __shared__ float sRed[64];
     __shared__ float sMed[3], sMad[3];
     const int N = (int)a.n_rays, tid = threadIdx.x;
-    const int target = (N - 1) / 2;                               // torch.median: the lower of the two middle elements
-    // ---- medians by rank counting (rank = # smaller, ties broken by index) ----
-    for (int v = 0; v < 3; ++v) {
-        const float* src = v == 0 ? a.depth_fine : (v == 1 ? a.depth_coarse : a.disps);
-        if (src == nullptr) { if (tid == 0) { sMed[v] = 0.f; } continue; }
-        __syncthreads();
-        for (int i = tid; i < N; i += 1024) sX[i] = v == 2 ? -src[i] : src[i];
-        __syncthreads();
-        for (int i = tid; i < N; i += 1024) {
-            const float x = sX[i];
-            int rank = 0;
-            for (int j = 0; j < N; ++j) { const float y = sX[j]; rank += (y < x || (y == x && j < i)) ? 1 : 0; }
-            if (rank == target) { sMed[v] = x; a.stats[ST_MED + v] = x; a.stats[ST_IDX + v] = __int_as_float(i); }
-        }
-        __syncthreads();
+    // ---- mean absolute deviations around the medians of loss_median_kernel ----
+    {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < N; i += 1024) acc[0] += fabsf(sX[i] - sMed[v]);
+        const float m0 = a.stats[ST_MED], m1 = a.stats[ST_MED + 1], m2 = a.stats[ST_MED + 2];
+        for (int i = tid; i < N; i += 1024) {
+            acc[0] += fabsf(a.depth_fine[i] - m0);
+            if (a.depth_coarse != nullptr) acc[1] += fabsf(a.depth_coarse[i] - m1);
+            acc[2] += fabsf(-a.disps[i] - m2);
+        }
         block_sum4(acc, sRed);
-        if (tid == 0) { sMad[v] = acc[0] / (float)N; a.stats[ST_MAD + v] = sMad[v]; }
+        if (tid == 0) {
+            for (int v = 0; v < 3; ++v) { sMed[v] = a.stats[ST_MED + v]; sMad[v] = acc[v] / (float)N; a.stats[ST_MAD + v] = sMad[v]; }
+        }
     }
     __syncthreads();
     // ---- second-level sums of the depth terms: y = (x - m) / s, target t = (-disp - m_t) / s_t, g = 2 (y - t) lambda / N ----
@@ -164,10 +175,13 @@ __global__ __launch_bounds__(1024) void loss_stats_kernel(const NsffLossArgs a) 
 template <int MODE>
 __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
     const int lane = threadIdx.x & 63;
-    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= a.n_rays) return;
     const int S = a.n_samples;
     const float N = (float)a.n_rays;
+    __shared__ float sPart[4][N_TERMS];
+    float tot[N_TERMS];
+#pragma unroll
+    for (int k = 0; k < N_TERMS; ++k) tot[k] = 0.f;
+    for (long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.n_rays; n += (long long)gridDim.x * 4) {
     const float* st = a.stats;
     const float lam_d = a.hyper[0], lam_f = a.hyper[1], cross_w = a.hyper[2], lam_reg = a.hyper[3], lam_ent = a.hyper[4];
     float w[N_TERMS];
@@ -330,9 +344,19 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
     }
     if (MODE == 1) {
 #pragma unroll
+        for (int k = 0; k < N_TERMS; ++k) tot[k] += part[k];
+    }
+    }   // rays of this wave
+    if (MODE == 1) {      // one atomic per term and WORKGROUP (they serialise in the L2: ~13 ns each)
+#pragma unroll
         for (int k = 0; k < N_TERMS; ++k) {
-            const float t = wave_sum(part[k]) / N;
-            if (lane == 0 && t != 0.f) atomicAdd(a.terms + k, t);
+            const float t = wave_sum(tot[k]) / N;
+            if (lane == 0) sPart[threadIdx.x >> 6][k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < N_TERMS) {
+            const float t = sPart[0][threadIdx.x] + sPart[1][threadIdx.x] + sPart[2][threadIdx.x] + sPart[3][threadIdx.x];
+            if (t != 0.f) atomicAdd(a.terms + threadIdx.x, t);
         }
     }
 }
@@ -361,8 +385,9 @@ int nsff_nerfw_loss(const NsffLossArgs* args, int mode, void* stream) {
         if (e != hipSuccess) return nsff_hip_fail(e);
         const long long total = a.n_rays * a.n_samples;
         hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)std::min<long long>((total + 2047) / 2048, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(loss_median_kernel, dim3((unsigned)((a.n_rays + 255) / 256), 3), dim3(256), 0, st, a);
         hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(1024), 0, st, a);
-        hipLaunchKernelGGL(loss_rays_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(loss_rays_kernel<1>, dim3(std::min(blocks, 64u)), dim3(256), 0, st, a);
     } else {
         if (!a.term_w || !a.g_rgb_fine || !a.g_depth_fine || !a.g_t_weights || !a.g_s_weights || !a.g_xyz_fw || !a.g_xyz_bw ||
             !a.g_rgb_fw || !a.g_rgb_bw || !a.g_xyzs_fw_bw || !a.g_xyzs_bw_fw || !a.g_xyzs_fw || !a.g_xyzs_bw) return NSFF_ERR_NULL;

@@ -56,7 +56,7 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
             if keys is not None and k not in keys:
                 continue
             results.setdefault(k, []).append(v.cpu() if to_cpu else v)
-    return {k: torch.cat(v, 0) for k, v in results.items()}
+    return {k: v[0] if len(v) == 1 else torch.cat(v, 0) for k, v in results.items()}
 
 
 @torch.no_grad()

@@ -257,11 +257,8 @@ class _FieldFn(torch.autograd.Function):
                         put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
 
         d_xyz = d_t = d_a = None
-        if d_xin is not None:
-            if ctx.needs_input_grad[2]:
-                d_t = d_xin[:, 64:64 + n_t].reshape(P // s, s, -1).sum(1)
-            if ctx.needs_input_grad[1]:
-                d_xyz = _posenc_backward(d_xin, xyz, freqs)
+        if d_xin is not None:              # derivative of the positional encoding + per-ray sum of the time-code rows
+            d_xyz, d_t = _lib.field_input_backward(d_xin, xyz, s, freqs, n_t, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         if d_side is not None:               # per-ray appearance code: sum over the ray's points (rendering.py:168,172)
             c0 = model.in_channels_dir
             d_a = d_side[:, c0:c0 + model.in_channels_a].reshape(P // s, s, -1).sum(1)

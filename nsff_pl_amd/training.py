@@ -59,9 +59,9 @@ class NSFFTrainer:
 
     def __init__(self, models, embeddings, n_frames, hparams=None, Ks=None, Ps=None,
                  output_transient=True, output_transient_flow=("fw", "bw", "disocc"), graph=False):
-        """graph=True: the whole step (forward kernels, loss, backward kernels, Adam) is captured once into a
-        hipGraph (``torch.cuda.CUDAGraph``) and replayed -- the step is ~1100 small launches and otherwise
-        launch-bound.  Needs fixed batch shapes, topk == 1, a single process (no collective inside the graph)."""
+        """graph=True: the step is captured once into two hipGraphs (``torch.cuda.CUDAGraph``) and replayed: graph A =
+        zero_grad + forward kernels + loss + backward kernels, graph B = Adam; between them -- outside any capture --
+        the flat RCCL gradient all-reduce when world > 1.  Needs fixed batch shapes and topk == 1."""
         hp = dict(self.DEFAULTS)
         if hparams is not None:
             given = hparams if isinstance(hparams, dict) else vars(hparams)
@@ -80,11 +80,35 @@ class NSFFTrainer:
         self.params = grad_parameters(models, embeddings)
         self.optimizer = self.scheduler = None
         self.current_epoch = 0
-        self._graph = self._static_batch = self._static_log = None
+        self._graph = self._graph_opt = self._static_batch = self._static_log = None
+        self._flat_grad = None
         self._geo = None                     # device scalars the captured loss reads (lambda_geo, epoch ramp)
+
+    def _setup_flat_grads(self):
+        """Every .grad becomes a view of ONE flat buffer: zero_grad is a single memset and the data-parallel
+        all-reduce a single collective on the buffer itself (no cat / copy-back of ~100 tensors)."""
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        if self._flat_grad is None or self._flat_grad.numel() != total or self._flat_grad.device != dev:
+            self._flat_grad = torch.zeros(total, device=dev, dtype=self.params[0].dtype)
+        off = 0
+        for p in self.params:
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_grad(self):
+        self._flat_grad.zero_()
+
+    def allreduce(self):
+        """One flat RCCL all-reduce (mean) of all gradients."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if world > 1:
+            dist.all_reduce(self._flat_grad)
+            self._flat_grad /= world
 
     def _make_optimizer(self):
         hp = self.hp
+        self._setup_flat_grads()
         if self.graph:                        # capturable Adam: step counter and lr live on the device
             lr = torch.tensor(float(hp["lr"]), device=self.params[0].device)
             self.optimizer = torch.optim.Adam(self.params, lr=lr, eps=1e-8, weight_decay=hp["weight_decay"], capturable=True)
@@ -114,7 +138,8 @@ class NSFFTrainer:
                                 test_time=test_time, **kwargs)
             for k, v in chunk.items():
                 results[k].append(v)
-        return {k: torch.cat(v, 0) for k, v in results.items()}
+        # (a single chunk -- every training batch -- is handed on as is: torch.cat of one tensor would copy all 47 keys)
+        return {k: v[0] if len(v) == 1 else torch.cat(v, 0) for k, v in results.items()}
 
     # train.py:174-176
     def on_train_epoch_start(self, epoch):
@@ -160,41 +185,44 @@ class NSFFTrainer:
             self._make_optimizer()
         if self.graph:
             return self._graph_step(batch)
-        self.optimizer.zero_grad(set_to_none=True)
+        g0 = self.params[0].grad
+        if g0 is None or g0.data_ptr() != self._flat_grad.data_ptr():      # a caller replaced the .grad tensors
+            self._setup_flat_grads()
+        self.zero_grad()
         loss, log = self.training_step(batch)
         with field_grad.deferred_weight_grads():
             loss.backward()
-        allreduce_gradients(self.params)
+        self.allreduce()
         self.optimizer.step()
         return log
 
-    def _eager_graph_body(self):
-        self.optimizer.zero_grad(set_to_none=False)
+    def _graph_body_backward(self):
+        self.zero_grad()
         loss, log = self.training_step(self._static_batch)
         with field_grad.deferred_weight_grads():
             loss.backward()
-        self.optimizer.step()
         return log
 
     def _graph_step(self, batch):
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            raise RuntimeError("graph=True captures a single-process step (no collective inside the graph)")
         if self._graph is None:
             if self._geo is None:
                 self.on_train_epoch_start(self.current_epoch)
             self._static_batch = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
-            for p in self.params:
-                p.grad = torch.zeros_like(p)
+            self._setup_flat_grads()
             keep = [p.detach().clone() for p in self.params]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):              # warm-up off the capture stream (allocator, pack caches, Adam state)
                 for _ in range(3):
-                    self._eager_graph_body()
+                    self._graph_body_backward()
+                    self.optimizer.step()
             torch.cuda.current_stream().wait_stream(side)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._static_log = self._eager_graph_body()
+                self._static_log = self._graph_body_backward()
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt):
+                self.optimizer.step()
             # the warm-up steps were not part of the schedule: undo them (parameters and Adam moments / step count)
             with torch.no_grad():
                 for p, k in zip(self.params, keep):
@@ -206,6 +234,8 @@ class NSFFTrainer:
         for k, v in self._static_batch.items():
             v.copy_(batch[k])
         self._graph.replay()
+        self.allreduce()                        # outside the captures: RCCL is not captured
+        self._graph_opt.replay()
         for m in self.models.values():          # replays change the weights without bumping tensor versions
             m._pack_cache.invalidate()
         return self._static_log

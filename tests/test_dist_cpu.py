@@ -140,7 +140,7 @@ def _trainer_worker(rank, world, port, ret):
                 ("static_rgb.0.bias", "static_xyz_encoding_1.0.weight", "static_sigma.bias"))
     in_sync = bool(torch.equal(gathered[0], gathered[1]))
     # control: without the gradient all-reduce the replicas (different batches) must drift apart
-    training.allreduce_gradients = lambda params, group=None: None
+    tr.allreduce = lambda: None
     _, gathered = three_steps()
     drifted = not torch.equal(gathered[0], gathered[1])
     ret[rank] = in_sync and moved and drifted and bool(torch.isfinite(log["train/loss"]))
