@@ -148,11 +148,11 @@ class Bench:
             rays_f = evaluate.frame_rays(K, c2w, H, W, device=device, first_pixel=lo, n_pixels=hi - lo)
             ts_f = torch.full((hi - lo,), t, device=device, dtype=torch.long)
             return evaluate.render_frame(self.models, self.emb, rays_f, ts_f, scenes.N_FRAMES - 1, 128, 64, 1024 * 32,
-                                         keys=keys, **ekw)
+                                         keys=keys, to_host=to_host or None, **ekw)
 
         def eval_step():
             out = render_t(7, ("rgb_fine", "depth_fine"))
-            if world > 1:
+            if world > 1 and not to_host:
                 counts = [b - a_ for a_, b in (ndist.shard_bounds(H * W, world, r) for r in range(world))]
                 ndist.all_gather_pixels(out, ("rgb_fine", "depth_fine"), counts=counts)
             return out
@@ -237,6 +237,9 @@ def aux_block(bench, args):
     t, _ = timed(bench.frame_steps(False), 3, 1, 1, dev)
     aux["eval_ms_per_frame"] = t / 3 * 1e3
     aux["eval_ray_samples_per_s"] = 288 * 512 * (128 + 64) * 3 / t
+    # ... and with the pixels (rgb_fine, depth_fine) delivered to pinned host memory chunk by chunk on a copy stream (row N4)
+    t, _ = timed(bench.frame_steps(False, to_host=True), 3, 1, 1, dev)
+    aux["eval_ms_per_frame_pixels_to_pinned_host"] = t / 3 * 1e3
     # (3) C5 inner loop: 2 rendered + 9 interpolated frames
     t, _ = timed(bench.frame_steps(True), 2, 1, 1, dev)
     aux["interp_ms_per_11_frames"] = t / 2 * 1e3

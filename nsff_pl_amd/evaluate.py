@@ -7,7 +7,9 @@ and PSNR -- the renderer-side pieces of the reference's ``eval.py`` / ``datasets
 * :func:`render_frame`  -- the ray-chunk loop of ``eval.f`` (eval.py:81-110): ``test_time=True``,
                            ``perturb = noise_std = 0``, per-key concatenation.  Results stay on the GPU and
                            ``keys=`` selects what is kept (the reference copies EVERY key of every chunk
-                           to the host, eval.py:106-107; pass ``to_cpu=True`` for that behaviour).
+                           to the host with a blocking ``.cpu()``, eval.py:106-107; ``to_cpu=True`` does that).
+                           ``to_host=`` is the asynchronous form of the same egress (row N4): the kept keys of
+                           chunk i travel to PINNED host buffers on a copy stream while chunk i+1 renders.
 * :func:`render_frame_sharded` -- the same frame split across the ranks of ``torch.distributed``
                            with one pixel all-gather (:mod:`nsff_pl_amd.dist`).
 * :func:`psnr`          -- metrics.py:6-16.
@@ -36,15 +38,51 @@ def frame_rays(K, c2w, H, W, near=1.0, device="cuda", first_pixel=0, n_pixels=No
     return rays
 
 
+_PINNED = {}          # (key, shape) -> pinned host tensor, reused frame after frame (hipHostMalloc is slow)
+_COPY_STREAM = {}
+
+
+def pinned_buffer(key, shape):
+    """A page-locked host tensor for result `key` of a whole frame; cached, so a frame loop allocates once."""
+    ck = (key, tuple(shape))
+    if ck not in _PINNED:
+        _PINNED[ck] = torch.empty(*shape, dtype=torch.float32, pin_memory=True)
+    return _PINNED[ck]
+
+
+class HostFrame(dict):
+    """Result of ``render_frame(..., to_host=...)``: {key: pinned host tensor}.  The device-to-host copies may still be
+    in flight on the copy stream; ``wait()`` (or ``render_frame(..., sync=True)``, the default) blocks until they landed."""
+    event = None
+
+    def wait(self):
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+        return self
+
+
 @torch.no_grad()
 def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, chunk=1024 * 32,
-                 keys=None, to_cpu=False, **kwargs):
+                 keys=None, to_cpu=False, to_host=None, sync=True, **kwargs):
     """Batched inference on the rays of one frame (reference eval.py:81-110).
 
     keys: iterable of result keys to keep (default: all, like the reference).
+    to_cpu=True: the reference's egress -- a blocking ``.cpu()`` of every kept key after every chunk (eval.py:106-107).
+    to_host=True | {key: pinned tensor}: asynchronous egress -- the kept keys of each chunk are copied into page-locked
+    host buffers (frame-sized, cached / caller-provided) on a side stream while the next chunk renders; returns a
+    :class:`HostFrame` of host tensors (``sync=False`` leaves the last copies in flight: call ``.wait()``).
     """
     B = rays.shape[0]
     results = {}
+    host, copy_stream = None, None
+    if to_host:
+        dev = rays.device
+        if dev not in _COPY_STREAM:
+            _COPY_STREAM[dev] = torch.cuda.Stream(device=dev)
+        copy_stream = _COPY_STREAM[dev]
+        host = HostFrame()
+        given = to_host if isinstance(to_host, dict) else {}
     for i in range(0, B, chunk):
         kw = dict(kwargs)
         for per_ray in ("view_dir", "t_embedded", "a_embedded"):
@@ -52,10 +90,27 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
                 kw[per_ray] = kw[per_ray][i:i + chunk]
         out = render_rays(models, embeddings, rays[i:i + chunk], None if ts is None else ts[i:i + chunk],
                           max_t, N_samples, 0, 0, N_importance, chunk, test_time=True, **kw)
-        for k, v in out.items():
-            if keys is not None and k not in keys:
-                continue
+        kept = {k: v for k, v in out.items() if keys is None or k in keys}
+        if host is not None:
+            done = torch.cuda.Event()
+            done.record()                                     # this chunk's kernels, on the render stream
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                for k, v in kept.items():
+                    if k not in host:
+                        shape = (B,) + tuple(v.shape[1:])
+                        host[k] = given[k] if k in given else pinned_buffer(k, shape)
+                        if tuple(host[k].shape) != shape or not host[k].is_pinned():
+                            raise ValueError(f"to_host['{k}'] must be a pinned float32 tensor of shape {shape}")
+                    host[k][i:i + v.shape[0]].copy_(v, non_blocking=True)
+                    v.record_stream(copy_stream)              # the allocator must not recycle it before the copy ran
+            continue
+        for k, v in kept.items():
             results.setdefault(k, []).append(v.cpu() if to_cpu else v)
+    if host is not None:
+        host.event = torch.cuda.Event()
+        host.event.record(copy_stream)
+        return host.wait() if sync else host
     return {k: v[0] if len(v) == 1 else torch.cat(v, 0) for k, v in results.items()}
 
 

@@ -371,3 +371,47 @@ def test_full_frame_eval_512x288(hip_lib, precision):
     parity.assert_close("depth_fine", out["depth_fine"].cpu().numpy()[idx], want["depth_fine"])
     p = float(evaluate.psnr(torch.from_numpy(got), torch.from_numpy(want["rgb_fine"])))
     assert p > 80.0, f"PSNR(build, oracle) = {p:.1f} dB"
+
+
+def test_frame_egress_to_pinned_host_buffers(hip_lib, precision):
+    """Row N4 (reference eval.py:87-110,222: per-chunk .cpu() of every key): the asynchronous egress returns exactly
+    the GPU-resident values, in pinned memory, and does not slow the frame loop down."""
+    if precision != "f16x3":
+        pytest.skip("one arithmetic is enough for the copy path")
+    import time
+    from nsff_pl_amd import evaluate
+    cfg = dict(scenes.CASES["g4_nsff_test"])
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    H, W = 144, 256
+    K = np.array([[200., 0, W / 2], [0, 200., H / 2], [0, 0, 1]], np.float32)
+    c2w = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 0.1]], np.float32)
+    rays = evaluate.frame_rays(K, c2w, H, W, device=DEV)
+    ts = torch.full((H * W,), 7, dtype=torch.long, device=DEV)
+    kw = scenes.render_kwargs(cfg)
+    keys = ("rgb_fine", "depth_fine", "static_rgbs_fine", "zs_fine")           # pixels and two per-sample tensors
+    args = (models, emb, rays, ts, 29, 64, 64)
+    gpu = evaluate.render_frame(*args, chunk=8192, keys=keys, **kw)
+    host = evaluate.render_frame(*args, chunk=8192, keys=keys, to_host=True, **kw)
+    assert isinstance(host, evaluate.HostFrame) and set(host) == set(keys)
+    for k in keys:
+        assert not host[k].is_cuda and host[k].is_pinned() and torch.equal(host[k], gpu[k].cpu()), k
+    # caller-provided buffers, copies left in flight
+    mine = {"rgb_fine": torch.empty(H * W, 3, pin_memory=True)}
+    out = evaluate.render_frame(*args, chunk=8192, keys=("rgb_fine",), to_host=mine, sync=False, **kw)
+    assert out["rgb_fine"] is mine["rgb_fine"]
+    assert torch.equal(out.wait()["rgb_fine"], gpu["rgb_fine"].cpu())
+    with pytest.raises(ValueError):
+        evaluate.render_frame(*args, chunk=8192, keys=("rgb_fine",), to_host={"rgb_fine": torch.empty(5, 3, pin_memory=True)}, **kw)
+
+    def timed(**extra):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            evaluate.render_frame(*args, chunk=8192, keys=keys, **extra, **kw)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3
+    timed(); timed(to_host=True)                              # warm both paths
+    t_gpu, t_host, t_block = timed(), timed(to_host=True), timed(to_cpu=True)
+    print(f"frame {H}x{W}: resident {t_gpu * 1e3:.1f} ms, async pinned egress {t_host * 1e3:.1f} ms, blocking .cpu() {t_block * 1e3:.1f} ms")
+    assert t_host <= 1.05 * t_gpu + 2e-3, (t_host, t_gpu)
