@@ -39,7 +39,8 @@ extern "C" {
 /* Raw field record (what NeRF.forward returns per point, reference nerf.py:187-213):
  *   [0..2] static rgb (sigmoid)  [3] static sigma (raw)
  *   [4..6] transient rgb         [7] transient sigma (raw)
- *   [8..10] flow_fw = flow_scale*tanh(.)   [11..13] flow_bw   [14..15] unused */
+ *   [8..10] flow_fw = flow_scale*tanh(.)   [11..13] flow_bw   [14..15] unused
+ * nsff_field_query writes whole 64-byte records: slots a launch does not evaluate are written as 0. */
 
 /* ---- model description: mirrors NeRF.__init__ (reference nerf.py:34-40) ---- */
 typedef struct NsffModelDesc {

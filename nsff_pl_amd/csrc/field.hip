@@ -227,8 +227,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void nsff_field_kernel(const FieldKArg
     const long long p0 = (long long)blockIdx.x * TM;
     const float* __restrict__ pk = a.packed;
     const float* sA = sX + (lane & 31) * LDA + (lane >> 5) * 4;
-    const bool valid = (p0 + lane) < a.n_points;
-    float* raw_rec = a.raw + (p0 + lane) * NSFF_RAW_STRIDE;
+    const bool valid = true;      // (every record of the tile's LDS image is filled; the tail is cut when it is written out)
+    // raw records of the tile: filled by the heads, written out as whole 64-byte rows at the end (scattered 4-byte
+    // stores made the HBM side read-modify-write every record); slots this launch does not evaluate are written as 0
+    __shared__ __attribute__((aligned(16))) float sRaw[TM * NSFF_RAW_STRIDE];
+    for (int i = threadIdx.x; i < TM * NSFF_RAW_STRIDE; i += NTHREADS) sRaw[i] = 0.f;
+    float* raw_rec = sRaw + lane * NSFF_RAW_STRIDE;
 
     f32x16 acc[2][2];
     auto seg = [&](uint32_t off, int nkb) {
@@ -296,6 +300,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void nsff_field_kernel(const FieldKArg
         const unsigned kinds = 0x15u | (0xAAAu << 8);
         heads(sX, pk + a.L.t_head_w, pk + a.L.t_head_b, (int)a.L.t_head_rows, kinds, a.flow_scale,
               raw_rec, 4, valid, wave, lane);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TM * (NSFF_RAW_STRIDE / 4); i += NTHREADS) {
+        if (p0 + i / (NSFF_RAW_STRIDE / 4) < a.n_points)
+            reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
     }
 }
 

@@ -13,8 +13,10 @@
 //   * A operand = weights, streamed from L2 as pre-packed hi/lo tiles (nsff_layout_h3.h);
 //   * B operand = activations, kept in LDS as two fp16 planes Xh/Xl [points][264] (528-B rows:
 //     conflict-free ds_read_b128);
-//   * the 32x32 accumulator then holds 4 consecutive neurons of one point per register quad, so
-//     the epilogue packs them to 8-byte hi / lo stores (ds_write_b64).
+//   * the 32x32 accumulator then holds 4 consecutive neurons of one point per register quad; the
+//     epilogue packs them to fp16 and lanes i / i+32 trade halves (v_permlane32_swap) so that every
+//     lane owns 8 consecutive neurons = one 16-byte, bank-conflict-free ds_write_b128 per plane
+//     (the direct 8-byte stores are 2-way conflicted with 528-byte rows).
 // SPLIT = false is the FAST MODE ("f16", not parity-grade): the same kernel with every operand rounded once to
 // fp16 (round-to-nearest-even, clamped to the fp16 range) and ONE MFMA per product -- only the hi halfs of the
 // packed weights are fetched, the LDS tile is a single fp16 plane (so a 128-point workgroup needs 67.6 KB and two
@@ -50,7 +52,23 @@ __device__ unsigned long long g_h3_span[2] = {~0ull, 0ull};     // first / last 
 
 namespace {
 
-constexpr int LDH = 264;          // halfs per LDS row (528 B; 528/16 = 33 odd)
+#ifndef H3_LDH
+#define H3_LDH 264
+#endif
+constexpr int LDH = H3_LDH;       // halfs per LDS row.  264 (528 B = 33 x 16 B): conflict-free ds_read_b128, 2-way conflicts on the
+                                  // epilogue's ds_write_b64.  260 (520 B, experiment): rows only 8-byte aligned -> B operands as two
+                                  // ds_read_b64, and both the reads and the 8-byte epilogue stores are conflict-free.
+// 8 consecutive halfs of an LDS row (one B-operand fragment)
+__device__ __forceinline__ h8 lds_h8(const _Float16* p) {
+    if constexpr (LDH % 8 == 0) {
+        return *reinterpret_cast<const h8*>(p);
+    } else {
+        const h4 a = *reinterpret_cast<const h4*>(p), b = *reinterpret_cast<const h4*>(p + 4);
+        h8 r;
+        r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+        return r;
+    }
+}
 
 // The network is executed as a short program of GEMM steps (built on the host), so that the
 // kernel holds exactly one copy of the GEMM loop, the epilogue, the input builders and the heads.
@@ -148,12 +166,22 @@ __device__ __forceinline__ void load_w(WFrag<MTW, true>& f, const uint4* __restr
     }
 }
 
+// B-operand rows of this lane: one LDS pointer per 32-point tile (hi plane, lo plane), row stride baked in.
+template <int NT> struct BRows { const _Float16* h[NT]; const _Float16* l[NT]; };
+template <int NT>
+__device__ __forceinline__ BRows<NT> b_rows(const _Float16* bh, const _Float16* bl, int ld) {
+    BRows<NT> b;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { b.h[nt] = bh + nt * 32 * ld; b.l[nt] = bl + nt * 32 * ld; }
+    return b;
+}
+
 template <int NT, bool SPLIT>
-__device__ __forceinline__ void load_x(XFrag<NT, SPLIT>& f, const _Float16* sBh, const _Float16* sBl, int ks) {
+__device__ __forceinline__ void load_x(XFrag<NT, SPLIT>& f, const BRows<NT>& b, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        f.xh[nt] = *reinterpret_cast<const h8*>(sBh + nt * 32 * LDH + ks * 16);
-        if constexpr (SPLIT) f.xl[nt] = *reinterpret_cast<const h8*>(sBl + nt * 32 * LDH + ks * 16);
+        f.xh[nt] = lds_h8(b.h[nt] + ks * 16);
+        if constexpr (SPLIT) f.xl[nt] = lds_h8(b.l[nt] + ks * 16);
     }
 }
 
@@ -200,45 +228,46 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW
 // k-steps ahead of the MFMAs, activations (LDS) one.
 template <int NT, int MTW, bool SPLIT>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLIT>& ring, const uint4* __restrict__ wp,
-                                         const _Float16* sBh, const _Float16* sBl, int nks) {
+                                         BRows<NT> b, int nks) {
     // nks is a multiple of 4 (every K-segment is zero-padded to 64 columns): no per-step branches.
     XFrag<NT, SPLIT> x0, x1;
-    load_x<NT>(x0, sBh, sBl, 0);
+    load_x<NT, SPLIT>(x0, b, 0);
 #pragma unroll 1
     for (int ks = 4; ks < nks; ks += 4) {        // every group but the last: refill the ring
         // sched_barrier pins (a) each activation read one k-step AHEAD of the MFMAs that consume it (left alone hipcc
         // sinks the ds_reads behind the previous k-step's MFMAs, merges x0/x1 and exposes the LDS latency every k-step)
         // and (b) each weight refill right behind the MFMAs that free its ring slot (left alone hipcc sinks all 16
         // loads to the end of the group and the ring never runs ahead)
-        load_x<NT>(x1, sBh, sBl, 1);
+        load_x<NT, SPLIT>(x1, b, 1);
         H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[0], x0);
         load_w(ring.r[0], wp);
         H3_PIN();
-        load_x<NT>(x0, sBh, sBl, 2);
+        load_x<NT, SPLIT>(x0, b, 2);
         H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[1], x1);
         load_w(ring.r[1], wp);
         H3_PIN();
-        load_x<NT>(x1, sBh, sBl, 3);
+        load_x<NT, SPLIT>(x1, b, 3);
         H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[2], x0);
         load_w(ring.r[2], wp);
         H3_PIN();
-        load_x<NT>(x0, sBh, sBl, 4);
+        load_x<NT, SPLIT>(x0, b, 4);
         H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[3], x1);
         load_w(ring.r[3], wp);
         H3_PIN();
-        sBh += 64; sBl += 64;                    // four k-steps of 16 halfs
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { b.h[nt] += 64; if constexpr (SPLIT) b.l[nt] += 64; }      // four k-steps of 16 halfs
     }
-    load_x<NT>(x1, sBh, sBl, 1);
+    load_x<NT, SPLIT>(x1, b, 1);
     H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[0], x0);
-    load_x<NT>(x0, sBh, sBl, 2);
+    load_x<NT, SPLIT>(x0, b, 2);
     H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[1], x1);
-    load_x<NT>(x1, sBh, sBl, 3);
+    load_x<NT, SPLIT>(x1, b, 3);
     H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[2], x0);
     mma_step<NT, MTW>(acc, ring.r[3], x1);
@@ -270,10 +299,27 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[MTW][NT], const BiasRegs<
 }
 
 // `mask` (or null) receives the ReLU sign bits of this lane's accumulators: bit (mt*NT + nt)*16 + 4q + e.
+// Two 8-byte groups (4 neurons x fp16 each) of lane i and lane i+32 -> one 16-byte group per lane: lanes 0..31 end up
+// with neurons [8p, 8p+8) of the 32-neuron block, lanes 32..63 with [16+8p, 16+8p+8) (v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another).  `a` = group q = p, `b` = group q = p + 2.
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u4v pair_halves(h4 a, h4 b) {
+    const u2v ua = __builtin_bit_cast(u2v, a), ub = __builtin_bit_cast(u2v, b);
+    const u2v s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+    const u2v s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+    u4v r;
+    r[0] = s0[0]; r[1] = s1[0]; r[2] = s0[1]; r[3] = s1[1];
+    return r;
+}
+// column (halfs) of the 16-byte group pair_halves() leaves in this lane
+__device__ __forceinline__ int pair_col(int p, int lane) { return 8 * p + 16 * (lane >> 5); }
+
 // fast mode: clamp to the fp16 range (one v_med3 that is also the ReLU), round to nearest, one 8-byte store
 template <int NT, bool RELU, int MTW>
 __device__ __forceinline__ void acc_store_f16(_Float16* sXh, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane) {
     typedef float f2 __attribute__((ext_vector_type(2)));
+    h4 hq[4];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -288,8 +334,12 @@ __device__ __forceinline__ void acc_store_f16(_Float16* sXh, const f32x16 (&acc)
                 const h2f h01 = __builtin_convertvector(a, h2f), h23 = __builtin_convertvector(b, h2f);
                 h4 hv;
                 hv[0] = h01[0]; hv[1] = h01[1]; hv[2] = h23[0]; hv[3] = h23[1];
-                const int idx = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt + 8 * q + 4 * (lane >> 5);
-                *reinterpret_cast<h4*>(sXh + idx) = hv;
+                hq[q] = hv;
+                if (q == 3) {
+                    const int row = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt;
+                    *reinterpret_cast<u4v*>(sXh + row + pair_col(0, lane)) = pair_halves(hq[0], hq[2]);
+                    *reinterpret_cast<u4v*>(sXh + row + pair_col(1, lane)) = pair_halves(hq[1], hq[3]);
+                }
             }
 }
 
@@ -311,11 +361,12 @@ __device__ __forceinline__ float relu1(float v) {      // one v_max (fmaxf would
 }
 
 // Epilogue: [ReLU ->] hi/lo split -> LDS.  3 VALU per value: v_max, half a v_cvt_pkrtz (hi), v_fma_mix (v - hi),
-// half a v_cvt_pkrtz (lo).
+// half a v_cvt_pkrtz (lo); + one v_permlane32_swap per stored dword.
 template <int NT, bool RELU, int MTW>
 __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane,
                                           unsigned long long* mask = nullptr) {
     unsigned long long bits = 0ull;
+    h4 hq[4], lq[4];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -332,12 +383,17 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
                 const h2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                 const h2 l01 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h01, v[0]), minus_hi_half(h01, v[1]));
                 const h2 l23 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h23, v[2]), minus_hi_half(h23, v[3]));
-                const int idx = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt + 8 * q + 4 * (lane >> 5);
                 h4 hv, lv;
                 hv[0] = (_Float16)h01[0]; hv[1] = (_Float16)h01[1]; hv[2] = (_Float16)h23[0]; hv[3] = (_Float16)h23[1];
                 lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
-                *reinterpret_cast<h4*>(sXh + idx) = hv;
-                *reinterpret_cast<h4*>(sXl + idx) = lv;
+                hq[q] = hv; lq[q] = lv;
+                if (q == 3) {
+                    const int row = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt;
+                    *reinterpret_cast<u4v*>(sXh + row + pair_col(0, lane)) = pair_halves(hq[0], hq[2]);
+                    *reinterpret_cast<u4v*>(sXh + row + pair_col(1, lane)) = pair_halves(hq[1], hq[3]);
+                    *reinterpret_cast<u4v*>(sXl + row + pair_col(0, lane)) = pair_halves(lq[0], lq[2]);
+                    *reinterpret_cast<u4v*>(sXl + row + pair_col(1, lane)) = pair_halves(lq[1], lq[3]);
+                }
                 if (mask != nullptr) {
                     unsigned m = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
                     bits |= (unsigned long long)m << (((mt * NT + nt) * 4 + q) * 4);
@@ -485,11 +541,12 @@ enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
 template <int NPT, int NW, bool SPLIT>
 __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, float* sRed, const uint32_t* __restrict__ pk,
                                       uint32_t w_off, uint32_t b_off, int n_rows, unsigned kinds, float flow_scale,
-                                      float* raw, long long p0, long long n_points, int slot0, int wave, int lane) {
-    constexpr int KS = NW / NPT;                 // k-splits
+                                      float* sRaw, int slot0, int wave, int lane) {
+    constexpr int KS = NW / NPT;                 // k-splits (waves beyond NPT * KS idle)
     constexpr int NK = 16 / KS;                  // k-steps per wave
-    static_assert(NW % NPT == 0 && (KS == 1 || KS == 2), "heads: 1 or 2 waves per point tile");
+    static_assert(KS == 1 || KS == 2, "heads: 1 or 2 waves per point tile");
     const int pt = wave % NPT, kh = wave / NPT;
+    if (KS == 1 && wave >= NPT) return;
     f32x16 acc0, acc1, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
@@ -510,10 +567,10 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
             const int ks = half * 8 + j;
             const h8 wh = __builtin_bit_cast(h8, wr[j][0]);
             const h8 wl = __builtin_bit_cast(h8, wr[j][1]);
-            const h8 xh = *reinterpret_cast<const h8*>(bh + ks * 16);
+            const h8 xh = lds_h8(bh + ks * 16);
             acc0 = MFMA_H(wl, xh, acc0);               // the narrow heads keep the weights' lo halfs in both modes
             if constexpr (SPLIT) {
-                const h8 xl = *reinterpret_cast<const h8*>(bl + ks * 16);
+                const h8 xl = lds_h8(bl + ks * 16);
                 acc1 = MFMA_H(wh, xl, acc1);
                 acc2 = MFMA_H(wh, xh, acc2);
             } else {
@@ -534,7 +591,8 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
 #pragma unroll
         for (int r = 0; r < 8; ++r) part[r] += sRed[(pt * 8 + r) * 64 + lane];
     }
-    const long long p = p0 + 32 * pt + (lane & 31);
+    // the values go to the tile's raw-record image in LDS; the kernel writes whole 64-byte records at its end
+    float* rec = sRaw + (32 * pt + (lane & 31)) * NSFF_RAW_STRIDE + slot0;
     const float* bias = reinterpret_cast<const float*>(pk + b_off);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -544,7 +602,7 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
             const unsigned kind = (kinds >> (2 * row)) & 3u;
             if (kind == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
             else if (kind == ACT_FLOW) v = flow_scale * tanhf(v);
-            if (p < n_points) raw[p * NSFF_RAW_STRIDE + slot0 + row] = v;
+            rec[row] = v;
         }
     }
 }
@@ -567,6 +625,10 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     __shared__ __attribute__((aligned(16))) _Float16 sX[(SPLIT ? 2 : 1) * M * LDH];
     constexpr int NPT = M / 32, NW = THREADS / 64;                       // heads: point tiles, waves
     __shared__ float sRed[NW > NPT ? NPT * 8 * 64 : 1];                  // k-split partial sums of the heads
+    // raw records of the tile (16 floats per point): the heads fill them in, the kernel's last act writes them out as
+    // whole 64-byte rows (scattered 4-byte stores made the HBM side read-modify-write every record: 5x the bytes)
+    __shared__ __attribute__((aligned(16))) float sRaw[M * NSFF_RAW_STRIDE];
+    for (int i = threadIdx.x; i < M * NSFF_RAW_STRIDE; i += THREADS) sRaw[i] = 0.f;
     _Float16* sXh = sX;
     _Float16* sXl = SPLIT ? sX + M * LDH : sX;        // (never dereferenced when !SPLIT)
     const int lane = threadIdx.x & 63;
@@ -638,7 +700,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         }
         H3_STAMP(1);
         if (st.bias_off != NSFF_NONE) acc_init<NT, MTW>(acc, br);
-        gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, sBh, sBl, st.nks);
+        gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks);
         H3_STAMP(2);
         if (i + 1 < a.n_steps) {                   // next segment's weights + bias fly during the epilogue
             const H3Step nx = step_at(i + 1);
@@ -677,10 +739,15 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                     w_off = a.L.t_head_w; b_off = a.L.t_head_b; n_rows = (int)a.L.t_head_rows; slot0 = 4;
                     kinds = 0x15u | (0xAAAu << 8);
                 }
-                heads<NPT, NW, SPLIT>(sXh, sXl, sRed, pk, w_off, b_off, n_rows, kinds, a.flow_scale, a.raw, p0, a.n_points,
-                                      slot0, wave_id, lane);
+                heads<NPT, NW, SPLIT>(sXh, sXl, sRed, pk, w_off, b_off, n_rows, kinds, a.flow_scale, sRaw, slot0, wave_id, lane);
             }
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
+        const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
+        if (p < a.n_points)
+            reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
     }
     H3_SPAN(1);
 }

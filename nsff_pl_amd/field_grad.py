@@ -118,7 +118,7 @@ class _FieldFn(torch.autograd.Function):
             ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *([side] if side is not None else []), *params)
             return raw.detach().view_as(raw)
         dev = xyz.device
-        raw = torch.zeros(P, _lib.RAW_STRIDE, device=dev)
+        raw = torch.empty(P, _lib.RAW_STRIDE, device=dev)      # (the kernel writes whole records, zeros in unevaluated slots)
         acts, xin, masks, side = alloc_saves(model, P, dev, transient, static)
         xyz_c = xyz.detach().contiguous()
         use_side = model.use_viewdir and static

@@ -91,7 +91,6 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         already is the training forward: it keeps the activations the backward kernels need."""
         saves = {}
         if ctx.rec is not None and field_grad.forward_can_save(model, static_mode, transient_mode):
-            raw_out.zero_()                          # slots of heads this launch does not write read as zeros in backward
             acts, xin, masks, side_rows = field_grad.alloc_saves(model, P, zs.device, bool(transient_mode), bool(static_mode))
             saves = dict(save_acts=acts, save_xin=xin, save_masks=masks, save_side=side_rows)
             ctx.rec.setdefault("saved", {})[tag] = (raw_out, acts, xin, masks, pts.view(-1, 3), side_rows)
