@@ -535,8 +535,8 @@ enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
 
 // Narrow heads as one zero-padded 32-row MFMA tile per 32 points.  The workgroup's NW waves split the NPT point
 // tiles AND (when NW > NPT) the K range: wave w takes point tile w % NPT and k-steps [16/KS * (w / NPT), ...), the
-// partial sums of the upper k ranges travel through `sRed` (one barrier).  Every product term has its own
-// accumulator chain (a 32x32x16 MFMA on the same accumulator can only issue every 64 cycles).
+// partial sums of the upper k ranges travel through `sRed` (one barrier).  One accumulator chain: separate chains per
+// product term shorten the dependent-MFMA latency but cost 14 spilled VGPRs (scratch = HBM traffic) -- measured 1.3 % slower.
 // out row = (r&3) + 8*(r>>2) + 4*(lane>>5); only r < 8 (rows < 16) can be live.
 template <int NPT, int NW, bool SPLIT>
 __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, float* sRed, const uint32_t* __restrict__ pk,
@@ -547,9 +547,9 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
     static_assert(KS == 1 || KS == 2, "heads: 1 or 2 waves per point tile");
     const int pt = wave % NPT, kh = wave / NPT;
     if (KS == 1 && wave >= NPT) return;
-    f32x16 acc0, acc1, acc2;
+    f32x16 acc0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
     const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane + kh * NK * 2 * 64;
     const _Float16* bh = sXh + (32 * pt + (lane & 31)) * LDH + 8 * (lane >> 5) + kh * NK * 16;
     const _Float16* bl = sXl + (32 * pt + (lane & 31)) * LDH + 8 * (lane >> 5) + kh * NK * 16;
@@ -571,8 +571,8 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
             acc0 = MFMA_H(wl, xh, acc0);               // the narrow heads keep the weights' lo halfs in both modes
             if constexpr (SPLIT) {
                 const h8 xl = lds_h8(bl + ks * 16);
-                acc1 = MFMA_H(wh, xl, acc1);
-                acc2 = MFMA_H(wh, xh, acc2);
+                acc0 = MFMA_H(wh, xl, acc0);
+                acc0 = MFMA_H(wh, xh, acc0);
             } else {
                 acc0 = MFMA_H(wh, xh, acc0);
             }
@@ -580,7 +580,7 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
     }
     float part[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) part[r] = SPLIT ? (acc0[r] + acc1[r]) + acc2[r] : acc0[r];
+    for (int r = 0; r < 8; ++r) part[r] = acc0[r];
     if constexpr (KS == 2) {
         if (kh == 1) {
 #pragma unroll

@@ -14,9 +14,9 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNELS = ("nsff_field_kernel_h3", "nsff_field_kernel(", "composite_kernel", "fine_samples_kernel", "coarse_samples_kernel",
-           "warp_points_kernel", "splat_tiles_kernel", "splat_far_kernel", "mpi_composite_kernel", "nsff_field_bwd_kernel",
-           "nsff_wgrad_kernel", "nsff_wgrad_reduce_kernel", "composite_bwd_kernel", "field_input_bwd_kernel", "loss_rays_kernel")
+KERNELS = ("nsff_field_kernel_h3", "nsff_field_kernel(", "mpi_composite_kernel", "composite_bwd_kernel", "composite_kernel",
+           "fine_samples_kernel", "coarse_samples_kernel", "warp_points_kernel", "splat_tiles_kernel", "splat_far_kernel",
+           "nsff_field_bwd_kernel", "nsff_wgrad_kernel", "nsff_wgrad_reduce_kernel", "field_input_bwd_kernel", "loss_rays_kernel")
 
 
 def short(name):
