@@ -92,6 +92,9 @@ struct H3KArgs {
     H3Step steps[MAX_STEPS];
     int n_steps;
     int n_static_steps;   // steps [0, n_static_steps) = static trunk; the rest = dynamic trunk
+    int split_trunks;     // 1: workgroups [0, grid_tiles) run the static trunk of tile b, [grid_tiles, 2*grid_tiles) the
+                          // dynamic trunk of tile b - grid_tiles (see nsff_h3_field_query)
+    long long grid_tiles; // tiles of this launch's tile size
     const uint32_t* packed;
     const float* xyz;
     const float* x_emb;
@@ -637,7 +640,17 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     const int mt0 = MTW == 2 ? 0 : (wave_id & 1);                  // this wave's 32-neuron half of it (MTW = 1)
     const int nb0 = 64 * wave + 32 * mt0;                          // first neuron of this wave
     const int nt0 = MTW == 2 ? (wave_id >> 2) * NT : 0;            // first point tile of this wave
-    const long long p0 = (long long)blockIdx.x * M;
+    // Both trunks in one workgroup stream 4.6 MB of (hi + lo) weights -- more than the 4 MB L2 of an XCD, so with tiles
+    // in every phase at once 4-5 % of the weight requests miss to the Infinity Cache.  In split mode a workgroup runs ONE
+    // trunk of its tile; workgroups are dispatched in index order, so the chip streams the static trunk's 2.2 MB for the
+    // first half of the grid and the dynamic trunk's 2.4 MB for the second -- each fits the L2.
+    long long tile = blockIdx.x;
+    int s_begin = 0, s_end = a.n_steps, piece = 0;               // piece: 0 whole raw record, 1 static slots [0,4), 2 slots [4,16)
+    if (a.split_trunks) {
+        if (tile < a.grid_tiles) { s_end = a.n_static_steps; piece = 1; }
+        else { tile -= a.grid_tiles; s_begin = a.n_static_steps; piece = 2; }
+    }
+    const long long p0 = tile * M;
     const uint32_t* __restrict__ pk = a.packed;
     const _Float16* sBh = sXh + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
     const _Float16* sBl = sXl + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
@@ -664,15 +677,15 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     // Every workgroup streams the same weights; if all of them walk the program in the same order
     // they hit the same few L2 channels at the same instant.  Half of the workgroups therefore run
     // the dynamic trunk first (the two trunks are independent: separate outputs, the tile is rebuilt).
-    const int rot = (a.n_static_steps > 0 && a.n_static_steps < a.n_steps && ((blockIdx.x >> 3) & 1))
+    const int rot = (!a.split_trunks && a.n_static_steps > 0 && a.n_static_steps < a.n_steps && ((blockIdx.x >> 3) & 1))
                         ? a.n_static_steps : 0;
     auto step_at = [&](int i) { int j = i + rot; if (j >= a.n_steps) j -= a.n_steps; return a.steps[j]; };
     H3_SPAN(0);
-    const H3Step s0 = step_at(0);
+    const H3Step s0 = step_at(s_begin);
     const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
     load_bias<MTW>(br, fbias(s0.bias_off), nb0, lane);
 #pragma unroll 1
-    for (int i = 0; i < a.n_steps; ++i) {
+    for (int i = s_begin; i < s_end; ++i) {
         const H3Step st = step_at(i);
         H3_STAMP(0);
         if (st.pre != PRE_NONE) {
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                 if constexpr (SAVE) {
                     if (a.save_side != nullptr) {
                         __syncthreads();
-                        tile_to_fragments<THREADS>(sXh, sXl, a.save_side + (long long)blockIdx.x * (64 * 128), 128, (int)a.L.side_k);
+                        tile_to_fragments<THREADS>(sXh, sXl, a.save_side + tile * (64 * 128), 128, (int)a.L.side_k);
                     }
                 }
             } else {
@@ -693,7 +706,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             if constexpr (SAVE) {
                 // trunk input of layer 0: columns [0,64) xyz embedding, [64,128) time code (zero when absent)
                 if (a.save_xin != nullptr && st.bias_off != NSFF_NONE && (st.pre == PRE_INPUT_T || a.transient_mode == 0)) {
-                    tile_to_fragments<THREADS>(sXh, sXl, a.save_xin + (long long)blockIdx.x * (64 * 128), 128,
+                    tile_to_fragments<THREADS>(sXh, sXl, a.save_xin + tile * (64 * 128), 128,
                                                st.pre == PRE_INPUT_T ? 128 : 64);     // static only: rows 64.. stay unwritten
                 }
             }
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         if (st.bias_off != NSFF_NONE) acc_init<NT, MTW>(acc, br);
         gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks);
         H3_STAMP(2);
-        if (i + 1 < a.n_steps) {                   // next segment's weights + bias fly during the epilogue
+        if (i + 1 < s_end) {                       // next segment's weights + bias fly during the epilogue
             const H3Step nx = step_at(i + 1);
             wnext = prefetch_w<MTW, SPLIT>(ring, seg(nx.w_off, nx.nks));
             if (nx.bias_off != NSFF_NONE) load_bias<MTW>(br, fbias(nx.bias_off), nb0, lane);
@@ -713,7 +726,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             unsigned long long* mk = nullptr;
             if constexpr (SAVE) {
                 if (st.save && a.save_masks != nullptr && st.post == POST_RELU)
-                    mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + blockIdx.x) * THREADS + threadIdx.x;
+                    mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + tile) * THREADS + threadIdx.x;
             }
             if constexpr (!SPLIT) {
                 if (st.post == POST_RELU) acc_store_f16<NT, true, MTW>(sXh, acc, nb0, nt0, lane);
@@ -726,7 +739,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             if constexpr (SAVE) {
                 if (st.save && a.save_acts != nullptr)
                     tile_to_fragments<THREADS>(sXh, sXl, a.save_acts + (long long)(st.save - 1) * a.save_stride
-                                                             + (long long)blockIdx.x * (64 * NSFF_W), NSFF_W, NSFF_W);
+                                                             + tile * (64 * NSFF_W), NSFF_W, NSFF_W);
             }
             if (st.head != HEAD_NONE) {
                 // static sigma reads the last trunk activation, before *_final (nerf.py:169);
@@ -746,7 +759,8 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     __syncthreads();
     for (int i = threadIdx.x; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
         const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
-        if (p < a.n_points)
+        const int q4 = i % (NSFF_RAW_STRIDE / 4);                   // 16-byte quarter of the record
+        if (p < a.n_points && (piece == 0 || (piece == 1) == (q4 == 0)))
             reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
     }
     H3_SPAN(1);
@@ -968,31 +982,35 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     if (n > MAX_STEPS) return NSFF_ERR_INVALID;
     k.n_steps = n;
 
+    // one trunk per workgroup when the launch evaluates both (see the kernel): grid = 2 x tiles
+#ifdef H3_NO_SPLIT          // A/B experiments only
+    const bool both = false;
+#else
+    const bool both = n > k.n_static_steps && k.n_static_steps > 0;
+#endif
+    auto launch = [&](auto kernel, int tile_points, int threads) -> int {
+        const long long tiles = (g.n_points + tile_points - 1) / tile_points;
+        if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        k.grid_tiles = tiles;
+        k.split_trunks = both ? 1 : 0;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(both ? 2 * tiles : tiles)), dim3(threads), 0, st, k);
+        return NSFF_OK;
+    };
+    int lrc;
     if (points_per_block == NSFF_H3_FAST) {       // "f16": one product per MAC, 128-point tiles, two workgroups per CU
         if (k.save_acts || k.save_xin || k.save_masks || k.save_side) return NSFF_ERR_INVALID;
-        const long long tiles = (g.n_points + 127) / 128;
-        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1, false, 2, false>), dim3((unsigned)tiles), dim3(256), 0, st, k);
-    } else if (k.save_acts || k.save_xin || k.save_masks) {
-        const long long tiles = (g.n_points + 63) / 64;
-        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1, true>), dim3((unsigned)tiles), dim3(256), 0, st, k);
+        lrc = launch(nsff_field_kernel_h3<4, 1, false, 2, false>, 128, 256);
+    } else if (k.save_acts || k.save_xin || k.save_masks || k.save_side) {
+        lrc = launch(nsff_field_kernel_h3<2, 1, true>, 64, 256);
     } else if (points_per_block == 64) {
-        const long long tiles = (g.n_points + 63) / 64;
-        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL((nsff_field_kernel_h3<2, 1>), dim3((unsigned)tiles), dim3(256), 0, st, k);
+        lrc = launch(nsff_field_kernel_h3<2, 1>, 64, 256);
     } else if (points_per_block == 130) {         // 128 points, eight waves of 32 neurons (half the weight stream)
-        const long long tiles = (g.n_points + 127) / 128;
-        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1, false, 1>), dim3((unsigned)tiles), dim3(512), 0, st, k);
+        lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
     } else if (points_per_block == 129) {         // experiment: 128 points, one wave per SIMD
-        const long long tiles = (g.n_points + 127) / 128;
-        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1>), dim3((unsigned)tiles), dim3(256), 0, st, k);
+        lrc = launch(nsff_field_kernel_h3<4, 1>, 128, 256);
     } else {
-        const long long tiles = (g.n_points + 127) / 128;
-        if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
-        hipLaunchKernelGGL((nsff_field_kernel_h3<2, 2>), dim3((unsigned)tiles), dim3(512), 0, st, k);
+        lrc = launch(nsff_field_kernel_h3<2, 2>, 128, 512);
     }
+    if (lrc != NSFF_OK) return lrc;
     return nsff_launch_status();
 }
