@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      10
+#define NSFF_ABI_VERSION      12
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -185,6 +185,34 @@ typedef struct NsffWgradJob {
 int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits);
 int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
                      float* scratch, float* out, float* bias, const float* gmax, void* stream);
+
+/* The same GEMMs, but the second launch ACCUMULATES straight into the parameters' gradient memory (what autograd's
+ * AccumulateGrad does for torch.nn.Linear's grad_weight / grad_bias): for every map entry
+ *   grad_base[dst] += (1/G) * (S(job_a, e_a) + S(job_b, e_b)),      S(j, e) = sum over the splits of job j's partials,
+ * e < a_rows*b_rows: element e of out_j (row-major);  e >= a_rows*b_rows: row sum (bias gradient) e - a_rows*b_rows;
+ * job_b < 0: no second term (it carries the fp16-remainder rows of the head gradients).  Every dst must appear at most
+ * once (one owner per gradient element: the result is deterministic).  `map` is a DEVICE array, 16-byte aligned;
+ * jobs[].out_off is ignored.                                                                                       */
+typedef struct NsffGradMapEntry {
+    int32_t dst;                /* floats from grad_base */
+    int32_t e_a, e_b;
+    int16_t job_a, job_b;
+} NsffGradMapEntry;
+int nsff_weight_grad_accumulate(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, float* scratch,
+                                const NsffGradMapEntry* map, int64_t n_map, float* grad_base, const float* gmax, void* stream);
+
+/* out[0] = max |x[i]| (0 for n == 0): the device scalar `gmax` of nsff_field_backward / nsff_weight_grad without a
+ * host round trip (replaces d_raw.abs().max()).  x 16-byte aligned.                                                */
+int nsff_absmax(const float* x, int64_t n, float* out, void* stream);
+
+/* ---- N1: the optimizer step: torch.optim.Adam(lr, betas, eps, weight_decay) as the reference builds it
+ * (utils/__init__.py:45-47 get_optimizer, used by train.py:140-146), amsgrad off, on flat fp32 buffers of n elements
+ * (n % 4 == 0, 16-byte aligned):  g' = g + weight_decay * p;  m = lerp(m, g', 1 - beta1);  v = beta2 * v + (1 - beta2) * g'^2;
+ * p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps).
+ * state: DEVICE float[4]; state[0] = number of steps taken so far (zero it once; the call increments it), state[1..2]
+ * scratch.  lr: DEVICE scalar.  Two launches, no host round trip: capturable into a hipGraph.                      */
+int nsff_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                   const float* lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 /* ---- N1: the training objective NeRFWLoss (reference losses.py:8-28, 31-171) on the render dict, NSFF train-mode
  * configuration (flows + disocclusion present, topk == 1, no per-ray weights, thickness == 1), every term reduced to

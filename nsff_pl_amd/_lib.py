@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 10
+ABI_VERSION = 12
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -139,6 +139,10 @@ _SIGNATURES = {
                                             _fp, _fp]),
     "nsff_weight_grad_scratch": (C.c_int64, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32]),
     "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
+    "nsff_weight_grad_accumulate": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, C.c_int64,
+                                              _fp, _fp, _fp]),
+    "nsff_absmax": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
+    "nsff_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double, _fp]),
     "nsff_composite_backward": (C.c_int, [C.POINTER(CompositeBwdArgs), _fp]),
     "nsff_nerfw_loss": (C.c_int, [C.POINTER(LossArgs), C.c_int, _fp]),
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
@@ -384,6 +388,35 @@ def weight_grad(jobs, n_tiles, n_splits, out, bias, gmax):
     scratch = torch.empty(n, device=out.device)
     _check(load().nsff_weight_grad(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(scratch), _ptr(out), _ptr(bias),
                                    _ptr(gmax), _stream()), "nsff_weight_grad")
+
+
+def weight_grad_accumulate(jobs, n_tiles, n_splits, grad_map, grad_base_ptr, gmax):
+    """The same GEMMs, accumulated straight into the parameters' gradient memory.  grad_map: (n,4) int32 device tensor of
+    NsffGradMapEntry rows; grad_base_ptr: device address the map's `dst` offsets count from."""
+    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=0) for j in jobs])
+    n = load().nsff_weight_grad_scratch(arr, len(jobs), int(n_tiles), int(n_splits))
+    if n < 0:
+        raise RuntimeError("nsff_weight_grad_scratch failed")
+    assert grad_map.dtype == torch.int32 and grad_map.is_contiguous() and grad_map.shape[1] == 4
+    scratch = torch.empty(n, device=gmax.device)
+    _check(load().nsff_weight_grad_accumulate(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(scratch),
+                                              C.c_void_p(grad_map.data_ptr()), grad_map.shape[0], C.c_void_p(grad_base_ptr),
+                                              _ptr(gmax), _stream()), "nsff_weight_grad_accumulate")
+    return scratch
+
+
+def absmax(x):
+    """max |x| as a device scalar (one launch, no host round trip)."""
+    x = x.contiguous()
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    _check(load().nsff_absmax(_ptr(x), x.numel(), _ptr(out), _stream()), "nsff_absmax")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay):
+    """One Adam step on flat buffers (include/nsff_render.h: nsff_adam_step); state / lr are device tensors."""
+    _check(load().nsff_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(state), _ptr(lr),
+                                 float(beta1), float(beta2), float(eps), float(weight_decay), _stream()), "nsff_adam_step")
 
 
 def composite_backward(n_rays, n_samples, has_transient, flow_mode, noise_std, **tensors):

@@ -41,6 +41,7 @@ class _CompositeFn(torch.autograd.Function):
     def forward(ctx, cfg, raw, raw_fw, raw_bw, f_fw, f_bw):
         values = cfg["values"]
         ctx.cfg = cfg
+        ctx.set_materialize_grads(False)         # outputs nobody differentiates arrive as None -> NULL, not as zero tensors
         ctx.save_for_backward(*[t for t in (raw, raw_fw, raw_bw, f_fw, f_bw) if t is not None])
         ctx.present = [t is not None for t in (raw, raw_fw, raw_bw, f_fw, f_bw)]
         return tuple(values[k].detach().view_as(values[k]) for k, _ in cfg["spec"])
@@ -48,6 +49,8 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         cfg = ctx.cfg
+        if all(g is None for g in grads):
+            return (None,) * 6
         it = iter(ctx.saved_tensors)
         raw, raw_fw, raw_bw, f_fw, f_bw = [next(it) if p else None for p in ctx.present]
         n, s = cfg["zs"].shape

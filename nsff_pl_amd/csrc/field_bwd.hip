@@ -213,8 +213,15 @@ __device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, con
             out1[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[1] * r, -65504.f, 65504.f);
         }
         _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
+#if defined(B_NO_STORE)
+        if (sRel[0] == 123.456f) { *reinterpret_cast<h8*>(d) = out0; *reinterpret_cast<h8*>(d + 8) = out1; }
+#elif defined(B_PLAIN_STORE)
         *reinterpret_cast<h8*>(d) = out0;
         *reinterpret_cast<h8*>(d + 8) = out1;
+#else
+        __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad:
+        __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));     // keep the weights' L2 lines (-17 % per launch)
+#endif
     }
 }
 
@@ -238,12 +245,23 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
         return reinterpret_cast<const uint4*>(pk + s_.w_off) + (wave * s_.nks) * 2 * 64 + lane;
     };
     const uint4* wnext = prefetch_w1(ring, seg(a.steps[0]));
+    // The tile a step leaves in sB goes to HBM (fragment order, global scale) only AFTER the next step's GEMM: vmcnt counts
+    // loads and stores in one in-order queue, so a store issued right before a GEMM stalls its weight loads until the
+    // store is acknowledged (measured: +240 us per launch = the whole store time serialised); issued after the GEMM and
+    // the next prefetch, the acknowledgements have the epilogue and the first ring round to arrive.
+    int pending_slot = -1;
+    auto flush_tile = [&]() {
+        if (pending_slot >= 0)
+            tile_to_fragments_scaled(sB, sRel, a.dpre + (long long)pending_slot * slot_stride + tile * (64 * NSFF_W), NSFF_W);
+        pending_slot = -1;
+    };
 #pragma unroll 1
     for (int i = 0; i < a.n_steps; ++i) {
         const BStep st = a.steps[i];
         const bool is_static = i < a.n_static_steps;
         if (i == 0 || i == a.n_static_steps) {
             // ---- head stage of this trunk: activation derivatives, per-point scale, head gradients into the tile ----
+            flush_tile();                                  // (the previous trunk's last tile, still in sB / sRel)
             __syncthreads();
             const int pt = threadIdx.x & 63, grp = threadIdx.x >> 6;
             const long long p = p0 + pt;
@@ -320,6 +338,18 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
         if (!(st.flags & F_HALF_ROWS) || wave < 2)
             gemm1(acc, ring, wnext, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks);
         if (i + 1 < a.n_steps) wnext = prefetch_w1(ring, seg(a.steps[i + 1]));    // flies during the epilogue
+        float wsig[2][4][4];
+        if (st.flags & F_SIGMA) {
+            const float* ws = reinterpret_cast<const float*>(pk + a.s_sigma);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(ws + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
+                    wsig[mt][q][0] = w4.x; wsig[mt][q][1] = w4.y; wsig[mt][q][2] = w4.z; wsig[mt][q][3] = w4.w;
+                }
+        }
+        flush_tile();                                     // the previous step's tile (sB is still intact)
         if (st.epi == EPI_KEEP) continue;
         if (st.epi == EPI_DXIN) {
             float* dst_in = (st.flags & F_TO_SIDE) ? a.d_side : a.d_xin;
@@ -344,17 +374,6 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
             continue;
         }
         // ---- epilogue: (+ rank-1 sigma term) (ReLU mask) -> fp16 tile (B operand of the next step) ----
-        float wsig[2][4][4];
-        if (st.flags & F_SIGMA) {
-            const float* ws = reinterpret_cast<const float*>(pk + a.s_sigma);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(ws + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
-                    wsig[mt][q][0] = w4.x; wsig[mt][q][1] = w4.y; wsig[mt][q][2] = w4.z; wsig[mt][q][3] = w4.w;
-                }
-        }
         __syncthreads();                                  // every wave is done reading the tile
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -380,8 +399,12 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                 }
             }
         __syncthreads();
-        tile_to_fragments_scaled(sB, sRel, a.dpre + (long long)st.slot * slot_stride + tile * (64 * NSFF_W), NSFF_W);
+        pending_slot = st.slot;
+#ifdef B_EARLY_COPY
+        flush_tile();
+#endif
     }
+    flush_tile();
 }
 
 
@@ -621,9 +644,83 @@ __global__ __launch_bounds__(256) void nsff_wgrad_reduce_kernel(const RKArgs a) 
     }
 }
 
+// Gather form of the same reduction: the destination is the parameters' own gradient memory.  Entry i names one
+// gradient element (dst, floats from grad_base) and the one or two partial-sum elements it is made of (job, e; e >= size
+// addresses the bias row sums); grad[dst] += (sum_A + sum_B) / G.  Deterministic: every destination has one owner.
+struct GKArgs {
+    RJob jobs[MAX_WJOBS];
+    const float* part; const float* gmax;
+    const NsffGradMapEntry* map; float* grad;
+    long long n_map; int n_jobs;
+};
+
+__global__ __launch_bounds__(256) void nsff_wgrad_accumulate_kernel(const GKArgs a) {
+    __shared__ long long sOff[MAX_WJOBS], sBiasOff[MAX_WJOBS];
+    __shared__ int sSize[MAX_WJOBS], sSplits[MAX_WJOBS];
+    for (int j = threadIdx.x; j < a.n_jobs; j += 256) {
+        sOff[j] = a.jobs[j].part_off; sBiasOff[j] = a.jobs[j].bias_part_off;
+        sSize[j] = a.jobs[j].size; sSplits[j] = a.jobs[j].n_splits;
+    }
+    __syncthreads();
+    const float inv_g = 1.0f / pow2_scale(*a.gmax);
+    auto partial = [&](int job, int e) {
+        const int size = sSize[job], n = sSplits[job];
+        const bool w = e < size;
+        const float* p = a.part + (w ? sOff[job] + e : sBiasOff[job] + (e - size));
+        const long long stride = w ? size : 256;
+        float t = 0.f;
+        int s = 0;
+        for (; s + 8 <= n; s += 8) {                       // eight loads in flight, summed in split order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + (s + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; s < n; ++s) t += __builtin_nontemporal_load(p + s * stride);
+        return t;
+    };
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n_map; i += (long long)gridDim.x * 256) {
+        const NsffGradMapEntry m = a.map[i];
+        float t = partial(m.job_a, m.e_a);
+        if (m.job_b >= 0) t += partial(m.job_b, m.e_b);
+        a.grad[m.dst] += t * inv_g;
+    }
+}
+
+// max |x| as a device scalar (the global scale of nsff_field_backward): non-negative floats order like their bits
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
+    float m = 0.f;
+    const long long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        m = fmaxf(m, fabsf(x[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float sM[4];
+    if ((threadIdx.x & 63) == 0) sM[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(sM[0], sM[1]), fmaxf(sM[2], sM[3]))));
+}
+
 }  // namespace
 
 extern "C" {
+
+int nsff_absmax(const float* x, int64_t n, float* out, void* stream) {
+    if (!out || (n > 0 && !x)) return NSFF_ERR_NULL;
+    if (n < 0) return NSFF_ERR_INVALID;
+    if ((uintptr_t)x & 15) return NSFF_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) return nsff_launch_status();
+    if (n == 0) return NSFF_OK;
+    const long long blocks = std::min<long long>((n / 4 + 255) / 256 + 1, 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)n, reinterpret_cast<unsigned*>(out));
+    return nsff_launch_status();
+}
 
 int nsff_bwd_packed_bytes(const NsffModelDesc* desc, size_t* bytes) {
     if (!desc || !bytes) return NSFF_ERR_NULL;
@@ -791,30 +888,26 @@ int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64
     return total;
 }
 
-int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
-                     float* scratch, float* out, float* bias, const float* gmax, void* stream) {
-    if (!jobs || !scratch || !out || !bias || !gmax) return NSFF_ERR_NULL;
-    if (n_jobs < 0 || n_jobs > MAX_WJOBS || n_tiles < 0 || n_splits < 1) return NSFF_ERR_INVALID;
-    if (n_jobs == 0 || n_tiles == 0) return NSFF_OK;
+// validates the jobs, lays the split-K partials out in `scratch` (r.jobs) and launches the GEMM classes
+static int wgrad_gemms(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, float* scratch,
+                       RJob* rjobs, int* max_size_out, hipStream_t st) {
     for (int j = 0; j < n_jobs; ++j) {
         const bool ok = (jobs[j].a_rows == 256 || jobs[j].a_rows == 32) && (jobs[j].b_rows == 256 || jobs[j].b_rows == 128) &&
                         !(jobs[j].a_rows == 32 && jobs[j].b_rows == 128);
         if (!ok) return NSFF_ERR_INVALID;
         if (!jobs[j].a || !jobs[j].b) return NSFF_ERR_NULL;
     }
-    hipStream_t st = (hipStream_t)stream;
-    RKArgs r{};
-    r.part = scratch; r.bias_part = scratch; r.gmax = gmax; r.out = out; r.bias = bias; r.n_jobs = n_jobs;
     long long off = 0;
     int max_size = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const int sp = wgrad_splits(jobs[j], n_tiles, n_splits);
         const int size = jobs[j].a_rows * jobs[j].b_rows;
-        r.jobs[j].part_off = off; off += (long long)sp * size;
-        r.jobs[j].bias_part_off = off; off += (long long)sp * 256;
-        r.jobs[j].out_off = jobs[j].out_off; r.jobs[j].size = size; r.jobs[j].n_splits = sp; r.jobs[j].job_index = j;
+        rjobs[j].part_off = off; off += (long long)sp * size;
+        rjobs[j].bias_part_off = off; off += (long long)sp * 256;
+        rjobs[j].out_off = jobs[j].out_off; rjobs[j].size = size; rjobs[j].n_splits = sp; rjobs[j].job_index = j;
         max_size = std::max(max_size, size);
     }
+    *max_size_out = max_size;
     for (int cls = 0; cls < 3; ++cls) {
         const int ar = cls == 2 ? 32 : 256, brw = cls == 1 ? 128 : 256;
         WKArgs k{};
@@ -824,8 +917,8 @@ int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, 
             if (jobs[j].a_rows != ar || jobs[j].b_rows != brw) continue;
             k.jobs[m].a = reinterpret_cast<const _Float16*>(jobs[j].a);
             k.jobs[m].b = reinterpret_cast<const _Float16*>(jobs[j].b);
-            k.jobs[m].out_off = r.jobs[j].part_off; k.jobs[m].bias_off = r.jobs[j].bias_part_off;
-            k.n_splits = r.jobs[j].n_splits;                 // equal within a class
+            k.jobs[m].out_off = rjobs[j].part_off; k.jobs[m].bias_off = rjobs[j].bias_part_off;
+            k.n_splits = rjobs[j].n_splits;                 // equal within a class
             ++m;
         }
         if (m == 0) continue;
@@ -834,8 +927,39 @@ int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, 
         else if (cls == 1) hipLaunchKernelGGL((nsff_wgrad_kernel<4, 2, 2, 2>), grid, dim3(256), 0, st, k);
         else hipLaunchKernelGGL(nsff_wgrad_head_kernel, grid, dim3(256), 0, st, k);
     }
+    return NSFF_OK;
+}
+
+int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
+                     float* scratch, float* out, float* bias, const float* gmax, void* stream) {
+    if (!jobs || !scratch || !out || !bias || !gmax) return NSFF_ERR_NULL;
+    if (n_jobs < 0 || n_jobs > MAX_WJOBS || n_tiles < 0 || n_splits < 1) return NSFF_ERR_INVALID;
+    if (n_jobs == 0 || n_tiles == 0) return NSFF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    RKArgs r{};
+    r.part = scratch; r.bias_part = scratch; r.gmax = gmax; r.out = out; r.bias = bias; r.n_jobs = n_jobs;
+    int max_size = 0;
+    const int rc = wgrad_gemms(jobs, n_jobs, n_tiles, n_splits, scratch, r.jobs, &max_size, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(nsff_wgrad_reduce_kernel, dim3((unsigned)std::min((max_size + 256 + 255) / 256, 64), (unsigned)n_jobs),
                        dim3(256), 0, st, r);
+    return nsff_launch_status();
+}
+
+int nsff_weight_grad_accumulate(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, float* scratch,
+                                const NsffGradMapEntry* map, int64_t n_map, float* grad_base, const float* gmax, void* stream) {
+    if (!jobs || !scratch || !gmax || (n_map > 0 && (!map || !grad_base))) return NSFF_ERR_NULL;
+    if (n_jobs < 0 || n_jobs > MAX_WJOBS || n_tiles < 0 || n_splits < 1 || n_map < 0) return NSFF_ERR_INVALID;
+    if ((uintptr_t)map & 15) return NSFF_ERR_ALIGN;
+    if (n_jobs == 0 || n_tiles == 0 || n_map == 0) return NSFF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GKArgs g{};
+    g.part = scratch; g.gmax = gmax; g.map = map; g.grad = grad_base; g.n_map = n_map; g.n_jobs = n_jobs;
+    int max_size = 0;
+    const int rc = wgrad_gemms(jobs, n_jobs, n_tiles, n_splits, scratch, g.jobs, &max_size, st);
+    if (rc) return rc;
+    const long long blocks = std::min<long long>((n_map + 255) / 256, 2048);
+    hipLaunchKernelGGL(nsff_wgrad_accumulate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
     return nsff_launch_status();
 }
 

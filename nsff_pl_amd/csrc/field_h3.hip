@@ -424,8 +424,13 @@ __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Fl
         }
         // 1 KiB blocks of 32 rows, lane-linear inside: [ks][row/32][(row&31) + 32*(point group&1)][8 points]
         _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
+#ifdef H3_NT_SAVE
+        __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));
+        __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));
+#else
         *reinterpret_cast<h8*>(d) = out0;
         *reinterpret_cast<h8*>(d + 8) = out1;
+#endif
     }
 }
 

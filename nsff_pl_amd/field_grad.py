@@ -22,6 +22,8 @@ refused by name -- there is no torch fallback in the product.
 """
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib, config
@@ -154,7 +156,7 @@ class _FieldFn(torch.autograd.Function):
         S_DIR = 2 * D + 2
         n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
         d_raw = d_raw.contiguous()
-        gmax = d_raw.abs().max()
+        gmax = _lib.absmax(d_raw)
         dpre = torch.empty(n_slots(model), tiles, 64 * 256, device=dev, dtype=torch.float16)
         dhead = torch.empty(2, tiles, 64 * 32, device=dev, dtype=torch.float16)
         want_in = transient and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
@@ -164,30 +166,24 @@ class _FieldFn(torch.autograd.Function):
         _lib.field_backward(model, P, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side)
 
         # ---- weight-gradient GEMMs: one batched launch per output shape ----
-        jobs, sizes, meta = [], [], []            # meta: (kind, trunk, layer)
-
-        def job(a, b, a_rows, b_rows, tag):
-            jobs.append([a.data_ptr(), b.data_ptr(), a_rows, b_rows, 0])
-            sizes.append(a_rows * b_rows)
-            meta.append(tag)
-        for t in ([0] if static else []) + ([1] if transient else []):
+        meta = _wgrad_jobs(model, static, transient)             # (kind, trunk, layer)
+        jobs, sizes = [], []
+        for kind, t, l in meta:
             base = t * (D + 1)
-            for l in range(D):
-                if l == 0:
-                    job(dpre[base], xin, 256, 128, ("x", t, l))
-                else:
-                    job(dpre[base + l], acts[base + l - 1], 256, 256, ("h", t, l))
-                    if l == skip:
-                        job(dpre[base + l], xin, 256, 128, ("x", t, l))
-            job(dpre[base + D], acts[base + D - 1], 256, 256, ("h", t, D))
-            if t == 0 and viewdir:            # static_dir_encoding: [*_final | dir | a] -> 256, static_rgb reads it
-                job(dpre[S_DIR], acts[D], 256, 256, ("dir_h", 0, 0))
-                job(dpre[S_DIR], side, 256, 128, ("dir_x", 0, 0))
-                job(dhead[0], acts[S_DIR], 32, 256, ("head", 0, 0))
+            if kind == "x":
+                a_, b_, rows = dpre[base + l], xin, (256, 128)
+            elif kind == "h":
+                a_, b_, rows = dpre[base + l], acts[base + l - 1], (256, 256)
+            elif kind == "dir_h":
+                a_, b_, rows = dpre[S_DIR], acts[D], (256, 256)
+            elif kind == "dir_x":
+                a_, b_, rows = dpre[S_DIR], side, (256, 128)
+            elif l == 1:                                          # static sigma reads the trunk
+                a_, b_, rows = dhead[0], acts[base + D - 1], (32, 256)
             else:
-                job(dhead[t], acts[base + D], 32, 256, ("head", t, 0))
-            if t == 0:
-                job(dhead[0], acts[base + D - 1], 32, 256, ("head", t, 1))    # static sigma reads the trunk
+                a_, b_, rows = dhead[t], acts[S_DIR if (t == 0 and viewdir) else base + D], (32, 256)
+            jobs.append([a_.data_ptr(), b_.data_ptr(), rows[0], rows[1], 0])
+            sizes.append(rows[0] * rows[1])
         n_splits = max(1, min(int(os.environ.get("NSFF_WGRAD_SPLITS", "32")), tiles // 4))
         off = 0
         for j, sz in zip(jobs, sizes):
@@ -203,58 +199,22 @@ class _FieldFn(torch.autograd.Function):
         side = _side_stream(dev) if (overlap and not torch.cuda.is_current_stream_capturing()) else main
         if side is not main:
             side.wait_stream(main)
+        plist = _lib.param_list(model)
+        grad_map = _grad_map(model, static, transient, meta, jobs, sizes, plist) if overlap else None
         with torch.cuda.stream(side):
-            out = torch.empty(off, device=dev)
-            bias = torch.empty(len(jobs), 256, device=dev)
-            _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias, gmax)  # summed and unscaled in there
-
-        with torch.cuda.stream(side):
-            def result(i):
-                j = jobs[i]
-                return out[j[4]:j[4] + sizes[i]].view(j[2], j[3])
-
-            index = {p_: i for i, p_ in enumerate(id(q) for q in _lib.param_list(model))}
-            grads = [None] * len(params)
-
-            def put(layer, w, b):
-                grads[index[id(layer.weight)]] = w
-                grads[index[id(layer.bias)]] = b
-
-            def xcols(m, in_t):                       # (256,128) in trunk-input rows -> (256, in_dim) in Linear columns
-                return m[:, :n_xyz] if in_t == 0 else torch.cat([m[:, :n_xyz], m[:, 64:64 + in_t]], 1)
-            res = {tag: i for i, tag in enumerate(meta)}
-            for t in ([0] if static else []) + ([1] if transient else []):
-                prefix, in_t = ("static", 0) if t == 0 else ("transient", n_t)
-                for l in range(D):
-                    layer = _lin(getattr(model, f"{prefix}_xyz_encoding_{l + 1}"))
-                    if l == 0:
-                        i = res[("x", t, 0)]
-                        put(layer, xcols(result(i), in_t), bias[i])
-                    elif l == skip:
-                        i = res[("h", t, l)]
-                        put(layer, torch.cat([xcols(result(res[("x", t, l)]), in_t), result(i)], 1), bias[i])
-                    else:
-                        i = res[("h", t, l)]
-                        put(layer, result(i), bias[i])
-                i = res[("h", t, D)]
-                put(_lin(getattr(model, f"{prefix}_xyz_encoding_final")), result(i), bias[i])
-                i = res[("head", t, 0)]
-                hw, hb = result(i), bias[i]
-                hw, hb = hw[0:16] + hw[16:32], hb[0:16] + hb[16:32]      # fp16 value + rounding remainder rows
-                if t == 0 and viewdir:
-                    ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
-                    n_side = model.in_channels_dir + model.in_channels_a
-                    put(_lin(model.static_dir_encoding), torch.cat([result(ih), result(ix)[:, :n_side]], 1), bias[ih])
-                if t == 0:
-                    put(_lin(model.static_rgb), hw[0:3], hb[0:3])
-                    i2 = res[("head", 0, 1)]
-                    put(_lin(model.static_sigma), result(i2)[3:4] + result(i2)[19:20], bias[i2][3:4] + bias[i2][19:20])
-                else:
-                    put(_lin(model.transient_rgb), hw[0:3], hb[0:3])
-                    put(_lin(model.transient_sigma), hw[3:4], hb[3:4])
-                    if model.output_flow:
-                        put(_lin(model.transient_flow_fw), hw[4:7], hb[4:7])
-                        put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
+            if grad_map is not None:
+                # deferred mode with every .grad in place: the reduction of the split-K partials accumulates straight
+                # into the parameters' gradient memory (no per-parameter tensors, adds or cats)
+                keep = _lib.weight_grad_accumulate([tuple(j) for j in jobs], tiles, n_splits, grad_map[0], grad_map[1], gmax)
+                grads = None
+            else:
+                out = torch.empty(off, device=dev)
+                bias = torch.empty(len(jobs), 256, device=dev)
+                _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias, gmax)  # summed and unscaled in there
+                keep = (out, bias)
+                grads = _assemble(model, static, transient, meta, plist,
+                                  lambda i: out[jobs[i][4]:jobs[i][4] + sizes[i]].view(jobs[i][2], jobs[i][3]),
+                                  lambda i: bias[i], torch.cat)
 
         d_xyz = d_t = d_a = None
         if d_xin is not None:              # derivative of the positional encoding + per-ray sum of the time-code rows
@@ -266,7 +226,7 @@ class _FieldFn(torch.autograd.Function):
             # keep what the side stream still reads alive until the join, then hand the gradients over there.
             # Every node queues the (idempotent) flush: a callback queued by an earlier backward pass that died
             # half-way is dropped by the engine, so "already queued" cannot be remembered across passes.
-            _PENDING.append((list(_lib.param_list(model)), grads, (dpre, dhead, acts, xin, side, out, bias, gmax)))
+            _PENDING.append((list(plist), grads, (dpre, dhead, acts, xin, side, keep, gmax)))
             torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
             return (None, d_xyz, d_t, None, d_a) + (None,) * len(params)
         return (None, d_xyz, d_t, None, d_a) + tuple(grads)
@@ -379,6 +339,162 @@ class _FieldFn(torch.autograd.Function):
         return (None, d_xyz, d_t, None, None) + tuple(grads)
 
 
+_JOB_SHAPE = {"x": (256, 128), "h": (256, 256), "dir_h": (256, 256), "dir_x": (256, 128), "head": (32, 256)}
+
+
+def _wgrad_jobs(model, static, transient):
+    """The weight-gradient GEMMs of one node as (kind, trunk, layer) tags: 'x' = trunk-input part of layer l, 'h' =
+    hidden part of layer l (l == D: *_final), 'dir_h' / 'dir_x' = the two parts of static_dir_encoding, 'head' =
+    the output heads (layer 1: static_sigma, which reads the trunk instead of *_final)."""
+    D, skip = model.D, model.skips[0]
+    viewdir = bool(model.use_viewdir and static)
+    meta = []
+    for t in ([0] if static else []) + ([1] if transient else []):
+        for l in range(D):
+            if l == 0:
+                meta.append(("x", t, 0))
+            else:
+                meta.append(("h", t, l))
+                if l == skip:
+                    meta.append(("x", t, l))
+        meta.append(("h", t, D))
+        if t == 0 and viewdir:            # static_dir_encoding: [*_final | dir | a] -> 256, static_rgb reads it
+            meta += [("dir_h", 0, 0), ("dir_x", 0, 0)]
+        meta.append(("head", t, 0))
+        if t == 0:
+            meta.append(("head", 0, 1))
+    return meta
+
+
+def _assemble(model, static, transient, meta, plist, result, bias_of, cat):
+    """Gradients of every parameter of `model` (order of `plist`) from the weight-gradient jobs of one node.
+    result(i): the (a_rows, b_rows) matrix of job i; bias_of(i): its 256 row sums; `meta[i]` = (kind, trunk, layer).
+    Works on tensors and on the index objects of :func:`_grad_map` alike (only slicing, `+` and `cat` are used)."""
+    D, skip = model.D, model.skips[0]
+    viewdir = bool(model.use_viewdir and static)
+    n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
+    index = {id(q): i for i, q in enumerate(plist)}
+    grads = [None] * len(plist)
+    res = {tag: i for i, tag in enumerate(meta)}
+
+    def put(layer, w, b):
+        grads[index[id(layer.weight)]] = w
+        grads[index[id(layer.bias)]] = b
+
+    def xcols(m, in_t):                       # (256,128) in trunk-input rows -> (256, in_dim) in Linear columns
+        return m[:, :n_xyz] if in_t == 0 else cat([m[:, :n_xyz], m[:, 64:64 + in_t]], 1)
+    for t in ([0] if static else []) + ([1] if transient else []):
+        prefix, in_t = ("static", 0) if t == 0 else ("transient", n_t)
+        for l in range(D):
+            layer = _lin(getattr(model, f"{prefix}_xyz_encoding_{l + 1}"))
+            if l == 0:
+                i = res[("x", t, 0)]
+                put(layer, xcols(result(i), in_t), bias_of(i))
+            elif l == skip:
+                i = res[("h", t, l)]
+                put(layer, cat([xcols(result(res[("x", t, l)]), in_t), result(i)], 1), bias_of(i))
+            else:
+                i = res[("h", t, l)]
+                put(layer, result(i), bias_of(i))
+        i = res[("h", t, D)]
+        put(_lin(getattr(model, f"{prefix}_xyz_encoding_final")), result(i), bias_of(i))
+        i = res[("head", t, 0)]
+        hw, hb = result(i), bias_of(i)
+        hw, hb = hw[0:16] + hw[16:32], hb[0:16] + hb[16:32]      # fp16 value + rounding remainder rows
+        if t == 0 and viewdir:
+            ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
+            n_side = model.in_channels_dir + model.in_channels_a
+            put(_lin(model.static_dir_encoding), cat([result(ih), result(ix)[:, :n_side]], 1), bias_of(ih))
+        if t == 0:
+            put(_lin(model.static_rgb), hw[0:3], hb[0:3])
+            i2 = res[("head", 0, 1)]
+            put(_lin(model.static_sigma), result(i2)[3:4] + result(i2)[19:20], bias_of(i2)[3:4] + bias_of(i2)[19:20])
+        else:
+            put(_lin(model.transient_rgb), hw[0:3], hb[0:3])
+            put(_lin(model.transient_sigma), hw[3:4], hb[3:4])
+            if model.output_flow:
+                put(_lin(model.transient_flow_fw), hw[4:7], hb[4:7])
+                put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
+    return grads
+
+
+class _Idx:
+    """Stand-in for a gradient matrix that remembers where each element comes from: (job, element) of the primary
+    source and, after a `+`, of a second one.  Slicing and concatenation behave like the tensor's."""
+
+    def __init__(self, ja, ea, jb=None, eb=None):
+        self.ja, self.ea = ja, ea
+        self.jb = np.full_like(ja, -1) if jb is None else jb
+        self.eb = np.zeros_like(ea) if eb is None else eb
+
+    def __getitem__(self, key):
+        return _Idx(self.ja[key], self.ea[key], self.jb[key], self.eb[key])
+
+    def __add__(self, other):
+        assert (self.jb < 0).all() and (other.jb < 0).all() and self.ja.shape == other.ja.shape
+        return _Idx(self.ja, self.ea, other.ja, other.ea)
+
+    @staticmethod
+    def cat(items, dim):
+        return _Idx(*[np.concatenate([getattr(it, f) for it in items], dim) for f in ("ja", "ea", "jb", "eb")])
+
+
+_GRAD_MAPS = {}
+
+
+def _grad_map(model, static, transient, meta, jobs, sizes, plist):
+    """(device (n,4) int32 NsffGradMapEntry rows, base address) telling nsff_weight_grad_accumulate where every
+    gradient element of this node lives, or None when some parameter has no fp32 contiguous .grad of its own shape yet
+    (first backward of a caller that does not pre-allocate: the node then hands tensors to the flush instead)."""
+    if os.environ.get("NSFF_WGRAD_INPLACE", "1") == "0":          # debug switch (A/B against the tensor hand-over)
+        return None
+    live = [(i, p) for i, p in enumerate(plist) if p.requires_grad]
+    for _, p in live:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not g.is_cuda:
+            return None
+    if not live:
+        return None
+    ptrs = tuple(p.grad.data_ptr() for _, p in live)
+    shape_key = tuple((j[2], j[3]) for j in jobs)
+    key = (id(model), bool(static), bool(transient), tuple(meta), shape_key, ptrs)
+    hit = _GRAD_MAPS.get(key)
+    if hit is not None:
+        return hit
+    base = min(ptrs)
+    if (max(ptrs) - base) // 4 + max(p.numel() for _, p in live) >= 2 ** 31:
+        return None
+    if torch.cuda.is_current_stream_capturing():      # the map is built (host work + an upload) by the eager warm-up
+        return None
+
+    def result(i):
+        rows, cols = jobs[i][2], jobs[i][3]
+        return _Idx(np.full((rows, cols), i, np.int16), np.arange(rows * cols, dtype=np.int32).reshape(rows, cols))
+
+    def bias_of(i):
+        return _Idx(np.full(256, i, np.int16), sizes[i] + np.arange(256, dtype=np.int32))
+    srcs = _assemble(model, static, transient, meta, plist, result, bias_of, _Idx.cat)
+    rows = []
+    for i, p in live:
+        src = srcs[i]
+        if src is None:
+            continue
+        assert src.ja.shape == tuple(p.shape), (src.ja.shape, tuple(p.shape))
+        n = p.numel()
+        ent = np.empty((n, 4), np.int32)
+        ent[:, 0] = (p.grad.data_ptr() - base) // 4 + np.arange(n, dtype=np.int64)
+        ent[:, 1] = src.ea.reshape(-1)
+        ent[:, 2] = src.eb.reshape(-1)
+        pair = np.stack([src.ja.reshape(-1).astype(np.int16), src.jb.reshape(-1).astype(np.int16)], 1)   # little-endian
+        ent[:, 3] = np.ascontiguousarray(pair).view(np.int32).reshape(-1)
+        rows.append(ent)
+    table = torch.from_numpy(np.concatenate(rows, 0)).to(plist[0].device)
+    if len(_GRAD_MAPS) > 64:
+        _GRAD_MAPS.clear()
+    _GRAD_MAPS[key] = (table, base)
+    return _GRAD_MAPS[key]
+
+
 _FREQ_CACHE = {}
 _PENDING = []            # (parameters, gradients, buffers to keep alive) of the field nodes of the running backward pass
 _SIDE = {}
@@ -429,6 +545,8 @@ def _flush_weight_grads():
         torch.cuda.current_stream(dev).wait_stream(side)
     with torch.no_grad():
         for plist, grads, _keep in items:
+            if grads is None:                # already accumulated in place by nsff_weight_grad_accumulate
+                continue
             have, new = [], []
             for p, g in zip(plist, grads):
                 if g is None or not p.requires_grad:

@@ -19,6 +19,7 @@ import torch.distributed as dist
 from . import field_grad
 from .autograd import grad_parameters
 from .losses import NeRFWLoss
+from .optim import FlatAdam
 from .rendering import render_rays
 
 
@@ -58,7 +59,7 @@ class NSFFTrainer:
                     decay_step=[20], decay_gamma=0.1)
 
     def __init__(self, models, embeddings, n_frames, hparams=None, Ks=None, Ps=None,
-                 output_transient=True, output_transient_flow=("fw", "bw", "disocc"), graph=False):
+                 output_transient=True, output_transient_flow=("fw", "bw", "disocc"), graph=False, optimizer_cls=FlatAdam):
         """graph=True: the step is captured once into two hipGraphs (``torch.cuda.CUDAGraph``) and replayed: graph A =
         zero_grad + forward kernels + loss + backward kernels, graph B = Adam; between them -- outside any capture --
         the flat RCCL gradient all-reduce when world > 1.  Needs fixed batch shapes and topk == 1."""
@@ -71,6 +72,7 @@ class NSFFTrainer:
         self.output_transient = output_transient
         self.output_transient_flow = list(output_transient_flow) if output_transient else []
         self.graph = bool(graph)
+        self.optimizer_cls = optimizer_cls       # (tests drive the step on CPU with a torch-op twin of FlatAdam)
         self.loss = NeRFWLoss(lambda_geo=hp["lambda_geo_init"], thickness=hp["thickness"], topk=hp["topk"],
                               static_shapes=self.graph)
         if self.output_transient_flow:                                   # train.py:136-138
@@ -78,23 +80,21 @@ class NSFFTrainer:
             self.loss.register_buffer("Ps", Ps)
             self.loss.max_t = n_frames - 1
         self.params = grad_parameters(models, embeddings)
-        self.optimizer = self.scheduler = None
+        self.optimizer = None
         self.current_epoch = 0
         self._graph = self._graph_opt = self._static_batch = self._static_log = None
         self._flat_grad = None
         self._geo = None                     # device scalars the captured loss reads (lambda_geo, epoch ramp)
 
     def _setup_flat_grads(self):
-        """Every .grad becomes a view of ONE flat buffer: zero_grad is a single memset and the data-parallel
-        all-reduce a single collective on the buffer itself (no cat / copy-back of ~100 tensors)."""
-        total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        if self._flat_grad is None or self._flat_grad.numel() != total or self._flat_grad.device != dev:
-            self._flat_grad = torch.zeros(total, device=dev, dtype=self.params[0].dtype)
-        off = 0
-        for p in self.params:
-            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        """Every parameter and every .grad is a view of ONE flat buffer each (optim.FlatAdam): zero_grad is a single
+        memset, the data-parallel all-reduce a single collective on the gradient buffer itself (no cat / copy-back of
+        ~100 tensors), Adam one launch."""
+        if self.optimizer is None:
+            self._make_optimizer()
+        elif not self.optimizer.in_place():      # a caller replaced parameter or gradient tensors
+            self.optimizer.gather()
+        self._flat_grad = self.optimizer.flat_grad
 
     def zero_grad(self):
         self._flat_grad.zero_()
@@ -108,14 +108,13 @@ class NSFFTrainer:
 
     def _make_optimizer(self):
         hp = self.hp
-        self._setup_flat_grads()
-        if self.graph:                        # capturable Adam: step counter and lr live on the device
-            lr = torch.tensor(float(hp["lr"]), device=self.params[0].device)
-            self.optimizer = torch.optim.Adam(self.params, lr=lr, eps=1e-8, weight_decay=hp["weight_decay"], capturable=True)
-        else:
-            self.optimizer = torch.optim.Adam(self.params, lr=hp["lr"], eps=1e-8, weight_decay=hp["weight_decay"])
-            self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(hp["decay_step"]),
-                                                                  gamma=hp["decay_gamma"])
+        self.optimizer = self.optimizer_cls(self.params, lr=hp["lr"], eps=1e-8, weight_decay=hp["weight_decay"])
+        self._flat_grad = self.optimizer.flat_grad
+        self._lr_epoch = -1
+
+    def _invalidate_packs(self):
+        for m in self.models.values():          # the native step changes the weights without bumping tensor versions
+            m._pack_cache.invalidate()
 
     def to(self, device):
         for m in self.models.values():
@@ -163,7 +162,7 @@ class NSFFTrainer:
         if self.graph:
             kwargs["epoch_ramp"] = self._ramp
         loss_d = self.loss(results, batch, epoch=self.current_epoch, **kwargs)
-        loss = sum(loss_d.values())
+        loss = loss_d.total() if hasattr(loss_d, "total") else sum(loss_d.values())
         with torch.no_grad():
             log = {f"train/{k}": v.detach() for k, v in loss_d.items()}
             log["train/loss"] = loss.detach()
@@ -185,15 +184,14 @@ class NSFFTrainer:
             self._make_optimizer()
         if self.graph:
             return self._graph_step(batch)
-        g0 = self.params[0].grad
-        if g0 is None or g0.data_ptr() != self._flat_grad.data_ptr():      # a caller replaced the .grad tensors
-            self._setup_flat_grads()
+        self._setup_flat_grads()
         self.zero_grad()
         loss, log = self.training_step(batch)
         with field_grad.deferred_weight_grads():
             loss.backward()
         self.allreduce()
         self.optimizer.step()
+        self._invalidate_packs()
         return log
 
     def _graph_body_backward(self):
@@ -210,12 +208,14 @@ class NSFFTrainer:
             self._static_batch = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
             self._setup_flat_grads()
             keep = [p.detach().clone() for p in self.params]
+            keep_opt = self.optimizer.state_dict()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):              # warm-up off the capture stream (allocator, pack caches, Adam state)
                 for _ in range(3):
                     self._graph_body_backward()
                     self.optimizer.step()
+                    self._invalidate_packs()
             torch.cuda.current_stream().wait_stream(side)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
@@ -227,21 +227,16 @@ class NSFFTrainer:
             with torch.no_grad():
                 for p, k in zip(self.params, keep):
                     p.copy_(k)
-                for st in self.optimizer.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
+            self.optimizer.load_state_dict(keep_opt)
         for k, v in self._static_batch.items():
             v.copy_(batch[k])
         self._graph.replay()
         self.allreduce()                        # outside the captures: RCCL is not captured
         self._graph_opt.replay()
-        for m in self.models.values():          # replays change the weights without bumping tensor versions
-            m._pack_cache.invalidate()
+        self._invalidate_packs()
         return self._static_log
 
     def on_train_epoch_end(self):
-        if self.scheduler is not None:
-            self.scheduler.step()
-        elif self.optimizer is not None and (self.current_epoch + 1) in list(self.hp["decay_step"]):
-            self.optimizer.param_groups[0]["lr"].mul_(self.hp["decay_gamma"])
+        """MultiStepLR(milestones=decay_step, gamma=decay_gamma) of train.py:143-146, stepped once per epoch."""
+        if self.optimizer is not None and (self.current_epoch + 1) in list(self.hp["decay_step"]):
+            self.optimizer.lr.mul_(self.hp["decay_gamma"])

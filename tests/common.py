@@ -86,3 +86,32 @@ def fine_sample_tolerances(cfg, coarse, u_s, u_t):
     if "transient_weights_coarse" in coarse:
         tol_t = parity.sample_tolerance(mids, coarse["transient_weights_coarse"][:, 1:-1], u_t)
     return tol_s, tol_t
+
+
+def cpu_flat_adam():
+    """A twin of nsff_pl_amd.optim.FlatAdam whose step is written with torch ops (torch.optim.Adam's single-tensor
+    formulas, amsgrad off) so that NSFFTrainer's data-parallel step can be driven on CPU by the gloo tests, and the HIP
+    step has something to be compared with."""
+    import math
+    import torch
+    from nsff_pl_amd.optim import FlatAdam
+
+    class TorchFlatAdam(FlatAdam):
+        @staticmethod
+        def _check_device(dev):
+            pass
+
+        @torch.no_grad()
+        def step(self):
+            b1, b2 = self.betas
+            p, g, m, v = self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq
+            self.state[0] += 1
+            t = float(self.state[0])
+            if self.weight_decay:
+                g = g + self.weight_decay * p
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            step_size = float(self.lr) / (1 - b1 ** t)
+            denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(self.eps)
+            p.addcdiv_(m, denom, value=-step_size)
+    return TorchFlatAdam

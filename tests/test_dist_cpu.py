@@ -120,7 +120,9 @@ def _trainer_worker(rank, world, port, ret):
         h = torch.sigmoid(rays[:, :3] @ m.static_xyz_encoding_1[0].weight[:3, :3] + m.static_rgb[0].bias)
         return {"rgb_fine": h, "depth_fine": (rays[:, 3:] ** 2).sum(1) * m.static_sigma.bias.abs().sum()}
     training.render_rays = cpu_render
-    tr = training.NSFFTrainer(models, emb, 30, dict(N_samples=8, perturb=0, noise_std=0), output_transient=False)
+    import common
+    tr = training.NSFFTrainer(models, emb, 30, dict(N_samples=8, perturb=0, noise_std=0), output_transient=False,
+                              optimizer_cls=common.cpu_flat_adam())
     tr.on_train_epoch_start(0)
     g = torch.Generator().manual_seed(100 + rank)          # every rank trains on its own batch
     before = {n: p.detach().clone() for n, p in models["fine"].named_parameters()}

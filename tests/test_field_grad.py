@@ -129,3 +129,52 @@ def test_failed_backward_does_not_lose_later_weight_gradients(hip_lib):
         assert trunk.grad is not None
         assert torch.allclose(trunk.grad, got, rtol=1e-5, atol=1e-6 * float(got.abs().max()))
         assert not field_grad._PENDING
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,static", [("g3_nsff_train", True), ("g3_nsff_train", False), ("g13_viewdir_train", True)])
+def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_lib):
+    """Deferred mode with .grad tensors in place: nsff_weight_grad_accumulate adds every gradient element straight into
+    the parameters' own memory.  Result must be bit-identical to (existing .grad) + (what the node returns through
+    autograd), for scattered .grad tensors and for views of one flat buffer, twice in a row (accumulation)."""
+    dev = torch.device("cuda:0")
+    cfg = scenes.CASES[scene]
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    model = models["fine"].to(dev)
+    freqs = [float(f) for f in emb["xyz"].freqs]
+    g = torch.Generator().manual_seed(11)
+    n_rays, s = 8, 64
+    xyz = (torch.rand(n_rays * s, 3, generator=g) * 2 - 1).to(dev)
+    t_rows = torch.randn(n_rays, scenes.N_TAU, generator=g).to(dev)
+    side = {}
+    if model.use_viewdir and static:
+        side["dir_rows"] = torch.randn(n_rays, model.in_channels_dir, generator=g).to(dev)
+        if model.in_channels_a > 0:
+            side["a_rows"] = torch.randn(n_rays, model.in_channels_a, generator=g).to(dev)
+    cot = torch.randn(n_rays * s, 16, generator=g).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def loss():
+        return (field_grad.field(model, xyz, freqs, t_rows, s, static, True, **side) * cot).sum()
+
+    want = torch.autograd.grad(loss(), params, allow_unused=True)
+    start = [torch.randn(p.shape, generator=g).to(dev) * 1e-3 for p in params]
+    for layout in ("scattered", "flat"):
+        if layout == "flat":
+            flat = torch.cat([t.reshape(-1) for t in start])
+            off = 0
+            for p, t in zip(params, start):
+                p.grad = flat[off:off + t.numel()].view_as(p)
+                off += t.numel()
+        else:
+            for p, t in zip(params, start):
+                p.grad = t.clone()
+        with field_grad.deferred_weight_grads():
+            loss().backward()
+            loss().backward()
+        torch.cuda.synchronize()
+        assert not field_grad._PENDING
+        for p, t, w in zip(params, start, want):
+            expect = t if w is None else (t + w) + w
+            assert torch.equal(p.grad, expect), (layout, tuple(p.shape))
+    assert field_grad._GRAD_MAPS, "the in-place path was not taken"

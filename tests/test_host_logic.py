@@ -55,7 +55,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_struct_layouts_match_the_header_sizes():
@@ -160,3 +160,48 @@ def test_unsupported_architectures_are_refused_by_name():
         with pytest.raises(RuntimeError, match="unsupported NeRF architecture.*" + needle):
             _lib.model_desc(m)
     _lib.model_desc(A.NeRF('fine', D=6, skips=[2], use_viewdir=False))       # fine
+
+
+@pytest.mark.parametrize("kw,static,transient", [
+    (dict(use_viewdir=False, encode_transient=True, output_flow=True), True, True),
+    (dict(use_viewdir=False, encode_transient=True, output_flow=True), False, True),
+    (dict(use_viewdir=True, encode_appearance=True, in_channels_a=48, encode_transient=True, output_flow=True), True, True),
+    (dict(use_viewdir=True, encode_transient=False, D=5, skips=[2]), True, False)])
+def test_gradient_map_names_the_same_elements_as_the_tensor_assembly(kw, static, transient):
+    """nsff_weight_grad_accumulate's map (field_grad._grad_map) is built by running the tensor assembly on index
+    objects: gathering through those indices must reproduce the tensors, element for element, with one owner each."""
+    from nsff_pl_amd import field_grad as fg
+    model = A.NeRF('fine', **kw)
+    plist = _lib.param_list(model)
+    meta = fg._wgrad_jobs(model, static, transient)
+    rng = np.random.default_rng(5)
+    mats = [rng.standard_normal(fg._JOB_SHAPE[k]).astype(np.float32) for k, _, _ in meta]
+    rows = [rng.standard_normal(256).astype(np.float32) for _ in meta]
+    sizes = [m.size for m in mats]
+    tens = fg._assemble(model, static, transient, meta, plist, lambda i: torch.from_numpy(mats[i]),
+                        lambda i: torch.from_numpy(rows[i]), torch.cat)
+    idx = fg._assemble(model, static, transient, meta, plist,
+                       lambda i: fg._Idx(np.full(mats[i].shape, i, np.int16),
+                                         np.arange(sizes[i], dtype=np.int32).reshape(mats[i].shape)),
+                       lambda i: fg._Idx(np.full(256, i, np.int16), sizes[i] + np.arange(256, dtype=np.int32)), fg._Idx.cat)
+
+    def fetch(job, e):                      # what the kernel reads: e < size -> matrix element, else row sum e - size
+        out = np.zeros(job.shape, np.float32)
+        for j in np.unique(job[job >= 0]):
+            sel = job == j
+            flat = np.concatenate([mats[j].reshape(-1), rows[j]])
+            out[sel] = flat[e[sel]]
+        return out
+    n_grads = 0
+    for p, g, ix in zip(plist, tens, idx):
+        assert (g is None) == (ix is None)
+        if g is None:
+            continue
+        n_grads += 1
+        assert tuple(g.shape) == tuple(p.shape) == ix.ja.shape, (g.shape, p.shape)
+        assert (ix.ja >= 0).all()
+        got = fetch(ix.ja, ix.ea) + fetch(ix.jb, ix.eb)
+        np.testing.assert_array_equal(got, g.numpy())
+    expect = sum(1 for n, _ in model.named_parameters()
+                 if (static and n.startswith("static")) or (transient and n.startswith("transient")))
+    assert n_grads == expect

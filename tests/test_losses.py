@@ -277,6 +277,21 @@ def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, hip_lib, 
         torch.cuda.synchronize()
         out[fused] = ({k: float(v.detach()) for k, v in terms.items()},
                       {k: v.grad.detach().cpu().numpy() for k, v in leaves.items() if v.grad is not None})
+    # the single-node total of the fused dict: same value and the same gradients as sum(values) (reference train.py:184)
+    monkeypatch.setenv("NSFF_FUSED_LOSS", "1")
+    grads = []
+    for use_total in (True, False):
+        leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.startswith(("zs_", "disocc")) and k != "xyzs_fine")
+                  for k, v in res.items()}
+        terms = loss_fn(leaves, targets, epoch=3, **kw)
+        assert isinstance(terms, fused_loss.LossTerms)
+        total = terms.total() if use_total else sum(terms.values())
+        total.backward()
+        grads.append((float(total), {k: v.grad.clone() for k, v in leaves.items() if v.grad is not None}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[1][0])
+    assert sorted(grads[0][1]) == sorted(grads[1][1])
+    for k in grads[0][1]:
+        assert torch.equal(grads[0][1][k], grads[1][1][k]), k
     t1, g1 = out["1"]
     t0, g0 = out["0"]
     assert sorted(t1) == sorted(t0) == sorted(fused_loss.TERMS)

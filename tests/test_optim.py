@@ -1,0 +1,104 @@
+"""The native Adam step (nsff_pl_amd/optim.py, csrc/optim.hip) against torch.optim.Adam as the reference configures it
+(utils/__init__.py:45-47: lr, eps=1e-8, weight_decay; train.py:143-146: MultiStepLR)."""
+import numpy as np
+import pytest
+import torch
+
+import common
+from nsff_pl_amd.optim import FlatAdam
+
+SHAPES = [(256, 63), (256,), (3, 256), (1,), (5, 7, 3), (48, 30)]          # total not a multiple of 4
+
+
+def _params(dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter((torch.randn(*s, generator=g) * 0.3).to(dev)) for s in SHAPES]
+
+
+def _run(opt_factory, dev, wd, steps=6, lr_drop_at=3):
+    params = _params(dev)
+    opt = opt_factory(params, wd)
+    g = torch.Generator().manual_seed(7)
+    for i in range(steps):
+        opt.zero_grad()
+        for p in params:
+            grad = (torch.randn(*p.shape, generator=g) * 10.0 ** float(torch.randint(-4, 2, (1,), generator=g))).to(dev)
+            if p.grad is None:
+                p.grad = grad
+            else:
+                p.grad.copy_(grad)
+        opt.step()
+        if i + 1 == lr_drop_at:
+            if isinstance(opt, FlatAdam):
+                opt.lr.mul_(0.1)
+            else:
+                opt.param_groups[0]["lr"] *= 0.1
+    return [p.detach().cpu().numpy().copy() for p in params]
+
+
+def _torch_adam(params, wd):
+    return torch.optim.Adam(params, lr=5e-4, eps=1e-8, weight_decay=wd)
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_torch_op_twin_equals_torch_adam_on_cpu(wd):
+    Twin = common.cpu_flat_adam()
+    got = _run(lambda ps, w: Twin(ps, lr=5e-4, eps=1e-8, weight_decay=w), torch.device("cpu"), wd)
+    want = _run(_torch_adam, torch.device("cpu"), wd)
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
+
+
+def test_flat_adam_refuses_cpu_parameters():
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        FlatAdam(_params(torch.device("cpu")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_native_adam_equals_torch_adam(wd, hip_lib):
+    dev = torch.device("cuda:0")
+    got = _run(lambda ps, w: FlatAdam(ps, lr=5e-4, eps=1e-8, weight_decay=w), dev, wd)
+    want = _run(_torch_adam, dev, wd)
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_native_adam_views_state_and_graph_capture(hip_lib):
+    dev = torch.device("cuda:0")
+    params = _params(dev)
+    before = [p.detach().clone() for p in params]
+    opt = FlatAdam(params, lr=1e-3)
+    assert opt.in_place() and all(torch.equal(p.detach(), b) for p, b in zip(params, before))   # adoption keeps the values
+    assert opt.flat_param.numel() % 4 == 0 and opt.numel == sum(int(np.prod(s)) for s in SHAPES)
+    for p in params:
+        p.grad.fill_(0.5)                                   # .grad is a view of the flat buffer
+    assert float(opt.flat_grad[:opt.numel].min()) == 0.5
+    # eager step, then the same step replayed from a hipGraph: identical trajectories
+    ref = FlatAdam(_params(dev), lr=1e-3)
+    ref.flat_grad.copy_(opt.flat_grad)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step()                                          # warm-up
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step()
+    graph.replay()
+    graph.replay()                                          # warm-up + two replays = three steps
+    for _ in range(3):
+        ref.step()
+    torch.cuda.synchronize()
+    assert float(opt.state[0]) == float(ref.state[0]) == 3.0
+    assert torch.equal(opt.flat_param, ref.flat_param)
+    # a caller that swaps a tensor is noticed and re-adopted without losing its values
+    params[2].data = torch.full_like(params[2], 2.0)
+    assert not opt.in_place()
+    opt.gather()
+    assert float(params[2].min()) == 2.0 and opt.in_place()
+    sd = opt.state_dict()
+    other = FlatAdam(_params(dev), lr=5e-4)
+    other.load_state_dict(sd)
+    assert float(other.state[0]) == 3.0 and torch.equal(other.exp_avg, opt.exp_avg) and float(other.lr) == float(opt.lr)
