@@ -173,7 +173,8 @@ int nsff_field_input_backward(const float* d_xin, const float* xyz, int64_t n_ra
 
 /* Batched weight-gradient GEMMs, K = points:  out_j = (1/G) * A_j^T . B_j over all point tiles, G as above.
  * A_j: fp16 fragment-major (T,4,a_rows,16), a_rows in {256, 32};  B_j: (T,4,b_rows,16), b_rows in {256, 128}.
- * Split-K: every job is cut into n_splits tile ranges (heads: 8x as many) whose partial sums go to `scratch`
+ * Split-K: every job is cut into about n_splits tile ranges (rounded per job shape so that the workgroups of equally
+ * shaped jobs fill whole rounds of the 256 CUs; heads: 8x as many) whose partial sums go to `scratch`
  * (nsff_weight_grad_scratch floats) and are summed, scaled and written by a second launch to
  *   out + out_off[j]  : fp32 a_rows_j x b_rows_j (row-major),     bias + 256*j : fp32 row sums of A_j (bias gradients).
  * `jobs` is a HOST array.                                                                                      */

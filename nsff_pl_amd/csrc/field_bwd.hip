@@ -13,6 +13,7 @@
 // row, not on the 1e6:1 spread between points; what K2 consumes is re-expressed on one global scale G.
 // Reference semantics: autograd of models/nerf.py:118-213 (+ PosEmbedding :17-30 on the host side).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 #include "nsff_layout_h3.h"
@@ -874,17 +875,35 @@ int nsff_field_input_backward(const float* d_xin, const float* xyz, int64_t n_ra
     return nsff_launch_status();
 }
 
-static inline int wgrad_splits(const NsffWgradJob& j, int64_t n_tiles, int32_t n_splits) {
-    long long s = j.a_rows == 32 ? 8LL * n_splits : n_splits;       // the head jobs are tiny: cut them finer
-    if (s > n_tiles) s = n_tiles;
-    return (int)(s < 1 ? 1 : s);
+// Split-K factor of every job.  The two GEMM classes run one workgroup per CU (their LDS ring takes 96-128 KiB), so a
+// class of m jobs is cut into floor(256 r / m) splits each -- whole rounds of the 256 CUs -- with the smallest r that gives
+// at least 3/4 of the requested n_splits (18 jobs x 32 splits = 576 workgroups would be 2.25 rounds: a quarter of the
+// last one idle; 28 splits = 504 fill two).  The head jobs are tiny: 8x as many splits.
+constexpr int WGRAD_CUS = 256;
+static inline int wgrad_class(const NsffWgradJob& j) { return j.a_rows == 32 ? 2 : (j.b_rows == 128 ? 1 : 0); }
+static void wgrad_plan(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, int* splits) {
+    int m[3] = {0, 0, 0};
+    for (int j = 0; j < n_jobs; ++j) ++m[wgrad_class(jobs[j])];
+    long long per_class[3];
+    for (int c = 0; c < 2; ++c) {
+        long long r = 1;
+        while (m[c] > 0 && 4LL * (WGRAD_CUS * r / m[c]) < 3LL * n_splits) ++r;
+        per_class[c] = m[c] > 0 ? WGRAD_CUS * r / m[c] : 1;
+    }
+    per_class[2] = 8LL * n_splits;
+    for (int j = 0; j < n_jobs; ++j) {
+        long long s = per_class[wgrad_class(jobs[j])];
+        if (s > n_tiles) s = n_tiles;
+        splits[j] = (int)(s < 1 ? 1 : s);
+    }
 }
 
 int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits) {
-    if (!jobs || n_jobs < 0 || n_splits < 1) return -1;
+    if (!jobs || n_jobs < 0 || n_jobs > MAX_WJOBS || n_splits < 1) return -1;
+    int splits[MAX_WJOBS];
+    wgrad_plan(jobs, n_jobs, n_tiles, n_splits, splits);
     int64_t total = 0;
-    for (int j = 0; j < n_jobs; ++j)
-        total += (int64_t)wgrad_splits(jobs[j], n_tiles, n_splits) * ((int64_t)jobs[j].a_rows * jobs[j].b_rows + 256);
+    for (int j = 0; j < n_jobs; ++j) total += (int64_t)splits[j] * ((int64_t)jobs[j].a_rows * jobs[j].b_rows + 256);
     return total;
 }
 
@@ -899,8 +918,10 @@ static int wgrad_gemms(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles
     }
     long long off = 0;
     int max_size = 0;
+    int splits[MAX_WJOBS];
+    wgrad_plan(jobs, n_jobs, n_tiles, n_splits, splits);
     for (int j = 0; j < n_jobs; ++j) {
-        const int sp = wgrad_splits(jobs[j], n_tiles, n_splits);
+        const int sp = splits[j];
         const int size = jobs[j].a_rows * jobs[j].b_rows;
         rjobs[j].part_off = off; off += (long long)sp * size;
         rjobs[j].bias_part_off = off; off += (long long)sp * 256;

@@ -117,6 +117,7 @@ struct H3KArgs {
     int use_viewdir;
     float flow_scale;
     int n_freqs;
+    int octave_freqs;                // freqs[f+1] == 2 freqs[f], n_freqs <= 10, one 64-column segment: the doubling encoder applies
     float freqs[NSFF_MAX_FREQS];
     int ld_emb, off_xyz, off_dir, off_a, off_t;
 };
@@ -450,12 +451,35 @@ __device__ __forceinline__ void split_store4(_Float16* xh, _Float16* xl, int idx
 // (Re)build the trunk input tile [xyz embedding | zero pad to k0s | time code | zero pad to kt] of this workgroup's
 // points.  `x` = the point of row threadIdx % M, read once at kernel start (raw-position mode).  The time-code
 // loads are issued first (16-byte loads when the rows allow it) so that their L2 latency hides behind the sincos work.
+// Thread -> (point row, part) of the input builders.  With four threads per row, 32 consecutive lanes are 8 rows x 4 parts:
+// row stride 132 dwords (= 4 banks) x 8 rows + part stride 9 dwords x 4 parts touch 32 different banks, so the narrow
+// (2- and 4-byte) stores of the encoders are conflict-free; lanes = 32 rows of one part were 4-way conflicted.
+template <int M, int THREADS>
+__device__ __forceinline__ int build_row(int tid) {
+    if constexpr (THREADS / M == 4) return 8 * (tid >> 5) + (tid & 7);
+    else return tid % M;
+}
+template <int M, int THREADS>
+__device__ __forceinline__ int build_part(int tid) {
+    if constexpr (THREADS / M == 4) return (tid >> 3) & 3;
+    else return tid / M;
+}
+
+// two consecutive columns (idx even) -> one 4-byte store per plane
+template <bool SPLIT>
+__device__ __forceinline__ void split_store2(_Float16* xh, _Float16* xl, int idx, float v0, float v1) {
+    const h2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    *reinterpret_cast<h2*>(xh + idx) = h;
+    if constexpr (SPLIT)
+        *reinterpret_cast<h2*>(xl + idx) = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h, v0), minus_hi_half(h, v1));
+}
+
 template <int M, int THREADS, bool SPLIT>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
                                             const float (&x)[3]) {
     constexpr int G = THREADS / M;               // threads per point row
     constexpr int CH = 16 / G;                   // float4 chunks of a 64-column time-code segment per thread
-    const int r = threadIdx.x % M, q = threadIdx.x / M;
+    const int r = build_row<M, THREADS>(threadIdx.x), q = build_part<M, THREADS>(threadIdx.x);
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
     const int base = r * LDH;
@@ -475,7 +499,43 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
             tv[j] = (valid && c < a.in_t) ? *reinterpret_cast<const float4*>(tsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if (a.xyz != nullptr) {
+    if (G == 4 && a.xyz != nullptr && a.octave_freqs) {
+        // Part q encodes octaves [3q, 3q+3) of all three axes = columns [3 + 18q, 21 + 18q): one sincos per axis at its
+        // first octave, the next two by angle doubling (freqs[f+1] == 2 freqs[f], checked on the host; two doublings add
+        // < 4 ulp); the 18 values leave as one 2-byte, eight 4-byte and one 2-byte store per plane.
+        float sn[3], cs[3];
+        const int f0 = 3 * q;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sn[c] = 0.f; cs[c] = 0.f;
+            if (f0 < a.n_freqs) sincosf(a.freqs[f0] * x[c], &sn[c], &cs[c]);
+            __builtin_amdgcn_sched_barrier(0);                      // one range reduction at a time (register pressure)
+        }
+        const int c0 = 3 + 18 * q;                                  // odd: first value alone, then even-aligned pairs
+        float carry = 0.f;                                          // cos of the last axis waits for the next octave's first sin
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (f0 + k >= a.n_freqs) { sn[0] = sn[1] = sn[2] = cs[0] = cs[1] = cs[2] = 0.f; }   // (zero padding up to k0s)
+            const int ck = c0 + 6 * k;                              // [sin x3 | cos x3] of octave f0 + k
+            if (k == 0) split_store<SPLIT>(sXh, sXl, base + ck, sn[0]);
+            else if (ck - 1 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck - 1, carry, sn[0]);
+            if (ck + 1 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck + 1, sn[1], sn[2]);
+            if (ck + 3 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck + 3, cs[0], cs[1]);
+            carry = cs[2];
+            if (k < 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float s2 = 2.f * sn[c] * cs[c], c2 = fmaf(-2.f * sn[c], sn[c], 1.f);
+                    sn[c] = s2; cs[c] = c2;
+                }
+            }
+        }
+        if (c0 + 17 < k0s) split_store<SPLIT>(sXh, sXl, base + c0 + 17, carry);
+        if (q == 0) {
+            split_store2<SPLIT>(sXh, sXl, base + 0, x[0], x[1]);
+            split_store<SPLIT>(sXh, sXl, base + 2, x[2]);
+        }
+    } else if (a.xyz != nullptr) {
         if (q == 0) {
             split_store<SPLIT>(sXh, sXl, base + 0, x[0]); split_store<SPLIT>(sXh, sXl, base + 1, x[1]);
             split_store<SPLIT>(sXh, sXl, base + 2, x[2]);
@@ -514,7 +574,7 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
 template <int M, int THREADS, bool SPLIT>
 __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0) {
     constexpr int G = THREADS / M;
-    const int r = threadIdx.x % M, q = threadIdx.x / M;
+    const int r = build_row<M, THREADS>(threadIdx.x), q = build_part<M, THREADS>(threadIdx.x);
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
     const float* sd = nullptr; const float* sa = nullptr;
@@ -673,7 +733,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     constexpr bool KEEP_POINT = SPLIT;
     float px[3] = {0.f, 0.f, 0.f};
     auto read_point = [&]() {
-        const long long bp = p0 + threadIdx.x % M;
+        const long long bp = p0 + build_row<M, THREADS>(threadIdx.x);
         if (a.xyz != nullptr && bp < a.n_points) { px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2]; }
     };
     if constexpr (KEEP_POINT) read_point();
@@ -945,6 +1005,12 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.use_viewdir = d.use_viewdir; k.flow_scale = d.flow_scale;
     k.n_freqs = g.n_freqs;
     for (int i = 0; i < NSFF_MAX_FREQS; ++i) k.freqs[i] = g.freqs[i];
+    k.octave_freqs = (g.xyz != nullptr && g.n_freqs >= 1 && g.n_freqs <= 10 && k.L.k0s == 64) ? 1 : 0;
+    for (int i = 0; i + 1 < g.n_freqs; ++i)
+        if (g.freqs[i + 1] != 2.0f * g.freqs[i]) k.octave_freqs = 0;
+#ifdef H3_NO_OCTAVE
+    k.octave_freqs = 0;
+#endif
     k.ld_emb = g.ld_emb; k.off_xyz = g.off_xyz; k.off_dir = g.off_dir; k.off_a = g.off_a; k.off_t = g.off_t;
 
     // ---- step program (reference nerf.py:162-208) ----
