@@ -425,13 +425,8 @@ __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Fl
         }
         // 1 KiB blocks of 32 rows, lane-linear inside: [ks][row/32][(row&31) + 32*(point group&1)][8 points]
         _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
-#ifdef H3_NT_SAVE
-        __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));
+        __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad
         __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));
-#else
-        *reinterpret_cast<h8*>(d) = out0;
-        *reinterpret_cast<h8*>(d + 8) = out1;
-#endif
     }
 }
 
@@ -499,22 +494,24 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
             tv[j] = (valid && c < a.in_t) ? *reinterpret_cast<const float4*>(tsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if (G == 4 && a.xyz != nullptr && a.octave_freqs) {
-        // Part q encodes octaves [3q, 3q+3) of all three axes = columns [3 + 18q, 21 + 18q): one sincos per axis at its
-        // first octave, the next two by angle doubling (freqs[f+1] == 2 freqs[f], checked on the host; two doublings add
-        // < 4 ulp); the 18 values leave as one 2-byte, eight 4-byte and one 2-byte store per plane.
+    if ((G == 4 || G == 2) && a.xyz != nullptr && a.octave_freqs) {
+        // Part q encodes octaves [OPP q, OPP (q+1)) of all three axes = columns [3 + 6 OPP q, 3 + 6 OPP (q+1)): one sincos per
+        // axis at its first octave, the following ones by angle doubling (freqs[f+1] == 2 freqs[f], checked on the host;
+        // the parity-grade kernels re-anchor after two doublings, < 4 ulp); the values leave as 4-byte stores per plane
+        // (the first and the last one of a part as 2-byte stores: parts start on odd columns).
+        constexpr int OPP = G == 4 ? 3 : 5;                         // 12 / 10 octaves of capacity (n_freqs <= 10)
         float sn[3], cs[3];
-        const int f0 = 3 * q;
+        const int f0 = OPP * q;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             sn[c] = 0.f; cs[c] = 0.f;
             if (f0 < a.n_freqs) sincosf(a.freqs[f0] * x[c], &sn[c], &cs[c]);
             __builtin_amdgcn_sched_barrier(0);                      // one range reduction at a time (register pressure)
         }
-        const int c0 = 3 + 18 * q;                                  // odd: first value alone, then even-aligned pairs
+        const int c0 = 3 + 6 * OPP * q;                             // odd: first value alone, then even-aligned pairs
         float carry = 0.f;                                          // cos of the last axis waits for the next octave's first sin
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < OPP; ++k) {
             if (f0 + k >= a.n_freqs) { sn[0] = sn[1] = sn[2] = cs[0] = cs[1] = cs[2] = 0.f; }   // (zero padding up to k0s)
             const int ck = c0 + 6 * k;                              // [sin x3 | cos x3] of octave f0 + k
             if (k == 0) split_store<SPLIT>(sXh, sXl, base + ck, sn[0]);
@@ -522,15 +519,20 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
             if (ck + 1 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck + 1, sn[1], sn[2]);
             if (ck + 3 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck + 3, cs[0], cs[1]);
             carry = cs[2];
-            if (k < 2) {
+            if (k + 1 < OPP) {
+                if (SPLIT && k == 2 && f0 + 3 < a.n_freqs) {        // (five octaves per part only)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float s2 = 2.f * sn[c] * cs[c], c2 = fmaf(-2.f * sn[c], sn[c], 1.f);
-                    sn[c] = s2; cs[c] = c2;
+                    for (int c = 0; c < 3; ++c) sincosf(a.freqs[f0 + 3] * x[c], &sn[c], &cs[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float s2 = 2.f * sn[c] * cs[c], c2 = fmaf(-2.f * sn[c], sn[c], 1.f);
+                        sn[c] = s2; cs[c] = c2;
+                    }
                 }
             }
         }
-        if (c0 + 17 < k0s) split_store<SPLIT>(sXh, sXl, base + c0 + 17, carry);
+        if (c0 + 6 * OPP - 1 < k0s) split_store<SPLIT>(sXh, sXl, base + c0 + 6 * OPP - 1, carry);
         if (q == 0) {
             split_store2<SPLIT>(sXh, sXl, base + 0, x[0], x[1]);
             split_store<SPLIT>(sXh, sXl, base + 2, x[2]);

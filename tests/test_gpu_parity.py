@@ -232,6 +232,33 @@ def test_weight_repack_follows_parameter_updates(hip_lib):
                         orc.nerf_forward(f["params"], f["cfg"], x.cpu().numpy(), output_transient=False))
 
 
+@pytest.mark.parametrize("logscale,n_freqs", [(True, 10), (False, 10), (True, 4)])
+def test_field_query_encodes_raw_points_for_any_frequency_list(logscale, n_freqs, hip_lib):
+    """Raw-position input of nsff_field_query (rendering.py:153-175 = PosEmbedding + cat + NeRF.forward): octave
+    frequencies take the angle-doubling encoder of the f16x3 kernel, any other list (PosEmbedding(logscale=False),
+    nerf.py:9-12) the generic one; both against the oracle, on a ragged point count."""
+    from nsff_pl_amd import _lib
+    emb = A.PosEmbedding(n_freqs - 1, n_freqs, logscale=logscale)
+    torch.manual_seed(5)
+    m = A.NeRF("fine", in_channels_xyz=3 + 6 * n_freqs, use_viewdir=False, encode_transient=True, output_flow=True).to(DEV)
+    S, n_rays = 50, 7                                       # 350 points: five full 64-point tiles + 30
+    P = S * n_rays
+    g = torch.Generator().manual_seed(2)
+    xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
+    t_rows = torch.randn(n_rays, m.in_channels_t, generator=g).to(DEV)
+    raw = torch.empty(P, _lib.RAW_STRIDE, device=DEV)
+    freqs = [float(f) for f in emb.freqs]
+    _lib.field_query(m, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows)
+    f = orc.field_from_module(m)
+    x_emb = np.concatenate([orc.pos_embedding(xyz.cpu().numpy(), np.asarray(freqs, np.float32)),
+                            np.repeat(t_rows.cpu().numpy(), S, 0)], 1)
+    cfg = dict(f["cfg"], in_dir=0, in_a=0)
+    want = orc.nerf_forward(f["params"], cfg, x_emb, output_transient=True, output_transient_flow=("fw", "bw"))
+    got = raw.cpu().numpy()
+    got = np.concatenate([got[:, 0:4], got[:, 4:8], got[:, 8:14]], 1)
+    parity.assert_close(f"raw records logscale={logscale} n_freqs={n_freqs}", got, want, parity.RTOL)
+
+
 def test_sample_pdf(stages, hip_lib, monkeypatch):
     bins, w = stages["pdf/bins"], stages["pdf/weights"]
     tb, tw = torch.from_numpy(bins).to(DEV), torch.from_numpy(w).to(DEV)
