@@ -202,7 +202,7 @@ def timed(step, steps, warmup, world, device, prof=False):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kern = (0, 0.0, 0.0)
+    kern = (0, 0.0, 0.0, 0.0)
     if prof:
         kern = _lib.prof_collect()
         _lib.prof_enable(False)
@@ -214,8 +214,9 @@ def timed(step, steps, warmup, world, device, prof=False):
 
 
 def roofline_block(precision, kern):
-    launches, kernel_ms, kernel_flops = kern
+    launches, kernel_ms, kernel_flops, executed_flops = kern
     achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    executed = executed_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     try:    # measured separately with rocprofv3 --pmc (profiles/collect_pmc.sh): bytes cannot be counted from here
         traffic = json.load(open(os.path.join(ROOT, "profiles", "field_traffic.json"))).get(precision)
     except Exception:
@@ -223,9 +224,12 @@ def roofline_block(precision, kern):
     return {"bound": "mfma", "kernel": KERNEL_NAME[precision], "achieved": achieved, "peak": PEAK_TFLOPS[precision],
             "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision], "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/field_traffic.json)",
-            "mfma_issue_frac": achieved * MFMA_PER_PRODUCT[precision] / PEAK_TFLOPS[precision],
-            "note": "achieved = algorithmic FLOPs (2*MACs of the fp32 Linear layers); the f16x3 mode issues 3 f16 MFMAs "
-                    "per algorithmic product, so frac <= 1/3 there",
+            "executed": executed,
+            "mfma_issue_frac": executed * MFMA_PER_PRODUCT[precision] / PEAK_TFLOPS[precision],
+            "note": "achieved = algorithmic FLOPs of the reference network (2*MACs of its fp32 Linear layers) / kernel time; "
+                    "executed = what the kernel actually multiplies: inference launches of the f16 kernels fold the two "
+                    "activation-free *_xyz_encoding_final layers (nerf.py:170,195) into pre-multiplied head rows, i.e. skip "
+                    "2 of the 18 256x256 layers; the f16x3 mode issues 3 f16 MFMAs per executed product (mfma_issue_frac)",
             "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
             "flop_per_launch": kernel_flops / max(launches, 1)}
 

@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      12
+#define NSFF_ABI_VERSION      13
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -387,8 +387,10 @@ int nsff_composite_backward(const NsffCompositeBwdArgs* args, void* stream);
 /* ---- profiling hooks used by bench.py (HIP events around field-query launches) ---- */
 int nsff_prof_enable(int on);
 /* Synchronises the recorded events; returns launches, summed milliseconds and summed
- * algorithmic FLOPs (2*MACs of the Linear layers, unpadded K) since the last reset. */
-int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
+ * algorithmic FLOPs (2*MACs of the reference's Linear layers, unpadded K) since the last reset, and the FLOPs the
+ * kernels executed for them: inference launches of the f16 kernels evaluate the heads that read the activation-free
+ * *_xyz_encoding_final layers (nerf.py:170,195) with pre-multiplied rows and skip those 256x256 layers. */
+int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops);
 
 int         nsff_abi_version(void);
 const char* nsff_last_hip_error(void);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -148,7 +148,7 @@ _SIGNATURES = {
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
     "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
-    "nsff_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nsff_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -461,6 +461,6 @@ def prof_enable(on):
 
 
 def prof_collect():
-    n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
-    _check(load().nsff_prof_collect(C.byref(n), C.byref(ms), C.byref(fl)), "nsff_prof_collect")
-    return n.value, ms.value, fl.value
+    n, ms, fl, ex = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    _check(load().nsff_prof_collect(C.byref(n), C.byref(ms), C.byref(fl), C.byref(ex)), "nsff_prof_collect")
+    return n.value, ms.value, fl.value, ex.value

@@ -366,7 +366,7 @@ __global__ void nsff_posenc_kernel(const PosencArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t e0, e1; double flops; };
+struct ProfRec { hipEvent_t e0, e1; double flops, executed; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -581,6 +581,11 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
         hipEventRecord(pr.e1, st);
         pr.flops = field_flops_per_point(d, g.static_mode, g.transient_mode,
                                          g.transient_mode == 2 ? g.flow_heads : 0) * (double)g.n_points;
+        // the f16 kernels' inference launches fold the activation-free *_final layers into their head rows
+        const bool h3 = g.precision == NSFF_PREC_F16X3 || g.precision == NSFF_PREC_F16;
+        const bool folds = h3 && !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
+        const int folded = folds ? ((g.static_mode == 2 && !d.use_viewdir) ? 1 : 0) + (g.transient_mode ? 1 : 0) : 0;
+        pr.executed = pr.flops - 2.0 * d.W * d.W * folded * (double)g.n_points;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(pr);
     }
@@ -593,25 +598,26 @@ int nsff_prof_enable(int on) {
     return NSFF_OK;
 }
 
-int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops) {
+int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops) {
     std::vector<ProfRec> recs;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         recs.swap(g_prof);
     }
-    double ms = 0, fl = 0;
+    double ms = 0, fl = 0, ex = 0;
     for (auto& r : recs) {
         hipError_t e = hipEventSynchronize(r.e1);
         if (e != hipSuccess) return nsff_hip_fail(e);
         float t = 0;
         e = hipEventElapsedTime(&t, r.e0, r.e1);
         if (e != hipSuccess) return nsff_hip_fail(e);
-        ms += t; fl += r.flops;
+        ms += t; fl += r.flops; ex += r.executed;
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
     }
     if (launches) *launches = (int64_t)recs.size();
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
+    if (executed_flops) *executed_flops = ex;
     return NSFF_OK;
 }
 

@@ -84,7 +84,7 @@ struct H3Step {
 };
 enum { PRE_NONE = 0, PRE_INPUT = 1, PRE_INPUT_T = 2, PRE_SIDE = 3 };
 enum { POST_NONE = 0, POST_RELU = 1, POST_LINEAR = 2 };
-enum { HEAD_NONE = 0, HEAD_S_SIGMA = 1, HEAD_S_RGB = 2, HEAD_T = 3 };
+enum { HEAD_NONE = 0, HEAD_S_SIGMA = 1, HEAD_S_RGB = 2, HEAD_T = 3, HEAD_S_FOLD = 4, HEAD_T_FOLD = 5 };
 constexpr int MAX_STEPS = 28;
 
 struct H3KArgs {
@@ -469,7 +469,10 @@ __device__ __forceinline__ void split_store2(_Float16* xh, _Float16* xl, int idx
         *reinterpret_cast<h2*>(xl + idx) = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h, v0), minus_hi_half(h, v1));
 }
 
-template <int M, int THREADS, bool SPLIT>
+// OCTAVE: allow the angle-doubling encoder (inference).  The training forward keeps one exact sincos per column: its
+// gradients are compared with autograd of the reference network, whose ReLU pattern -- a function of sin(512 x) eight
+// layers deep -- answers a 4-ulp change of the encoding with per-cent changes of single weight gradients.
+template <int M, int THREADS, bool SPLIT, bool OCTAVE = true>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
                                             const float (&x)[3]) {
     constexpr int G = THREADS / M;               // threads per point row
@@ -494,7 +497,7 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
             tv[j] = (valid && c < a.in_t) ? *reinterpret_cast<const float4*>(tsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if ((G == 4 || G == 2) && a.xyz != nullptr && a.octave_freqs) {
+    if (OCTAVE && (G == 4 || G == 2) && a.xyz != nullptr && a.octave_freqs) {
         // Part q encodes octaves [OPP q, OPP (q+1)) of all three axes = columns [3 + 6 OPP q, 3 + 6 OPP (q+1)): one sincos per
         // axis at its first octave, the following ones by angle doubling (freqs[f+1] == 2 freqs[f], checked on the host;
         // the parity-grade kernels re-anchor after two doublings, < 4 ulp); the values leave as 4-byte stores per plane
@@ -533,6 +536,8 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
             }
         }
         if (c0 + 6 * OPP - 1 < k0s) split_store<SPLIT>(sXh, sXl, base + c0 + 6 * OPP - 1, carry);
+        if (q == G - 1)                                             // columns past the last part's range (G = 2: column 63)
+            for (int c = 3 + 6 * OPP * G; c < k0s; ++c) split_store<SPLIT>(sXh, sXl, base + c, 0.f);
         if (q == 0) {
             split_store2<SPLIT>(sXh, sXl, base + 0, x[0], x[1]);
             split_store<SPLIT>(sXh, sXl, base + 2, x[2]);
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                 }
             } else {
                 if constexpr (!KEEP_POINT) read_point();
-                build_input<M, THREADS, SPLIT>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px);
+                build_input<M, THREADS, SPLIT, !SAVE>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px);
             }
             __syncthreads();
             if constexpr (SAVE) {
@@ -815,8 +820,11 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                 int n_rows = 1, slot0 = 3;
                 unsigned kinds = ACT_NONE;
                 if (st.head == HEAD_S_RGB) { w_off = a.L.s_rgb_w; b_off = a.L.s_rgb_b; n_rows = 3; slot0 = 0; kinds = 0x15u; }
-                if (st.head == HEAD_T) {
-                    w_off = a.L.t_head_w; b_off = a.L.t_head_b; n_rows = (int)a.L.t_head_rows; slot0 = 4;
+                if (st.head == HEAD_S_FOLD) { w_off = a.L.s_fold_w; b_off = a.L.s_fold_b; n_rows = 4; slot0 = 0; kinds = 0x15u; }
+                if (st.head == HEAD_T || st.head == HEAD_T_FOLD) {
+                    w_off = st.head == HEAD_T ? a.L.t_head_w : a.L.t_fold_w;
+                    b_off = st.head == HEAD_T ? a.L.t_head_b : a.L.t_fold_b;
+                    n_rows = (int)a.L.t_head_rows; slot0 = 4;
                     kinds = 0x15u | (0xAAAu << 8);
                 }
                 heads<NPT, NW, SPLIT>(sXh, sXl, sRed, pk, w_off, b_off, n_rows, kinds, a.flow_scale, sRaw, slot0, wave_id, lane);
@@ -831,6 +839,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
     }
     H3_SPAN(1);
+    { [[maybe_unused]] const int i = 31; H3_STAMP(0); }   // (timing build) end of the workgroup's work: slot 31, stamp 0
 }
 
 // ---------------------------------------------------------------------------------
@@ -885,6 +894,37 @@ __global__ void nsff_pack_kernel_h3(const PackArgsH3 a) {
     reinterpret_cast<h8*>(a.dst + s.dst)[idx] = out;
 }
 
+// Folded head rows (see NsffLayoutH3): out_w[r][i] = sum_o W_head[r][o] * W_final[o][i],  out_b[r] = sum_o W_head[r][o] *
+// b_final[o] + b_head[r]  for the rows of the heads that read *_final; `plain` rows (static sigma) are copied.  One
+// workgroup per row, one thread per input column, double accumulation (once per weight update: the cost is nothing).
+struct FoldArgs {
+    const float* w_head[4]; const float* b_head[4];     // folded heads: (nrows, 256) weights, (nrows) biases
+    int row0[4], nrows[4], n_heads;
+    const float* w_final; const float* b_final;         // (256, 256), (256)
+    const float* w_plain; const float* b_plain; int plain_row;   // a (1, 256) head that reads h itself, or plain_row < 0
+    float* out_w; float* out_b;                         // (32, 256) fp32 scratch, 32 fp32 biases
+};
+__global__ __launch_bounds__(256) void nsff_fold_kernel_h3(const FoldArgs a) {
+    const int r = blockIdx.x, i = threadIdx.x;
+    float w = 0.f, b = 0.f;
+    if (r == a.plain_row) {
+        w = a.w_plain[i]; b = a.b_plain[0];
+    } else {
+        for (int j = 0; j < a.n_heads; ++j) {
+            if (r < a.row0[j] || r >= a.row0[j] + a.nrows[j]) continue;
+            const float* wh = a.w_head[j] + (long long)(r - a.row0[j]) * NSFF_W;
+            double sw = 0.0, sb = 0.0;
+            for (int o = 0; o < NSFF_W; ++o) {
+                sw += (double)wh[o] * (double)a.w_final[(long long)o * NSFF_W + i];
+                sb += (double)wh[o] * (double)a.b_final[o];
+            }
+            w = (float)sw; b = (float)(sb + (double)a.b_head[j][r - a.row0[j]]);
+        }
+    }
+    a.out_w[(long long)r * NSFF_W + i] = w;
+    if (i == 0) a.out_b[r] = b;
+}
+
 }  // namespace
 
 #ifdef H3_TIMING
@@ -922,6 +962,7 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
     auto head = [&](const float* src, uint32_t dst, int row0, int nrows) {
         segs.push_back(PackSegH3{src, dst, 2, NSFF_W, NSFF_W, 0, 0, 0, 0, 0, row0, nrows});
     };
+    const float* final_w = nullptr; const float* final_b = nullptr;
     auto trunk = [&](const NsffTrunkLayoutH3& T, int in_t) {
         const int in = d.in_xyz + in_t;
         for (int l = 0; l < d.D; ++l) {
@@ -939,8 +980,11 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
         const float* w = params[pi++]; const float* b = params[pi++];
         tiled(w, T.final_w, NSFF_W, NSFF_W, NSFF_W, 0, 0, 0, 0);
         flat(b, T.final_b, NSFF_W);
+        final_w = w; final_b = b;
     };
+    FoldArgs fs{}, ft{};                               // folded head rows of the static / dynamic trunk
     trunk(L.st, 0);
+    fs.w_final = final_w; fs.b_final = final_b;
     if (d.use_viewdir) {
         const float* w = params[pi++]; const float* b = params[pi++];
         const int ld = NSFF_W + d.in_dir + d.in_a;
@@ -948,12 +992,17 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
         tiled(w, L.dir_x, ld, (int)L.side_k, d.in_dir + d.in_a, NSFF_W, 0, 0, 0);
         flat(b, L.dir_b, NSFF_W);
     }
-    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_sigma_w, 0, 1); flat(b, L.s_sigma_b, 1); }
-    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_rgb_w, 0, 3); flat(b, L.s_rgb_b, 3); }
+    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_sigma_w, 0, 1); flat(b, L.s_sigma_b, 1);
+      fs.w_plain = w; fs.b_plain = b; fs.plain_row = 3; }
+    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_rgb_w, 0, 3); flat(b, L.s_rgb_b, 3);
+      fs.w_head[0] = w; fs.b_head[0] = b; fs.row0[0] = 0; fs.nrows[0] = 3; fs.n_heads = 1; }
     if (d.has_transient) {
         trunk(L.tr, d.in_t);
+        ft.w_final = final_w; ft.b_final = final_b; ft.plain_row = -1;
         const float* ws = params[pi++]; const float* bs = params[pi++];
         const float* wc = params[pi++]; const float* bc = params[pi++];
+        ft.w_head[0] = wc; ft.b_head[0] = bc; ft.row0[0] = 0; ft.nrows[0] = 3;
+        ft.w_head[1] = ws; ft.b_head[1] = bs; ft.row0[1] = 3; ft.nrows[1] = 1; ft.n_heads = 2;
         head(wc, L.t_head_w, 0, 3); flat(bc, L.t_head_b, 3);
         head(ws, L.t_head_w, 3, 1); flat(bs, L.t_head_b + 3, 1);
         if (d.has_flow) {
@@ -961,6 +1010,8 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
             const float* wb = params[pi++]; const float* bb = params[pi++];
             head(wf, L.t_head_w, 4, 3); flat(bf, L.t_head_b + 4, 3);
             head(wb, L.t_head_w, 7, 3); flat(bb, L.t_head_b + 7, 3);
+            ft.w_head[2] = wf; ft.b_head[2] = bf; ft.row0[2] = 4; ft.nrows[2] = 3;
+            ft.w_head[3] = wb; ft.b_head[3] = bb; ft.row0[3] = 7; ft.nrows[3] = 3; ft.n_heads = 4;
         }
     }
     for (int i = 0; i < pi; ++i) if (!params[i]) return NSFF_ERR_NULL;
@@ -979,6 +1030,19 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
         }
         hipLaunchKernelGGL(nsff_pack_kernel_h3, dim3((max_threads + 255) / 256, n), dim3(256), 0, st, pa);
     }
+    // folded head rows: products in fp32 scratch (inside the packed buffer), then one head tile per trunk
+    uint32_t* pw = reinterpret_cast<uint32_t*>(packed);
+    PackArgsH3 pf{};
+    pf.dst = pw;
+    int nf = 0;
+    auto fold = [&](FoldArgs& f, uint32_t scratch, uint32_t tile, uint32_t bias) {
+        f.out_w = reinterpret_cast<float*>(pw + scratch); f.out_b = reinterpret_cast<float*>(pw + bias);
+        hipLaunchKernelGGL(nsff_fold_kernel_h3, dim3(32), dim3(256), 0, st, f);
+        pf.seg[nf++] = PackSegH3{f.out_w, tile, 2, NSFF_W, NSFF_W, 0, 0, 0, 0, 0, 0, 32};
+    };
+    if (!d.use_viewdir) fold(fs, L.fold_f32, L.s_fold_w, L.s_fold_b);
+    if (d.has_transient) fold(ft, L.fold_f32 + 32 * NSFF_W, L.t_fold_w, L.t_fold_b);
+    if (nf > 0) hipLaunchKernelGGL(nsff_pack_kernel_h3, dim3((8 * NSFF_W + 255) / 256, nf), dim3(256), 0, st, pf);
     return nsff_launch_status();
 }
 
@@ -1037,7 +1101,16 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             }
         }
     };
-    if (g.static_mode) {
+    // Inference launches (nothing saved for a backward pass) never execute the activation-free *_xyz_encoding_final
+    // layers: the heads that read them are evaluated on the last trunk activation with pre-multiplied rows (NsffLayoutH3).
+#ifdef H3_NO_FOLD           // A/B experiments only
+    const bool fold = false;
+#else
+    const bool fold = !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
+#endif
+    if (g.static_mode == 2 && fold && !d.use_viewdir) {
+        trunk(k.L.st, PRE_INPUT, HEAD_S_FOLD, 0);
+    } else if (g.static_mode) {
         trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
         if (g.static_mode == 2) {
             push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB, d.D);
@@ -1048,7 +1121,9 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         }
     }
     k.n_static_steps = n;
-    if (g.transient_mode) {
+    if (g.transient_mode && fold) {
+        trunk(k.L.tr, PRE_INPUT_T, HEAD_T_FOLD, d.D + 1);
+    } else if (g.transient_mode) {
         trunk(k.L.tr, PRE_INPUT_T, HEAD_NONE, d.D + 1);
         push(k.L.tr.final_w, k.L.tr.final_b, NSFF_W, PRE_NONE, POST_LINEAR, HEAD_T, 2 * d.D + 1);
     }

@@ -35,6 +35,12 @@ struct NsffLayoutH3 {
     uint32_t s_rgb_w, s_rgb_b;
     uint32_t t_head_w, t_head_b;       // rows: rgb(3) sigma(1) [fw(3) bw(3)]
     uint32_t t_head_rows;
+    // Inference-only folded heads: *_xyz_encoding_final is a Linear WITHOUT activation (nerf.py:170,195), so the heads that
+    // read it are linear maps of the last trunk activation h:  W_head (W_final h + b_final) + b_head = (W_head W_final) h +
+    // (W_head b_final + b_head).  One 32-row tile per trunk holds the products (static: rgb rows 0-2 folded + sigma row 3,
+    // which reads h anyway; dynamic: all t_head_rows folded); the 256x256 *_final layer is then never executed.
+    uint32_t s_fold_w, s_fold_b, t_fold_w, t_fold_b;
+    uint32_t fold_f32;                 // scratch: 2 x (32 x 256) fp32 products the tiles are packed from
     uint32_t total;                    // words
 };
 
@@ -84,6 +90,9 @@ static inline int nsff_make_layout_h3(const NsffModelDesc& d, NsffLayoutH3& L) {
     } else {
         L.tr = NsffTrunkLayoutH3{};
     }
+    L.s_fold_w = take(NSFF_H3_HEAD_WORDS); L.s_fold_b = take(32);
+    L.t_fold_w = take(NSFF_H3_HEAD_WORDS); L.t_fold_b = take(32);
+    L.fold_f32 = take(2 * 32 * NSFF_W);
     L.total = off;
     return NSFF_OK;
 }

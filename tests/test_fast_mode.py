@@ -109,6 +109,13 @@ def test_fast_mode_is_inference_only(hip_lib):
     config.set_precision("f16x3")
     with torch.no_grad():
         want = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)
-    assert torch.equal(res["rgb_fine"].detach(), want["rgb_fine"])
+    config.set_precision("f16")
+    with torch.no_grad():
+        fast = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)
+    # (not bit-equal: the inference launch evaluates the heads with pre-multiplied *_final rows, the training forward
+    # executes the layer because the backward pass needs its output)
+    d_train = float((res["rgb_fine"].detach() - want["rgb_fine"]).abs().max())
+    d_fast = float((fast["rgb_fine"] - want["rgb_fine"]).abs().max())
+    assert d_train <= 2e-5 and d_fast > 4 * d_train, (d_train, d_fast)
     res["rgb_fine"].sum().backward()
     assert models["fine"].static_xyz_encoding_3[0].weight.grad is not None

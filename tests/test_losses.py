@@ -287,11 +287,11 @@ def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, hip_lib, 
         assert isinstance(terms, fused_loss.LossTerms)
         total = terms.total() if use_total else sum(terms.values())
         total.backward()
-        grads.append((float(total), {k: v.grad.clone() for k, v in leaves.items() if v.grad is not None}))
+        grads.append((float(total.detach()), {k: v.grad.clone() for k, v in leaves.items() if v.grad is not None}))
     assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[1][0])
     assert sorted(grads[0][1]) == sorted(grads[1][1])
-    for k in grads[0][1]:
-        assert torch.equal(grads[0][1][k], grads[1][1][k]), k
+    for k in grads[0][1]:     # (not bit-equal: the batch statistics are summed with float atomics, run to run they differ in the last bit)
+        assert torch.allclose(grads[0][1][k], grads[1][1][k], rtol=1e-5, atol=1e-12), k
     t1, g1 = out["1"]
     t0, g0 = out["0"]
     assert sorted(t1) == sorted(t0) == sorted(fused_loss.TERMS)

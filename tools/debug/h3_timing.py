@@ -44,14 +44,27 @@ assert lib.nsff_debug_read_timing(buf, n) == 0
 t = np.frombuffer(buf, dtype=np.uint32).reshape(256, 8, 32, 6).astype(np.int64)
 waves = 8 if tile == 130 else 4
 t = t[:, :waves]
-nsteps = 20
+# the first 256 workgroups of a two-trunk launch each run the STATIC trunk of their tile (grid = 2 x tiles, static first)
+nsteps = int((t[0, 0, :31, 1] != 0).sum())
+post = [bool(t[0, 0, s_, 3] != 0) for s_ in range(nsteps)]       # steps with an epilogue (the skip layer's first half has none)
+print("steps per workgroup:", nsteps, " with epilogue:", post)
 d = lambda a, b: ((t[:, :, :nsteps, b] - t[:, :, :nsteps, a]) & 0xffffffff).astype(np.float64)
-names = [("pre (barrier+build)", 0, 1), ("gemm issue", 1, 2), ("barrier 1 (gemm drain)", 2, 3), ("acc_store", 3, 4), ("barrier 2", 4, 5)]
-print("s_memtime ticks (100 MHz?) per step, mean over 256 WGs x waves; steps:", nsteps)
-tot = ((t[:, :, nsteps - 1, 5] - t[:, :, 0, 0]) & 0xffffffff).astype(np.float64)
-print("whole tile mean ticks", tot.mean())
-for nm, a_, b_ in names:
-    x = d(a_, b_)
-    print(f"{nm:26s} mean/step {x.mean():9.1f}   share {x.sum() / tot.sum() * 100:5.1f}%   per-step means: " + " ".join(f"{v:6.0f}" for v in x.mean((0, 1))))
-nxt = ((t[:, :, 1:nsteps, 0] - t[:, :, :nsteps - 1, 5]) & 0xffffffff).astype(np.float64)
-print(f"{'after barrier 2 (heads)':26s} mean/step {nxt.mean():9.1f}   share {nxt.sum() / tot.sum() * 100:5.1f}%")
+tot = ((t[:, :, 31, 0] - t[:, :, 0, 0]) & 0xffffffff).astype(np.float64)
+print(f"whole workgroup (first stamp -> end of kernel) mean cycles {tot.mean():.0f}")
+rows = [("pre (barrier+build)", d(0, 1)), ("gemm issue", d(1, 2))]
+mask = np.array(post)
+dr, st_, b2 = d(2, 3), d(3, 4), d(4, 5)
+for x in (dr, st_, b2):
+    x[:, :, ~mask] = 0
+rows += [("barrier 1 (gemm drain)", dr), ("acc_store", st_), ("barrier 2", b2)]
+acc = 0.0
+for nm, x in rows:
+    acc += x.sum()
+    print(f"{nm:26s} share {x.sum() / tot.sum() * 100:5.1f}%   per-step means: " + " ".join(f"{v:6.0f}" for v in x.mean((0, 1))))
+last = np.where(mask, 5, 2)                                  # last stamp a step leaves
+gaps = []
+for s_ in range(nsteps):
+    nxt_t = t[:, :, s_ + 1, 0] if s_ + 1 < nsteps else t[:, :, 31, 0]
+    gaps.append((((nxt_t - t[:, :, s_, last[s_]]) & 0xffffffff).astype(np.float64)).mean())
+print("after each step (heads / next pre-barrier / end of kernel): " + " ".join(f"{v:6.0f}" for v in gaps))
+print(f"{'heads, raw records, rest':26s} share {(tot.sum() - acc) / tot.sum() * 100:5.1f}%")
