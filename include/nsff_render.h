@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      13
+#define NSFF_ABI_VERSION      14
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -85,6 +85,17 @@ int nsff_param_count(const NsffModelDesc* desc);
  * `params`: HOST array of nsff_param_count() device pointers. */
 int nsff_pack_weights(const NsffModelDesc* desc, int precision, const float* const* params,
                       void* packed, void* stream);
+
+/* Finer-grained form for callers that re-pack after every optimizer step.  Inference launches of the f16 kernels read
+ * "folded" head rows -- the heads that consume the activation-free *_xyz_encoding_final layers (nerf.py:170,195),
+ * pre-multiplied with them, so that those two 256x256 layers are never executed.  nsff_pack_weights builds them;
+ * nsff_pack_weights_ex(..., NSFF_PACK_SKIP_FOLD, ...) does not (enough for training forwards, i.e. nsff_field_query
+ * with save_* buffers, which execute the layers because the backward pass needs their output), and nsff_fold_heads
+ * adds them to such a buffer later.  An inference launch on a buffer without them computes garbage heads.          */
+#define NSFF_PACK_SKIP_FOLD 1
+int nsff_pack_weights_ex(const NsffModelDesc* desc, int precision, const float* const* params,
+                         void* packed, int32_t flags, void* stream);
+int nsff_fold_heads(const NsffModelDesc* desc, int precision, const float* const* params, void* packed, void* stream);
 
 /* ---- a1: PosEmbedding.forward (reference nerf.py:17-30) ---- */
 int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_freqs,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -121,6 +121,8 @@ _SIGNATURES = {
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
     "nsff_param_count": (C.c_int, [C.POINTER(ModelDesc)]),
     "nsff_pack_weights": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_fp), _fp, _fp]),
+    "nsff_pack_weights_ex": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_fp), _fp, C.c_int32, _fp]),
+    "nsff_fold_heads": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_fp), _fp, _fp]),
     "nsff_posenc": (C.c_int, [_fp, C.c_int64, C.POINTER(C.c_float), C.c_int, _fp, _fp]),
     "nsff_field_query": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldArgs), _fp]),
     "nsff_coarse_samples": (C.c_int, [_fp, C.c_int64, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, _fp]),
@@ -249,7 +251,11 @@ def packed_bytes(desc, precision=0):
     return n.value
 
 
-def pack_weights(desc, params, packed, precision=0):
+PACK_SKIP_FOLD = 1
+
+
+def pack_weights(desc, params, packed, precision=0, fold=True):
+    """fold=False: without the folded head rows inference launches read (include/nsff_render.h: NSFF_PACK_SKIP_FOLD)."""
     lib = load()
     if lib.nsff_param_count(C.byref(desc)) != len(params):
         raise RuntimeError("parameter list does not match the model description")
@@ -257,9 +263,16 @@ def pack_weights(desc, params, packed, precision=0):
     for p in keep:
         require_gpu_tensor(p, "model parameter")
     arr = (_fp * len(keep))(*[p.data_ptr() for p in keep])
-    _check(lib.nsff_pack_weights(C.byref(desc), int(precision), arr, _ptr(packed), _stream()),
-           "nsff_pack_weights")
+    _check(lib.nsff_pack_weights_ex(C.byref(desc), int(precision), arr, _ptr(packed), 0 if fold else PACK_SKIP_FOLD,
+                                    _stream()), "nsff_pack_weights_ex")
     return keep  # caller keeps temporaries alive until the stream has consumed them
+
+
+def fold_heads(desc, params, packed, precision):
+    keep = [p.detach().contiguous().float() for p in params]
+    arr = (_fp * len(keep))(*[p.data_ptr() for p in keep])
+    _check(load().nsff_fold_heads(C.byref(desc), int(precision), arr, _ptr(packed), _stream()), "nsff_fold_heads")
+    return keep
 
 
 def posenc(x, freqs, out):
@@ -275,7 +288,9 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     from . import config
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
-    packed = model.packed(1 if prec == 3 else prec)      # the "f16" fast mode reads the f16x3 pack (hi halfs only)
+    saves = not (save_acts is None and save_xin is None and save_masks is None and save_side is None)
+    # the "f16" fast mode reads the f16x3 pack (hi halfs only); training forwards do not need the folded head rows
+    packed = model.packed(1 if prec == 3 else prec, inference=not saves)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()
     a.n_points, a.pts_per_ray = int(n_points), int(pts_per_ray)

@@ -416,10 +416,24 @@ int nsff_param_count(const NsffModelDesc* d) {
 
 int nsff_pack_weights(const NsffModelDesc* desc, int precision, const float* const* params, void* packed_v,
                       void* stream) {
+    return nsff_pack_weights_ex(desc, precision, params, packed_v, 0, stream);
+}
+
+int nsff_fold_heads(const NsffModelDesc* desc, int precision, const float* const* params, void* packed_v, void* stream) {
     if (!desc || !params || !packed_v) return NSFF_ERR_NULL;
     if ((uintptr_t)packed_v & 15) return NSFF_ERR_ALIGN;
+    if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16)
+        return nsff_h3_fold_heads(desc, params, packed_v, (hipStream_t)stream);
+    return precision == NSFF_PREC_F32 ? NSFF_OK : NSFF_ERR_INVALID;          // the fp32 kernel executes every layer
+}
+
+int nsff_pack_weights_ex(const NsffModelDesc* desc, int precision, const float* const* params, void* packed_v,
+                         int32_t flags, void* stream) {
+    if (!desc || !params || !packed_v) return NSFF_ERR_NULL;
+    if ((uintptr_t)packed_v & 15) return NSFF_ERR_ALIGN;
+    if (flags & ~NSFF_PACK_SKIP_FOLD) return NSFF_ERR_INVALID;
     if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16)      // one packed layout serves both
-        return nsff_h3_pack_weights(desc, params, packed_v, (hipStream_t)stream);
+        return nsff_h3_pack_weights(desc, params, packed_v, !(flags & NSFF_PACK_SKIP_FOLD), (hipStream_t)stream);
     if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
     float* packed = reinterpret_cast<float*>(packed_v);
     NsffLayout L;

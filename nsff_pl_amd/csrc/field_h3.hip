@@ -946,7 +946,7 @@ int nsff_h3_packed_bytes(const NsffModelDesc* desc, size_t* bytes) {
     return NSFF_OK;
 }
 
-int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st) {
+int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, void* packed, bool fold, hipStream_t st) {
     NsffLayoutH3 L;
     const int rc = nsff_make_layout_h3(*desc, L);
     if (rc) return rc;
@@ -962,7 +962,6 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
     auto head = [&](const float* src, uint32_t dst, int row0, int nrows) {
         segs.push_back(PackSegH3{src, dst, 2, NSFF_W, NSFF_W, 0, 0, 0, 0, 0, row0, nrows});
     };
-    const float* final_w = nullptr; const float* final_b = nullptr;
     auto trunk = [&](const NsffTrunkLayoutH3& T, int in_t) {
         const int in = d.in_xyz + in_t;
         for (int l = 0; l < d.D; ++l) {
@@ -980,11 +979,8 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
         const float* w = params[pi++]; const float* b = params[pi++];
         tiled(w, T.final_w, NSFF_W, NSFF_W, NSFF_W, 0, 0, 0, 0);
         flat(b, T.final_b, NSFF_W);
-        final_w = w; final_b = b;
     };
-    FoldArgs fs{}, ft{};                               // folded head rows of the static / dynamic trunk
     trunk(L.st, 0);
-    fs.w_final = final_w; fs.b_final = final_b;
     if (d.use_viewdir) {
         const float* w = params[pi++]; const float* b = params[pi++];
         const int ld = NSFF_W + d.in_dir + d.in_a;
@@ -992,17 +988,12 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
         tiled(w, L.dir_x, ld, (int)L.side_k, d.in_dir + d.in_a, NSFF_W, 0, 0, 0);
         flat(b, L.dir_b, NSFF_W);
     }
-    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_sigma_w, 0, 1); flat(b, L.s_sigma_b, 1);
-      fs.w_plain = w; fs.b_plain = b; fs.plain_row = 3; }
-    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_rgb_w, 0, 3); flat(b, L.s_rgb_b, 3);
-      fs.w_head[0] = w; fs.b_head[0] = b; fs.row0[0] = 0; fs.nrows[0] = 3; fs.n_heads = 1; }
+    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_sigma_w, 0, 1); flat(b, L.s_sigma_b, 1); }
+    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_rgb_w, 0, 3); flat(b, L.s_rgb_b, 3); }
     if (d.has_transient) {
         trunk(L.tr, d.in_t);
-        ft.w_final = final_w; ft.b_final = final_b; ft.plain_row = -1;
         const float* ws = params[pi++]; const float* bs = params[pi++];
         const float* wc = params[pi++]; const float* bc = params[pi++];
-        ft.w_head[0] = wc; ft.b_head[0] = bc; ft.row0[0] = 0; ft.nrows[0] = 3;
-        ft.w_head[1] = ws; ft.b_head[1] = bs; ft.row0[1] = 3; ft.nrows[1] = 1; ft.n_heads = 2;
         head(wc, L.t_head_w, 0, 3); flat(bc, L.t_head_b, 3);
         head(ws, L.t_head_w, 3, 1); flat(bs, L.t_head_b + 3, 1);
         if (d.has_flow) {
@@ -1010,8 +1001,6 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
             const float* wb = params[pi++]; const float* bb = params[pi++];
             head(wf, L.t_head_w, 4, 3); flat(bf, L.t_head_b + 4, 3);
             head(wb, L.t_head_w, 7, 3); flat(bb, L.t_head_b + 7, 3);
-            ft.w_head[2] = wf; ft.b_head[2] = bf; ft.row0[2] = 4; ft.nrows[2] = 3;
-            ft.w_head[3] = wb; ft.b_head[3] = bb; ft.row0[3] = 7; ft.nrows[3] = 3; ft.n_heads = 4;
         }
     }
     for (int i = 0; i < pi; ++i) if (!params[i]) return NSFF_ERR_NULL;
@@ -1030,7 +1019,38 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
         }
         hipLaunchKernelGGL(nsff_pack_kernel_h3, dim3((max_threads + 255) / 256, n), dim3(256), 0, st, pa);
     }
-    // folded head rows: products in fp32 scratch (inside the packed buffer), then one head tile per trunk
+    return fold ? nsff_h3_fold_heads(desc, params, packed, st) : nsff_launch_status();
+}
+
+// Folded head rows (NsffLayoutH3): products in fp32 scratch inside the packed buffer, then one head tile per trunk.
+// Separate from the pack so that a caller that re-packs after every optimizer step (training forwards execute the *_final
+// layers: the backward pass needs their output) does not pay for rows nobody reads.
+int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st) {
+    NsffLayoutH3 L;
+    const int rc = nsff_make_layout_h3(*desc, L);
+    if (rc) return rc;
+    const NsffModelDesc& d = *desc;
+    // parameter order (nsff_pack_weights): static trunk [w, b] x D, static final, [dir], static sigma, static rgb,
+    // dynamic trunk [w, b] x D, dynamic final, dynamic sigma, dynamic rgb, [flow fw, flow bw]
+    int pi = 2 * d.D;
+    FoldArgs fs{}, ft{};
+    fs.w_final = params[pi]; fs.b_final = params[pi + 1]; pi += 2;
+    if (d.use_viewdir) pi += 2;
+    fs.w_plain = params[pi]; fs.b_plain = params[pi + 1]; fs.plain_row = 3; pi += 2;
+    fs.w_head[0] = params[pi]; fs.b_head[0] = params[pi + 1]; fs.row0[0] = 0; fs.nrows[0] = 3; fs.n_heads = 1; pi += 2;
+    if (d.has_transient) {
+        pi += 2 * d.D;
+        ft.w_final = params[pi]; ft.b_final = params[pi + 1]; ft.plain_row = -1; pi += 2;
+        ft.w_head[1] = params[pi]; ft.b_head[1] = params[pi + 1]; ft.row0[1] = 3; ft.nrows[1] = 1; pi += 2;    // sigma
+        ft.w_head[0] = params[pi]; ft.b_head[0] = params[pi + 1]; ft.row0[0] = 0; ft.nrows[0] = 3; pi += 2;    // rgb
+        ft.n_heads = 2;
+        if (d.has_flow) {
+            ft.w_head[2] = params[pi]; ft.b_head[2] = params[pi + 1]; ft.row0[2] = 4; ft.nrows[2] = 3; pi += 2;
+            ft.w_head[3] = params[pi]; ft.b_head[3] = params[pi + 1]; ft.row0[3] = 7; ft.nrows[3] = 3; pi += 2;
+            ft.n_heads = 4;
+        }
+    }
+    for (int i = 0; i < pi; ++i) if (!params[i]) return NSFF_ERR_NULL;
     uint32_t* pw = reinterpret_cast<uint32_t*>(packed);
     PackArgsH3 pf{};
     pf.dst = pw;

@@ -14,13 +14,20 @@ class PackCache:
     def __init__(self):
         self._key = {}
         self._buf = {}
+        self._folded = {}
 
     def invalidate(self):
         self._key = {}
 
-    def get(self, model, precision=0):
+    def get(self, model, precision=0, inference=True):
+        """inference=False: the buffer is wanted for a training forward, which does not read the folded head rows of the
+        f16 kernels (nsff_fold_heads); they are added the first time an inference launch asks for the same weights."""
         params = _lib.param_list(model)
         key = tuple((p.data_ptr(), p._version) for p in params)
+        if key == self._key.get(precision) and inference and not self._folded.get(precision, True):
+            with torch.cuda.device(params[0].device):
+                _lib.fold_heads(_lib.model_desc(model), params, self._buf[precision], precision)
+            self._folded[precision] = True
         if key != self._key.get(precision):
             dev = params[0].device
             _lib.require_gpu_tensor(params[0], "model parameter")
@@ -33,6 +40,7 @@ class PackCache:
                 if precision == _lib.BWD_PACK:
                     _lib.pack_weights_bwd(desc, params, buf)
                 else:
-                    _lib.pack_weights(desc, params, buf, precision)
+                    _lib.pack_weights(desc, params, buf, precision, fold=inference)
+                    self._folded[precision] = bool(inference)
             self._key[precision] = key
         return self._buf[precision]

@@ -37,7 +37,7 @@ for w in $WHAT; do
       pmc interp_pmc fetch "python $ROOT/tools/bench_interp.py --reps 2" FETCH_SIZE
       pmc interp_pmc write "python $ROOT/tools/bench_interp.py --reps 2" WRITE_SIZE ;;
     train)
-      rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o train -- python $ROOT/bench.py --workload train --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_stats.log 2>&1
+      rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o train -- python $ROOT/bench.py --workload train --graph --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_stats.log 2>&1
       T="python $ROOT/bench.py --workload train --steps 2 --warmup 2 --no-cpu-baseline"
       pmc train_pmc mfma "$T" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
       pmc train_pmc fetch "$T" FETCH_SIZE
