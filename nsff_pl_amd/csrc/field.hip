@@ -598,7 +598,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
         // the f16 kernels' inference launches fold the activation-free *_final layers into their head rows
         const bool h3 = g.precision == NSFF_PREC_F16X3 || g.precision == NSFF_PREC_F16;
         const bool folds = h3 && !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
-        const int folded = folds ? ((g.static_mode == 2 && !d.use_viewdir) ? 1 : 0) + (g.transient_mode ? 1 : 0) : 0;
+        const int folded = folds ? (g.static_mode == 2 ? 1 : 0) + (g.transient_mode ? 1 : 0) : 0;
         pr.executed = pr.flops - 2.0 * d.W * d.W * folded * (double)g.n_points;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(pr);

@@ -898,8 +898,8 @@ __global__ void nsff_pack_kernel_h3(const PackArgsH3 a) {
 // b_final[o] + b_head[r]  for the rows of the heads that read *_final; `plain` rows (static sigma) are copied.  One
 // workgroup per row, one thread per input column, double accumulation (once per weight update: the cost is nothing).
 struct FoldArgs {
-    const float* w_head[4]; const float* b_head[4];     // folded heads: (nrows, 256) weights, (nrows) biases
-    int row0[4], nrows[4], n_heads;
+    const float* w_head[4]; const float* b_head[4];     // folded heads: (nrows, ld_head) weights (first 256 columns), (nrows) biases
+    int row0[4], nrows[4], n_heads, ld_head;
     const float* w_final; const float* b_final;         // (256, 256), (256)
     const float* w_plain; const float* b_plain; int plain_row;   // a (1, 256) head that reads h itself, or plain_row < 0
     float* out_w; float* out_b;                         // (32, 256) fp32 scratch, 32 fp32 biases
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void nsff_fold_kernel_h3(const FoldArgs a) {
     } else {
         for (int j = 0; j < a.n_heads; ++j) {
             if (r < a.row0[j] || r >= a.row0[j] + a.nrows[j]) continue;
-            const float* wh = a.w_head[j] + (long long)(r - a.row0[j]) * NSFF_W;
+            const float* wh = a.w_head[j] + (long long)(r - a.row0[j]) * a.ld_head;
             double sw = 0.0, sb = 0.0;
             for (int o = 0; o < NSFF_W; ++o) {
                 sw += (double)wh[o] * (double)a.w_final[(long long)o * NSFF_W + i];
@@ -1033,9 +1033,15 @@ int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, vo
     // parameter order (nsff_pack_weights): static trunk [w, b] x D, static final, [dir], static sigma, static rgb,
     // dynamic trunk [w, b] x D, dynamic final, dynamic sigma, dynamic rgb, [flow fw, flow bw]
     int pi = 2 * d.D;
-    FoldArgs fs{}, ft{};
+    FoldArgs fs{}, ft{}, fd{};
+    fs.ld_head = ft.ld_head = NSFF_W;
     fs.w_final = params[pi]; fs.b_final = params[pi + 1]; pi += 2;
-    if (d.use_viewdir) pi += 2;
+    if (d.use_viewdir) {                                   // static_dir_encoding: 256 rows, its first 256 columns read *_final
+        fd.w_final = fs.w_final; fd.b_final = fs.b_final; fd.plain_row = -1;
+        fd.w_head[0] = params[pi]; fd.b_head[0] = params[pi + 1]; fd.row0[0] = 0; fd.nrows[0] = NSFF_W; fd.n_heads = 1;
+        fd.ld_head = NSFF_W + d.in_dir + d.in_a;
+        pi += 2;
+    }
     fs.w_plain = params[pi]; fs.b_plain = params[pi + 1]; fs.plain_row = 3; pi += 2;
     fs.w_head[0] = params[pi]; fs.b_head[0] = params[pi + 1]; fs.row0[0] = 0; fs.nrows[0] = 3; fs.n_heads = 1; pi += 2;
     if (d.has_transient) {
@@ -1062,7 +1068,14 @@ int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, vo
     };
     if (!d.use_viewdir) fold(fs, L.fold_f32, L.s_fold_w, L.s_fold_b);
     if (d.has_transient) fold(ft, L.fold_f32 + 32 * NSFF_W, L.t_fold_w, L.t_fold_b);
-    if (nf > 0) hipLaunchKernelGGL(nsff_pack_kernel_h3, dim3((8 * NSFF_W + 255) / 256, nf), dim3(256), 0, st, pf);
+    int max_threads = 8 * NSFF_W;
+    if (d.use_viewdir) {                                   // a whole 256 x 256 segment, tiled like any trunk layer
+        fd.out_w = reinterpret_cast<float*>(pw + L.dir_fold_f32); fd.out_b = reinterpret_cast<float*>(pw + L.dir_b_fold);
+        hipLaunchKernelGGL(nsff_fold_kernel_h3, dim3(NSFF_W), dim3(256), 0, st, fd);
+        pf.seg[nf++] = PackSegH3{fd.out_w, L.dir_h_fold, 1, NSFF_W, NSFF_W, NSFF_W, 0, 0, 0, 0, 0, 0};
+        max_threads = 64 * NSFF_W;
+    }
+    if (nf > 0) hipLaunchKernelGGL(nsff_pack_kernel_h3, dim3((max_threads + 255) / 256, nf), dim3(256), 0, st, pf);
     return nsff_launch_status();
 }
 
@@ -1130,6 +1143,10 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
 #endif
     if (g.static_mode == 2 && fold && !d.use_viewdir) {
         trunk(k.L.st, PRE_INPUT, HEAD_S_FOLD, 0);
+    } else if (g.static_mode == 2 && fold) {               // view directions: *_final folded into static_dir_encoding
+        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
+        push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
+        push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
     } else if (g.static_mode) {
         trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
         if (g.static_mode == 2) {

@@ -41,6 +41,9 @@ struct NsffLayoutH3 {
     // which reads h anyway; dynamic: all t_head_rows folded); the 256x256 *_final layer is then never executed.
     uint32_t s_fold_w, s_fold_b, t_fold_w, t_fold_b;
     uint32_t fold_f32;                 // scratch: 2 x (32 x 256) fp32 products the tiles are packed from
+    // view-direction models: static_dir_encoding reads [*_final | dir | a]; its *_final part folds the same way,
+    // (W_dir[:, :256] W_final) h + (W_dir[:, :256] b_final + b_dir), a full 256 x 256 segment
+    uint32_t dir_h_fold, dir_b_fold, dir_fold_f32;
     uint32_t total;                    // words
 };
 
@@ -93,6 +96,12 @@ static inline int nsff_make_layout_h3(const NsffModelDesc& d, NsffLayoutH3& L) {
     L.s_fold_w = take(NSFF_H3_HEAD_WORDS); L.s_fold_b = take(32);
     L.t_fold_w = take(NSFF_H3_HEAD_WORDS); L.t_fold_b = take(32);
     L.fold_f32 = take(2 * 32 * NSFF_W);
+    L.dir_h_fold = L.dir_b_fold = L.dir_fold_f32 = NSFF_NONE;
+    if (d.use_viewdir) {
+        L.dir_h_fold = take(NSFF_W * NSFF_W);
+        L.dir_b_fold = take(NSFF_W);
+        L.dir_fold_f32 = take(NSFF_W * NSFF_W);
+    }
     L.total = off;
     return NSFF_OK;
 }
