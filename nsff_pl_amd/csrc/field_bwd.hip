@@ -85,7 +85,7 @@ struct PackSegB {
     int32_t nks;
     int32_t in_xyz, in_t;
 };
-constexpr int PACKB_BATCH = 8;
+constexpr int PACKB_BATCH = 32;
 struct PackArgsB { PackSegB seg[PACKB_BATCH]; uint32_t* dst; };
 
 __global__ void pack_kernel_b(const PackArgsB a) {

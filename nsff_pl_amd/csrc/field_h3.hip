@@ -852,7 +852,7 @@ struct PackSegH3 {
     int32_t n0, s0, p1, n1, s1;   // column map (tiled)
     int32_t row0, nrows;          // head: destination row range
 };
-constexpr int PACK_BATCH = 12;
+constexpr int PACK_BATCH = 56;          // one launch per model (3.1 KB of kernel arguments)
 struct PackArgsH3 { PackSegH3 seg[PACK_BATCH]; uint32_t* dst; };
 
 __device__ __forceinline__ float seg_value(const PackSegH3& s, int n, int c) {
