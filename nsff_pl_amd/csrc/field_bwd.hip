@@ -214,15 +214,8 @@ __device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, con
             out1[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[1] * r, -65504.f, 65504.f);
         }
         _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
-#if defined(B_NO_STORE)
-        if (sRel[0] == 123.456f) { *reinterpret_cast<h8*>(d) = out0; *reinterpret_cast<h8*>(d + 8) = out1; }
-#elif defined(B_PLAIN_STORE)
-        *reinterpret_cast<h8*>(d) = out0;
-        *reinterpret_cast<h8*>(d + 8) = out1;
-#else
         __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad:
         __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));     // keep the weights' L2 lines (-17 % per launch)
-#endif
     }
 }
 
@@ -401,9 +394,6 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
             }
         __syncthreads();
         pending_slot = st.slot;
-#ifdef B_EARLY_COPY
-        flush_tile();
-#endif
     }
     flush_tile();
 }

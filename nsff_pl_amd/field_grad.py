@@ -495,7 +495,6 @@ def _grad_map(model, static, transient, meta, jobs, sizes, plist):
     return _GRAD_MAPS[key]
 
 
-_FREQ_CACHE = {}
 _PENDING = []            # (parameters, gradients, buffers to keep alive) of the field nodes of the running backward pass
 _SIDE = {}
 _DEFER = [False]
@@ -558,18 +557,6 @@ def _flush_weight_grads():
                     new.append(g)
             if have:
                 torch._foreach_add_(have, new)
-
-
-def _posenc_backward(d_xin, xyz, freqs):
-    """d(xyz) from d(embedding) (reference nerf.py:17-30: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...])."""
-    nf = len(freqs)
-    key = (xyz.device, tuple(freqs))
-    if key not in _FREQ_CACHE:               # built once, outside any graph capture (the eager warm-up comes first)
-        _FREQ_CACHE[key] = torch.tensor(freqs, device=xyz.device, dtype=torch.float32).view(1, nf, 1)
-    fr = _FREQ_CACHE[key]
-    ang = xyz[:, None, :] * fr                                         # (P, nf, 3)
-    de = d_xin[:, 3:3 + 6 * nf].reshape(-1, nf, 2, 3)                   # [.., 0, :] = d sin, [.., 1, :] = d cos
-    return d_xin[:, 0:3] + (fr * (torch.cos(ang) * de[:, :, 0] - torch.sin(ang) * de[:, :, 1])).sum(1)
 
 
 def _unfragment(frag, n_rows):
