@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      14
+#define NSFF_ABI_VERSION      15
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -44,9 +44,9 @@ extern "C" {
 
 /* ---- model description: mirrors NeRF.__init__ (reference nerf.py:34-40) ---- */
 typedef struct NsffModelDesc {
-    int32_t D;              /* trunk depth, must be 8                              */
+    int32_t D;              /* trunk depth, 2..8 (reference: 8)                     */
     int32_t W;              /* width, must be 256                                  */
-    int32_t skip;           /* layer index (0-based) that re-reads the input, 4    */
+    int32_t skip;           /* the layer (0-based, 1..D-1) that re-reads the input (reference: 4); 0 = none or see skip_mask */
     int32_t in_xyz;         /* 63                                                  */
     int32_t in_dir;         /* 27                                                  */
     int32_t in_a;           /* appearance code width or 0                          */
@@ -55,7 +55,16 @@ typedef struct NsffModelDesc {
     int32_t has_transient;  /* encode_transient                                    */
     int32_t has_flow;       /* transient_flow_fw / _bw heads present               */
     float   flow_scale;     /* 0.2                                                 */
+    int32_t skip_mask;      /* several skip layers (the reference's `skips` list, nerf.py:34-40,163-167): bit l set = layer l
+                               reads [input | previous layer]; 0 = just `skip`.  Inference kernels take any subset of
+                               layers 1..D-1; the backward kernels (nsff_pack_weights_bwd / nsff_field_backward and the
+                               save_* forward) exactly one                                                  */
 } NsffModelDesc;
+
+/* effective set of skip layers of a description */
+static inline uint32_t nsff_skip_layers(const NsffModelDesc* d) {
+    return d->skip_mask ? (uint32_t)d->skip_mask : (d->skip > 0 ? 1u << d->skip : 0u);
+}
 
 /* Arithmetic of the field kernel's dense layers:
  *   NSFF_PREC_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -31,7 +31,7 @@ class ModelDesc(C.Structure):
                 ("in_xyz", C.c_int32), ("in_dir", C.c_int32), ("in_a", C.c_int32),
                 ("in_t", C.c_int32), ("use_viewdir", C.c_int32),
                 ("has_transient", C.c_int32), ("has_flow", C.c_int32),
-                ("flow_scale", C.c_float)]
+                ("flow_scale", C.c_float), ("skip_mask", C.c_int32)]
 
 
 class FieldArgs(C.Structure):
@@ -203,18 +203,19 @@ def _stream():
 # ----------------------------------------------------------------------------------
 def model_desc(model):
     """NsffModelDesc of a NeRF module.  The reference constructor (models/nerf.py:34-40) takes any width W and a
-    list of skip layers; the gfx950 kernels are built for W = 256 trunks with exactly one skip connection (every
-    configuration the reference's train.py / eval.py create) -- anything else is refused here, by name."""
+    list of skip layers; the gfx950 kernels are built for W = 256 trunks, 2..8 layers deep, with any set of skip layers
+    among 1..D-1 (inference; the backward kernels want exactly one: field_grad.why_unsupported) -- anything else is
+    refused here, by name."""
     if model.W != 256:
         raise RuntimeError(f"unsupported NeRF architecture: W={model.W} (the gfx950 field kernels tile W=256 trunks "
                            "into 4 x 64-neuron wave blocks; other widths are not built)")
-    if len(model.skips) != 1:
-        raise RuntimeError(f"unsupported NeRF architecture: skips={list(model.skips)} (the kernels' layer program "
-                           "has exactly one skip connection; pass a single layer index)")
-    if not 1 <= model.skips[0] < model.D or not 2 <= model.D <= 8:
+    skips = sorted(set(int(s) for s in model.skips))
+    if not 2 <= model.D <= 8 or any(not 1 <= s < model.D for s in skips):
         raise RuntimeError(f"unsupported NeRF architecture: D={model.D}, skips={list(model.skips)} (need 2 <= D <= 8 "
-                           "and 1 <= skip < D)")
-    return ModelDesc(D=model.D, W=model.W, skip=model.skips[0], in_xyz=model.in_channels_xyz,
+                           "and every skip layer in 1..D-1; a skip at layer 0 would concatenate the input with itself)")
+    mask = sum(1 << s for s in skips)
+    return ModelDesc(D=model.D, W=model.W, skip=skips[0] if len(skips) == 1 else 0, skip_mask=mask if len(skips) != 1 else 0,
+                     in_xyz=model.in_channels_xyz,
                      in_dir=model.in_channels_dir,
                      in_a=model.in_channels_a if model.use_viewdir else 0,
                      in_t=model.in_channels_t, use_viewdir=int(model.use_viewdir),

@@ -41,7 +41,7 @@ struct FieldKArgs {
     long long n_points;
     int pts_per_ray;
     int static_mode, transient_mode;
-    int D, skip;
+    int D; unsigned skip_mask;
     int in_xyz, in_dir, in_a, in_t;
     int use_viewdir;
     float flow_scale;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void nsff_field_kernel(const FieldKArg
                 gemm_seg(acc, sA, seg(T.seg_x[0], nk0), nk0);
             } else {
                 gemm_seg(acc, sA, seg(T.seg_h[l], NSFF_W / 8), NSFF_W / 8);
-                if (l == a.skip) {
+                if ((a.skip_mask >> l) & 1u) {
                     __syncthreads();
                     build_input(sX, a, p0, with_t);
                     __syncthreads();
@@ -455,7 +455,7 @@ int nsff_pack_weights_ex(const NsffModelDesc* desc, int precision, const float* 
             const float* w = params[pi++]; const float* b = params[pi++];
             if (l == 0) {
                 tiled(w, T.seg_x[0], in, (int)T.k0, d.in_xyz, 0, (int)L.k0s, in_t, d.in_xyz);
-            } else if (l == d.skip) {
+            } else if ((nsff_skip_layers(&d) >> l) & 1u) {
                 tiled(w, T.seg_x[l], in + NSFF_W, (int)T.k0, d.in_xyz, 0, (int)L.k0s, in_t, d.in_xyz);
                 tiled(w, T.seg_h[l], in + NSFF_W, NSFF_W, NSFF_W, in, 0, 0, 0);
             } else {
@@ -559,7 +559,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     k.xyz = g.xyz; k.x_emb = g.x_emb; k.dir_emb = g.dir_emb; k.a_emb = g.a_emb; k.t_emb = g.t_emb;
     k.raw = g.raw; k.n_points = g.n_points; k.pts_per_ray = g.pts_per_ray;
     k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
-    k.D = d.D; k.skip = d.skip;
+    k.D = d.D; k.skip_mask = nsff_skip_layers(&d);
     k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;
     k.use_viewdir = d.use_viewdir; k.flow_scale = d.flow_scale;
     k.n_freqs = g.n_freqs;

@@ -50,11 +50,14 @@ struct LayoutB {
     uint32_t total;
 };
 
+inline int skip_of(const NsffModelDesc& d) { return __builtin_ctz(nsff_skip_layers(&d) | (1u << 31)); }   // the one skip layer
+
 inline int make_layout_b(const NsffModelDesc& d, LayoutB& L) {
     NsffLayoutH3 f;
     const int rc = nsff_make_layout_h3(d, f);
     if (rc) return rc;
     if (f.k0s != 64 || f.kt > 64 || f.side_k > 128) return NSFF_ERR_INVALID;
+    if (__builtin_popcount(nsff_skip_layers(&d)) != 1) return NSFF_ERR_INVALID;        // the backward chain has one stash tile
     uint32_t off = 0;
     auto take = [&](uint32_t halfs) { uint32_t o = off; off += halfs / 2; return o; };
     auto trunk = [&](TrunkLayoutB& T, bool xparts) {
@@ -743,7 +746,7 @@ int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params,
         for (int l = 0; l < d.D; ++l) {
             const float* w = params[pi]; pi += 2;
             if (l == 0) { if (T.x0 != NSFF_NONE) xrows(w, T.x0, in, in_t); }
-            else if (l == d.skip) { lin(w, T.layer[l], in + NSFF_W, in); if (T.xskip != NSFF_NONE) xrows(w, T.xskip, in + NSFF_W, in_t); }
+            else if (l == skip_of(d)) { lin(w, T.layer[l], in + NSFF_W, in); if (T.xskip != NSFF_NONE) xrows(w, T.xskip, in + NSFF_W, in_t); }
             else lin(w, T.layer[l], NSFF_W, 0);
         }
         const float* wf = params[pi]; pi += 2;
@@ -833,9 +836,9 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
         } else {
             push(T.head, 4, EPI_LINEAR, base + d.D, 0);
         }
-        push(T.fin, 16, EPI_MASK, base + d.D - 1, (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == d.skip && want_xin) ? F_STASH : 0));
+        push(T.fin, 16, EPI_MASK, base + d.D - 1, (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == skip_of(d) && want_xin) ? F_STASH : 0));
         for (int l = d.D - 1; l >= 1; --l)
-            push(T.layer[l], 16, EPI_MASK, base + l - 1, (l - 1 == d.skip && want_xin) ? F_STASH : 0);
+            push(T.layer[l], 16, EPI_MASK, base + l - 1, (l - 1 == skip_of(d) && want_xin) ? F_STASH : 0);
         if (want_xin) {
             push(T.x0, 16, EPI_KEEP, 0, F_HALF_ROWS);
             push(T.xskip, 16, EPI_DXIN, 0, F_HALF_ROWS | F_CONTINUE | F_FROM_STASH);

@@ -968,7 +968,7 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
             const float* w = params[pi++]; const float* b = params[pi++];
             if (l == 0) {
                 tiled(w, T.seg_x[0], in, (int)T.k0, d.in_xyz, 0, (int)L.k0s, in_t, d.in_xyz);
-            } else if (l == d.skip) {
+            } else if ((nsff_skip_layers(&d) >> l) & 1u) {
                 tiled(w, T.seg_x[l], in + NSFF_W, (int)T.k0, d.in_xyz, 0, (int)L.k0s, in_t, d.in_xyz);
                 tiled(w, T.seg_h[l], in + NSFF_W, NSFF_W, NSFF_W, in, 0, 0, 0);
             } else {
@@ -1096,10 +1096,11 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.save_side = reinterpret_cast<_Float16*>(g.save_side);
     k.n_tiles = (g.n_points + 63) / 64;
     k.save_stride = k.n_tiles * 64 * NSFF_W;
-    if ((g.save_acts || g.save_xin || g.save_masks || g.save_side) && (!g.xyz || k.L.k0s != 64 || k.L.kt > 64 || k.L.side_k > 128))
+    if ((g.save_acts || g.save_xin || g.save_masks || g.save_side) &&
+        (!g.xyz || k.L.k0s != 64 || k.L.kt > 64 || k.L.side_k > 128 || __builtin_popcount(nsff_skip_layers(&d)) != 1))
         return NSFF_ERR_INVALID;
     k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
-    k.D = d.D; k.skip = d.skip;
+    k.D = d.D; k.skip = d.skip;   // (the step program below carries the skip layers)
     k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;
     k.use_viewdir = d.use_viewdir; k.flow_scale = d.flow_scale;
     k.n_freqs = g.n_freqs;
@@ -1126,7 +1127,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             const int head = (l == d.D - 1) ? last_head : HEAD_NONE;
             if (l == 0) {
                 push(T.seg_x[0], T.bias[0], T.k0, pre_kind, POST_RELU, HEAD_NONE, slot0);
-            } else if (l == d.skip) {
+            } else if ((nsff_skip_layers(&d) >> l) & 1u) {
                 push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
                 push(T.seg_x[l], NSFF_NONE, T.k0, pre_kind, POST_RELU, head, slot0 + l);
             } else {

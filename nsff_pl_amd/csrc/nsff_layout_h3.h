@@ -52,7 +52,8 @@ static inline uint32_t nsff_ceil64(uint32_t v) { return (v + 63u) & ~63u; }
 
 static inline int nsff_make_layout_h3(const NsffModelDesc& d, NsffLayoutH3& L) {
     if (d.W != NSFF_W || d.D < 2 || d.D > NSFF_MAX_LAYERS) return NSFF_ERR_INVALID;
-    if (d.skip < 1 || d.skip >= d.D) return NSFF_ERR_INVALID;
+    const uint32_t skips = nsff_skip_layers(&d);
+    if (skips & ~(((1u << d.D) - 1u) & ~1u)) return NSFF_ERR_INVALID;       // skip layers are among 1..D-1
     if (d.in_xyz < 1 || d.in_xyz > 192) return NSFF_ERR_INVALID;
     if (d.in_t < 0 || d.in_a < 0 || d.in_dir < 0) return NSFF_ERR_INVALID;
     if (d.has_transient && d.in_t < 1) return NSFF_ERR_INVALID;
@@ -68,7 +69,7 @@ static inline int nsff_make_layout_h3(const NsffModelDesc& d, NsffLayoutH3& L) {
         T.k0 = k0;
         for (int l = 0; l < NSFF_MAX_LAYERS; ++l) T.seg_x[l] = T.seg_h[l] = T.bias[l] = NSFF_NONE;
         for (int l = 0; l < d.D; ++l) {
-            if (l == 0 || l == d.skip) T.seg_x[l] = take(NSFF_W * k0);
+            if (l == 0 || ((skips >> l) & 1u)) T.seg_x[l] = take(NSFF_W * k0);
             if (l > 0) T.seg_h[l] = take(NSFF_W * NSFF_W);
             T.bias[l] = take(NSFF_W);
         }

@@ -37,8 +37,9 @@ def enabled():
 
 def why_unsupported(model):
     """None, or what csrc/field_bwd.hip and the SAVE variant of csrc/field_h3.hip are not built for."""
-    if model.W != 256 or len(model.skips) != 1:
-        return f"W={model.W}, skips={list(model.skips)} (the kernels need W=256 and one skip layer)"
+    if model.W != 256 or len(set(model.skips)) != 1:
+        return (f"W={model.W}, skips={list(model.skips)} (the backward kernels need W=256 and exactly one skip layer; "
+                "several or none run at inference only)")
     if model.in_channels_xyz > 64:
         return f"in_channels_xyz={model.in_channels_xyz} > 64 (the saved trunk input has 64 position columns)"
     if model.encode_transient and model.in_channels_t > 64:

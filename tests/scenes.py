@@ -44,6 +44,12 @@ CASES = {
     # view directions + appearance code in TRAIN mode (static_dir_encoding on the gradient path; ctor default use_viewdir=True)
     "g13_viewdir_train": dict(n_rays=16, N_samples=64, N_importance=64, transient=True, viewdir=True, appearance=True,
                               test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=13),
+    # the reference's `skips` is a list (nerf.py:34-40,163-167): two skip layers / none at all (test-time: the backward kernels
+    # want exactly one skip layer, these architectures run at inference only)
+    "g14_two_skips": dict(n_rays=10, N_samples=32, N_importance=24, transient=True, viewdir=False, appearance=False,
+                          test_time=True, flow=['fw', 'bw'], gain=2.5, seed=14, D=8, skips=[2, 5]),
+    "g15_no_skip": dict(n_rays=10, N_samples=48, N_importance=0, transient=True, viewdir=True, appearance=False,
+                        test_time=True, flow=[], gain=2.5, seed=15, D=4, skips=[]),
     "g7b_static_noise_odd": dict(n_rays=9, N_samples=48, N_importance=40, transient=False, viewdir=True,
                                  appearance=False, test_time=False, flow=[], gain=2.5, seed=8,
                                  perturb=0.5, noise_std=0.7),

@@ -218,6 +218,21 @@ def test_nerf_forward_rejects_cpu_and_bad_shapes(hip_lib):
     assert m(torch.zeros(0, 63 + 27, device=DEV), output_transient=False).shape == (0, 4)
 
 
+def test_skip_lists_render_but_refuse_to_train_by_name(hip_lib):
+    """Several skip layers (nerf.py:34-40) run through the inference kernels (goldens g14 / g15); a call that would be
+    differentiated is refused with the reason, not served by a fallback."""
+    cfg = dict(scenes.CASES["g14_two_skips"], test_time=False)
+    rays, ts = scenes.synthetic_rays(cfg["n_rays"], cfg["seed"])
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    args = (models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, 32, 0, 0, 24, 32768)
+    with pytest.raises(RuntimeError, match="cannot be differentiated.*exactly one skip"):
+        A.render_rays(*args, test_time=False, output_transient_flow=['fw', 'bw', 'disocc'])
+    with torch.no_grad():
+        out = A.render_rays(*args, test_time=False, output_transient_flow=['fw', 'bw', 'disocc'])
+    assert torch.isfinite(out["rgb_fine"]).all() and "transient_flow_fw" in out
+
+
 def test_weight_repack_follows_parameter_updates(hip_lib):
     torch.manual_seed(3)
     m = A.NeRF("fine", use_viewdir=False).to(DEV)

@@ -51,16 +51,17 @@ def test_header_symbols_are_exported_and_bound():
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "nsff_render.h")).read()
     declared = set(re.findall(r"\b(nsff_[a-z_]+)\s*\(", header))
+    declared -= set(re.findall(r"static inline [a-z0-9_ ]*?\b(nsff_[a-z_]+)\s*\(", header))     # header-only helpers
     assert declared, "no declarations found in the header"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 15
 
 
 def test_struct_layouts_match_the_header_sizes():
     # natural-alignment layout of the C structs (pointer = 8 bytes)
-    assert C.sizeof(_lib.ModelDesc) == 44
+    assert C.sizeof(_lib.ModelDesc) == 48
     assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 64 + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8
     assert C.sizeof(_lib.FieldBwdArgs) == 16 + 8 * 8 and C.sizeof(_lib.WgradJob) == 32
     assert C.sizeof(_lib.SplatArgs) == 12 + 16 + 48 + 4 + 5 * 8 and C.sizeof(_lib.MpiArgs) == 16 + 7 * 8
@@ -84,8 +85,10 @@ def test_layout_and_argument_validation_without_gpu():
     assert lib.nsff_param_count(C.byref(d)) == len(_lib.param_list(m)) == 48
     bad = _lib.model_desc(m); bad.W = 128
     assert lib.nsff_packed_bytes(C.byref(bad), 0, C.byref(n)) == -1         # NSFF_ERR_INVALID
-    bad = _lib.model_desc(m); bad.skip = 0
+    bad = _lib.model_desc(m); bad.skip = 8                                     # a skip layer must be one of 1..D-1
     assert lib.nsff_packed_bytes(C.byref(bad), 0, C.byref(n)) == -1
+    bad = _lib.model_desc(m); bad.skip = 0; bad.skip_mask = 0b101              # (layer 0 cannot be a skip layer)
+    assert lib.nsff_packed_bytes(C.byref(bad), 1, C.byref(n)) == -1
     assert lib.nsff_packed_bytes(None, 0, C.byref(n)) == -2                    # NSFF_ERR_NULL
     a = _lib.FieldArgs()
     a.n_points, a.pts_per_ray, a.static_mode = 64, 1, 2
@@ -153,12 +156,24 @@ def test_compositing_node_outputs_are_result_keys_of_the_reference():
 
 
 def test_unsupported_architectures_are_refused_by_name():
-    """models/nerf.py:34-40 accepts any W and a list of skips; the kernels do not -- the error must say which field."""
-    for kw, needle in ((dict(W=128), "W=128"), (dict(skips=[2, 5]), r"skips=\[2, 5\]"), (dict(skips=[]), r"skips=\[\]"),
-                       (dict(D=8, skips=[8]), "skips="), (dict(D=1, skips=[0]), "D=1")):
+    """models/nerf.py:34-40 accepts any W and a list of skips; the kernels take W = 256 and any skip layers among
+    1..D-1 (the backward kernels exactly one) -- the error must say which field."""
+    from nsff_pl_amd import field_grad
+    for kw, needle in ((dict(W=128), "W=128"), (dict(D=8, skips=[8]), "skips="), (dict(D=8, skips=[0, 4]), "skips="),
+                       (dict(D=1, skips=[]), "D=1")):
         m = A.NeRF('fine', use_viewdir=False, **kw)
         with pytest.raises(RuntimeError, match="unsupported NeRF architecture.*" + needle):
             _lib.model_desc(m)
+    for skips, mask in (([2, 5], 0b100100), ([], 0), ([1, 2, 3], 0b1110)):
+        m = A.NeRF('fine', D=6, skips=skips, use_viewdir=False)
+        d = _lib.model_desc(m)                                                 # several / no skip layers: inference only
+        assert (d.skip, d.skip_mask) == (0, mask)
+        assert "exactly one skip" in field_grad.why_unsupported(m)
+        n = C.c_size_t(0)
+        assert _lib.load().nsff_packed_bytes(C.byref(d), 1, C.byref(n)) == 0 and n.value > 0
+        assert _lib.load().nsff_bwd_packed_bytes(C.byref(d), C.byref(n)) != 0          # the backward pack refuses
+    d = _lib.model_desc(A.NeRF('fine', D=6, skips=[2], use_viewdir=False))
+    assert (d.skip, d.skip_mask) == (2, 0)
     _lib.model_desc(A.NeRF('fine', D=6, skips=[2], use_viewdir=False))       # fine
 
 
