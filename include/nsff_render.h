@@ -114,7 +114,8 @@ int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_f
 typedef struct NsffFieldArgs {
     int64_t n_points;        /* P                                                   */
     int32_t precision;       /* NSFF_PREC_*: must match the packed buffer           */
-    int32_t tile_points;     /* F16X3 only: points per workgroup, 0 (default 64), 64 or 128 */
+    int32_t tile_points;     /* F16X3 only: 0 = library default (128 points as eight waves of 32 neurons; 64 points for
+                                launches below 32768 points), 64, or the other 128-point tilings 128 / 129 / 130 */
     int32_t pts_per_ray;     /* ray index of point p is p / pts_per_ray             */
     int32_t static_mode;     /* 0 skip, 1 sigma only, 2 rgb+sigma                   */
     int32_t transient_mode;  /* 0 skip, 1 sigma only, 2 rgb+sigma(+flow heads)      */

@@ -39,7 +39,9 @@ def get_precision():
 
 
 def set_tile_points(n):
-    """f16x3 only: points per workgroup (0 = library default = 64; the others are slower experiments kept selectable)."""
+    """f16x3 only: tiling of the inference kernel.  0 = library default (130 for launches of >= 32768 points, else 64);
+    64 = 64 points, four waves, two workgroups per CU; 130 = 128 points, eight waves of 32 neurons, one workgroup per CU;
+    128 / 129 = slower experiments kept selectable."""
     global _tile_points
     if n not in (0, 64, 128, 129, 130):
         raise ValueError("tile_points must be 0 (library default), 64, 128 (8 waves, two wave rows), "
