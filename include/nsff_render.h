@@ -95,8 +95,8 @@ int nsff_param_count(const NsffModelDesc* desc);
 int nsff_pack_weights(const NsffModelDesc* desc, int precision, const float* const* params,
                       void* packed, void* stream);
 
-/* Finer-grained form for callers that re-pack after every optimizer step.  Inference launches of the f16 kernels read
- * "folded" head rows -- the heads that consume the activation-free *_xyz_encoding_final layers (nerf.py:170,195),
+/* Finer-grained form for callers that re-pack after every optimizer step.  Inference launches (every precision; the
+ * exact-fp32 kernel folds everything but the static trunk of view-direction models) read "folded" head rows -- the heads that consume the activation-free *_xyz_encoding_final layers (nerf.py:170,195),
  * pre-multiplied with them, so that those two 256x256 layers are never executed.  nsff_pack_weights builds them;
  * nsff_pack_weights_ex(..., NSFF_PACK_SKIP_FOLD, ...) does not (enough for training forwards, i.e. nsff_field_query
  * with save_* buffers, which execute the layers because the backward pass needs their output), and nsff_fold_heads
@@ -409,7 +409,7 @@ int nsff_composite_backward(const NsffCompositeBwdArgs* args, void* stream);
 int nsff_prof_enable(int on);
 /* Synchronises the recorded events; returns launches, summed milliseconds and summed
  * algorithmic FLOPs (2*MACs of the reference's Linear layers, unpadded K) since the last reset, and the FLOPs the
- * kernels executed for them: inference launches of the f16 kernels evaluate the heads that read the activation-free
+ * kernels executed for them: inference launches evaluate the heads that read the activation-free
  * *_xyz_encoding_final layers (nerf.py:170,195) with pre-multiplied rows and skip those 256x256 layers. */
 int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops);
 

@@ -44,6 +44,7 @@ struct FieldKArgs {
     int D; unsigned skip_mask;
     int in_xyz, in_dir, in_a, in_t;
     int use_viewdir;
+    int fold;                // evaluate the heads that read *_final with the pre-multiplied rows; the layer is not executed
     float flow_scale;
     int n_freqs;
     float freqs[NSFF_MAX_FREQS];
@@ -270,6 +271,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void nsff_field_kernel(const FieldKArg
         build_input(sX, a, p0, false);
         __syncthreads();
         trunk(a.L.st, false);
+        if (a.static_mode == 2 && a.fold && !a.use_viewdir) {
+            // rgb rows pre-multiplied with static_xyz_encoding_final (a Linear without activation, nerf.py:170) + the sigma row
+            heads(sX, pk + a.L.s_fold_w, pk + a.L.s_fold_b, 4, 0x15u /* 3x sigmoid, sigma raw */, 0.f, raw_rec, 0, valid, wave, lane);
+        } else {
         // sigma reads the last trunk activation, before *_final (nerf.py:169)
         heads(sX, pk + a.L.s_sigma_w, pk + a.L.s_sigma_b, 1, ACT_NONE, 0.f, raw_rec, 3, valid, wave, lane);
         if (a.static_mode == 2) {
@@ -289,17 +294,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void nsff_field_kernel(const FieldKArg
             heads(sX, pk + a.L.s_rgb_w, pk + a.L.s_rgb_b, 3, 0x15u /* 3x sigmoid */, 0.f,
                   raw_rec, 0, valid, wave, lane);
         }
+        }
         __syncthreads();
     }
     if (a.transient_mode != 0) {
         build_input(sX, a, p0, true);
         __syncthreads();
         trunk(a.L.tr, true);
-        final_layer(a.L.tr);
-        // rows: rgb(3) sigmoid, sigma raw, fw(3) / bw(3) = flow_scale*tanh (nerf.py:197-208)
+        if (!a.fold) final_layer(a.L.tr);
+        // rows: rgb(3) sigmoid, sigma raw, fw(3) / bw(3) = flow_scale*tanh (nerf.py:197-208); folded: the same rows
+        // pre-multiplied with transient_xyz_encoding_final (nerf.py:195), applied to the last trunk activation
         const unsigned kinds = 0x15u | (0xAAAu << 8);
-        heads(sX, pk + a.L.t_head_w, pk + a.L.t_head_b, (int)a.L.t_head_rows, kinds, a.flow_scale,
-              raw_rec, 4, valid, wave, lane);
+        heads(sX, pk + (a.fold ? a.L.t_fold_w : a.L.t_head_w), pk + (a.fold ? a.L.t_fold_b : a.L.t_head_b),
+              (int)a.L.t_head_rows, kinds, a.flow_scale, raw_rec, 4, valid, wave, lane);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < TM * (NSFF_RAW_STRIDE / 4); i += NTHREADS) {
@@ -424,7 +431,14 @@ int nsff_fold_heads(const NsffModelDesc* desc, int precision, const float* const
     if ((uintptr_t)packed_v & 15) return NSFF_ERR_ALIGN;
     if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16)
         return nsff_h3_fold_heads(desc, params, packed_v, (hipStream_t)stream);
-    return precision == NSFF_PREC_F32 ? NSFF_OK : NSFF_ERR_INVALID;          // the fp32 kernel executes every layer
+    if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
+    NsffLayout L;
+    const int rc = nsff_make_layout(*desc, L);
+    if (rc) return rc;
+    float* packed = reinterpret_cast<float*>(packed_v);
+    return nsff_fold_rows_f32(desc, params, packed + L.s_fold_w, packed + L.s_fold_b,
+                              desc->has_transient ? packed + L.t_fold_w : nullptr,
+                              desc->has_transient ? packed + L.t_fold_b : nullptr, (hipStream_t)stream);
 }
 
 int nsff_pack_weights_ex(const NsffModelDesc* desc, int precision, const float* const* params, void* packed_v,
@@ -506,7 +520,10 @@ int nsff_pack_weights_ex(const NsffModelDesc* desc, int precision, const float* 
         hipLaunchKernelGGL(nsff_pack_kernel, grid, dim3(256), 0, st, pa);
     }
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? NSFF_OK : nsff_hip_fail(e);
+    if (e != hipSuccess) return nsff_hip_fail(e);
+    if (flags & NSFF_PACK_SKIP_FOLD) return NSFF_OK;
+    return nsff_fold_rows_f32(desc, params, packed + L.s_fold_w, packed + L.s_fold_b,
+                              d.has_transient ? packed + L.t_fold_w : nullptr, d.has_transient ? packed + L.t_fold_b : nullptr, st);
 }
 
 int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_freqs, float* out, void* stream) {
@@ -562,6 +579,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     k.D = d.D; k.skip_mask = nsff_skip_layers(&d);
     k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;
     k.use_viewdir = d.use_viewdir; k.flow_scale = d.flow_scale;
+    k.fold = 1;                                     // (the fp32 kernel has no training variant: every launch is inference)
     k.n_freqs = g.n_freqs;
     for (int i = 0; i < NSFF_MAX_FREQS; ++i) k.freqs[i] = g.freqs[i];
     k.ld_emb = g.ld_emb; k.off_xyz = g.off_xyz; k.off_dir = g.off_dir; k.off_a = g.off_a; k.off_t = g.off_t;
@@ -601,8 +619,8 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
                                          g.transient_mode == 2 ? g.flow_heads : 0) * (double)g.n_points;
         // the f16 kernels' inference launches fold the activation-free *_final layers into their head rows
         const bool h3 = g.precision == NSFF_PREC_F16X3 || g.precision == NSFF_PREC_F16;
-        const bool folds = h3 && !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
-        const int folded = folds ? (g.static_mode == 2 ? 1 : 0) + (g.transient_mode ? 1 : 0) : 0;
+        const bool folds = !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
+        const int folded = folds ? ((g.static_mode == 2 && (h3 || !d.use_viewdir)) ? 1 : 0) + (g.transient_mode ? 1 : 0) : 0;
         pr.executed = pr.flops - 2.0 * d.W * d.W * folded * (double)g.n_points;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(pr);

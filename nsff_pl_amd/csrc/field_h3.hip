@@ -1025,15 +1025,13 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
 // Folded head rows (NsffLayoutH3): products in fp32 scratch inside the packed buffer, then one head tile per trunk.
 // Separate from the pack so that a caller that re-packs after every optimizer step (training forwards execute the *_final
 // layers: the backward pass needs their output) does not pay for rows nobody reads.
-int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st) {
-    NsffLayoutH3 L;
-    const int rc = nsff_make_layout_h3(*desc, L);
-    if (rc) return rc;
-    const NsffModelDesc& d = *desc;
-    // parameter order (nsff_pack_weights): static trunk [w, b] x D, static final, [dir], static sigma, static rgb,
-    // dynamic trunk [w, b] x D, dynamic final, dynamic sigma, dynamic rgb, [flow fw, flow bw]
+// the head sets of a model as FoldArgs (parameter order of nsff_pack_weights): fs static (rgb folded, sigma plain), ft dynamic
+// (all rows folded), fd static_dir_encoding (use_viewdir); returns the number of parameters read
+static int fold_args(const NsffModelDesc& d, const float* const* params, FoldArgs& fs, FoldArgs& ft, FoldArgs& fd) {
+    // static trunk [w, b] x D, static final, [dir], static sigma, static rgb, dynamic trunk [w, b] x D, dynamic final,
+    // dynamic sigma, dynamic rgb, [flow fw, flow bw]
     int pi = 2 * d.D;
-    FoldArgs fs{}, ft{}, fd{};
+    fs = FoldArgs{}; ft = FoldArgs{}; fd = FoldArgs{};
     fs.ld_head = ft.ld_head = NSFF_W;
     fs.w_final = params[pi]; fs.b_final = params[pi + 1]; pi += 2;
     if (d.use_viewdir) {                                   // static_dir_encoding: 256 rows, its first 256 columns read *_final
@@ -1056,6 +1054,34 @@ int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, vo
             ft.n_heads = 4;
         }
     }
+    return pi;
+}
+
+// fp32 rows for the exact-fp32 kernel's VALU heads: s_w (4, 256) / s_b (4) unless use_viewdir, t_w (rows, 256) / t_b (rows)
+int nsff_fold_rows_f32(const NsffModelDesc* desc, const float* const* params, float* s_w, float* s_b, float* t_w, float* t_b,
+                       hipStream_t st) {
+    const NsffModelDesc& d = *desc;
+    FoldArgs fs, ft, fd;
+    const int pi = fold_args(d, params, fs, ft, fd);
+    for (int i = 0; i < pi; ++i) if (!params[i]) return NSFF_ERR_NULL;
+    if (!d.use_viewdir) {
+        fs.out_w = s_w; fs.out_b = s_b;
+        hipLaunchKernelGGL(nsff_fold_kernel_h3, dim3(4), dim3(256), 0, st, fs);
+    }
+    if (d.has_transient) {
+        ft.out_w = t_w; ft.out_b = t_b;
+        hipLaunchKernelGGL(nsff_fold_kernel_h3, dim3(d.has_flow ? 10 : 4), dim3(256), 0, st, ft);
+    }
+    return nsff_launch_status();
+}
+
+int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st) {
+    NsffLayoutH3 L;
+    const int rc = nsff_make_layout_h3(*desc, L);
+    if (rc) return rc;
+    const NsffModelDesc& d = *desc;
+    FoldArgs fs, ft, fd;
+    const int pi = fold_args(d, params, fs, ft, fd);
     for (int i = 0; i < pi; ++i) if (!params[i]) return NSFF_ERR_NULL;
     uint32_t* pw = reinterpret_cast<uint32_t*>(packed);
     PackArgsH3 pf{};

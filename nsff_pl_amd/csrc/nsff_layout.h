@@ -36,6 +36,9 @@ struct NsffLayout {
     uint32_t s_rgb_w, s_rgb_b;         // (3,256) + 3
     uint32_t t_head_w, t_head_b;       // rows: rgb(3) sigma(1) [fw(3) bw(3)]
     uint32_t t_head_rows;              // 0, 4 or 10
+    // folded heads (see nsff_layout_h3.h): rows pre-multiplied with the activation-free *_final layers, applied to the
+    // last trunk activation -- static (no view directions): rgb(3) folded + sigma(1); dynamic: all t_head_rows
+    uint32_t s_fold_w, s_fold_b, t_fold_w, t_fold_b;
     uint32_t total;                    // floats
 };
 
@@ -86,6 +89,9 @@ static inline int nsff_make_layout(const NsffModelDesc& d, NsffLayout& L) {
     } else {
         L.tr = NsffTrunkLayout{};
     }
+    L.s_fold_w = take(4 * NSFF_W); L.s_fold_b = take(4);
+    L.t_fold_w = L.t_fold_b = NSFF_NONE;
+    if (d.has_transient) { L.t_fold_w = take(L.t_head_rows * NSFF_W); L.t_fold_b = take(L.t_head_rows); }
     L.total = off;
     return NSFF_OK;
 }
