@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      15
+#define NSFF_ABI_VERSION      16
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -109,6 +109,12 @@ int nsff_fold_heads(const NsffModelDesc* desc, int precision, const float* const
 /* ---- a1: PosEmbedding.forward (reference nerf.py:17-30) ---- */
 int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_freqs,
                 float* out, void* stream);
+
+/* ---- a2: the two neighbouring-frame gathers of the warp path, embedding_t(clamp(ts + 1, max=max_t)) and
+ * embedding_t(clamp(ts - 1, min=0)) (reference rendering.py:218,224), from the table of an nn.Embedding:
+ * table (n_table, width) fp32, ts (n) int64 on the device; next / prev (n, width), either may be NULL. */
+int nsff_time_rows(const float* table, int64_t n_table, int32_t width, const int64_t* ts, int64_t n, int64_t max_t,
+                   float* next, float* prev, void* stream);
 
 /* ---- a3/a5: fused field query = encode -> trunk(s) -> heads (NeRF.forward) ---- */
 typedef struct NsffFieldArgs {

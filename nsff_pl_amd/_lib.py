@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -124,6 +124,7 @@ _SIGNATURES = {
     "nsff_pack_weights_ex": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_fp), _fp, C.c_int32, _fp]),
     "nsff_fold_heads": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_fp), _fp, _fp]),
     "nsff_posenc": (C.c_int, [_fp, C.c_int64, C.POINTER(C.c_float), C.c_int, _fp, _fp]),
+    "nsff_time_rows": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, C.c_int64, C.c_int64, _fp, _fp, _fp]),
     "nsff_field_query": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldArgs), _fp]),
     "nsff_coarse_samples": (C.c_int, [_fp, C.c_int64, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, _fp]),
     "nsff_fine_samples": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp,
@@ -274,6 +275,17 @@ def fold_heads(desc, params, packed, precision):
     arr = (_fp * len(keep))(*[p.data_ptr() for p in keep])
     _check(load().nsff_fold_heads(C.byref(desc), int(precision), arr, _ptr(packed), _stream()), "nsff_fold_heads")
     return keep
+
+
+def time_rows(table, ts, max_t, want_next=True, want_prev=True):
+    """(E[clamp(ts + 1, max=max_t)], E[clamp(ts - 1, min=0)]) of an embedding table in one launch (rendering.py:218,224)."""
+    n, width = ts.shape[0], table.shape[1]
+    nxt = torch.empty(n, width, device=table.device) if want_next else None
+    prv = torch.empty(n, width, device=table.device) if want_prev else None
+    assert ts.dtype == torch.int64 and ts.is_cuda and ts.is_contiguous()
+    _check(load().nsff_time_rows(_ptr(table), table.shape[0], width, C.c_void_p(ts.data_ptr()), n, int(max_t),
+                                 _ptr(nxt), _ptr(prv), _stream()), "nsff_time_rows")
+    return nxt, prv
 
 
 def posenc(x, freqs, out):

@@ -444,9 +444,47 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_kernel(const N
     }
 }
 
+// rows of the time-code table for the neighbouring frames: next[r] = E[min(ts[r] + 1, max_t)], prev[r] = E[max(ts[r] - 1, 0)]
+// (reference rendering.py:218,224: embedding_t(torch.clamp(ts +- 1, ...))) -- one launch instead of two add / clamp / gather
+// triples; either output may be NULL.  One thread per float4 (width % 4 == 0) or per float.
+__global__ __launch_bounds__(256) void time_rows_kernel(const float* __restrict__ table, long long n_table, int width,
+                                                         const long long* __restrict__ ts, long long n, long long max_t,
+                                                         float* __restrict__ next, float* __restrict__ prev, int vec) {
+    const int per_row = vec ? width / 4 : width;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * per_row) return;
+    const long long r = i / per_row;
+    const int c = (int)(i - r * per_row);
+    const long long t = ts[r];
+    long long tn = t + 1 < max_t ? t + 1 : max_t, tp = t - 1 > 0 ? t - 1 : 0;
+    tn = tn < 0 ? 0 : (tn > n_table - 1 ? n_table - 1 : tn);
+    tp = tp > n_table - 1 ? n_table - 1 : tp;
+    if (vec) {
+        if (next) reinterpret_cast<float4*>(next)[i] = reinterpret_cast<const float4*>(table + tn * width)[c];
+        if (prev) reinterpret_cast<float4*>(prev)[i] = reinterpret_cast<const float4*>(table + tp * width)[c];
+    } else {
+        if (next) next[i] = table[tn * width + c];
+        if (prev) prev[i] = table[tp * width + c];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int nsff_time_rows(const float* table, int64_t n_table, int32_t width, const int64_t* ts, int64_t n, int64_t max_t,
+                   float* next, float* prev, void* stream) {
+    if (n < 0 || n_table < 1 || width < 1) return NSFF_ERR_INVALID;
+    if (n == 0 || (!next && !prev)) return NSFF_OK;
+    if (!table || !ts) return NSFF_ERR_NULL;
+    const int vec = (width % 4 == 0) && !(((uintptr_t)table | (uintptr_t)next | (uintptr_t)prev) & 15);
+    const long long total = n * (vec ? width / 4 : width);
+    hipLaunchKernelGGL(time_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table,
+                       (long long)n_table, (int)width, reinterpret_cast<const long long*>(ts), (long long)n, (long long)max_t,
+                       next, prev, vec);
+    return nsff_launch_status();
+}
+
 
 int nsff_coarse_samples(const float* rays, int64_t n_rays, const float* z_lin, int32_t n_samples,
                         float perturb, const float* perturb_rand, float* zs, float* xyz, void* stream) {

@@ -62,6 +62,17 @@ def _embed_rows(embeddings, key, idx):
     return embeddings[key](idx).detach().contiguous().float()
 
 
+def _neighbour_time_rows(embeddings, ts, max_t):
+    """(E_t[clamp(ts + 1, max=max_t)], E_t[clamp(ts - 1, min=0)]) -- reference rendering.py:218,224.  A plain nn.Embedding
+    table is read by one kernel; any other module the caller passed as embeddings['t'] is simply called twice."""
+    m = embeddings['t']
+    if (isinstance(m, torch.nn.Embedding) and m.padding_idx is None and m.max_norm is None and m.weight.is_cuda
+            and m.weight.dtype == torch.float32 and m.weight.is_contiguous() and ts.is_cuda and ts.dtype == torch.int64):
+        return _lib.time_rows(m.weight.detach(), ts.contiguous(), max_t)
+    return (_embed_rows(embeddings, 't', torch.clamp(ts + 1, max=max_t)),
+            _embed_rows(embeddings, 't', torch.clamp(ts - 1, min=0)))
+
+
 def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
                t_embedded, a_embedded):
     """One model pass: field query, optional flow-warp re-queries, compositing.
@@ -140,14 +151,13 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         xyz_bw = _new(zs, n_rays, S, 3)
         raw_fw = _new(zs, P, _lib.RAW_STRIDE)
         raw_bw = _new(zs, P, _lib.RAW_STRIDE)
-        tp1 = _embed_rows(ctx.embeddings, 't', torch.clamp(ts + 1, max=ctx.max_t))
+        tp1, tm1 = _neighbour_time_rows(ctx.embeddings, ts, ctx.max_t)
         if P:
             _lib.warp_points(raw, xyz, zs, Z_FAR, xyz_fw, xyz_bw)
             query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1)
         noise_fw = torch.randn(n_rays, S, device=zs.device)
         out('rgb_fw', n_rays, 3)
         results['xyzs_bw'] = xyz_bw
-        tm1 = _embed_rows(ctx.embeddings, 't', torch.clamp(ts - 1, min=0))
         if P:
             query(f"{typ}_warp_bw", raw_bw, xyz_bw, 0, 2, 1, tm1)
         noise_bw = torch.randn(n_rays, S, device=zs.device)

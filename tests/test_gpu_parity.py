@@ -276,6 +276,22 @@ def test_field_query_encodes_raw_points_for_any_frequency_list(logscale, n_freqs
     parity.assert_close(f"raw records logscale={logscale} n_freqs={n_freqs}", got, want, parity.RTOL)
 
 
+def test_neighbour_time_rows_equal_the_embedding_gathers(hip_lib):
+    """nsff_time_rows vs embedding_t(clamp(ts +- 1)) (rendering.py:218,224): bit-equal, both ends of the clamp, both widths
+    of store (16-byte and 4-byte), an empty batch."""
+    from nsff_pl_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    for width in (48, 18):
+        table = torch.randn(30, width, generator=g).to(DEV)
+        ts = torch.cat([torch.tensor([0, 0, 29, 29, 28, 1]), torch.randint(0, 30, (500,), generator=g)]).to(DEV)
+        nxt, prv = _lib.time_rows(table, ts, 29)
+        assert torch.equal(nxt, table[torch.clamp(ts + 1, max=29)]) and torch.equal(prv, table[torch.clamp(ts - 1, min=0)])
+        nxt, prv = _lib.time_rows(table, ts, 12)                    # max_t below the table size, as in a cropped sequence
+        assert torch.equal(nxt, table[torch.clamp(ts + 1, max=12)])
+    e, _ = _lib.time_rows(table, ts[:0], 29, want_prev=False)
+    assert e.shape == (0, 18) and _ is None
+
+
 def test_sample_pdf(stages, hip_lib, monkeypatch):
     bins, w = stages["pdf/bins"], stages["pdf/weights"]
     tb, tw = torch.from_numpy(bins).to(DEV), torch.from_numpy(w).to(DEV)
