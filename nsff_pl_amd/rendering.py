@@ -62,6 +62,19 @@ def _embed_rows(embeddings, key, idx):
     return embeddings[key](idx).detach().contiguous().float()
 
 
+_LINSPACE = {}
+
+
+def _unit_linspace(n, device):
+    """torch.linspace(0, 1, n) on `device`, built once per (n, device): the reference re-creates it in every call."""
+    key = (int(n), str(device))
+    if key not in _LINSPACE:
+        if len(_LINSPACE) > 64:
+            _LINSPACE.clear()
+        _LINSPACE[key] = torch.linspace(0, 1, n, device=device)
+    return _LINSPACE[key]
+
+
 def _neighbour_time_rows(embeddings, ts, max_t):
     """(E_t[clamp(ts + 1, max=max_t)], E_t[clamp(ts - 1, min=0)]) -- reference rendering.py:218,224.  A plain nn.Embedding
     table is read by one kernel; any other module the caller passed as embeddings['t'] is simply called twice."""
@@ -262,7 +275,7 @@ def render_rays(models,
             ctx.dir_embedded = embedding_dir(view_dir.contiguous().float())
 
         # coarse depths: one linspace shared by all rays, optional stratified jitter
-        z_lin = torch.linspace(0, 1, N_samples, device=rays.device)
+        z_lin = _unit_linspace(N_samples, rays.device)
         perturb_rand = torch.rand(n_rays, N_samples, device=rays.device) if perturb > 0 else None
         zs = _new(rays, n_rays, N_samples)
         xyz_coarse = _new(rays, n_rays, N_samples, 3)
@@ -280,7 +293,7 @@ def render_rays(models,
 
             det = perturb == 0
             if det:
-                u_s = torch.linspace(0, 1, N_importance, device=rays.device)
+                u_s = _unit_linspace(N_importance, rays.device)
                 u_t = u_s
             else:
                 u_s = torch.rand(n_rays, N_importance, device=rays.device)
