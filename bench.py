@@ -104,6 +104,31 @@ class Bench:
         self.scenes, self.rank, self.world, self.device, self.graph, self.standin = scenes, rank, world, device, graph, standin
         self.cfg, self.models, self.emb = build_scene()
         self.cpu = None
+        import torch.distributed as dist
+        self.live = dist.is_initialized()       # a process group exists (torchrun / self-launch; world size 1 included)
+        self.gather_spans = []                  # (start, end) of every pixel all-gather: HIP events on the GPU, seconds on the CPU
+
+    def gather(self, out, keys, counts=None):
+        """The step's one collective, bracketed so that rank 0 can report it separately from the render time."""
+        from nsff_pl_amd import dist as ndist
+        if self.device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            merged = ndist.all_gather_pixels(out, keys, counts=counts)
+            e1.record()
+            self.gather_spans.append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            merged = ndist.all_gather_pixels(out, keys, counts=counts)
+            self.gather_spans.append((t0, time.perf_counter()))
+        return merged
+
+    def gather_ms(self):
+        """Total milliseconds of the recorded gathers (call after a synchronize); clears the record."""
+        spans, self.gather_spans = self.gather_spans, []
+        if self.device.type == "cuda":
+            return sum(a.elapsed_time(b) for a, b in spans)
+        return sum((b - a) * 1e3 for a, b in spans)
 
     def to_device(self):
         for m in list(self.models.values()) + [self.emb["t"]]:
@@ -116,20 +141,20 @@ class Bench:
     def render_step(self):
         import nsff_pl_amd as A
         from nsff_pl_amd import dist as ndist
-        scenes, world = self.scenes, self.world
+        scenes, live = self.scenes, self.live
         if self.standin:                                   # CPU plumbing check only (tests): no kernels, constant pixels
             px = {"rgb_fine": torch.full((N_RAYS, 3), float(self.rank)), "depth_fine": torch.zeros(N_RAYS)}
 
             def step():
-                return ndist.all_gather_pixels(px, ("rgb_fine", "depth_fine")) if world > 1 else px
+                return self.gather(px, ("rgb_fine", "depth_fine")) if live else px
             return step
 
         def step():
             with torch.no_grad():      # the render workload measures the forward path; the train workload the full step
                 out = A.render_rays(self.models, self.emb, self.rays, self.ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
                                     N_IMPORTANCE, 1024 * 32, test_time=False, **self.kw)
-            if world > 1:
-                ndist.all_gather_pixels(out, ("rgb_fine", "depth_fine"))
+            if live:
+                self.gather(out, ("rgb_fine", "depth_fine"))
             return out
         return step
 
@@ -165,9 +190,9 @@ class Bench:
 
         def eval_step():
             out = render_t(7, ("rgb_fine", "depth_fine"))
-            if world > 1 and not to_host:
+            if self.live and not to_host:
                 counts = [b - a_ for a_, b in (ndist.shard_bounds(H * W, world, r) for r in range(world))]
-                ndist.all_gather_pixels(out, ("rgb_fine", "depth_fine"), counts=counts)
+                self.gather(out, ("rgb_fine", "depth_fine"), counts=counts)
             return out
 
         def interp_step():
@@ -178,39 +203,54 @@ class Bench:
         return interp_step if interp else eval_step
 
 
-def timed(step, steps, warmup, world, device, prof=False):
+def timed(step, steps, warmup, world, device, prof=False, bench=None):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; returns (seconds [max over ranks],
-    field-kernel (launches, ms, flops) from HIP events on the launch stream when prof)."""
+    field-kernel (launches, ms, flops) from HIP events on the launch stream when prof, per-rank report).  The report
+    (`bench` given and a process group alive) holds every rank's own seconds for the K steps and the milliseconds it
+    spent in the pixel all-gather: rank 0 prints their min / max, so a scaling line explains itself."""
     import torch.distributed as dist
     from nsff_pl_amd import _lib
     gpu = device.type == "cuda"
+    live = dist.is_initialized()
 
     def fence():
         if gpu:
             torch.cuda.synchronize()
-        if world > 1:
+        if live:
             dist.barrier()
         if gpu:
             torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     fence()
+    if bench is not None:
+        bench.gather_ms()                       # (drop the warm-up's record)
     if prof:
         _lib.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if gpu:
+        torch.cuda.synchronize()
+    own = time.perf_counter() - t0              # this rank's own K steps, before waiting for the others
     fence()
     elapsed = time.perf_counter() - t0
     kern = (0, 0.0, 0.0, 0.0)
     if prof:
         kern = _lib.prof_collect()
         _lib.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed, kern
+    per_rank = None
+    if live:
+        mine = torch.tensor([elapsed, own, bench.gather_ms() if bench is not None else 0.0], device=device, dtype=torch.float64)
+        allv = torch.empty(world * 3, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(allv, mine)
+        allv = allv.view(world, 3).cpu()
+        elapsed = float(allv[:, 0].max())
+        per_rank = {"ms_per_step_min": float(allv[:, 1].min()) / steps * 1e3, "ms_per_step_max": float(allv[:, 1].max()) / steps * 1e3,
+                    "gather_ms_per_step_min": float(allv[:, 2].min()) / steps, "gather_ms_per_step_max": float(allv[:, 2].max()) / steps,
+                    "note": "each rank's own time for the K steps (host clock around its loop + device synchronize, before the "
+                            "closing barrier) and the part of it inside the pixel all-gather (HIP events around the collective)"}
+    return elapsed, kern, per_rank
 
 
 def roofline_block(precision, kern):
@@ -242,7 +282,7 @@ def aux_block(bench, args):
     # (1) single-product fast mode of the SAME C2 workload: labelled, never the headline
     config.set_precision("f16")
     config.set_tile_points(0)
-    t, kern = timed(bench.render_step(), 10, 2, 1, dev, prof=True)
+    t, kern, _ = timed(bench.render_step(), 10, 2, 1, dev, prof=True)
     rf = roofline_block("f16", kern)
     aux["fast_mode_f16"] = {"label": "FAST MODE, not parity-grade (one f16 MFMA per product; ~5e-3 max-norm error, see DESIGN.md 8)",
                             "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 10 / t, "ms_per_step": t / 10 * 1e3,
@@ -251,21 +291,21 @@ def aux_block(bench, args):
     config.set_precision(args.precision)
     config.set_tile_points(args.tile_points if args.precision == "f16x3" else 0)
     # (2) C3: one 512x288 test-time frame
-    t, _ = timed(bench.frame_steps(False), 3, 1, 1, dev)
+    t, _, _ = timed(bench.frame_steps(False), 3, 1, 1, dev)
     aux["eval_ms_per_frame"] = t / 3 * 1e3
     aux["eval_ray_samples_per_s"] = 288 * 512 * (128 + 64) * 3 / t
     # ... and with the pixels (rgb_fine, depth_fine) delivered to pinned host memory chunk by chunk on a copy stream (row N4)
-    t, _ = timed(bench.frame_steps(False, to_host=True), 3, 1, 1, dev)
+    t, _, _ = timed(bench.frame_steps(False, to_host=True), 3, 1, 1, dev)
     aux["eval_ms_per_frame_pixels_to_pinned_host"] = t / 3 * 1e3
     # (3) C5 inner loop: 2 rendered + 9 interpolated frames
-    t, _ = timed(bench.frame_steps(True), 2, 1, 1, dev)
+    t, _, _ = timed(bench.frame_steps(True), 2, 1, 1, dev)
     aux["interp_ms_per_11_frames"] = t / 2 * 1e3
     aux["interp_frames_per_s"] = 10 * 2 / t
     # (4) C4 per GPU: training step (changes the weights, so it goes last)
     for graph in (False, True):
         bench.graph = graph
         cfg_models = bench.models
-        t, _ = timed(bench.train_step(), 5, 3 if not graph else 1, 1, dev)
+        t, _, _ = timed(bench.train_step(), 5, 3 if not graph else 1, 1, dev)
         aux["train_ms_per_step" + ("_graph" if graph else "_eager")] = t / 5 * 1e3
         bench.models = cfg_models
     aux["train_ray_samples_per_s"] = N_RAYS * (N_SAMPLES + N_IMPORTANCE) / (aux["train_ms_per_step_graph"] * 1e-3)
@@ -320,7 +360,7 @@ def main():
     step = {"render": bench.render_step, "train": bench.train_step,
             "eval": lambda: bench.frame_steps(False), "eval_interp": lambda: bench.frame_steps(True)}[args.workload]()
 
-    elapsed, kern = timed(step, args.steps, args.warmup, world, device, prof=not args.standin)
+    elapsed, kern, per_rank = timed(step, args.steps, args.warmup, world, device, prof=not args.standin, bench=bench)
 
     aux = None
     if rank == 0 and world == 1 and args.workload == "render" and not args.no_aux and not args.standin:
@@ -338,7 +378,7 @@ def main():
                                    "64 importance -> 192 fine pts), train-mode fwd, fw/bw flow warp t+-1, "
                                    "perturb=1 noise_std=1, 8x256 MLPs, N_tau=48, all 47 outputs on device",
                        "rays_per_gpu": N_RAYS, "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE,
-                       "parallelism": f"ray-shard x{world}, pixel all-gather" if world > 1 else "single GPU",
+                       "parallelism": f"ray-shard x{world}, pixel all-gather" if bench.live else "single GPU",
                        "rays_per_s": world * N_RAYS * args.steps / elapsed,
                        "mlp_tflops_whole_step": world * N_RAYS * args.steps * FLOP_PER_RAY_C2_TRAIN / elapsed / 1e12},
         }
@@ -373,12 +413,14 @@ def main():
             line["config"]["parallelism"] = f"data-parallel x{world}, one flat gradient all-reduce per step"
             line["config"]["hip_graph"] = bool(bench.trainer.graph)
             line["config"].pop("mlp_tflops_whole_step")
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if aux is not None:
             line["aux"] = aux
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

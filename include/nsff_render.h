@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      16
+#define NSFF_ABI_VERSION      17
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       16
 #define NSFF_MAX_LAYERS       8
@@ -121,7 +121,7 @@ typedef struct NsffFieldArgs {
     int64_t n_points;        /* P                                                   */
     int32_t precision;       /* NSFF_PREC_*: must match the packed buffer           */
     int32_t tile_points;     /* F16X3 only: 0 = library default (128 points as eight waves of 32 neurons; 64 points for
-                                launches below 32768 points), 64, or the other 128-point tilings 128 / 129 / 130 */
+                                inference launches below 32768 points), 64 = 64-point tiles, 130 = the 128-point tiling */
     int32_t pts_per_ray;     /* ray index of point p is p / pts_per_ray             */
     int32_t static_mode;     /* 0 skip, 1 sigma only, 2 rgb+sigma                   */
     int32_t transient_mode;  /* 0 skip, 1 sigma only, 2 rgb+sigma(+flow heads)      */
@@ -314,6 +314,15 @@ int nsff_warp_points(const float* raw, const float* xyz, const float* zs, int64_
 int nsff_frame_rays(const float* K4_host, const float* c2w_host, int32_t H, int32_t W, float near, float shift_near,
                     int64_t first_pixel, int64_t n_pixels, float* rays, void* stream);
 
+/* ---- a6: eval-only frustum visibility (reference rendering.py:190-200 with datasets/ray_utils.py:127-151,154-181) ---- */
+typedef struct NsffFrustumArgs {
+    const float*   w2c;         /* device (n_cams * n_frames, 12): row-major first three rows of inverse([c2w; 0 0 0 1]),
+                                   camera i of frame f at row i * n_frames + f (dataset.poses order, rendering.py:199)  */
+    const int64_t* ts;          /* device: the frame is ts[0] (read on the device: no host synchronisation)            */
+    float   K4[4];              /* fx, fy, cx, cy of dataset.Ks[0]                                                     */
+    int32_t n_cams, n_frames, H, W;
+} NsffFrustumArgs;
+
 /* ---- a7/a8: sigma->alpha compositing and every per-ray / per-sample output ---- */
 typedef struct NsffCompositeArgs {
     int64_t n_rays;
@@ -350,9 +359,17 @@ typedef struct NsffCompositeArgs {
     float* xyz_exp;  float* flow_fw_exp;  float* flow_bw_exp;  float* xyz_fw_exp;  float* xyz_bw_exp;
     float* rgb_fw;   float* rgb_bw;
     float* disocc_fw;  float* disocc_bw;
+    NsffFrustumArgs vis;        /* a6 evaluated INSIDE this kernel: vis.w2c != NULL => the raw transient sigma of every sample
+                                   no training camera of frame ts[0] sees becomes -10 (`visibility` above is the same mask
+                                   handed in as an array) */
 } NsffCompositeArgs;
 
 int nsff_composite(const NsffCompositeArgs* args, void* stream);
+
+/* The a6 mask as a stage of its own (tests, callers that want the mask): vis_count[p] = number of the frame's training
+ * cameras whose image contains NDC point xyz[p] (float, like the reference's `visibilities`). */
+int nsff_frustum_visibility(const NsffFrustumArgs* vis, const float* xyz, int64_t n_points, float* vis_count,
+                            void* stream);
 
 /* ---- N2: time interpolation of two test-time renders (reference models/rendering.py:365-460 with
  * models/softsplat.py:6-44,303-326 'average' splatting).  The S sample planes of a frame are splatted by ONE

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_FREQS = 16
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -59,12 +59,18 @@ _COMPOSITE_PTRS_OUT = ["static_rgbs", "transient_rgbs", "flows_fw", "flows_bw",
                        "rgb_fw", "rgb_bw", "disocc_fw", "disocc_bw"]
 
 
+class FrustumArgs(C.Structure):
+    _fields_ = [("w2c", _fp), ("ts", _fp), ("K4", C.c_float * 4), ("n_cams", C.c_int32), ("n_frames", C.c_int32),
+                ("H", C.c_int32), ("W", C.c_int32)]
+
+
 class CompositeArgs(C.Structure):
     _fields_ = ([("n_rays", C.c_int64), ("n_samples", C.c_int32), ("has_transient", C.c_int32),
                  ("has_rgb", C.c_int32), ("flow_mode", C.c_int32), ("want_disocc", C.c_int32),
                  ("noise_std", C.c_float), ("z_far", C.c_float)]
                 + [(n, _fp) for n in _COMPOSITE_PTRS_IN]
-                + [(n, _fp) for n in _COMPOSITE_PTRS_OUT])
+                + [(n, _fp) for n in _COMPOSITE_PTRS_OUT]
+                + [("vis", FrustumArgs)])
 
 
 _CBWD_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "f_fw", "f_bw", "noise_static", "noise_transient", "noise_fw", "noise_bw"]
@@ -133,6 +139,7 @@ _SIGNATURES = {
                                   C.c_float, _fp, _fp]),
     "nsff_warp_points": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_float, _fp, _fp, _fp]),
     "nsff_composite": (C.c_int, [C.POINTER(CompositeArgs), _fp]),
+    "nsff_frustum_visibility": (C.c_int, [C.POINTER(FrustumArgs), _fp, C.c_int64, _fp, _fp]),
     "nsff_frame_rays": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_float,
                                   C.c_float, C.c_int64, C.c_int64, _fp, _fp]),
     "nsff_bwd_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
@@ -354,13 +361,30 @@ def warp_points(raw, xyz, zs, z_far, xyz_fw, xyz_bw):
                                    _ptr(xyz_fw), _ptr(xyz_bw), _stream()), "nsff_warp_points")
 
 
-def composite(**kw):
+def frustum_args(w2c, ts, K4, n_cams, n_frames, H, W):
+    """NsffFrustumArgs: w2c (n_cams * n_frames, 12) fp32 and ts (>= 1,) int64 on the device (the frame is ts[0])."""
+    assert w2c.is_cuda and w2c.dtype == torch.float32 and w2c.is_contiguous() and w2c.shape == (n_cams * n_frames, 12)
+    assert ts.is_cuda and ts.dtype == torch.int64 and ts.is_contiguous() and ts.numel() >= 1
+    a = FrustumArgs(w2c=w2c.data_ptr(), ts=ts.data_ptr(), n_cams=int(n_cams), n_frames=int(n_frames), H=int(H), W=int(W))
+    a.K4[:] = [float(v) for v in K4]
+    a._keep = (w2c, ts)                      # the structure only holds addresses
+    return a
+
+
+def frustum_visibility(vis, xyz, out):
+    _check(load().nsff_frustum_visibility(C.byref(vis), _ptr(xyz), xyz.shape[0], _ptr(out), _stream()),
+           "nsff_frustum_visibility")
+
+
+def composite(vis=None, **kw):
     a = CompositeArgs()
     for k, v in kw.items():
         if k in _COMPOSITE_PTRS_IN or k in _COMPOSITE_PTRS_OUT:
             setattr(a, k, _ptr(v))
         else:
             setattr(a, k, v)
+    if vis is not None:
+        a.vis = vis
     _check(load().nsff_composite(C.byref(a), _stream()), "nsff_composite")
 
 

@@ -39,13 +39,12 @@ def get_precision():
 
 
 def set_tile_points(n):
-    """f16x3 only: tiling of the inference kernel.  0 = library default (130 for launches of >= 32768 points, else 64);
-    64 = 64 points, four waves, two workgroups per CU; 130 = 128 points, eight waves of 32 neurons, one workgroup per CU;
-    128 / 129 = slower experiments kept selectable."""
+    """f16x3 only: tiling of the field kernel.  0 = library default (130; inference launches below 32768 points: 64);
+    64 = 64 points, four waves of 64 neurons, two workgroups per CU; 130 = 128 points, eight waves of 32 neurons, one
+    workgroup per CU (also the training forward's default)."""
     global _tile_points
-    if n not in (0, 64, 128, 129, 130):
-        raise ValueError("tile_points must be 0 (library default), 64, 128 (8 waves, two wave rows), "
-                         "129 (128 points, 4 waves) or 130 (128 points, 8 waves x 32 neurons)")
+    if n not in (0, 64, 130):
+        raise ValueError("tile_points must be 0 (library default), 64 or 130 (128 points, 8 waves x 32 neurons)")
     _tile_points = n
 
 

@@ -24,11 +24,26 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+#ifdef BWD_TIMING
+// debug build only (make timing): s_memtime stamps of the first 256 workgroups, 6 per step and wave + the end of the workgroup
+__device__ unsigned g_bwd_timing[256 * 4 * 32 * 6];
+#define BWD_STAMP(k) do { if (lane == 0 && blockIdx.x < 256 && i < 31) \
+    g_bwd_timing[((blockIdx.x * 4 + wave) * 32 + i) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define BWD_STAMP_END() do { if (lane == 0 && blockIdx.x < 256) \
+    g_bwd_timing[((blockIdx.x * 4 + wave) * 32 + 31) * 6] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BWD_STAMP(k) do {} while (0)
+#define BWD_STAMP_END() do {} while (0)
+#endif
+
 namespace {
 
 constexpr int LDH = 264;           // halfs per LDS row (528 B: conflict-free ds_read_b128)
 constexpr int NT = 2;              // 32-point column tiles per workgroup (64 points)
 constexpr int MAX_BSTEPS = 24;
+#ifndef BWD_STORE_INTERLEAVE
+#define BWD_STORE_INTERLEAVE 1     // the HBM copy of a step's tile rides inside the next step's GEMM (see the kernel)
+#endif
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define B_PIN() __builtin_amdgcn_sched_barrier(0)
 
@@ -177,22 +192,31 @@ __device__ __forceinline__ const uint4* prefetch_w1(WRing1& ring, const uint4* _
 }
 
 // acc += Wt_seg . B^T for this wave's 64 output rows and the 64 points; nks is a multiple of 4; `ring` holds
-// k-steps 0..3 and wp points at k-step 4.
-__device__ __forceinline__ void gemm1(f32x16 (&acc)[2][NT], WRing1& ring, const uint4* __restrict__ wp, const _Float16* sB, int nks) {
+// k-steps 0..3 and wp points at k-step 4.  `side(j)` is called once per group of four k-steps (j = 0, 1, ...) right behind
+// the group's last weight refill, `side_rest(j)` once at the end: the caller's share of the HBM copy of the tile this very
+// GEMM reads (see the kernel), so that its LDS reads / conversions issue in the shadow of the MFMAs and its stores sit
+// BEHIND the refills in the wave's in-order memory queue (vmcnt counts loads and stores together on gfx9).
+template <class Side, class Rest>
+__device__ __forceinline__ void gemm1(f32x16 (&acc)[2][NT], WRing1& ring, const uint4* __restrict__ wp, const _Float16* sB, int nks,
+                                      Side&& side, Rest&& side_rest) {
     XF1 x0, x1;
     load_x1(x0, sB, 0);
+    int j = 0;
 #pragma unroll 1
     for (int ks = 4; ks < nks; ks += 4) {
         load_x1(x1, sB, 1); mma1(acc, ring.r[0], x0); load_w1(ring.r[0], wp); B_PIN();
         load_x1(x0, sB, 2); mma1(acc, ring.r[1], x1); load_w1(ring.r[1], wp); B_PIN();
         load_x1(x1, sB, 3); mma1(acc, ring.r[2], x0); load_w1(ring.r[2], wp); B_PIN();
         load_x1(x0, sB, 4); mma1(acc, ring.r[3], x1); load_w1(ring.r[3], wp); B_PIN();
+        side(j++);
+        B_PIN();
         sB += 64;
     }
     load_x1(x1, sB, 1); mma1(acc, ring.r[0], x0);
     load_x1(x0, sB, 2); mma1(acc, ring.r[1], x1);
     load_x1(x1, sB, 3); mma1(acc, ring.r[2], x0);
     mma1(acc, ring.r[3], x1);
+    side_rest(j);
 }
 
 __device__ __forceinline__ float pow2_scale(float amax) {      // 2^k with amax * 2^k in [1024, 2048); 1 for amax == 0
@@ -203,29 +227,33 @@ __device__ __forceinline__ float pow2_scale(float amax) {      // 2^k with amax 
 }
 
 // LDS tile (fp16, [point][LDH]) -> HBM fragments dst[ks][row block][lane][8 pts] (layout of field_h3.hip's
-// tile_to_fragments), every point scaled by rel[p] (a power of two)
-__device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const float* sRel, _Float16* dst, int n_rows) {
+// tile_to_fragments), every point scaled by rel[p] (a power of two).  One task = (row pair, 8-point group) = two 16-byte
+// stores; a 256-row tile is 1024 tasks = four per thread.
+__device__ __forceinline__ void fragment_task(const _Float16* sB, const float* sRel, _Float16* dst, int n_rows, int task) {
     const int pairs = n_rows >> 1;                                         // two neurons per 4-byte LDS read
-    for (int task = threadIdx.x; task < pairs * 8; task += 256) {
-        const int row = 2 * (task % pairs), pg = task / pairs;
-        h8 out0, out1;
+    const int row = 2 * (task % pairs), pg = task / pairs;
+    h8 out0, out1;
+    const float4 r0 = *reinterpret_cast<const float4*>(sRel + 8 * pg), r1 = *reinterpret_cast<const float4*>(sRel + 8 * pg + 4);
+    const float rel[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const h2 v = *reinterpret_cast<const h2*>(sB + (8 * pg + t) * LDH + row);
-            const float r = sRel[8 * pg + t];          // fp32 on purpose: G/s reaches down to 2^-40, the PRODUCT is what must fit fp16
-            out0[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[0] * r, -65504.f, 65504.f);
-            out1[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[1] * r, -65504.f, 65504.f);
-        }
-        _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
-        __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad:
-        __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));     // keep the weights' L2 lines (-17 % per launch)
+    for (int t = 0; t < 8; ++t) {
+        const h2 v = *reinterpret_cast<const h2*>(sB + (8 * pg + t) * LDH + row);
+        const float r = rel[t];                    // fp32 on purpose: G/s reaches down to 2^-40, the PRODUCT is what must fit fp16
+        out0[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[0] * r, -65504.f, 65504.f);
+        out1[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[1] * r, -65504.f, 65504.f);
     }
+    _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
+    __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad:
+    __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));     // keep the weights' L2 lines (-17 % per launch)
+}
+__device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const float* sRel, _Float16* dst, int n_rows) {
+    for (int task = threadIdx.x; task < (n_rows >> 1) * 8; task += 256) fragment_task(sB, sRel, dst, n_rows, task);
 }
 
 __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 sB[64 * LDH];
     __shared__ __attribute__((aligned(16))) _Float16 sStash[64 * LDH];
-    __shared__ float sInv[64], sRel[64], sSig[64];
+    __shared__ __attribute__((aligned(16))) float sInv[64], sRel[64], sSig[64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long tile = blockIdx.x;
@@ -242,14 +270,16 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
         return reinterpret_cast<const uint4*>(pk + s_.w_off) + (wave * s_.nks) * 2 * 64 + lane;
     };
     const uint4* wnext = prefetch_w1(ring, seg(a.steps[0]));
-    // The tile a step leaves in sB goes to HBM (fragment order, global scale) only AFTER the next step's GEMM: vmcnt counts
-    // loads and stores in one in-order queue, so a store issued right before a GEMM stalls its weight loads until the
-    // store is acknowledged (measured: +240 us per launch = the whole store time serialised); issued after the GEMM and
-    // the next prefetch, the acknowledgements have the epilogue and the first ring round to arrive.
+    // The tile a step leaves in sB goes to HBM (fragment order, global scale) DURING the next step's GEMM, which reads the
+    // same tile: one (row pair, 8 points) task per group of four k-steps, issued right behind the group's weight refills.
+    // vmcnt counts loads and stores in one in-order queue, so a burst of stores in front of a GEMM holds its weight loads
+    // back until the stores are acknowledged (measured in round 2: +240 us per launch = the whole store time serialised;
+    // stores after the GEMM: -1.5 %); spread over the GEMM, every refill waits for at most two stores and has four k-steps
+    // of MFMAs to do so, and the copy's LDS reads / conversions issue in the shadow of the MFMAs.
     int pending_slot = -1;
+    auto pending_dst = [&]() { return a.dpre + (long long)pending_slot * slot_stride + tile * (64 * NSFF_W); };
     auto flush_tile = [&]() {
-        if (pending_slot >= 0)
-            tile_to_fragments_scaled(sB, sRel, a.dpre + (long long)pending_slot * slot_stride + tile * (64 * NSFF_W), NSFF_W);
+        if (pending_slot >= 0) tile_to_fragments_scaled(sB, sRel, pending_dst(), NSFF_W);
         pending_slot = -1;
     };
 #pragma unroll 1
@@ -321,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
             __syncthreads();
         }
 
+        BWD_STAMP(0);
         unsigned long long mbits = 0ull;
         if (st.epi == EPI_MASK)
             mbits = a.masks[((long long)st.slot * a.n_tiles + tile) * 256 + threadIdx.x];
@@ -332,8 +363,21 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
-        if (!(st.flags & F_HALF_ROWS) || wave < 2)
-            gemm1(acc, ring, wnext, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks);
+        if (!(st.flags & F_HALF_ROWS) || wave < 2) {
+            // (one instantiation of the GEMM loop: the copy is switched by a wave-uniform flag)
+            const bool copy = BWD_STORE_INTERLEAVE && pending_slot >= 0;
+            _Float16* dst = pending_dst();
+            gemm1(acc, ring, wnext, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks,
+                  [&](int j) { if (copy) fragment_task(sB, sRel, dst, NSFF_W, (int)threadIdx.x + 256 * j); },
+                  [&](int j) {
+                      if (copy) {
+#pragma unroll 1
+                          for (; j < 4; ++j) { fragment_task(sB, sRel, dst, NSFF_W, (int)threadIdx.x + 256 * j); B_PIN(); }
+                      }
+                  });
+            if (copy) pending_slot = -1;
+        }
+        BWD_STAMP(1);
         if (i + 1 < a.n_steps) wnext = prefetch_w1(ring, seg(a.steps[i + 1]));    // flies during the epilogue
         float wsig[2][4][4];
         if (st.flags & F_SIGMA) {
@@ -347,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                 }
         }
         flush_tile();                                     // the previous step's tile (sB is still intact)
+        BWD_STAMP(2);
         if (st.epi == EPI_KEEP) continue;
         if (st.epi == EPI_DXIN) {
             float* dst_in = (st.flags & F_TO_SIDE) ? a.d_side : a.d_xin;
@@ -372,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
         }
         // ---- epilogue: (+ rank-1 sigma term) (ReLU mask) -> fp16 tile (B operand of the next step) ----
         __syncthreads();                                  // every wave is done reading the tile
+        BWD_STAMP(3);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -395,10 +441,13 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                     if (st.flags & F_STASH) *reinterpret_cast<h4*>(sStash + idx) = hv;
                 }
             }
+        BWD_STAMP(4);
         __syncthreads();
+        BWD_STAMP(5);
         pending_slot = st.slot;
     }
     flush_tile();
+    BWD_STAMP_END();
 }
 
 
@@ -701,6 +750,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }
 
 }  // namespace
+
+#ifdef BWD_TIMING
+extern "C" int nsff_debug_read_bwd_timing(unsigned* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_timing), sizeof(unsigned) * n) == hipSuccess ? 0 : -4;
+}
+#endif
 
 extern "C" {
 

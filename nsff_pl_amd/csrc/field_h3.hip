@@ -52,23 +52,12 @@ __device__ unsigned long long g_h3_span[2] = {~0ull, 0ull};     // first / last 
 
 namespace {
 
-#ifndef H3_LDH
-#define H3_LDH 264
+#ifndef H3_SAVE_INTERLEAVE
+#define H3_SAVE_INTERLEAVE 1      // training forward: the activation saves ride inside the next GEMM (see the kernel)
 #endif
-constexpr int LDH = H3_LDH;       // halfs per LDS row.  264 (528 B = 33 x 16 B): conflict-free ds_read_b128, 2-way conflicts on the
-                                  // epilogue's ds_write_b64.  260 (520 B, experiment): rows only 8-byte aligned -> B operands as two
-                                  // ds_read_b64, and both the reads and the 8-byte epilogue stores are conflict-free.
+constexpr int LDH = 264;          // halfs per LDS row (528 B = 33 x 16 B): conflict-free ds_read_b128
 // 8 consecutive halfs of an LDS row (one B-operand fragment)
-__device__ __forceinline__ h8 lds_h8(const _Float16* p) {
-    if constexpr (LDH % 8 == 0) {
-        return *reinterpret_cast<const h8*>(p);
-    } else {
-        const h4 a = *reinterpret_cast<const h4*>(p), b = *reinterpret_cast<const h4*>(p + 4);
-        h8 r;
-        r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-        return r;
-    }
-}
+__device__ __forceinline__ h8 lds_h8(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
 
 // The network is executed as a short program of GEMM steps (built on the host), so that the
 // kernel holds exactly one copy of the GEMM loop, the epilogue, the input builders and the heads.
@@ -124,11 +113,6 @@ struct H3KArgs {
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H3_PIN() __builtin_amdgcn_sched_barrier(0)
-#ifdef H3_LDS_AHEAD      // experiment: also pin every activation read one k-step ahead of its MFMAs
-#define H3_PIN_X() __builtin_amdgcn_sched_barrier(0)
-#else
-#define H3_PIN_X() do {} while (0)
-#endif
 
 template <bool SPLIT = true>
 __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx, float v) {
@@ -230,51 +214,48 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW
 // acc += W_seg . X[:, 0:16*nks]^T  for this wave's 64 neurons and all 32*NT points.
 // `ring` already holds k-steps 0..3 and `wp` points at k-step 4 (prefetch_w); weights run four
 // k-steps ahead of the MFMAs, activations (LDS) one.
-template <int NT, int MTW, bool SPLIT>
+// `side(j)` runs once per group of four k-steps (j = 0, 1, ...) right behind the group's last weight refill and
+// `side_rest(j)` once at the end: the training forward's HBM copy of the very tile this GEMM reads (see the kernel).
+struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
+template <int NT, int MTW, bool SPLIT, class Side = NoSide, class Rest = NoSide>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLIT>& ring, const uint4* __restrict__ wp,
-                                         BRows<NT> b, int nks) {
+                                         BRows<NT> b, int nks, Side&& side = Side{}, Rest&& side_rest = Rest{}) {
     // nks is a multiple of 4 (every K-segment is zero-padded to 64 columns): no per-step branches.
     XFrag<NT, SPLIT> x0, x1;
     load_x<NT, SPLIT>(x0, b, 0);
+    int j = 0;
 #pragma unroll 1
     for (int ks = 4; ks < nks; ks += 4) {        // every group but the last: refill the ring
-        // sched_barrier pins (a) each activation read one k-step AHEAD of the MFMAs that consume it (left alone hipcc
-        // sinks the ds_reads behind the previous k-step's MFMAs, merges x0/x1 and exposes the LDS latency every k-step)
-        // and (b) each weight refill right behind the MFMAs that free its ring slot (left alone hipcc sinks all 16
-        // loads to the end of the group and the ring never runs ahead)
+        // sched_barrier pins each weight refill right behind the MFMAs that free its ring slot (left alone hipcc sinks all
+        // 16 loads to the end of the group and the ring never runs ahead)
         load_x<NT, SPLIT>(x1, b, 1);
-        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[0], x0);
         load_w(ring.r[0], wp);
         H3_PIN();
         load_x<NT, SPLIT>(x0, b, 2);
-        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[1], x1);
         load_w(ring.r[1], wp);
         H3_PIN();
         load_x<NT, SPLIT>(x1, b, 3);
-        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[2], x0);
         load_w(ring.r[2], wp);
         H3_PIN();
         load_x<NT, SPLIT>(x0, b, 4);
-        H3_PIN_X();
         mma_step<NT, MTW>(acc, ring.r[3], x1);
         load_w(ring.r[3], wp);
         H3_PIN();
+        if constexpr (!__is_same(Side, NoSide)) { side(j++); H3_PIN(); }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { b.h[nt] += 64; if constexpr (SPLIT) b.l[nt] += 64; }      // four k-steps of 16 halfs
     }
     load_x<NT, SPLIT>(x1, b, 1);
-    H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[0], x0);
     load_x<NT, SPLIT>(x0, b, 2);
-    H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[1], x1);
     load_x<NT, SPLIT>(x1, b, 3);
-    H3_PIN_X();
     mma_step<NT, MTW>(acc, ring.r[2], x0);
     mma_step<NT, MTW>(acc, ring.r[3], x1);
+    if constexpr (!__is_same(Rest, NoSide)) side_rest(j);
 }
 
 // bias of row (neuron) 64w + 32mt + 8q + 4h + e, e = 0..3 -- loaded early, applied by acc_init
@@ -368,7 +349,7 @@ __device__ __forceinline__ float relu1(float v) {      // one v_max (fmaxf would
 // half a v_cvt_pkrtz (lo); + one v_permlane32_swap per stored dword.
 template <int NT, bool RELU, int MTW>
 __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane,
-                                          unsigned long long* mask = nullptr) {
+                                          unsigned long long* mask = nullptr, bool two_tiles = true) {
     unsigned long long bits = 0ull;
     h4 hq[4], lq[4];
 #pragma unroll
@@ -403,31 +384,54 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
                     bits |= (unsigned long long)m << (((mt * NT + nt) * 4 + q) * 4);
                 }
             }
-    if (mask != nullptr) *mask = bits;
+    // `mask` = the 256 words of this workgroup's first 64-point tile.  The backward kernel (64-point tiles, four waves of
+    // 64 neurons) reads word [tile][64 w + lane], bit ((mt * 2 + nt) * 4 + q) * 4 + e.
+    if (mask != nullptr) {
+        if constexpr (MTW == 2) {
+            mask[64 * (nb0 >> 6) + lane] = bits;                     // this wave IS wave nb0 / 64 of the tile
+        } else {
+            // eight waves of 32 neurons x 128 points: this wave holds (mt = its neuron half) x (nt = 0..3); point tiles 0, 1
+            // belong to the first 64-point tile, 2, 3 to the second; each goes out as one 32-bit half of the word
+            static_assert(NT == 4 || MTW == 2, "mask layout of the 32-neuron-per-wave tiling");
+            unsigned* m32 = reinterpret_cast<unsigned*>(mask);
+            const int mt_b = (nb0 >> 5) & 1;
+            const int word = 64 * (nb0 >> 6) + lane;
+            m32[2 * word + mt_b] = (unsigned)bits;                   // (mt0 * NT + nt) * 16 bits, nt = 0, 1
+            if (two_tiles) m32[2 * (256 + word) + mt_b] = (unsigned)(bits >> 32);
+        }
+    }
 }
 
 // Copy the tile's activations (hi + lo planes, rounded to nearest) to HBM in the fragment order of the
 // weight-gradient GEMM (K = points): dst[ks][row block][lane][8 pts] -- every 1 KiB block is exactly one MFMA
-// operand fragment (32 rows x 16 points) in lane order; rows = neurons (n_rows, a multiple of 32), ks = 4 x 16 points.
-template <int THREADS>
-__device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows,
-                                                  int rows_copied) {
-    const int pairs = rows_copied >> 1;                                    // two neurons per 4-byte LDS read
-    for (int task = threadIdx.x; task < pairs * 8; task += THREADS) {      // (8-point group, row pair), pair fastest
-        const int row = 2 * (task % pairs), pg = task / pairs;
-        h8 out0, out1;
+// operand fragment (32 rows x 16 points) in lane order; rows = neurons (n_rows, a multiple of 32), ks = 16-point groups
+// (four per 64-point tile of the backward kernels; a 128-point workgroup writes two consecutive tiles).
+// One task = (row pair, 8-point group) = two 16-byte stores; hi + lo is one packed fp16 add (the sum of the two halfs
+// rounded to nearest even -- what the fp32 sum followed by a conversion gives, the fp32 sum being exact).
+// pg_end: 8-point groups that exist (the second 64-point tile of the last 128-point workgroup may not).
+__device__ __forceinline__ void fragment_task(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows, int pairs,
+                                              int task, int pg_end) {
+    const int row = 2 * (task % pairs), pg = task / pairs;
+    if (pg >= pg_end) return;
+    h8 out0, out1;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int idx = (8 * pg + t) * LDH + row;
-            const h2f hi = *reinterpret_cast<const h2f*>(sXh + idx), lo = *reinterpret_cast<const h2f*>(sXl + idx);
-            out0[t] = (_Float16)((float)hi[0] + (float)lo[0]);
-            out1[t] = (_Float16)((float)hi[1] + (float)lo[1]);
-        }
-        // 1 KiB blocks of 32 rows, lane-linear inside: [ks][row/32][(row&31) + 32*(point group&1)][8 points]
-        _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
-        __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad
-        __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));
+    for (int t = 0; t < 8; ++t) {
+        const int idx = (8 * pg + t) * LDH + row;
+        const h2f sum = *reinterpret_cast<const h2f*>(sXh + idx) + *reinterpret_cast<const h2f*>(sXl + idx);
+        out0[t] = sum[0];
+        out1[t] = sum[1];
     }
+    // 1 KiB blocks of 32 rows, lane-linear inside: [ks][row/32][(row&31) + 32*(point group&1)][8 points]
+    _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
+    __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad
+    __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));
+}
+template <int THREADS, int M>
+__device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows,
+                                                  int rows_copied, int pg_end) {
+    const int pairs = rows_copied >> 1;                                    // two neurons per 4-byte LDS read
+    for (int task = threadIdx.x; task < pairs * (M / 8); task += THREADS)  // (8-point group, row pair), pair fastest
+        fragment_task(sXh, sXl, dst, n_rows, pairs, task, pg_end);
 }
 
 // four consecutive columns of one row -> one 8-byte store per plane
@@ -752,6 +756,23 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     const int rot = (!a.split_trunks && a.n_static_steps > 0 && a.n_static_steps < a.n_steps && ((blockIdx.x >> 3) & 1))
                         ? a.n_static_steps : 0;
     auto step_at = [&](int i) { int j = i + rot; if (j >= a.n_steps) j -= a.n_steps; return a.steps[j]; };
+    // Training forward: the HBM copy of the tile an epilogue (or an input build) leaves in LDS rides inside the next
+    // GEMM that reads the same tile -- one (row pair, 8 points) task per four k-steps, behind the group's weight refills
+    // (vmcnt counts loads and stores in one in-order queue: a burst of stores in front of a GEMM holds its refills
+    // back until every store is acknowledged).  A tile that is rebuilt or abandoned first is flushed on the spot.
+    [[maybe_unused]] _Float16* pend_dst = nullptr;
+    [[maybe_unused]] int pend_rows = 0, pend_pairs = 0, pend_total = 0;
+    [[maybe_unused]] const long long tile64 = tile * (M / 64);
+    [[maybe_unused]] const int pg_end = (M == 128 && tile64 + 1 >= a.n_tiles) ? 8 : M / 8;
+    auto pend_set = [&](_Float16* dst, int n_rows, int rows_copied) {
+        pend_dst = dst; pend_rows = n_rows; pend_pairs = rows_copied >> 1; pend_total = pend_pairs * (M / 8);
+    };
+    auto pend_flush = [&]() {
+        if constexpr (SAVE) {
+            if (pend_dst != nullptr) tile_to_fragments<THREADS, M>(sXh, sXl, pend_dst, pend_rows, 2 * pend_pairs, pg_end);
+            pend_dst = nullptr;
+        }
+    };
     H3_SPAN(0);
     const H3Step s0 = step_at(s_begin);
     const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
@@ -761,31 +782,48 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         const H3Step st = step_at(i);
         H3_STAMP(0);
         if (st.pre != PRE_NONE) {
+            pend_flush();                          // (a tile nobody multiplied after it was saved: the last one of a trunk)
             __syncthreads();                       // everyone is done reading the previous tile
             if (st.pre == PRE_SIDE) {
                 build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0);
-                if constexpr (SAVE) {
-                    if (a.save_side != nullptr) {
-                        __syncthreads();
-                        tile_to_fragments<THREADS>(sXh, sXl, a.save_side + tile * (64 * 128), 128, (int)a.L.side_k);
-                    }
-                }
             } else {
                 if constexpr (!KEEP_POINT) read_point();
                 build_input<M, THREADS, SPLIT, !SAVE>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px);
             }
             __syncthreads();
             if constexpr (SAVE) {
-                // trunk input of layer 0: columns [0,64) xyz embedding, [64,128) time code (zero when absent)
-                if (a.save_xin != nullptr && st.bias_off != NSFF_NONE && (st.pre == PRE_INPUT_T || a.transient_mode == 0)) {
-                    tile_to_fragments<THREADS>(sXh, sXl, a.save_xin + tile * (64 * 128), 128,
-                                               st.pre == PRE_INPUT_T ? 128 : 64);     // static only: rows 64.. stay unwritten
+                if (st.pre == PRE_SIDE) {
+                    if (a.save_side != nullptr) pend_set(a.save_side + tile64 * (64 * 128), 128, (int)a.L.side_k);
+                } else if (a.save_xin != nullptr && st.bias_off != NSFF_NONE && (st.pre == PRE_INPUT_T || a.transient_mode == 0)) {
+                    // trunk input of layer 0: columns [0,64) xyz embedding, [64,128) time code (zero when absent);
+                    // static only: rows 64.. stay unwritten
+                    pend_set(a.save_xin + tile64 * (64 * 128), 128, st.pre == PRE_INPUT_T ? 128 : 64);
                 }
             }
         }
         H3_STAMP(1);
         if (st.bias_off != NSFF_NONE) acc_init<NT, MTW>(acc, br);
-        gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks);
+        if constexpr (SAVE) {
+            // (one instantiation of the GEMM loop; the copy is switched by a wave-uniform flag)
+            const bool copy = H3_SAVE_INTERLEAVE && pend_dst != nullptr;
+            gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks,
+                [&](int j) {
+                    const int task = (int)threadIdx.x + THREADS * j;
+                    if (copy && task < pend_total) fragment_task(sXh, sXl, pend_dst, pend_rows, pend_pairs, task, pg_end);
+                },
+                [&](int j) {
+                    if (copy) {
+#pragma unroll 1
+                        for (int task = (int)threadIdx.x + THREADS * j; task < pend_total; task += THREADS) {
+                            fragment_task(sXh, sXl, pend_dst, pend_rows, pend_pairs, task, pg_end);
+                            H3_PIN();
+                        }
+                    }
+                });
+            if (copy) pend_dst = nullptr;
+        } else {
+            gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks);
+        }
         H3_STAMP(2);
         if (i + 1 < s_end) {                       // next segment's weights + bias fly during the epilogue
             const H3Step nx = step_at(i + 1);
@@ -793,25 +831,25 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             if (nx.bias_off != NSFF_NONE) load_bias<MTW>(br, fbias(nx.bias_off), nb0, lane);
         }
         if (st.post != POST_NONE) {
+            pend_flush();                          // (only when the interleave is compiled out: the GEMM above took it along)
             __syncthreads();
             H3_STAMP(3);
             unsigned long long* mk = nullptr;
             if constexpr (SAVE) {
                 if (st.save && a.save_masks != nullptr && st.post == POST_RELU)
-                    mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + tile) * THREADS + threadIdx.x;
+                    mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + tile64) * 256;   // (per-thread slot: acc_store)
             }
             if constexpr (!SPLIT) {
                 if (st.post == POST_RELU) acc_store_f16<NT, true, MTW>(sXh, acc, nb0, nt0, lane);
                 else acc_store_f16<NT, false, MTW>(sXh, acc, nb0, nt0, lane);
-            } else if (st.post == POST_RELU) acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk);
-            else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk);
+            } else if (st.post == POST_RELU) acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk, pg_end > 8);
+            else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk, pg_end > 8);
             H3_STAMP(4);
             __syncthreads();
             H3_STAMP(5);
             if constexpr (SAVE) {
                 if (st.save && a.save_acts != nullptr)
-                    tile_to_fragments<THREADS>(sXh, sXl, a.save_acts + (long long)(st.save - 1) * a.save_stride
-                                                             + tile * (64 * NSFF_W), NSFF_W, NSFF_W);
+                    pend_set(a.save_acts + (long long)(st.save - 1) * a.save_stride + tile64 * (64 * NSFF_W), NSFF_W, NSFF_W);
             }
             if (st.head != HEAD_NONE) {
                 // static sigma reads the last trunk activation, before *_final (nerf.py:169);
@@ -831,6 +869,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             }
         }
     }
+    pend_flush();
     __syncthreads();
     for (int i = threadIdx.x; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
         const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
@@ -1134,9 +1173,6 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.octave_freqs = (g.xyz != nullptr && g.n_freqs >= 1 && g.n_freqs <= 10 && k.L.k0s == 64) ? 1 : 0;
     for (int i = 0; i + 1 < g.n_freqs; ++i)
         if (g.freqs[i + 1] != 2.0f * g.freqs[i]) k.octave_freqs = 0;
-#ifdef H3_NO_OCTAVE
-    k.octave_freqs = 0;
-#endif
     k.ld_emb = g.ld_emb; k.off_xyz = g.off_xyz; k.off_dir = g.off_dir; k.off_a = g.off_a; k.off_t = g.off_t;
 
     // ---- step program (reference nerf.py:162-208) ----
@@ -1163,11 +1199,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     };
     // Inference launches (nothing saved for a backward pass) never execute the activation-free *_xyz_encoding_final
     // layers: the heads that read them are evaluated on the last trunk activation with pre-multiplied rows (NsffLayoutH3).
-#ifdef H3_NO_FOLD           // A/B experiments only
-    const bool fold = false;
-#else
     const bool fold = !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
-#endif
     if (g.static_mode == 2 && fold && !d.use_viewdir) {
         trunk(k.L.st, PRE_INPUT, HEAD_S_FOLD, 0);
     } else if (g.static_mode == 2 && fold) {               // view directions: *_final folded into static_dir_encoding
@@ -1195,11 +1227,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.n_steps = n;
 
     // one trunk per workgroup when the launch evaluates both (see the kernel): grid = 2 x tiles
-#ifdef H3_NO_SPLIT          // A/B experiments only
-    const bool both = false;
-#else
     const bool both = n > k.n_static_steps && k.n_static_steps > 0;
-#endif
     auto launch = [&](auto kernel, int tile_points, int threads) -> int {
         const long long tiles = (g.n_points + tile_points - 1) / tile_points;
         if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
@@ -1209,19 +1237,18 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         return NSFF_OK;
     };
     int lrc;
+    const bool saves = k.save_acts || k.save_xin || k.save_masks || k.save_side;
     if (points_per_block == NSFF_H3_FAST) {       // "f16": one product per MAC, 128-point tiles, two workgroups per CU
-        if (k.save_acts || k.save_xin || k.save_masks || k.save_side) return NSFF_ERR_INVALID;
+        if (saves) return NSFF_ERR_INVALID;
         lrc = launch(nsff_field_kernel_h3<4, 1, false, 2, false>, 128, 256);
-    } else if (k.save_acts || k.save_xin || k.save_masks || k.save_side) {
+    } else if (saves && points_per_block == 64) { // training forward, 64-point tiling (A/B against the default below)
         lrc = launch(nsff_field_kernel_h3<2, 1, true>, 64, 256);
+    } else if (saves) {                           // training forward: 128 points, eight waves of 32 neurons
+        lrc = launch(nsff_field_kernel_h3<4, 1, true, 1>, 128, 512);
     } else if (points_per_block == 64) {
         lrc = launch(nsff_field_kernel_h3<2, 1>, 64, 256);
-    } else if (points_per_block == 130) {         // 128 points, eight waves of 32 neurons (half the weight stream)
+    } else {                                      // 128 points, eight waves of 32 neurons (half the weight stream)
         lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
-    } else if (points_per_block == 129) {         // experiment: 128 points, one wave per SIMD
-        lrc = launch(nsff_field_kernel_h3<4, 1>, 128, 256);
-    } else {
-        lrc = launch(nsff_field_kernel_h3<2, 2>, 128, 512);
     }
     if (lrc != NSFF_OK) return lrc;
     return nsff_launch_status();

@@ -232,6 +232,37 @@ __global__ void warp_points_kernel(const float* __restrict__ raw, const float* _
 }
 
 // ---------------------------------------------------------------------------------
+// a6: number of the training cameras of frame ts[0] that see an NDC point (reference rendering.py:190-200).
+// ndc2world (ray_utils.py:127-151): Rz = 2 / (z - 1 - eps), Rx = -Rz x cx / fx, Ry = -Rz y cy / fy; then per camera
+// (ray_utils.py:154-181): cam = R x_w + t with [R | t] = inverse pose, in front <=> cam_z < 0, axes -> right-down-front,
+// pixel = K cam, inside <=> 0 <= u < W and 0 <= v < H.  This file is compiled with -ffp-contract=off: products and sums
+// round like the reference's separate torch kernels; the 3-term dot products are fma chains like a BLAS matmul's.
+__device__ __forceinline__ float frustum_count(const NsffFrustumArgs& v, float x, float y, float z) {
+    const float fx = v.K4[0], fy = v.K4[1], cx = v.K4[2], cy = v.K4[3];
+    const float rz = 2.0f / (z - 1.0f - 1e-6f);
+    const float rx = -rz * x * cx / fx;
+    const float ry = -rz * y * cy / fy;
+    const long long frame = v.ts[0];
+    float count = 0.f;
+    for (int c = 0; c < v.n_cams; ++c) {
+        const float* m = v.w2c + ((long long)c * v.n_frames + frame) * 12;
+        const float cam0 = fmaf(m[2], rz, fmaf(m[1], ry, m[0] * rx)) + m[3];
+        const float cam1 = fmaf(m[6], rz, fmaf(m[5], ry, m[4] * rx)) + m[7];
+        const float cam2 = fmaf(m[10], rz, fmaf(m[9], ry, m[8] * rx)) + m[11];
+        if (!(cam2 < 0.f)) continue;                            // front is the negative z axis
+        const float c1 = -cam1, c2 = -cam2;
+        const float u = fmaf(cx, c2, fx * cam0) / c2, w = fmaf(cy, c2, fy * c1) / c2;
+        if (u >= 0.f && u < (float)v.W && w >= 0.f && w < (float)v.H) count += 1.f;
+    }
+    return count;
+}
+
+__global__ __launch_bounds__(256) void frustum_visibility_kernel(const NsffFrustumArgs v, const float* __restrict__ xyz,
+                                                                 long long n_points, float* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p < n_points) out[p] = frustum_count(v, xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
+}
+
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_kernel(const NsffCompositeArgs a) {
     const int lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -270,6 +301,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_kernel(const N
         if (tr) {
             sig_t = rec[7];
             if (a.visibility && a.visibility[idx] == 0.f) sig_t = -10.f;     // rendering.py:200
+            if (a.vis.w2c && frustum_count(a.vis, a.xyz[idx * 3], a.xyz[idx * 3 + 1], a.xyz[idx * 3 + 2]) == 0.f) sig_t = -10.f;
             if (a.noise_transient) sig_t += a.noise_transient[idx] * a.noise_std;
             sig_t = softplus(sig_t);
             al_t = 1.f - expf(-d_t * sig_t);
@@ -570,9 +602,24 @@ int nsff_composite(const NsffCompositeArgs* args, void* stream) {
     if (a.flow_mode && (!a.has_transient || !a.has_rgb)) return NSFF_ERR_INVALID;
     if (a.flow_mode >= 1 && !a.xyz) return NSFF_ERR_NULL;
     if (a.flow_mode == 2 && (!a.raw_fw || !a.raw_bw || !a.xyz_fw || !a.xyz_bw)) return NSFF_ERR_NULL;
+    if (a.vis.w2c && (!a.vis.ts || !a.xyz)) return NSFF_ERR_NULL;
+    if (a.vis.w2c && (a.vis.n_cams < 1 || a.vis.n_frames < 1)) return NSFF_ERR_INVALID;
     const unsigned blocks = (unsigned)((a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     hipLaunchKernelGGL(composite_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0,
                        (hipStream_t)stream, a);
+    return nsff_launch_status();
+}
+
+int nsff_frustum_visibility(const NsffFrustumArgs* vis, const float* xyz, int64_t n_points, float* vis_count,
+                            void* stream) {
+    if (!vis || !vis->w2c || !vis->ts) return NSFF_ERR_NULL;
+    if (n_points < 0 || vis->n_cams < 1 || vis->n_frames < 1) return NSFF_ERR_INVALID;
+    if (n_points == 0) return NSFF_OK;
+    if (!xyz || !vis_count) return NSFF_ERR_NULL;
+    const long long blocks = (n_points + 255) / 256;
+    if (blocks > 0x7fffffffLL) return NSFF_ERR_INVALID;
+    hipLaunchKernelGGL(frustum_visibility_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *vis, xyz,
+                       (long long)n_points, vis_count);
     return nsff_launch_status();
 }
 

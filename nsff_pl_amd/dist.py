@@ -19,9 +19,17 @@ import torch.distributed as dist
 DEFAULT_PIXEL_KEYS = ("rgb_fine", "depth_fine")
 
 
+INIT_ENV = "NSFF_DIST_INIT"          # optional rendezvous URL for init_from_env (launch_local passes a file:// one)
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's environment (RANK, WORLD_SIZE,
-    LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size, device)."""
+    LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size, device).
+
+    The group is created whenever a launcher set WORLD_SIZE -- also for WORLD_SIZE=1, so that a one-GPU
+    ``torchrun --nproc-per-node 1`` run drives the same RCCL calls (communicator bound to ``cuda:LOCAL_RANK`` through
+    ``device_id``) as an eight-GPU one.  A plain ``python script.py`` (no WORLD_SIZE) stays group-less.
+    ``NSFF_DIST_INIT`` (a ``file://`` / ``tcp://`` URL) replaces the MASTER_ADDR / MASTER_PORT rendezvous."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -29,35 +37,46 @@ def init_from_env(backend=None):
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+    if (world > 1 or "WORLD_SIZE" in os.environ) and not dist.is_initialized():
         kw = {}
-        if use_gpu:
+        if os.environ.get(INIT_ENV):
+            kw["init_method"] = os.environ[INIT_ENV]
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+        if use_gpu and (backend in (None, "nccl")):
             kw["device_id"] = device
         dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kw)
     return rank, world, device
 
 
-def launch_local(n_procs, argv, master_port=None, env=None, timeout=None):
+def launch_local(n_procs, argv, master_port=None, env=None, timeout=None, rocm_dmabuf_ipc=True):
     """Start `argv` (a command line, e.g. [sys.executable, "bench.py", ...]) as `n_procs` ranks on this node, the
-    way ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` would: RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment, one process per GPU (``init_from_env`` picks
-    ``cuda:LOCAL_RANK``).  stdout / stderr are inherited, so rank 0's single JSON line reaches the caller's stdout.
-    Returns the worst exit code; if one rank fails the others are terminated."""
-    import socket
+    way ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` would: RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment, one process per GPU (``init_from_env`` picks ``cuda:LOCAL_RANK``).  The ranks meet through a fresh
+    FILE (``NSFF_DIST_INIT=file://...`` in a private temporary directory) -- no port to pick, so nothing another process
+    or a second concurrent launch could grab between choosing and binding it; ``master_port`` selects the classic
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT rendezvous instead.  stdout / stderr are inherited, so rank 0's single JSON line
+    reaches the caller's stdout.  Returns the worst exit code; if one rank fails the others are terminated.
+    rocm_dmabuf_ipc: default ``HSA_ENABLE_IPC_MODE_LEGACY=0`` into the ranks' environment when the caller's does not set
+    it (ROCm hosts whose driver only offers dmabuf IPC -- RCCL fails with hipIpcGetMemHandle errors otherwise)."""
+    import shutil
     import subprocess
+    import tempfile
     import time
+    tmpdir = None
     if master_port is None:
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            master_port = sock.getsockname()[1]
+        tmpdir = tempfile.mkdtemp(prefix="nsff_rdzv_")
     procs = []
     for rank in range(n_procs):
         e = dict(os.environ if env is None else env)
-        e.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_procs), LOCAL_WORLD_SIZE=str(n_procs),
-                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port))
-        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+        e.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_procs), LOCAL_WORLD_SIZE=str(n_procs))
+        if tmpdir is not None:
+            e[INIT_ENV] = "file://" + os.path.join(tmpdir, "rendezvous")
+        else:
+            e.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port))
+        if rocm_dmabuf_ipc and getattr(torch.version, "hip", None):
+            e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(list(argv), env=e))
     deadline = None if timeout is None else time.monotonic() + timeout
     worst = 0
@@ -83,6 +102,8 @@ def launch_local(n_procs, argv, master_port=None, env=None, timeout=None):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        if tmpdir is not None:
+            shutil.rmtree(tmpdir, ignore_errors=True)
     return worst
 
 
@@ -94,11 +115,16 @@ def shard_bounds(n_items, world, rank):
 
 
 def _pack(results, keys, pad_to):
-    cols = [results[k].reshape(results[k].shape[0], -1).float() for k in keys]
-    buf = torch.cat(cols, 1).contiguous()
-    if buf.shape[0] < pad_to:
-        buf = torch.cat([buf, buf.new_zeros(pad_to - buf.shape[0], buf.shape[1])], 0)
-    return buf, [c.shape[1] for c in cols]
+    """One (pad_to, sum of widths) buffer holding the per-ray tensors `keys` side by side (rows past this rank's count: 0)."""
+    cols = [results[k].reshape(results[k].shape[0], -1) for k in keys]
+    widths = [c.shape[1] for c in cols]
+    n = cols[0].shape[0]
+    buf = (cols[0].new_empty if n == pad_to else cols[0].new_zeros)((pad_to, sum(widths)), dtype=torch.float32)
+    c0 = 0
+    for c, w in zip(cols, widths):
+        buf[:n, c0:c0 + w] = c
+        c0 += w
+    return buf, widths
 
 
 def all_gather_pixels(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group=None):
@@ -106,20 +132,25 @@ def all_gather_pixels(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group=None)
 
     results: this rank's render_rays dict.  counts: rays per rank (list, len world) when
     shards are uneven; None = every rank holds the same number.  Returns {key: (sum N, ...)}.
+    The collective runs whenever a process group exists (world size 1 included: same call path on one GPU as on eight).
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    live = dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
     n_local = results[keys[0]].shape[0]
     if counts is None:
         counts = [n_local] * world
     pad_to = max(counts)
     buf, widths = _pack(results, keys, pad_to)
-    if world == 1:
-        gathered = buf[None]
+    if not live:
+        out = buf
     else:
         out = buf.new_empty(world * pad_to, buf.shape[1])
         dist.all_gather_into_tensor(out, buf, group=group)
+    if all(c == pad_to for c in counts):
+        rows = out                                            # even shards: the gathered buffer already is the row list
+    else:
         gathered = out.view(world, pad_to, buf.shape[1])
-    rows = torch.cat([gathered[r, :counts[r]] for r in range(world)], 0)
+        rows = torch.cat([gathered[r, :counts[r]] for r in range(world)], 0)
     merged, c0 = {}, 0
     for k, wdt in zip(keys, widths):
         merged[k] = rows[:, c0:c0 + wdt].reshape((rows.shape[0],) + tuple(results[k].shape[1:]))

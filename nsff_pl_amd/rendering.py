@@ -10,8 +10,8 @@ on the current stream:
     coarse_samples -> field_query(coarse) -> composite -> fine_samples
                    -> field_query(fine) [-> warp_points -> field_query x2] -> composite
 
-Only the eval-time frustum-visibility mask (rendering.py:190-200, one camera, a 4x4
-inverse) is evaluated with torch ops on the device, in :mod:`nsff_pl_amd.ray_geometry`.
+The eval-time frustum-visibility mask (rendering.py:190-200) is part of the compositing kernel;
+:mod:`nsff_pl_amd.ray_geometry` only prepares its camera table (once per dataset, no host sync per call).
 """
 import torch
 
@@ -124,9 +124,9 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         query(typ, raw, xyz, 1 if sigma_only else 2, 0 if not output_transient else (1 if sigma_only else 2),
               2 if want_flow else 0, t_embedded if output_transient else None, **side)
 
-    visibility = None
-    if test_time and output_transient and 'dataset' in ctx.kwargs:
-        visibility = ray_geometry.training_view_visibility(xyz.view(-1, 3), ctx.kwargs['dataset'], ctx.ts)
+    vis = None            # a6: evaluated inside the compositing kernel for the frame ts[0] (read on the device)
+    if test_time and output_transient and 'dataset' in ctx.kwargs and P:
+        vis = ray_geometry.frustum_args(ctx.kwargs['dataset'], ctx.ts, zs.device)
 
     # RNG draws, in the reference's order (rendering.py:207, 213, then 128 for fw and bw)
     nstd = float(ctx.noise_std)
@@ -137,7 +137,7 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
 
     args = dict(n_rays=n_rays, n_samples=S, has_transient=int(output_transient),
                 has_rgb=int(not sigma_only), flow_mode=0, want_disocc=int(disocc),
-                noise_std=nstd, z_far=Z_FAR, raw=raw, zs=zs, xyz=xyz, visibility=visibility,
+                noise_std=nstd, z_far=Z_FAR, raw=raw, zs=zs, xyz=xyz, vis=vis,
                 noise_static=noise_s if nstd != 0 else None,
                 noise_transient=noise_t if (nstd != 0 and output_transient) else None)
 

@@ -100,11 +100,14 @@ class NSFFTrainer:
         self._flat_grad.zero_()
 
     def allreduce(self):
-        """One flat RCCL all-reduce (mean) of all gradients."""
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        if world > 1:
+        """One flat RCCL all-reduce (mean) of all gradients, in place on the gradient buffer.  Issued whenever a process
+        group exists -- world size 1 included, so that a one-GPU run under torchrun exercises the same collective between
+        the two hipGraphs as an eight-GPU one (the sum over one rank and the division by 1 leave every bit unchanged)."""
+        if dist.is_initialized():
             dist.all_reduce(self._flat_grad)
-            self._flat_grad /= world
+            world = dist.get_world_size()
+            if world > 1:
+                self._flat_grad /= world
 
     def _make_optimizer(self):
         hp = self.hp

@@ -28,6 +28,10 @@ def test_bench_self_launches_two_ranks():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["value"] > 0 and line["ms_per_step"] > 0 and "STAND-IN" in line["data"]
+    # rank 0 explains the line: every rank's own time and the time inside the pixel all-gather, min / max over the ranks
+    pr = line["per_rank"]
+    assert 0 < pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= line["ms_per_step"] * 1.001
+    assert 0 < pr["gather_ms_per_step_min"] <= pr["gather_ms_per_step_max"] <= pr["ms_per_step_max"]
 
 
 def test_bench_single_process_and_torchrun_forms():
@@ -42,6 +46,15 @@ def test_bench_single_process_and_torchrun_forms():
     assert tr.returncode == 0, tr.stderr[-2000:]
     lines = _json_lines(tr.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    # torchrun with ONE rank: the process group exists, so the step still ends with the (one-rank) collective
+    tr1 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29656", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "2", "--warmup", "0", "--standin"],
+                         capture_output=True, text=True, timeout=600, env=_env())
+    assert tr1.returncode == 0, tr1.stderr[-2000:]
+    lines = _json_lines(tr1.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["per_rank"]["gather_ms_per_step_max"] > 0
+    assert "per_rank" not in _json_lines(one.stdout)[0]          # plain `python bench.py`: no group, no collective
 
 
 def test_launcher_propagates_a_failing_rank():

@@ -26,9 +26,8 @@ DEV = "cuda:0"
 def precision(request):
     """Every test runs on the two parity-grade arithmetics: exact fp32 MFMA and the fp16-split kernel -- the latter in
     both tilings the library picks by launch size (64-point tiles for the small golden scenes = "f16x3", the 128-point
-    eight-wave tiling of large launches forced with "f16x3-130").  The experimental tilings have one smoke test each
-    (test_alternative_tilings_smoke); the single-product "f16" fast mode has its own error-reporting test
-    (tests/test_fast_mode.py)."""
+    eight-wave tiling of large launches forced with "f16x3-130").  The single-product "f16" fast mode has its own
+    error-reporting test (tests/test_fast_mode.py)."""
     from nsff_pl_amd import config
     name, _, tile = request.param.partition("-")
     config.set_precision(name)
@@ -163,23 +162,6 @@ def test_free_running_per_ray_keys_match_reference(name, hip_lib, monkeypatch, p
         f.write(f"{name} {precision} " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + "\n")
     for k, e in errs.items():
         assert np.isfinite(got[k]).all() and e <= rtol, f"{name} {k}: free-running max-norm rel err {e:.3e} > {rtol:g}"
-
-
-@pytest.mark.parametrize("variant", ["f16x3-128", "f16x3-129"])
-def test_alternative_tilings_smoke(variant, hip_lib, monkeypatch):
-    """The experimental f16x3 tilings stay selectable; one golden scene each keeps them honest."""
-    from nsff_pl_amd import config
-    name, _, tile = variant.partition("-")
-    config.set_precision(name)
-    config.set_tile_points(int(tile) if tile else 0)
-    try:
-        cfg, meta, rays, ts, models, emb, dataset, want = common.build_case("g3_nsff_train", A.NeRF, A.PosEmbedding)
-        _to_dev(models, emb)
-        got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, None, zs_fine=want["zs_fine"])
-        for k in want:
-            parity.assert_close(k, got[k], want[k], common.key_rtol(k, cfg))
-    finally:
-        config.set_tile_points(0)
 
 
 @pytest.fixture(scope="module")

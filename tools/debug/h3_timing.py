@@ -10,6 +10,7 @@ from nsff_pl_amd import _lib, config
 
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
+save = len(sys.argv) > 3 and sys.argv[3] == "save"          # the training forward (keeps activations) instead of inference
 config.set_precision(prec); config.set_tile_points(tile)
 dev = torch.device("cuda:0")
 cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024, seed=0)
@@ -22,8 +23,13 @@ xyz = (torch.rand(P, 3, device=dev) * 2 - 1)
 t_rows = torch.randn(1024, scenes.N_TAU, device=dev)
 raw = torch.zeros(P, 16, device=dev)
 freqs = [float(f) for f in emb["xyz"].freqs]
+kw = {}
+if save:
+    from nsff_pl_amd import field_grad
+    acts, xin, masks, _ = field_grad.alloc_saves(model, P, dev, True, True)
+    kw = dict(save_acts=acts, save_xin=xin, save_masks=masks)
 for _ in range(3):
-    _lib.field_query(model, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows)
+    _lib.field_query(model, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows, **kw)
 torch.cuda.synchronize()
 lib = _lib.load()
 # tick calibration: one launch bracketed by events vs first/last s_memtime stamp inside it
@@ -32,7 +38,7 @@ lib.nsff_debug_span.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.nsff_debug_span(span, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-_lib.field_query(model, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows)
+_lib.field_query(model, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows, **kw)
 e1.record()
 torch.cuda.synchronize()
 lib.nsff_debug_span(span, 0)
@@ -42,7 +48,7 @@ n = 256 * 8 * 32 * 6
 buf = (C.c_uint * n)()
 assert lib.nsff_debug_read_timing(buf, n) == 0
 t = np.frombuffer(buf, dtype=np.uint32).reshape(256, 8, 32, 6).astype(np.int64)
-waves = 8 if tile == 130 else 4
+waves = 4 if tile == 64 else 8
 t = t[:, :waves]
 # the first 256 workgroups of a two-trunk launch each run the STATIC trunk of their tile (grid = 2 x tiles, static first)
 nsteps = int((t[0, 0, :31, 1] != 0).sum())
