@@ -43,6 +43,7 @@ N_RAYS, N_SAMPLES, N_IMPORTANCE = 1024, 64, 64
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
 MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "f16": 1}
 KERNEL_NAME = {"f32": "nsff_field_kernel", "f16x3": "nsff_field_kernel_h3<4,1,false,1,true>", "f16": "nsff_field_kernel_h3<4,1,false,2,false>"}
+TRAIN_KERNEL_NAME = {"f16x3": "nsff_field_kernel_h3<4,1,true,1,true>"}
 DTYPE_TEXT = {"f32": "f32",
               "f16x3": "f16x3 (fp32 operands split into 2 halfs, 3 f16 MFMAs per product, fp32 accumulate; same 1e-4 parity as f32)",
               "f16": "f16 FAST MODE (operands rounded once to fp16, 1 MFMA per product, fp32 accumulate; NOT parity-grade)"}
@@ -138,7 +139,7 @@ class Bench:
         self.kw = self.scenes.render_kwargs(self.cfg)
 
     # -- C2: the headline render step
-    def render_step(self):
+    def render_step(self, train_forward=False):
         import nsff_pl_amd as A
         from nsff_pl_amd import dist as ndist
         scenes, live = self.scenes, self.live
@@ -150,7 +151,9 @@ class Bench:
             return step
 
         def step():
-            with torch.no_grad():      # the render workload measures the forward path; the train workload the full step
+            # the render workload measures the forward path (inference launches); train_forward=True keeps autograd on, so
+            # the same call runs the TRAINING forward kernels (every layer executed, activations kept for the backward pass)
+            with torch.set_grad_enabled(train_forward):
                 out = A.render_rays(self.models, self.emb, self.rays, self.ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
                                     N_IMPORTANCE, 1024 * 32, test_time=False, **self.kw)
             if live:
@@ -172,7 +175,10 @@ class Bench:
         return lambda: trainer.step(batch)
 
     # -- C3 / C5: full 512x288 frames
-    def frame_steps(self, interp, to_host=False):
+    def frame_steps(self, interp, to_host=False, visibility=True, flow_scale=None):
+        """visibility: pass `dataset` like eval.py:134 always does, i.e. run the a6 frustum test of every sample against the
+        frame's training camera (C3 is defined with it).  flow_scale: override of the models' scene-flow scale
+        for the interpolation workload (random-init flow heads saturate at +-flow_scale NDC = +-50 px at the default 0.2)."""
         from nsff_pl_amd import dist as ndist, evaluate, interpolate
         scenes, device, world, rank = self.scenes, self.device, self.world, self.rank
         H, W = 288, 512
@@ -180,13 +186,22 @@ class Bench:
         c2w = torch.tensor([[1.0, 0, 0, 0.02], [0, 1.0, 0, -0.01], [0, 0, 1.0, 0.0]])
         lo, hi = (0, H * W) if interp else ndist.shard_bounds(H * W, world, rank)
         ekw = dict(output_transient=True, output_transient_flow=['fw', 'bw'] if interp else [])
+        if visibility:
+            ekw["dataset"] = scenes.DatasetStub(5)
+        if flow_scale is not None:
+            for m in self.models.values():
+                if hasattr(m, "flow_scale"):
+                    m.flow_scale = float(flow_scale)
+                m._pack_cache.invalidate()
         self.frame = dict(H=H, W=W, lo=lo, hi=hi)
+
+        pool = evaluate.PinnedPool(depth=2) if to_host else None     # steady state of a frame loop: no allocation per frame
 
         def render_t(t, keys):
             rays_f = evaluate.frame_rays(K, c2w, H, W, device=device, first_pixel=lo, n_pixels=hi - lo)
             ts_f = torch.full((hi - lo,), t, device=device, dtype=torch.long)
             return evaluate.render_frame(self.models, self.emb, rays_f, ts_f, scenes.N_FRAMES - 1, 128, 64, 1024 * 32,
-                                         keys=keys, to_host=to_host or None, **ekw)
+                                         keys=keys, to_host=pool, **ekw)
 
         def eval_step():
             out = render_t(7, ("rgb_fine", "depth_fine"))
@@ -290,17 +305,33 @@ def aux_block(bench, args):
                                                                          "avg_launch_ms", "launches")}}
     config.set_precision(args.precision)
     config.set_tile_points(args.tile_points if args.precision == "f16x3" else 0)
-    # (2) C3: one 512x288 test-time frame
+    # (1b) the TRAINING forward of the same C2 call (what a training step launches: every layer executed, activations and
+    # ReLU sign bits kept for the backward pass) next to the headline's inference launches
+    t, kern, _ = timed(bench.render_step(train_forward=True), 10, 2, 1, dev, prof=True)
+    rf = roofline_block(args.precision, kern)
+    aux["train_forward"] = {"label": "C2 forward as a training step runs it (autograd on): activation-saving kernels, no folded layers",
+                            "ms_per_step": t / 10 * 1e3, "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 10 / t,
+                            "roofline": dict({k: rf[k] for k in ("achieved", "executed", "peak", "unit", "frac", "avg_launch_ms", "launches")},
+                                             kernel=TRAIN_KERNEL_NAME.get(args.precision, KERNEL_NAME[args.precision]))}
+    # (2) C3 as SURVEY 8d defines it: one 512x288 test-time frame WITH the frustum-visibility test of every sample point
+    # (eval.py:134 always passes `dataset`), and without it for comparison
     t, _, _ = timed(bench.frame_steps(False), 3, 1, 1, dev)
     aux["eval_ms_per_frame"] = t / 3 * 1e3
     aux["eval_ray_samples_per_s"] = 288 * 512 * (128 + 64) * 3 / t
+    aux["eval_note"] = "visibility on (dataset passed, a6 inside the compositing kernel)"
+    t, _, _ = timed(bench.frame_steps(False, visibility=False), 3, 1, 1, dev)
+    aux["eval_ms_per_frame_no_visibility"] = t / 3 * 1e3
     # ... and with the pixels (rgb_fine, depth_fine) delivered to pinned host memory chunk by chunk on a copy stream (row N4)
     t, _, _ = timed(bench.frame_steps(False, to_host=True), 3, 1, 1, dev)
     aux["eval_ms_per_frame_pixels_to_pinned_host"] = t / 3 * 1e3
-    # (3) C5 inner loop: 2 rendered + 9 interpolated frames
-    t, _, _ = timed(bench.frame_steps(True), 2, 1, 1, dev)
-    aux["interp_ms_per_11_frames"] = t / 2 * 1e3
-    aux["interp_frames_per_s"] = 10 * 2 / t
+    # (3) C5 inner loop: 2 rendered + 9 interpolated frames.  Random-init flow heads saturate at +-flow_scale: at the default
+    # 0.2 NDC every sample moves ~+-50 px and the splat runs on its FAR path; a trained field moves a few pixels -- the NEAR
+    # figure uses flow_scale 0.02 (+-5 px) on the same weights.  Both are reported, each labelled.
+    for label, fs in (("far_50px", 0.2), ("near_5px", 0.02)):
+        t, _, _ = timed(bench.frame_steps(True, flow_scale=fs), 2, 1, 1, dev)
+        aux[f"interp_ms_per_11_frames_{label}"] = t / 2 * 1e3
+        aux[f"interp_frames_per_s_{label}"] = 10 * 2 / t
+    bench.frame_steps(True, flow_scale=0.2)                      # (restore the models' flow scale)
     # (4) C4 per GPU: training step (changes the weights, so it goes last)
     for graph in (False, True):
         bench.graph = graph

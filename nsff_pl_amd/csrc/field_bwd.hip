@@ -227,33 +227,43 @@ __device__ __forceinline__ float pow2_scale(float amax) {      // 2^k with amax 
 }
 
 // LDS tile (fp16, [point][LDH]) -> HBM fragments dst[ks][row block][lane][8 pts] (layout of field_h3.hip's
-// tile_to_fragments), every point scaled by rel[p] (a power of two).  One task = (row pair, 8-point group) = two 16-byte
-// stores; a 256-row tile is 1024 tasks = four per thread.
-__device__ __forceinline__ void fragment_task(const _Float16* sB, const float* sRel, _Float16* dst, int n_rows, int task) {
+// tile_to_fragments), every point scaled by rel[p] = G / s_p, a power of two <= 1 that reaches down to 2^-40: it is applied
+// as two packed fp16 factors r1 = max(rel, 2^-14) and r2 = rel / r1 (sRel1 / sRel2 hold them duplicated in both halfs of a
+// dword).  The first product is exact unless it is subnormal, the second only ever shrinks it -- what comes out is the
+// fp16 rounding of v * rel up to a second rounding in the subnormal range (2^-25 absolute on a scale whose maximum is
+// 2^10), and no clamp is needed since |v * rel| <= |v|.  One task = (row pair, 8-point group) = two 16-byte stores; a
+// 256-row tile is 1024 tasks = four per thread.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fragment_task(const _Float16* sB, const unsigned* sRel1, const unsigned* sRel2, _Float16* dst,
+                                              int n_rows, int task) {
     const int pairs = n_rows >> 1;                                         // two neurons per 4-byte LDS read
     const int row = 2 * (task % pairs), pg = task / pairs;
+    const u4 a0 = *reinterpret_cast<const u4*>(sRel1 + 8 * pg), a1 = *reinterpret_cast<const u4*>(sRel1 + 8 * pg + 4);
+    const u4 b0 = *reinterpret_cast<const u4*>(sRel2 + 8 * pg), b1 = *reinterpret_cast<const u4*>(sRel2 + 8 * pg + 4);
+    const unsigned r1[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const unsigned r2[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
     h8 out0, out1;
-    const float4 r0 = *reinterpret_cast<const float4*>(sRel + 8 * pg), r1 = *reinterpret_cast<const float4*>(sRel + 8 * pg + 4);
-    const float rel[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const h2 v = *reinterpret_cast<const h2*>(sB + (8 * pg + t) * LDH + row);
-        const float r = rel[t];                    // fp32 on purpose: G/s reaches down to 2^-40, the PRODUCT is what must fit fp16
-        out0[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[0] * r, -65504.f, 65504.f);
-        out1[t] = (_Float16)__builtin_amdgcn_fmed3f((float)v[1] * r, -65504.f, 65504.f);
+        const h2 p = (v * __builtin_bit_cast(h2, r1[t])) * __builtin_bit_cast(h2, r2[t]);
+        out0[t] = p[0];
+        out1[t] = p[1];
     }
     _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
     __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad:
     __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));     // keep the weights' L2 lines (-17 % per launch)
 }
-__device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const float* sRel, _Float16* dst, int n_rows) {
-    for (int task = threadIdx.x; task < (n_rows >> 1) * 8; task += 256) fragment_task(sB, sRel, dst, n_rows, task);
+__device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const unsigned* sRel1, const unsigned* sRel2,
+                                                         _Float16* dst, int n_rows) {
+    for (int task = threadIdx.x; task < (n_rows >> 1) * 8; task += 256) fragment_task(sB, sRel1, sRel2, dst, n_rows, task);
 }
 
 __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 sB[64 * LDH];
     __shared__ __attribute__((aligned(16))) _Float16 sStash[64 * LDH];
-    __shared__ __attribute__((aligned(16))) float sInv[64], sRel[64], sSig[64];
+    __shared__ __attribute__((aligned(16))) float sInv[64], sSig[64];
+    __shared__ __attribute__((aligned(16))) unsigned sRel1[64], sRel2[64];      // G / s as two packed fp16 factors (fragment_task)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long tile = blockIdx.x;
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
     int pending_slot = -1;
     auto pending_dst = [&]() { return a.dpre + (long long)pending_slot * slot_stride + tile * (64 * NSFF_W); };
     auto flush_tile = [&]() {
-        if (pending_slot >= 0) tile_to_fragments_scaled(sB, sRel, pending_dst(), NSFF_W);
+        if (pending_slot >= 0) tile_to_fragments_scaled(sB, sRel1, sRel2, pending_dst(), NSFF_W);
         pending_slot = -1;
     };
 #pragma unroll 1
@@ -323,7 +333,11 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
             const float s = pow2_scale(amax);
             if (grp == 0) {
                 sInv[pt] = 1.0f / s;
-                sRel[pt] = G / s;
+                const float rel = fminf(G / s, 1.0f);                // (> 1 only for an all-zero row: any factor will do)
+                const float f1 = fmaxf(rel, 6.103515625e-05f);       // 2^-14: the smallest normal fp16
+                const h2 p1 = {(_Float16)f1, (_Float16)f1}, p2 = {(_Float16)(rel / f1), (_Float16)(rel / f1)};
+                sRel1[pt] = __builtin_bit_cast(unsigned, p1);
+                sRel2[pt] = __builtin_bit_cast(unsigned, p2);
                 sSig[pt] = is_static ? hv[3] * s : 0.f;     // the static sigma head reads the trunk, not *_final
                 h8 lo, hi;
 #pragma unroll
@@ -368,26 +382,34 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
             const bool copy = BWD_STORE_INTERLEAVE && pending_slot >= 0;
             _Float16* dst = pending_dst();
             gemm1(acc, ring, wnext, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks,
-                  [&](int j) { if (copy) fragment_task(sB, sRel, dst, NSFF_W, (int)threadIdx.x + 256 * j); },
+                  [&](int j) { if (copy) fragment_task(sB, sRel1, sRel2, dst, NSFF_W, (int)threadIdx.x + 256 * j); },
                   [&](int j) {
                       if (copy) {
 #pragma unroll 1
-                          for (; j < 4; ++j) { fragment_task(sB, sRel, dst, NSFF_W, (int)threadIdx.x + 256 * j); B_PIN(); }
+                          for (; j < 4; ++j) { fragment_task(sB, sRel1, sRel2, dst, NSFF_W, (int)threadIdx.x + 256 * j); B_PIN(); }
                       }
                   });
             if (copy) pending_slot = -1;
         }
         BWD_STAMP(1);
         if (i + 1 < a.n_steps) wnext = prefetch_w1(ring, seg(a.steps[i + 1]));    // flies during the epilogue
-        float wsig[2][4][4];
         if (st.flags & F_SIGMA) {
+            // the static sigma head reads the trunk, not *_final: its rank-1 term joins the accumulators here (one step per
+            // static trunk; wave-uniform branch)
             const float* ws = reinterpret_cast<const float*>(pk + a.s_sigma);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 w4 = *reinterpret_cast<const float4*>(ws + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
-                    wsig[mt][q][0] = w4.x; wsig[mt][q][1] = w4.y; wsig[mt][q][2] = w4.z; wsig[mt][q][3] = w4.w;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float sg = sSig[32 * nt + (lane & 31)];
+                        acc[mt][nt][4 * q + 0] = fmaf(w4.x, sg, acc[mt][nt][4 * q + 0]);
+                        acc[mt][nt][4 * q + 1] = fmaf(w4.y, sg, acc[mt][nt][4 * q + 1]);
+                        acc[mt][nt][4 * q + 2] = fmaf(w4.z, sg, acc[mt][nt][4 * q + 2]);
+                        acc[mt][nt][4 * q + 3] = fmaf(w4.w, sg, acc[mt][nt][4 * q + 3]);
+                    }
                 }
         }
         flush_tile();                                     // the previous step's tile (sB is still intact)
@@ -415,35 +437,42 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
             }
             continue;
         }
-        // ---- epilogue: (+ rank-1 sigma term) (ReLU mask) -> fp16 tile (B operand of the next step) ----
+        // ---- epilogue: (ReLU mask) -> clamp -> fp16 tile (B operand of the next step).  The mask is applied as a bit
+        // pattern (sign-extended bit of the forward's sign word AND the value): ~3.5 VALU per value, no branches ----
         __syncthreads();                                  // every wave is done reading the tile
         BWD_STAMP(3);
+        const unsigned mword[2] = {st.epi == EPI_MASK ? (unsigned)mbits : ~0u, st.epi == EPI_MASK ? (unsigned)(mbits >> 32) : ~0u};
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pt = 32 * nt + (lane & 31);
-                const float sg = (st.flags & F_SIGMA) ? sSig[pt] : 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[mt][nt][4 * q + e];
-                        if (st.flags & F_SIGMA) v[e] += wsig[mt][q][e] * sg;
-                        if (st.epi == EPI_MASK && !((mbits >> (((mt * NT + nt) * 4 + q) * 4 + e)) & 1ull)) v[e] = 0.f;
+                        const int bit = nt * 16 + 4 * q + e;               // (mt selects the word)
+                        const int keep = (int)(mword[mt] << (31 - bit)) >> 31;          // 0 or -1 (v_bfe_i32)
+                        v[e] = __int_as_float(__float_as_int(acc[mt][nt][4 * q + e]) & keep);
                         v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
                     }
                     h4 hv;
                     hv[0] = (_Float16)v[0]; hv[1] = (_Float16)v[1]; hv[2] = (_Float16)v[2]; hv[3] = (_Float16)v[3];
-                    const int idx = pt * LDH + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5);
-                    *reinterpret_cast<h4*>(sB + idx) = hv;
-                    if (st.flags & F_STASH) *reinterpret_cast<h4*>(sStash + idx) = hv;
+                    *reinterpret_cast<h4*>(sB + pt * LDH + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5)) = hv;
                 }
             }
         BWD_STAMP(4);
         __syncthreads();
         BWD_STAMP(5);
+        if (st.flags & F_STASH) {
+            // the skip layer's pre-activation gradient is needed again by the last step of the trunk (its trunk-input
+            // part): an LDS -> LDS copy of the finished tile, once per trunk (the next write to sB is two barriers away)
+            for (int c = threadIdx.x; c < 64 * 32; c += 256) {
+                const int off = (c >> 5) * LDH + (c & 31) * 8;
+                *reinterpret_cast<h8*>(sStash + off) = *reinterpret_cast<const h8*>(sB + off);
+            }
+        }
         pending_slot = st.slot;
     }
     flush_tile();

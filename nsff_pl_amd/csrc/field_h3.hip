@@ -345,59 +345,75 @@ __device__ __forceinline__ float relu1(float v) {      // one v_max (fmaxf would
     return r;
 }
 
-// Epilogue: [ReLU ->] hi/lo split -> LDS.  3 VALU per value: v_max, half a v_cvt_pkrtz (hi), v_fma_mix (v - hi),
-// half a v_cvt_pkrtz (lo); + one v_permlane32_swap per stored dword.
-template <int NT, bool RELU, int MTW>
+// min(bits of v, 1): 1 for every v > +0 once the ReLU has run (v is +0 or positive then).  Inline asm on purpose: written
+// as an integer expression hipcc turns it into v_cmp_class_f32 + v_cndmask + hazard nops (7 VALU per value).
+__device__ __forceinline__ unsigned positive_flag(float v) {
+    unsigned r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// Epilogue of one half of a 32x32 accumulator tile: the register quads q = p and q = p + 2 (8 values: neurons
+// 8p + 4h + e and 16 + 8p + 4h + e of the tile, h = lane / 32) -> [ReLU ->] hi/lo split -> LDS.  3 VALU per value: v_max, half
+// a v_cvt_pkrtz (hi), v_fma_mix (v - hi), half a v_cvt_pkrtz (lo); lanes i and i + 32 then trade halves (v_permlane32_swap)
+// so that every lane owns 8 consecutive neurons = one 16-byte, bank-conflict-free ds_write_b128 per plane.
+// rowh / rowl: this lane's point row at the tile's first neuron.  MASKS: also collect the ReLU sign bits, bit 4q + e of
+// `signs` (+ sign_shift) -- 2 VALU per value.
+template <bool RELU, bool MASKS>
+__device__ __forceinline__ void acc_store_unit(_Float16* rowh, _Float16* rowl, const f32x16& t, int p, int lane,
+                                               unsigned& signs, int sign_shift) {
+    h4 hq[2], lq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = p + 2 * j;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = t[4 * q + e];
+            if (RELU) v[e] = relu1(v[e]);
+            if constexpr (MASKS) signs |= positive_flag(v[e]) << (sign_shift + 4 * q + e);
+        }
+        const h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+        const h2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+        const h2 l01 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h01, v[0]), minus_hi_half(h01, v[1]));
+        const h2 l23 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h23, v[2]), minus_hi_half(h23, v[3]));
+        h4 hv, lv;
+        hv[0] = (_Float16)h01[0]; hv[1] = (_Float16)h01[1]; hv[2] = (_Float16)h23[0]; hv[3] = (_Float16)h23[1];
+        lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
+        hq[j] = hv; lq[j] = lv;
+    }
+    *reinterpret_cast<u4v*>(rowh + pair_col(p, lane)) = pair_halves(hq[0], hq[1]);
+    *reinterpret_cast<u4v*>(rowl + pair_col(p, lane)) = pair_halves(lq[0], lq[1]);
+}
+
+// Whole-tile epilogue of a wave.  `mask` (MASKS) = the 256 sign words of the workgroup's first 64-point tile: the backward
+// kernel (64-point tiles, four waves of 64 neurons x [mt][nt]) reads word [tile][64 w + lane], bit ((mt * 2 + nt) * 4 + q) * 4 + e.
+template <int NT, bool RELU, int MTW, bool MASKS = false>
 __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane,
                                           unsigned long long* mask = nullptr, bool two_tiles = true) {
-    unsigned long long bits = 0ull;
-    h4 hq[4], lq[4];
+    unsigned signs[2] = {0u, 0u};                  // two tiles of 16 values per 32-bit word
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            const int row = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt;
+            const int ti = mt * NT + nt;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[mt][nt][4 * q + e];
-                    if (RELU) v[e] = relu1(v[e]);
-                }
-                const h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-                const h2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                const h2 l01 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h01, v[0]), minus_hi_half(h01, v[1]));
-                const h2 l23 = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h23, v[2]), minus_hi_half(h23, v[3]));
-                h4 hv, lv;
-                hv[0] = (_Float16)h01[0]; hv[1] = (_Float16)h01[1]; hv[2] = (_Float16)h23[0]; hv[3] = (_Float16)h23[1];
-                lv[0] = (_Float16)l01[0]; lv[1] = (_Float16)l01[1]; lv[2] = (_Float16)l23[0]; lv[3] = (_Float16)l23[1];
-                hq[q] = hv; lq[q] = lv;
-                if (q == 3) {
-                    const int row = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt;
-                    *reinterpret_cast<u4v*>(sXh + row + pair_col(0, lane)) = pair_halves(hq[0], hq[2]);
-                    *reinterpret_cast<u4v*>(sXh + row + pair_col(1, lane)) = pair_halves(hq[1], hq[3]);
-                    *reinterpret_cast<u4v*>(sXl + row + pair_col(0, lane)) = pair_halves(lq[0], lq[2]);
-                    *reinterpret_cast<u4v*>(sXl + row + pair_col(1, lane)) = pair_halves(lq[1], lq[3]);
-                }
-                if (mask != nullptr) {
-                    unsigned m = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
-                    bits |= (unsigned long long)m << (((mt * NT + nt) * 4 + q) * 4);
-                }
-            }
-    // `mask` = the 256 words of this workgroup's first 64-point tile.  The backward kernel (64-point tiles, four waves of
-    // 64 neurons) reads word [tile][64 w + lane], bit ((mt * 2 + nt) * 4 + q) * 4 + e.
-    if (mask != nullptr) {
-        if constexpr (MTW == 2) {
-            mask[64 * (nb0 >> 6) + lane] = bits;                     // this wave IS wave nb0 / 64 of the tile
+            for (int p = 0; p < 2; ++p)
+                acc_store_unit<RELU, MASKS>(sXh + row, sXl + row, acc[mt][nt], p, lane, signs[ti >> 1], 16 * (ti & 1));
+        }
+    if constexpr (MASKS) {
+        unsigned* m32 = reinterpret_cast<unsigned*>(mask);
+        const int word = 64 * (nb0 >> 6) + lane;
+        if constexpr (MTW == 2) {                  // this wave IS wave nb0 / 64 of the (one) 64-point tile
+            m32[2 * word] = signs[0]; m32[2 * word + 1] = signs[1];
         } else {
             // eight waves of 32 neurons x 128 points: this wave holds (mt = its neuron half) x (nt = 0..3); point tiles 0, 1
             // belong to the first 64-point tile, 2, 3 to the second; each goes out as one 32-bit half of the word
             static_assert(NT == 4 || MTW == 2, "mask layout of the 32-neuron-per-wave tiling");
-            unsigned* m32 = reinterpret_cast<unsigned*>(mask);
             const int mt_b = (nb0 >> 5) & 1;
-            const int word = 64 * (nb0 >> 6) + lane;
-            m32[2 * word + mt_b] = (unsigned)bits;                   // (mt0 * NT + nt) * 16 bits, nt = 0, 1
-            if (two_tiles) m32[2 * (256 + word) + mt_b] = (unsigned)(bits >> 32);
+            m32[2 * word + mt_b] = signs[0];
+            if (two_tiles) m32[2 * (256 + word) + mt_b] = signs[1];
         }
     }
 }
@@ -478,10 +494,10 @@ __device__ __forceinline__ void split_store2(_Float16* xh, _Float16* xl, int idx
 // layers deep -- answers a 4-ulp change of the encoding with per-cent changes of single weight gradients.
 template <int M, int THREADS, bool SPLIT, bool OCTAVE = true>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
-                                            const float (&x)[3]) {
+                                            const float (&x)[3], int tid) {
     constexpr int G = THREADS / M;               // threads per point row
     constexpr int CH = 16 / G;                   // float4 chunks of a 64-column time-code segment per thread
-    const int r = build_row<M, THREADS>(threadIdx.x), q = build_part<M, THREADS>(threadIdx.x);
+    const int r = build_row<M, THREADS>(tid), q = build_part<M, THREADS>(tid);
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
     const int base = r * LDH;
@@ -583,9 +599,9 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
 }
 
 template <int M, int THREADS, bool SPLIT>
-__device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0) {
+__device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, int tid) {
     constexpr int G = THREADS / M;
-    const int r = build_row<M, THREADS>(threadIdx.x), q = build_part<M, THREADS>(threadIdx.x);
+    const int r = build_row<M, THREADS>(tid), q = build_part<M, THREADS>(tid);
     const long long p = p0 + r;
     const bool valid = p < a.n_points;
     const float* sd = nullptr; const float* sa = nullptr;
@@ -785,10 +801,10 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             pend_flush();                          // (a tile nobody multiplied after it was saved: the last one of a trunk)
             __syncthreads();                       // everyone is done reading the previous tile
             if (st.pre == PRE_SIDE) {
-                build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0);
+                build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0, threadIdx.x);
             } else {
                 if constexpr (!KEEP_POINT) read_point();
-                build_input<M, THREADS, SPLIT, !SAVE>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px);
+                build_input<M, THREADS, SPLIT, !SAVE>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px, threadIdx.x);
             }
             __syncthreads();
             if constexpr (SAVE) {
@@ -842,8 +858,10 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             if constexpr (!SPLIT) {
                 if (st.post == POST_RELU) acc_store_f16<NT, true, MTW>(sXh, acc, nb0, nt0, lane);
                 else acc_store_f16<NT, false, MTW>(sXh, acc, nb0, nt0, lane);
-            } else if (st.post == POST_RELU) acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk, pg_end > 8);
-            else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane, mk, pg_end > 8);
+            } else if (st.post == POST_RELU) {
+                if (SAVE && mk != nullptr) acc_store<NT, true, MTW, SAVE>(sXh, sXl, acc, nb0, nt0, lane, mk, pg_end > 8);
+                else acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane);
+            } else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane);
             H3_STAMP(4);
             __syncthreads();
             H3_STAMP(5);

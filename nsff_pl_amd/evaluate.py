@@ -38,22 +38,46 @@ def frame_rays(K, c2w, H, W, near=1.0, device="cuda", first_pixel=0, n_pixels=No
     return rays
 
 
-_PINNED = {}          # (key, shape) -> pinned host tensor, reused frame after frame (hipHostMalloc is slow)
 _COPY_STREAM = {}
 
 
-def pinned_buffer(key, shape):
-    """A page-locked host tensor for result `key` of a whole frame; cached, so a frame loop allocates once."""
-    ck = (key, tuple(shape))
-    if ck not in _PINNED:
-        _PINNED[ck] = torch.empty(*shape, dtype=torch.float32, pin_memory=True)
-    return _PINNED[ck]
+class PinnedPool:
+    """Page-locked host buffers for ``render_frame(..., to_host=pool)``, reused frame after frame (hipHostMalloc is slow)
+    WITHOUT handing the same memory to two live frames: the pool keeps ``depth`` buffer sets and rotates through them, so
+    a returned :class:`HostFrame` stays valid until ``depth`` further frames have been rendered into the same pool
+    (``depth=2``: frames t and t+1 of a time interpolation can be held together).  Before a set is written again the pool
+    waits for the copies of the frame that last used it, so ``sync=False`` frames never race each other."""
+
+    def __init__(self, depth=2):
+        if depth < 1:
+            raise ValueError("PinnedPool depth must be >= 1")
+        self.depth, self._turn = int(depth), 0
+        self._sets = [dict() for _ in range(self.depth)]     # slot -> {(key, shape): tensor}
+        self._last = [None] * self.depth                     # slot -> the HostFrame that was handed this set
+
+    def next_slot(self):
+        slot = self._turn % self.depth
+        self._turn += 1
+        old = self._last[slot]
+        if old is not None:
+            old.wait()                                        # its copies must have landed before the set is rewritten
+            old.stale = True
+        return slot
+
+    def buffer(self, slot, key, shape):
+        ck = (key, tuple(shape))
+        bufs = self._sets[slot]
+        if ck not in bufs:
+            bufs[ck] = torch.empty(*shape, dtype=torch.float32, pin_memory=True)
+        return bufs[ck]
 
 
 class HostFrame(dict):
     """Result of ``render_frame(..., to_host=...)``: {key: pinned host tensor}.  The device-to-host copies may still be
-    in flight on the copy stream; ``wait()`` (or ``render_frame(..., sync=True)``, the default) blocks until they landed."""
+    in flight on the copy stream; ``wait()`` (or ``render_frame(..., sync=True)``, the default) blocks until they landed.
+    ``stale`` turns True once a :class:`PinnedPool` has handed this frame's buffers to a later frame."""
     event = None
+    stale = False
 
     def wait(self):
         if self.event is not None:
@@ -69,9 +93,11 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
 
     keys: iterable of result keys to keep (default: all, like the reference).
     to_cpu=True: the reference's egress -- a blocking ``.cpu()`` of every kept key after every chunk (eval.py:106-107).
-    to_host=True | {key: pinned tensor}: asynchronous egress -- the kept keys of each chunk are copied into page-locked
-    host buffers (frame-sized, cached / caller-provided) on a side stream while the next chunk renders; returns a
-    :class:`HostFrame` of host tensors (``sync=False`` leaves the last copies in flight: call ``.wait()``).
+    to_host=True | PinnedPool | {key: pinned tensor}: asynchronous egress -- the kept keys of each chunk are copied into
+    frame-sized page-locked host buffers on a side stream while the next chunk renders; returns a :class:`HostFrame` of
+    host tensors (``sync=False`` leaves the last copies in flight: call ``.wait()``).  ``True`` allocates FRESH buffers
+    for this call (no two frames ever share memory); a :class:`PinnedPool` reuses ``depth`` rotating buffer sets (a frame
+    is valid until ``depth`` later frames went through the pool); a dict supplies caller-owned buffers per key.
     """
     B = rays.shape[0]
     results = {}
@@ -83,6 +109,8 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
         copy_stream = _COPY_STREAM[dev]
         host = HostFrame()
         given = to_host if isinstance(to_host, dict) else {}
+        pool = to_host if isinstance(to_host, PinnedPool) else None
+        slot = pool.next_slot() if pool is not None else None
     for i in range(0, B, chunk):
         kw = dict(kwargs)
         for per_ray in ("view_dir", "t_embedded", "a_embedded"):
@@ -99,7 +127,12 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
                 for k, v in kept.items():
                     if k not in host:
                         shape = (B,) + tuple(v.shape[1:])
-                        host[k] = given[k] if k in given else pinned_buffer(k, shape)
+                        if k in given:
+                            host[k] = given[k]
+                        elif pool is not None:
+                            host[k] = pool.buffer(slot, k, shape)
+                        else:
+                            host[k] = torch.empty(*shape, dtype=torch.float32, pin_memory=True)
                         if tuple(host[k].shape) != shape or not host[k].is_pinned():
                             raise ValueError(f"to_host['{k}'] must be a pinned float32 tensor of shape {shape}")
                     host[k][i:i + v.shape[0]].copy_(v, non_blocking=True)
@@ -110,6 +143,8 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
     if host is not None:
         host.event = torch.cuda.Event()
         host.event.record(copy_stream)
+        if pool is not None:
+            pool._last[slot] = host
         return host.wait() if sync else host
     return {k: v[0] if len(v) == 1 else torch.cat(v, 0) for k, v in results.items()}
 

@@ -113,7 +113,6 @@ class _FieldFn(torch.autograd.Function):
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
         static, transient = cfg["static"], cfg["transient"]
         P = xyz.shape[0]
-        drop_stale_pending()
         ctx.cfg, ctx.P = cfg, P
         if cfg.get("saved") is not None:         # render_rays' own launch was the training forward: nothing to redo
             raw, acts, xin, masks, xyz_c, side = cfg["saved"]
@@ -197,12 +196,12 @@ class _FieldFn(torch.autograd.Function):
         main = torch.cuda.current_stream()
         # inside a hipGraph capture the fork / join costs more than the concurrency returns (13.98 vs 12.56 ms per
         # step): there only the accumulation is deferred and fused, on the capture stream itself
-        side = _side_stream(dev) if (overlap and not torch.cuda.is_current_stream_capturing()) else main
-        if side is not main:
-            side.wait_stream(main)
+        wstream = _side_stream(dev) if (overlap and not torch.cuda.is_current_stream_capturing()) else main
+        if wstream is not main:
+            wstream.wait_stream(main)
         plist = _lib.param_list(model)
         grad_map = _grad_map(model, static, transient, meta, jobs, sizes, plist) if overlap else None
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(wstream):
             if grad_map is not None:
                 # deferred mode with every .grad in place: the reduction of the split-K partials accumulates straight
                 # into the parameters' gradient memory (no per-parameter tensors, adds or cats)
@@ -227,7 +226,7 @@ class _FieldFn(torch.autograd.Function):
             # keep what the side stream still reads alive until the join, then hand the gradients over there.
             # Every node queues the (idempotent) flush: a callback queued by an earlier backward pass that died
             # half-way is dropped by the engine, so "already queued" cannot be remembered across passes.
-            _PENDING.append((list(plist), grads, (dpre, dhead, acts, xin, side, keep, gmax)))
+            _PENDING.append((_graph_task_id(), list(plist), grads, (dpre, dhead, acts, xin, side, keep, gmax)))
             torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
             return (None, d_xyz, d_t, None, d_a) + (None,) * len(params)
         return (None, d_xyz, d_t, None, d_a) + tuple(grads)
@@ -521,10 +520,19 @@ def _overlap_enabled():
     return _DEFER[0] if env is None else env != "0"
 
 
+def _graph_task_id():
+    """Identity of the running backward pass (-1 outside one): what a pending entry belongs to."""
+    return torch._C._current_graph_task_id()
+
+
 def drop_stale_pending():
-    """Called when a new forward starts: anything still pending belongs to a backward pass that raised before its
-    end-of-pass callback ran (the engine drops queued callbacks then); release it."""
-    del _PENDING[:]
+    """Release what a backward pass that raised half-way left behind (the engine drops that pass's queued end-of-pass
+    callbacks).  Never needed for correctness -- :func:`_flush_weight_grads` only delivers the entries of the pass it
+    runs in and discards everything else -- it just frees the buffers early (``NSFFTrainer.step`` calls it).  Not called
+    from the field's forward: a forward may legitimately run INSIDE a backward pass (activation recomputation, a hook
+    that renders) and must not discard the gradients that pass has already queued."""
+    tid = _graph_task_id()
+    _PENDING[:] = [e for e in _PENDING if e[0] == tid and tid >= 0]
 
 
 def _side_stream(device):
@@ -537,7 +545,8 @@ def _flush_weight_grads():
     """End-of-backward callback: join the side stream and add the weight gradients of every field node to .grad
     (one fused add per node instead of one per parameter).  Gradients therefore reach the parameters through
     ``loss.backward()``; ``torch.autograd.grad(..., parameters)`` needs NSFF_WGRAD_OVERLAP=0."""
-    items = list(_PENDING)
+    tid = _graph_task_id()
+    items = [e[1:] for e in _PENDING if e[0] == tid]          # entries of other passes died with those passes: dropped
     del _PENDING[:]
     if not items:
         return

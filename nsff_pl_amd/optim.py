@@ -6,6 +6,20 @@ Every parameter becomes a view of one flat fp32 buffer, every ``.grad`` a view o
 weight-gradient kernel accumulates into and RCCL all-reduces); the two moment buffers are flat as well.  Step count and
 learning rate live on the device, so the step is the same two launches eagerly and inside a hipGraph.  Parameters keep
 their shapes, ``state_dict`` keys and identity (``nn.Parameter`` objects are untouched, only their storage moves).
+
+Where this differs from ``torch.optim.Adam`` -- read before swapping it in elsewhere:
+
+* **Every element is updated every step.**  torch skips parameters whose ``.grad`` is None; here ``.grad`` always exists
+  (a slice of the flat buffer, zero after ``zero_grad``).  With ``weight_decay == 0`` (the reference's default, opt.py) a
+  zero gradient only decays the moments, as torch would for a zero-valued gradient; with ``weight_decay > 0`` a parameter
+  that never receives a gradient (an unused head) WOULD BE DECAYED where torch leaves it alone -- so a non-zero
+  ``weight_decay`` must be acknowledged with ``decay_unused=True``.
+* **HIP device only.**  There is no CPU implementation (tests drive CPU runs with a torch-op twin, tests/common.py).
+* **Shared storage.**  ``module.state_dict()`` tensors are views of the one flat buffer: ``torch.save`` of such a dict
+  writes the whole buffer once per file.  Use :func:`detached_state` (or ``NSFFTrainer.checkpoint``) to get clones.
+* **Optimizer state.**  ``state_dict`` / ``load_state_dict`` use this class's flat layout; ``torch_state_dict`` /
+  ``load_torch_state_dict`` convert to and from ``torch.optim.Adam``'s per-parameter format (resuming a reference /
+  torch checkpoint, or handing a run back to torch).
 """
 import torch
 
@@ -13,10 +27,14 @@ from . import _lib
 
 
 class FlatAdam:
-    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decay_unused=False):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("FlatAdam: no parameters")
+        if weight_decay != 0 and not decay_unused:
+            raise ValueError("FlatAdam updates every element every step: with weight_decay != 0 parameters that never "
+                             "receive a gradient are decayed too (torch.optim.Adam skips them).  Pass decay_unused=True to "
+                             "accept that, or use weight_decay=0 (the reference's default).")
         dev = self.params[0].device
         self._check_device(dev)
         if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
@@ -96,9 +114,59 @@ class FlatAdam:
                     exp_avg_sq=self.exp_avg_sq[:self.numel].clone(), betas=self.betas, eps=self.eps,
                     weight_decay=self.weight_decay)
 
+    def torch_state_dict(self):
+        """The same state in ``torch.optim.Adam.state_dict()`` format (cloned tensors, parameter order of ``params``)."""
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            state[i] = {"step": self.state[0].detach().clone().cpu(),
+                        "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        group = {"lr": float(self.lr), "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_state_dict(self, sd):
+        """Take over moments, step count and hyper-parameters of a ``torch.optim.Adam.state_dict()`` over the same
+        parameters in the same order (one param group, no amsgrad).  Parameters without state keep zero moments."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or groups[0].get("amsgrad", False):
+            raise ValueError("FlatAdam takes one parameter group without amsgrad")
+        g = groups[0]
+        if len(g["params"]) != len(self.params):
+            raise ValueError(f"optimizer state covers {len(g['params'])} parameters, this optimizer has {len(self.params)}")
+        steps = set()
+        with torch.no_grad():
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            off = 0
+            for key, p in zip(g["params"], self.params):
+                n = p.numel()
+                st = sd["state"].get(key)
+                if st is not None:
+                    if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError(f"state of parameter {key} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
+                    self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(st["step"]))
+                off += n
+            if len(steps) > 1:
+                raise ValueError(f"parameters are at different step counts {sorted(steps)}: one shared counter here")
+            self.state.zero_(); self.state[0] = float(steps.pop()) if steps else 0.0
+            self.lr.fill_(float(g["lr"]))
+        self.betas, self.eps = (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
+        self.weight_decay = float(g.get("weight_decay", 0.0))
+
     def load_state_dict(self, sd):
         with torch.no_grad():
             self.state.zero_(); self.state[0:1].copy_(sd["step"])
             self.lr.copy_(sd["lr"])
             self.exp_avg[:self.numel].copy_(sd["exp_avg"]); self.exp_avg_sq[:self.numel].copy_(sd["exp_avg_sq"])
         self.betas, self.eps, self.weight_decay = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
+
+
+def detached_state(module):
+    """``module.state_dict()`` with every tensor cloned: safe to ``torch.save`` / keep while training goes on (the live
+    tensors are views of FlatAdam's one flat buffer and change in place)."""
+    return {k: v.detach().clone() for k, v in module.state_dict().items()}

@@ -188,6 +188,7 @@ class NSFFTrainer:
         if self.graph:
             return self._graph_step(batch)
         self._setup_flat_grads()
+        field_grad.drop_stale_pending()
         self.zero_grad()
         loss, log = self.training_step(batch)
         with field_grad.deferred_weight_grads():
@@ -238,6 +239,44 @@ class NSFFTrainer:
         self._graph_opt.replay()
         self._invalidate_packs()
         return self._static_log
+
+    # utils/__init__.py:82-104 + PL checkpoint layout (train.py:55,59,76,87): nerf_fine. / nerf_coarse. / embedding_t. / embedding_a.
+    def checkpoint(self):
+        """{'state_dict': reference-style prefixed model / embedding tensors (cloned), 'optimizer': torch.optim.Adam format,
+        'epoch'} -- independent of the flat training buffers, so it can be saved or kept while training continues."""
+        from .optim import detached_state
+        sd = {}
+        for typ, m in self.models.items():
+            sd.update({f"nerf_{typ}.{k}": v for k, v in detached_state(m).items()})
+        for k in ("t", "a"):
+            if k in self.embeddings:
+                sd.update({f"embedding_{k}.{kk}": v for kk, v in detached_state(self.embeddings[k]).items()})
+        opt = self.optimizer.torch_state_dict() if hasattr(self.optimizer, "torch_state_dict") else self.optimizer.state_dict()
+        return {"state_dict": sd, "optimizer": opt, "epoch": self.current_epoch}
+
+    def load_checkpoint(self, ckpt):
+        """Inverse of :meth:`checkpoint`; also takes a reference checkpoint's ``state_dict`` (same prefixes) with a
+        ``torch.optim.Adam`` optimizer state over the same parameter order."""
+        sd = ckpt["state_dict"]
+        with torch.no_grad():
+            for typ, m in self.models.items():
+                sub = {k[len(f"nerf_{typ}."):]: v for k, v in sd.items() if k.startswith(f"nerf_{typ}.")}
+                for k, p in m.state_dict().items():
+                    p.copy_(sub[k])                 # in place: parameters stay views of the flat buffer
+            for name in ("t", "a"):
+                if name in self.embeddings:
+                    sub = {k[len(f"embedding_{name}."):]: v for k, v in sd.items() if k.startswith(f"embedding_{name}.")}
+                    for k, p in self.embeddings[name].state_dict().items():
+                        p.copy_(sub[k])
+        if self.optimizer is None:
+            self._make_optimizer()
+        if "optimizer" in ckpt and ckpt["optimizer"] is not None:
+            if "param_groups" in ckpt["optimizer"]:
+                self.optimizer.load_torch_state_dict(ckpt["optimizer"])
+            else:
+                self.optimizer.load_state_dict(ckpt["optimizer"])
+        self.current_epoch = int(ckpt.get("epoch", self.current_epoch))
+        self._invalidate_packs()
 
     def on_train_epoch_end(self):
         """MultiStepLR(milestones=decay_step, gamma=decay_gamma) of train.py:143-146, stepped once per epoch."""

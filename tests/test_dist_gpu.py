@@ -3,8 +3,8 @@
 What the eight-GPU job runs -- ``dist.init_from_env`` with the communicator bound to ``cuda:LOCAL_RANK``, the packed pixel
 all-gather (even and ``counts=`` forms), ``render_frame_sharded``, ``NSFFTrainer(graph=True)`` with the flat gradient
 all-reduce issued between its two hipGraphs, and ``bench.py --gpus 1`` in the form the driver starts it for N > 1
-(``python -m torch.distributed.run``) -- executes here with a live process group; at world size 1 every result must
-equal the group-less one bit for bit.  The world-size-2 semantics (uneven shards, replicas kept in sync) are covered on
+(``python -m torch.distributed.run``) -- executes here with a live process group; at world size 1 the collectives must
+leave every bit of their buffers unchanged, so every result equals the group-less one.  The world-size-2 semantics (uneven shards, replicas kept in sync) are covered on
 CPU with gloo (tests/test_dist_cpu.py).  Reference: DDP of train.py:294-301; the pixel gather has no counterpart there.
 """
 import json
@@ -81,6 +81,10 @@ def test_sharded_frame_equals_the_unsharded_one(hip_lib, nccl_world1):
         assert torch.equal(shard[k], whole[k]), k
 
 
+def _batch(tr):
+    return tr._test_batch
+
+
 def _train(graph, steps=3):
     from nsff_pl_amd.training import NSFFTrainer
     name = "g3_nsff_train"
@@ -91,20 +95,23 @@ def _train(graph, steps=3):
     tr.on_train_epoch_start(scenes.LOSS_EPOCH)
     batch = {k: v.to(DEV) for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
     batch["rays"] = rays.to(DEV)
+    tr._test_batch = batch
     losses = [float(tr.step(batch)["train/loss"]) for _ in range(steps)]
     torch.cuda.synchronize()
-    return losses, torch.cat([p.detach().reshape(-1) for p in tr.params]).clone()
+    return losses, tr._flat_grad.detach().clone(), tr
 
 
 @pytest.mark.parametrize("graph", [False, True])
 def test_trainer_step_with_a_live_group_equals_the_group_less_step(graph, hip_lib, monkeypatch, request):
     """The flat gradient all-reduce sits between graph A (zero_grad .. backward) and graph B (Adam): with a process group
     alive it must be issued once per step, on the gradient buffer itself, and at world size 1 leave every bit of it
-    unchanged -- so the step is the group-less step (compared to 1e-6: the loss reductions use atomics, two runs of the
-    same schedule differ in the last bits with or without a group)."""
+    unchanged -- so the step is the group-less step.  Compared: the loss and the gradient buffer of the FIRST step (1e-6:
+    the loss reductions use atomics).  Later steps are not comparable between ANY two runs, group or not: Adam's first
+    update is lr * g / (|g| + 1e-8), so last-bit noise on near-zero gradient elements becomes +-lr parameter changes
+    (tools/debug/graph_determinism.py: run-to-run differences of 1e-4 in the third loss, eager and graph alike)."""
     A.set_precision("f16x3")
     try:
-        want_losses, want_params = _train(graph)
+        want_losses, want_grad, _ = _train(graph, steps=1)
         request.getfixturevalue("nccl_world1")
         calls, unchanged = [], []
         real = dist.all_reduce
@@ -117,12 +124,13 @@ def test_trainer_step_with_a_live_group_equals_the_group_less_step(graph, hip_li
             unchanged.append(bool(torch.equal(before, t)) and bool(before.abs().sum() > 0))
             return out
         monkeypatch.setattr(dist, "all_reduce", spy)
-        got_losses, got_params = _train(graph)
-        assert len(calls) >= 3 and len(set(calls[-3:])) == 1          # the same flat buffer every step (warm-ups may add calls)
-        assert calls[-1][1] >= got_params.numel() and all(unchanged)
-        for a_, b_ in zip(got_losses, want_losses):
-            assert abs(a_ - b_) <= 1e-6 * abs(b_), (got_losses, want_losses)
-        assert float((got_params - want_params).abs().max()) <= 1e-6 * float(want_params.abs().max())
+        got_losses, got_grad, tr = _train(graph, steps=1)
+        assert len(calls) == 1 and calls[0] == (tr._flat_grad.data_ptr(), tr._flat_grad.numel()) and all(unchanged)
+        assert abs(got_losses[0] - want_losses[0]) <= 1e-6 * abs(want_losses[0]), (got_losses, want_losses)
+        assert float((got_grad - want_grad).abs().max()) <= 1e-5 * float(want_grad.abs().max())
+        more = [float(tr.step(_batch(tr))["train/loss"]) for _ in range(2)]
+        assert len(calls) == 3 and len(set(calls)) == 1 and all(unchanged)      # once per step, always the same flat buffer
+        assert all(l == l for l in more) and more[-1] < got_losses[0]
     finally:
         A.set_precision(A.config.DEFAULT_PRECISION)
 

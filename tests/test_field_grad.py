@@ -80,6 +80,23 @@ def test_field_node_gradients(static, transient, spread, hip_lib):
     k = max(worst, key=worst.get)
     print("\nworst native", static, spread, worst[k], k, "fp32 torch there", base[k], "| fp32 torch worst", max(base.values()))
     assert not bad, bad
+    if spread == 0:
+        # self-test of this tolerance: a 1 % systematic error in ANY weight gradient (or in the input gradients) must be
+        # flagged -- the end-to-end gradient tests cannot promise that for the ill-conditioned flow paths, this one does
+        blind = []
+        for n, p in list(model.named_parameters()) + [("t", t)]:
+            if n.endswith(".bias") or n not in worst:
+                continue                       # (a bias gradient is judged on the scale of its layer: its own 1 % can be below it;
+                                               #  d/d(xyz) runs through sin(512 x): torch's own fp32 result is 3e-3 off there)
+            if n == "t":
+                err = rel(1.01 * p.grad, ref_t)
+            else:
+                layer = n.rsplit(".", 1)[0]
+                scale = torch.stack([ref_p[layer + ".weight"].abs().max(), ref_p[layer + ".bias"].abs().max()]).max()
+                err = rel(1.01 * p.grad, ref_p[n], scale)
+            if not err > tol + 3 * base[n]:
+                blind.append((n, err, tol + 3 * base[n]))
+        assert not blind, blind
 
 
 def test_failed_backward_does_not_lose_later_weight_gradients(hip_lib):
@@ -129,6 +146,37 @@ def test_failed_backward_does_not_lose_later_weight_gradients(hip_lib):
         assert trunk.grad is not None
         assert torch.allclose(trunk.grad, got, rtol=1e-5, atol=1e-6 * float(got.abs().max()))
         assert not field_grad._PENDING
+
+
+def test_a_forward_inside_a_backward_pass_keeps_the_queued_weight_gradients(hip_lib):
+    """Deferred mode: a field forward that runs WHILE a backward pass is in flight (activation recomputation, a hook that
+    renders) must not discard the weight gradients the pass has already queued."""
+    dev = torch.device("cuda:0")
+    cfg = scenes.CASES["g3_nsff_train"]
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    model = models["fine"].to(dev)
+    freqs = [float(f) for f in emb["xyz"].freqs]
+    g = torch.Generator().manual_seed(13)
+    xyz = (torch.rand(256, 3, generator=g) * 2 - 1).to(dev)
+    t_rows = torch.randn(4, scenes.N_TAU, generator=g).to(dev)
+    trunk = model.transient_xyz_encoding_3[0].weight
+    want = torch.autograd.grad(field_grad.field(model, xyz, freqs, t_rows, 64, True, True).sum(), [trunk])[0]
+    t_leaf = t_rows.clone().requires_grad_(True)
+    ran = []
+
+    def hook(grad):                                # runs after the field node's backward (the time codes are upstream of it)
+        with torch.no_grad():
+            field_grad.field(model, xyz, freqs, t_rows, 64, True, True)
+        ran.append(len(field_grad._PENDING))
+        return grad
+    t_leaf.register_hook(hook)
+    for p in model.parameters():
+        p.grad = None
+    with field_grad.deferred_weight_grads():
+        field_grad.field(model, xyz, freqs, t_leaf, 64, True, True).sum().backward()
+    torch.cuda.synchronize()
+    assert ran == [1] and not field_grad._PENDING
+    assert trunk.grad is not None and torch.allclose(trunk.grad, want, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
 
 
 @pytest.mark.gpu

@@ -129,14 +129,14 @@ def test_render_rays_matches_reference_goldens(name, hip_lib, monkeypatch):
 # Per-ray keys north_star names, FREE-RUNNING (no fine-depth override): the whole chain coarse field ->
 # compositing -> inverse-CDF sampling -> merge/sort -> fine field -> compositing against the reference's own
 # outputs (models/rendering.py:335-362).  On the well-conditioned scenes a 1e-6 depth shift stays small in the
-# per-ray expectations; the gain-3 stress scene is reported and bounded at 1e-2, not asserted at 1e-4.
+# per-ray expectations; the gain-3 stress scene is asserted at 3e-3 (twice the measured worst), not at 1e-4.
 FREE_RUN_KEYS = ("rgb_fine", "depth_fine", "transient_flow_fw", "transient_flow_bw", "xyz_fw", "xyz_bw",
                  "_static_rgb_fine", "rgb_coarse", "depth_coarse")
 FREE_RUN_STRICT = ("g2_static_c2f", "g3_nsff_train", "g4_nsff_test", "g5_nsff_test_vis", "g7_nsff_train_noise", "g13_viewdir_train",
                    "g7b_static_noise_odd", "g12_other_arch")
 # gain 3: sigma up to 33, weights near 0/1 -- a 1e-6 depth shift moves per-ray values by 1e-3 (the numpy oracle itself
-# sits 3e-4..1.5e-3 from the reference there); measured 1.6e-3 on the MI355X, bounded at 1e-2
-FREE_RUN_REPORTED = {"g3b_nsff_train_gain3": 1e-2}
+# sits 3e-4..1.5e-3 from the reference there); measured 3e-4 .. 1.6e-3 on the MI355X, asserted at twice the worst: 3e-3
+FREE_RUN_REPORTED = {"g3b_nsff_train_gain3": 3e-3}
 
 
 @pytest.mark.parametrize("name", FREE_RUN_STRICT + tuple(FREE_RUN_REPORTED))
@@ -445,6 +445,24 @@ def test_frame_egress_to_pinned_host_buffers(hip_lib, precision):
     assert torch.equal(out.wait()["rgb_fine"], gpu["rgb_fine"].cpu())
     with pytest.raises(ValueError):
         evaluate.render_frame(*args, chunk=8192, keys=("rgb_fine",), to_host={"rgb_fine": torch.empty(5, 3, pin_memory=True)}, **kw)
+    # two frames in flight at once (the pattern of the time interpolation: frame t is held while t + 1 renders): fresh
+    # buffers per call by default, and a PinnedPool(depth=2) rotates its sets -- neither may let frame t + 1 land in frame t
+    ts2 = ts + 1
+    gpu2 = evaluate.render_frame(models, emb, rays, ts2, 29, 64, 64, chunk=8192, keys=keys, **kw)
+    assert not torch.equal(gpu2["rgb_fine"], gpu["rgb_fine"])
+    for to_host in (True, evaluate.PinnedPool(depth=2)):
+        fa = evaluate.render_frame(*args, chunk=8192, keys=keys, to_host=to_host, sync=False, **kw)
+        fb = evaluate.render_frame(models, emb, rays, ts2, 29, 64, 64, chunk=8192, keys=keys, to_host=to_host, sync=False, **kw)
+        fa.wait(); fb.wait()
+        for k in keys:
+            assert fa[k].data_ptr() != fb[k].data_ptr(), k
+            assert torch.equal(fa[k], gpu[k].cpu()) and torch.equal(fb[k], gpu2[k].cpu()), k
+        assert not fa.stale and not fb.stale
+    pool = evaluate.PinnedPool(depth=2)
+    frames = [evaluate.render_frame(*args, chunk=8192, keys=("rgb_fine",), to_host=pool, sync=False, **kw) for _ in range(3)]
+    assert frames[0].stale and not frames[1].stale and not frames[2].stale          # the third frame took the first one's set
+    assert frames[2]["rgb_fine"].data_ptr() == frames[0]["rgb_fine"].data_ptr()
+    assert torch.equal(frames[2].wait()["rgb_fine"], gpu["rgb_fine"].cpu())
 
     def timed(**extra):
         torch.cuda.synchronize()
@@ -453,7 +471,8 @@ def test_frame_egress_to_pinned_host_buffers(hip_lib, precision):
             evaluate.render_frame(*args, chunk=8192, keys=keys, **extra, **kw)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / 3
-    timed(); timed(to_host=True)                              # warm both paths
-    t_gpu, t_host, t_block = timed(), timed(to_host=True), timed(to_cpu=True)
+    pool = evaluate.PinnedPool(depth=2)
+    timed(); timed(to_host=pool)                              # warm both paths
+    t_gpu, t_host, t_block = timed(), timed(to_host=pool), timed(to_cpu=True)
     print(f"frame {H}x{W}: resident {t_gpu * 1e3:.1f} ms, async pinned egress {t_host * 1e3:.1f} ms, blocking .cpu() {t_block * 1e3:.1f} ms")
     assert t_host <= 1.05 * t_gpu + 2e-3, (t_host, t_gpu)

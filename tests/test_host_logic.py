@@ -56,7 +56,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 16
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 17
 
 
 def test_struct_layouts_match_the_header_sizes():
@@ -67,7 +67,8 @@ def test_struct_layouts_match_the_header_sizes():
     assert C.sizeof(_lib.SplatArgs) == 12 + 16 + 48 + 4 + 5 * 8 and C.sizeof(_lib.MpiArgs) == 16 + 7 * 8
     assert C.sizeof(_lib.LossArgs) == 24 + 8 * (len(_lib._LOSS_IN) + len(_lib.LOSS_GRADS))
     n_ptr = len(_lib._COMPOSITE_PTRS_IN) + len(_lib._COMPOSITE_PTRS_OUT)
-    assert C.sizeof(_lib.CompositeArgs) == 40 + 8 * n_ptr
+    assert C.sizeof(_lib.FrustumArgs) == 16 + 16 + 16
+    assert C.sizeof(_lib.CompositeArgs) == 40 + 8 * n_ptr + C.sizeof(_lib.FrustumArgs)
 
 
 def test_layout_and_argument_validation_without_gpu():

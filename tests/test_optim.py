@@ -43,10 +43,21 @@ def _torch_adam(params, wd):
 @pytest.mark.parametrize("wd", [0.0, 0.01])
 def test_torch_op_twin_equals_torch_adam_on_cpu(wd):
     Twin = common.cpu_flat_adam()
-    got = _run(lambda ps, w: Twin(ps, lr=5e-4, eps=1e-8, weight_decay=w), torch.device("cpu"), wd)
+    got = _run(lambda ps, w: Twin(ps, lr=5e-4, eps=1e-8, weight_decay=w, decay_unused=True), torch.device("cpu"), wd)
     want = _run(_torch_adam, torch.device("cpu"), wd)
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
+
+
+def test_flat_adam_wants_weight_decay_of_unused_parameters_acknowledged():
+    class OnCpu(FlatAdam):                          # (the check comes before any device work)
+        @staticmethod
+        def _check_device(dev):
+            raise RuntimeError("stop here")
+    with pytest.raises(ValueError, match="decay_unused=True"):
+        OnCpu(_params(torch.device("cpu")), weight_decay=0.01)
+    with pytest.raises(RuntimeError, match="stop here"):
+        OnCpu(_params(torch.device("cpu")), weight_decay=0.01, decay_unused=True)
 
 
 def test_flat_adam_refuses_cpu_parameters():
@@ -58,7 +69,7 @@ def test_flat_adam_refuses_cpu_parameters():
 @pytest.mark.parametrize("wd", [0.0, 0.01])
 def test_native_adam_equals_torch_adam(wd, hip_lib):
     dev = torch.device("cuda:0")
-    got = _run(lambda ps, w: FlatAdam(ps, lr=5e-4, eps=1e-8, weight_decay=w), dev, wd)
+    got = _run(lambda ps, w: FlatAdam(ps, lr=5e-4, eps=1e-8, weight_decay=w, decay_unused=True), dev, wd)
     want = _run(_torch_adam, dev, wd)
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9)
@@ -102,3 +113,73 @@ def test_native_adam_views_state_and_graph_capture(hip_lib):
     other = FlatAdam(_params(dev), lr=5e-4)
     other.load_state_dict(sd)
     assert float(other.state[0]) == 3.0 and torch.equal(other.exp_avg, opt.exp_avg) and float(other.lr) == float(opt.lr)
+
+
+@pytest.mark.gpu
+def test_optimizer_state_round_trips_through_torch_adam(hip_lib):
+    """Resume a torch / reference run here and hand a run back: moments, step count and hyper-parameters convert both ways,
+    and the continued trajectories agree."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    grads = [[(torch.randn(*s, generator=g) * 0.1).to(dev) for s in SHAPES] for _ in range(5)]
+
+    def run(opt, params, which):
+        for i in which:
+            for p, gr in zip(params, grads[i]):
+                if p.grad is None:
+                    p.grad = gr.clone()
+                else:
+                    p.grad.copy_(gr)
+            opt.step()
+    # three steps in torch, then two here
+    pt = _params(dev)
+    ot = _torch_adam(pt, 0.0)
+    run(ot, pt, range(3))
+    pf = [torch.nn.Parameter(p.detach().clone()) for p in pt]
+    of = FlatAdam(pf, lr=1.0)                               # (hyper-parameters come from the state)
+    of.load_torch_state_dict(ot.state_dict())
+    assert float(of.state[0]) == 3.0 and abs(float(of.lr) - 5e-4) < 1e-9
+    run(of, pf, range(3, 5))
+    run(ot, pt, range(3, 5))
+    for a, b in zip(pf, pt):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol=1e-9)
+    # ... and back: a fresh torch Adam continues from this state
+    back = of.torch_state_dict()
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in pf]
+    o2 = _torch_adam(p2, 0.0)
+    o2.load_state_dict(back)
+    assert int(o2.state[p2[0]]["step"]) == 5
+    assert torch.equal(o2.state[p2[1]]["exp_avg"], back["state"][1]["exp_avg"])
+    # clones, not views of the flat buffers
+    keep = back["state"][0]["exp_avg"].clone()
+    of.exp_avg.add_(1.0)
+    assert torch.equal(back["state"][0]["exp_avg"], keep)
+
+
+@pytest.mark.gpu
+def test_trainer_checkpoint_is_detached_and_restores(hip_lib):
+    import scenes
+    import nsff_pl_amd as A
+    from nsff_pl_amd.training import NSFFTrainer
+    dev = "cuda:0"
+    cfg, meta, rays, ts, models, emb, _, _ = common.build_case("g3_nsff_train", A.NeRF, A.PosEmbedding)
+    Ks, Ps, _ = scenes.camera_buffers()
+    hp = dict(N_samples=cfg["N_samples"], N_importance=cfg["N_importance"], perturb=0, noise_std=0)
+    tr = NSFFTrainer(models, emb, scenes.N_FRAMES, hp, Ks, Ps, output_transient_flow=cfg["flow"]).to(dev)
+    tr.on_train_epoch_start(0)
+    batch = {k: v.to(dev) for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+    batch["rays"] = rays.to(dev)
+    tr.step(batch)
+    ck = tr.checkpoint()
+    assert {k.split(".")[0] for k in ck["state_dict"]} == {"nerf_fine", "nerf_coarse", "embedding_t"}
+    flat_lo, flat_hi = tr.optimizer.flat_param.data_ptr(), tr.optimizer.flat_param.data_ptr() + 4 * tr.optimizer.flat_param.numel()
+    assert all(not (flat_lo <= v.data_ptr() < flat_hi) for v in ck["state_dict"].values())     # clones, not views
+    at_ckpt = {k: v.clone() for k, v in ck["state_dict"].items()}
+    tr.step(batch); tr.step(batch)
+    assert all(torch.equal(ck["state_dict"][k], at_ckpt[k]) for k in at_ckpt)               # training did not touch it
+    after = tr.checkpoint()
+    assert any(not torch.equal(after["state_dict"][k], at_ckpt[k]) for k in at_ckpt)
+    tr.load_checkpoint(ck)
+    back = tr.checkpoint()
+    assert all(torch.equal(back["state_dict"][k], at_ckpt[k]) for k in at_ckpt)
+    assert int(back["optimizer"]["state"][0]["step"]) == 1 and tr.optimizer.in_place()
