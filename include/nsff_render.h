@@ -31,9 +31,9 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      17
+#define NSFF_ABI_VERSION      18
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
-#define NSFF_MAX_FREQS       16
+#define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
 
 /* Raw field record (what NeRF.forward returns per point, reference nerf.py:187-213):
@@ -56,9 +56,8 @@ typedef struct NsffModelDesc {
     int32_t has_flow;       /* transient_flow_fw / _bw heads present               */
     float   flow_scale;     /* 0.2                                                 */
     int32_t skip_mask;      /* several skip layers (the reference's `skips` list, nerf.py:34-40,163-167): bit l set = layer l
-                               reads [input | previous layer]; 0 = just `skip`.  Inference kernels take any subset of
-                               layers 1..D-1; the backward kernels (nsff_pack_weights_bwd / nsff_field_backward and the
-                               save_* forward) exactly one                                                  */
+                               reads [input | previous layer]; 0 = just `skip`.  Any subset of layers 1..D-1, in the
+                               inference kernels and in the training kernels alike                         */
 } NsffModelDesc;
 
 /* effective set of skip layers of a description */
@@ -140,17 +139,17 @@ typedef struct NsffFieldArgs {
     int32_t ld_emb;
     int32_t off_xyz, off_dir, off_a, off_t;  /* column offsets in x_emb, -1 = absent */
     float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
-    /* training forward (F16X3, input A, in_xyz <= 64, in_t <= 64, in_dir + in_a <= 128): also keep what
-     * nsff_field_backward / nsff_weight_grad need.  T = ceil(P/64) point tiles; any of them may be NULL.
-     * NS = 2*D+2 activation slots (+1 when use_viewdir):
+    /* training forward (F16X3, input A): also keep what nsff_field_backward / nsff_weight_grad need.  T = ceil(P/64) point
+     * tiles; any of them may be NULL.  NS = 2*D+2 activation slots (+1 when use_viewdir).  XR / t_row0 / SR: nsff_train_dims.
      *   save_acts : fp16 (NS, T, 4, 256, 16): slot l = ReLU output of static layer l, slot D = static_xyz_encoding_final
      *               output, slots D+1.. the same for the transient trunk, slot 2*D+2 = static_dir_encoding output (slots
      *               of a trunk that is not evaluated stay unwritten).  Inside a tile: [16-point group][neuron][point] =
      *               the fragment order of the weight-gradient GEMM (K = points);
-     *   save_xin  : fp16 (T, 4, 128, 16) trunk input, rows [0,in_xyz) xyz embedding, rows [64, 64+in_t) time code;
+     *   save_xin  : fp16 (T, 4, XR, 16) trunk input, rows [0,in_xyz) xyz embedding, rows [t_row0, t_row0+in_t) time code
+     *               (t_row0 = ceil64(in_xyz); XR = 128 or 256); rows from ceil64 of what the launch encodes up stay unwritten;
      *   save_masks: uint64 (NS, T, 256) ReLU sign bits of every trunk activation, in accumulator order;
-     *   save_side : fp16 (T, 4, 128, 16) [dir | a] input of static_dir_encoding (use_viewdir, static_mode 2), rows
-     *               [0, in_dir + in_a); rows from ceil64(in_dir + in_a) up stay unwritten.                         */
+     *   save_side : fp16 (T, 4, SR, 16) [dir | a] input of static_dir_encoding (use_viewdir, static_mode 2), rows
+     *               [0, in_dir + in_a); rows from ceil64(in_dir + in_a) up stay unwritten (SR = 128 or 256).          */
     void*   save_acts;
     void*   save_xin;
     void*   save_masks;
@@ -172,8 +171,11 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed,
  *   dhead: fp16 (2, T, 4, 32, 16) head pre-activation gradients * G, rows 0..15: static rgb(3) sigma(1);
  *          transient rgb(3) sigma(1) fw(3) bw(3); rows 16..31: the fp16 rounding remainder of rows 0..15 (the head
  *          weight / bias gradients are the sum of both halves);
- *   d_xin: fp32 (P, 128) true gradient w.r.t. the transient trunk input (rows as save_xin), or NULL;
- *   d_side: fp32 (P, 128) true gradient w.r.t. the [dir | a] input of static_dir_encoding (rows as save_side), or NULL. */
+ *   d_xin: fp32 (P, XR) true gradient w.r.t. the transient trunk input (rows as save_xin), or NULL;
+ *   d_side: fp32 (P, SR) true gradient w.r.t. the [dir | a] input of static_dir_encoding (rows as save_side), or NULL.
+ * nsff_train_dims: XR (xin_rows), t_row0 and SR (side_rows) of a model -- 128 unless ceil64(in_xyz) + ceil64(in_t) > 128
+ * (resp. in_dir + in_a > 128), then 256.  Any skip list the forward takes is differentiated (nerf.py:34-40,163-167). */
+int nsff_train_dims(const NsffModelDesc* desc, int32_t* xin_rows, int32_t* t_row0, int32_t* side_rows);
 int nsff_bwd_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
 int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params, void* packed, void* stream);
 
@@ -192,11 +194,12 @@ typedef struct NsffFieldBwdArgs {
 } NsffFieldBwdArgs;
 int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
 
-/* d_xin (P,128) of nsff_field_backward -> gradient w.r.t. the points (derivative of PosEmbedding, reference
+/* d_xin (P, xin_rows) of nsff_field_backward -> gradient w.r.t. the points (derivative of PosEmbedding, reference
  * nerf.py:17-30) and w.r.t. the per-ray time codes (sum over the ray's pts_per_ray consecutive points, the repeat of
  * rendering.py:168).  d_xyz (P,3) / d_t (n_rays, in_t): either may be NULL.  freqs_host: HOST array.                */
-int nsff_field_input_backward(const float* d_xin, const float* xyz, int64_t n_rays, int32_t pts_per_ray,
-                              const float* freqs_host, int32_t n_freqs, int32_t in_t, float* d_xyz, float* d_t, void* stream);
+int nsff_field_input_backward(const float* d_xin, int32_t xin_rows, int32_t t_row0, const float* xyz, int64_t n_rays,
+                              int32_t pts_per_ray, const float* freqs_host, int32_t n_freqs, int32_t in_t, float* d_xyz,
+                              float* d_t, void* stream);
 
 /* Batched weight-gradient GEMMs, K = points:  out_j = (1/G) * A_j^T . B_j over all point tiles, G as above.
  * A_j: fp16 fragment-major (T,4,a_rows,16), a_rows in {256, 32};  B_j: (T,4,b_rows,16), b_rows in {256, 128}.
@@ -244,14 +247,19 @@ int nsff_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 
 /* ---- N1: the training objective NeRFWLoss (reference losses.py:8-28, 31-171) on the render dict, NSFF train-mode
  * configuration (flows + disocclusion present, topk == 1, no per-ray weights, thickness == 1), every term reduced to
- * its scalar mean.  mode 1: terms[11] = col_l, disp_l, entropy_l, cross_entropy_l, flow_fw_l, flow_bw_l, pho_l, cyc_l,
- * reg_temp_sm_l, reg_min_l, reg_sp_sm_l (three launches; `stats` receives the batch statistics mode 2 re-uses).
- * mode 2: g_* = gradient of sum_k term_w[k] * term_k w.r.t. the tensor of the same name (one launch).
- * The two flow terms are masked means over the rays whose projection is valid (0 when there is none).
+ * its scalar.  mode 1: terms[11] = col_l, disp_l, entropy_l, cross_entropy_l, flow_fw_l, flow_bw_l, pho_l, cyc_l,
+ * reg_temp_sm_l, reg_min_l, reg_sp_sm_l (six launches; `stats`, `per_ray` and `coef` receive what mode 2 re-uses).
+ * mode 2: g_* = gradient of sum_k term_w[k] * term_k w.r.t. the tensor of the same name (two launches).
+ * Reduction of a term (losses.py:162-169): its per-ray values v_n (times weights[n] when given) over its population -- every
+ * ray, or for the two flow terms the M rays whose projection is valid -- are reduced to the mean of the K LARGEST,
+ * K = int(topk * M) for topk < 1, else K = M (the plain mean; 0 for an empty population).  `thickness` > 1 dilates the
+ * detached transient weights of cross_entropy_l with a 1 x thickness box filter, zero padded (losses.py:91-95).
  * n_rays <= 4096.  hyper (device): lambda_geo_d, lambda_geo_f, cross-entropy weight, lambda_reg, lambda_ent.      */
 typedef struct NsffLossArgs {
     int64_t n_rays; int32_t n_samples; int32_t n_keep;   /* n_keep = int(n_samples * z_far): samples the regularisers see */
     int32_t n_frames; int32_t max_t;
+    double  topk;                                        /* --topk (opt.py:80): >= 1 = plain means                 */
+    int32_t thickness; int32_t pad_;                     /* --thickness (opt.py:49), >= 1                          */
     /* render dict */
     const float* rgb_fine; const float* rgb_coarse;      /* (N,3); coarse pair may be NULL                         */
     const float* depth_fine; const float* depth_coarse;  /* (N)                                                    */
@@ -271,6 +279,11 @@ typedef struct NsffLossArgs {
     float* stats;                                        /* device, 24 floats: written by mode 1, read by mode 2   */
     float* terms;                                        /* OUT mode 1: 11 floats                                  */
     const float* term_w;                                 /* mode 2: 11 upstream scalars (device)                   */
+    const float* weights;                                /* (N) per-ray loss weights (hard sampling) or NULL       */
+    float* per_ray;                                      /* device (11, N): weighted per-ray values, mode 1 OUT; < 0 marks a
+                                                            ray outside a flow term's population                    */
+    float* coef;                                         /* device (11, N): d term_k / d v_n = weights[n] * [n selected] / K,
+                                                            mode 1 OUT, mode 2 IN                                   */
     float* g_rgb_fine; float* g_rgb_coarse; float* g_depth_fine; float* g_depth_coarse;
     float* g_t_weights; float* g_s_weights; float* g_xyz_fw; float* g_xyz_bw; float* g_rgb_fw; float* g_rgb_bw;
     float* g_xyzs_fw_bw; float* g_xyzs_bw_fw; float* g_xyzs_fw; float* g_xyzs_bw;

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 17
-MAX_FREQS = 16
+ABI_VERSION = 18
+MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
         -2: "NSFF_ERR_NULL (required pointer missing)",
@@ -117,7 +117,9 @@ LOSS_GRADS = ["g_rgb_fine", "g_rgb_coarse", "g_depth_fine", "g_depth_coarse", "g
 
 class LossArgs(C.Structure):
     _fields_ = ([("n_rays", C.c_int64), ("n_samples", C.c_int32), ("n_keep", C.c_int32), ("n_frames", C.c_int32),
-                 ("max_t", C.c_int32)] + [(n, _fp) for n in _LOSS_IN + LOSS_GRADS])
+                 ("max_t", C.c_int32), ("topk", C.c_double), ("thickness", C.c_int32), ("pad_", C.c_int32)]
+                + [(n, _fp) for n in _LOSS_IN] + [("weights", _fp), ("per_ray", _fp), ("coef", _fp)]
+                + [(n, _fp) for n in LOSS_GRADS])
 
 
 # name -> (restype, argtypes); also the list of symbols the header declares
@@ -145,8 +147,9 @@ _SIGNATURES = {
     "nsff_bwd_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
     "nsff_pack_weights_bwd": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp]),
     "nsff_field_backward": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldBwdArgs), _fp]),
-    "nsff_field_input_backward": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_int32, _fp,
-                                            _fp, _fp]),
+    "nsff_field_input_backward": (C.c_int, [_fp, C.c_int32, C.c_int32, _fp, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.c_int32,
+                                            C.c_int32, _fp, _fp, _fp]),
+    "nsff_train_dims": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "nsff_weight_grad_scratch": (C.c_int64, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32]),
     "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "nsff_weight_grad_accumulate": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, C.c_int64,
@@ -212,7 +215,7 @@ def _stream():
 def model_desc(model):
     """NsffModelDesc of a NeRF module.  The reference constructor (models/nerf.py:34-40) takes any width W and a
     list of skip layers; the gfx950 kernels are built for W = 256 trunks, 2..8 layers deep, with any set of skip layers
-    among 1..D-1 (inference; the backward kernels want exactly one: field_grad.why_unsupported) -- anything else is
+    among 1..D-1 (inference and training alike) -- anything else is
     refused here, by name."""
     if model.W != 256:
         raise RuntimeError(f"unsupported NeRF architecture: W={model.W} (the gfx950 field kernels tile W=256 trunks "
@@ -418,16 +421,24 @@ def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, 
            "nsff_field_backward")
 
 
-def field_input_backward(d_xin, xyz, pts_per_ray, freqs, in_t, want_xyz, want_t):
-    """(d_xyz (P,3) or None, d_t (n_rays, in_t) or None) from the (P,128) trunk-input gradient."""
-    P = d_xin.shape[0]
+def train_dims(model):
+    """(xin_rows, t_row0, side_rows) of the training buffers of `model` (include/nsff_render.h: nsff_train_dims)."""
+    desc = model_desc(model)
+    xr, t0, sr = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _check(load().nsff_train_dims(C.byref(desc), C.byref(xr), C.byref(t0), C.byref(sr)), "nsff_train_dims")
+    return xr.value, t0.value, sr.value
+
+
+def field_input_backward(d_xin, t_row0, xyz, pts_per_ray, freqs, in_t, want_xyz, want_t):
+    """(d_xyz (P,3) or None, d_t (n_rays, in_t) or None) from the (P, xin_rows) trunk-input gradient."""
+    P, xin_rows = d_xin.shape
     n_rays = P // pts_per_ray
     d_xyz = torch.empty(P, 3, device=d_xin.device) if want_xyz else None
     d_t = torch.empty(n_rays, in_t, device=d_xin.device) if want_t else None
     f = [float(v) for v in freqs]
     arr = (C.c_float * max(len(f), 1))(*f)
-    _check(load().nsff_field_input_backward(_ptr(d_xin), _ptr(xyz), n_rays, int(pts_per_ray), arr, len(f), int(in_t),
-                                            _ptr(d_xyz), _ptr(d_t), _stream()), "nsff_field_input_backward")
+    _check(load().nsff_field_input_backward(_ptr(d_xin), int(xin_rows), int(t_row0), _ptr(xyz), n_rays, int(pts_per_ray), arr,
+                                            len(f), int(in_t), _ptr(d_xyz), _ptr(d_t), _stream()), "nsff_field_input_backward")
     return d_xyz, d_t
 
 
@@ -479,12 +490,15 @@ def composite_backward(n_rays, n_samples, has_transient, flow_mode, noise_std, *
     _check(load().nsff_composite_backward(C.byref(a), _stream()), "nsff_composite_backward")
 
 
-def nerfw_loss(mode, n_rays, n_samples, n_keep, n_frames, max_t, **tensors):
-    """mode 1: term sums into tensors['terms']; mode 2: gradients into tensors['g_*'] (include/nsff_render.h)."""
-    a = LossArgs(n_rays=int(n_rays), n_samples=int(n_samples), n_keep=int(n_keep), n_frames=int(n_frames), max_t=int(max_t))
+def nerfw_loss(mode, n_rays, n_samples, n_keep, n_frames, max_t, topk=1.0, thickness=1, **tensors):
+    """mode 1: the terms into tensors['terms']; mode 2: gradients into tensors['g_*'] (include/nsff_render.h)."""
+    a = LossArgs(n_rays=int(n_rays), n_samples=int(n_samples), n_keep=int(n_keep), n_frames=int(n_frames), max_t=int(max_t),
+                 topk=float(topk), thickness=int(thickness))
     for k, v in tensors.items():
         if v is None:
             continue
+        if not torch.is_tensor(v):
+            raise TypeError(f"nerfw_loss: {k} must be a tensor")
         if v.dtype == torch.int64:
             assert v.is_cuda and v.is_contiguous()
             setattr(a, k, v.data_ptr())

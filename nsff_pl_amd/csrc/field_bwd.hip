@@ -40,7 +40,7 @@ namespace {
 
 constexpr int LDH = 264;           // halfs per LDS row (528 B: conflict-free ds_read_b128)
 constexpr int NT = 2;              // 32-point column tiles per workgroup (64 points)
-constexpr int MAX_BSTEPS = 24;
+constexpr int MAX_BSTEPS = 40;
 #ifndef BWD_STORE_INTERLEAVE
 #define BWD_STORE_INTERLEAVE 1     // the HBM copy of a step's tile rides inside the next step's GEMM (see the kernel)
 #endif
@@ -55,24 +55,29 @@ struct TrunkLayoutB {
     uint32_t head;                       // rows = *_final outputs, K = head rows (16, padded to 64)
     uint32_t fin;                        // rows = last trunk activation, K = 256
     uint32_t layer[NSFF_MAX_LAYERS];     // l = 1..D-1: rows = activation of layer l-1, K = 256 (pre-activations of l)
-    uint32_t x0, xskip;                  // rows = trunk input (128 used), K = 256 (pre-activations of layer 0 / skip)
+    uint32_t x0;                         // rows = trunk input (xin_rows used), K = 256 (pre-activations of layer 0)
+    uint32_t xskip[NSFF_MAX_LAYERS];     // the same for every skip layer l (NSFF_NONE elsewhere)
 };
 struct LayoutB {
     TrunkLayoutB st, tr;
     uint32_t s_sigma;                    // 256 fp32: static_sigma.weight (rank-1 term of the static head)
     uint32_t dir_h, dir_side;            // use_viewdir: static_dir_encoding transposed -- rows = *_final outputs (256) /
-                                         // rows = [dir | a] inputs (128 used), K = 256 (its pre-activations)
+                                         // rows = [dir | a] inputs (side_rows used), K = 256 (its pre-activations)
     uint32_t total;
+    // trunk-input rows as the forward saves them and d_xin returns them: [0, k0s) position embedding, [k0s, k0s + kt) time
+    // code, padded to xin_rows = 128 or 256 (the row counts the weight-gradient GEMM is built for); side_rows likewise
+    int32_t k0s, xin_rows, side_rows;
 };
 
-inline int skip_of(const NsffModelDesc& d) { return __builtin_ctz(nsff_skip_layers(&d) | (1u << 31)); }   // the one skip layer
+inline bool is_skip(const NsffModelDesc& d, int l) { return (nsff_skip_layers(&d) >> l) & 1u; }
 
 inline int make_layout_b(const NsffModelDesc& d, LayoutB& L) {
     NsffLayoutH3 f;
     const int rc = nsff_make_layout_h3(d, f);
     if (rc) return rc;
-    if (f.k0s != 64 || f.kt > 64 || f.side_k > 128) return NSFF_ERR_INVALID;
-    if (__builtin_popcount(nsff_skip_layers(&d)) != 1) return NSFF_ERR_INVALID;        // the backward chain has one stash tile
+    L.k0s = (int32_t)f.k0s;
+    L.xin_rows = (f.k0s + f.kt) <= 128 ? 128 : 256;          // (k0s + kt <= 256 is the forward layout's own limit)
+    L.side_rows = f.side_k <= 128 ? 128 : 256;
     uint32_t off = 0;
     auto take = [&](uint32_t halfs) { uint32_t o = off; off += halfs / 2; return o; };
     auto trunk = [&](TrunkLayoutB& T, bool xparts) {
@@ -80,8 +85,12 @@ inline int make_layout_b(const NsffModelDesc& d, LayoutB& L) {
         T.fin = take(256 * 256);
         for (int l = 0; l < NSFF_MAX_LAYERS; ++l) T.layer[l] = NSFF_NONE;
         for (int l = 1; l < d.D; ++l) T.layer[l] = take(256 * 256);
-        T.x0 = T.xskip = NSFF_NONE;
-        if (xparts) { T.x0 = take(256 * 256); T.xskip = take(256 * 256); }
+        T.x0 = NSFF_NONE;
+        for (int l = 0; l < NSFF_MAX_LAYERS; ++l) T.xskip[l] = NSFF_NONE;
+        if (xparts) {
+            T.x0 = take(256 * 256);
+            for (int l = 1; l < d.D; ++l) if (is_skip(d, l)) T.xskip[l] = take(256 * 256);
+        }
     };
     trunk(L.st, false);
     L.tr = TrunkLayoutB{};
@@ -101,7 +110,7 @@ struct PackSegB {
     int32_t kind;            // 0 flat fp32 copy (count = nks), 1 transposed Linear, 2 heads, 3 trunk-input rows, 4 side-input rows
     int32_t ld, c0;          // kind 1: Wt[k][n] = W[n][c0 + k];  kind 3: W[n][xmap(k)]
     int32_t nks;
-    int32_t in_xyz, in_t;
+    int32_t in_xyz, in_t, k0s;
 };
 constexpr int PACKB_BATCH = 32;
 struct PackArgsB { PackSegB seg[PACKB_BATCH]; uint32_t* dst; };
@@ -131,7 +140,7 @@ __global__ void pack_kernel_b(const PackArgsB a) {
         } else {
             int c = -1;
             if (k < s.in_xyz) c = k;
-            else if (k >= 64 && k < 64 + s.in_t) c = s.in_xyz + (k - 64);
+            else if (k >= s.k0s && k < s.k0s + s.in_t) c = s.in_xyz + (k - s.k0s);
             if (c >= 0) v = s.src[0][(long long)n * s.ld + c];
         }
         out[t] = (_Float16)v;
@@ -141,7 +150,7 @@ __global__ void pack_kernel_b(const PackArgsB a) {
 
 // ---- K1 ---------------------------------------------------------------------------------------
 enum { EPI_KEEP = 0, EPI_LINEAR = 1, EPI_MASK = 2, EPI_DXIN = 3 };
-enum { F_CONTINUE = 1, F_STASH = 2, F_SIGMA = 4, F_FROM_STASH = 8, F_HALF_ROWS = 16, F_TO_SIDE = 32 };
+enum { F_CONTINUE = 1, F_STASH = 2, F_SIGMA = 4, F_FROM_STASH = 8, F_HALF_ROWS = 16, F_TO_SIDE = 32, F_ACCUM = 64 };
 struct BStep {
     uint32_t w_off;
     uint8_t nks, epi, slot, flags;     // slot: dpre slot written (EPI_LINEAR / EPI_MASK); mask slot = slot too
@@ -163,6 +172,7 @@ struct BKArgs {
     int D;
     int t_head_rows;                   // 4 or 10
     float flow_scale;
+    int xin_rows, side_rows;           // row strides of d_xin / d_side (128 or 256)
 };
 
 struct WF1 { h8 w[2]; };
@@ -417,7 +427,9 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
         if (st.epi == EPI_KEEP) continue;
         if (st.epi == EPI_DXIN) {
             float* dst_in = (st.flags & F_TO_SIDE) ? a.d_side : a.d_xin;
-            if (wave < 2 && dst_in != nullptr) {
+            const int ld_in = (st.flags & F_TO_SIDE) ? a.side_rows : a.xin_rows;
+            const bool accum = st.flags & F_ACCUM;          // a skip layer's share arrived earlier: this one is added to it
+            if ((!(st.flags & F_HALF_ROWS) || wave < 2) && dst_in != nullptr) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -430,7 +442,9 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                                 float4 v;
                                 v.x = acc[mt][nt][4 * q + 0] * inv; v.y = acc[mt][nt][4 * q + 1] * inv;
                                 v.z = acc[mt][nt][4 * q + 2] * inv; v.w = acc[mt][nt][4 * q + 3] * inv;
-                                *reinterpret_cast<float4*>(dst_in + (p0 + pt) * 128 + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5)) = v;
+                                float4* dp = reinterpret_cast<float4*>(dst_in + (p0 + pt) * ld_in + 64 * wave + 32 * mt + 8 * q + 4 * (lane >> 5));
+                                if (accum) { const float4 o = *dp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }   // (rows owned by this workgroup)
+                                *dp = v;
                             }
                         }
                     }
@@ -481,16 +495,18 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
 
 
 // ---- d(trunk input) -> d(points), d(per-ray time codes) -------------------------------------------------------
-// One workgroup per ray: the ray's d_xin rows (fp32 [point][128]: columns [0,in_xyz) position embedding, [64,64+in_t)
-// time code) pass through LDS in 64-point chunks; d_xyz = derivative of PosEmbedding (reference nerf.py:17-30:
-// [x, sin(f0 x), cos(f0 x), ...]), d_t = sum over the ray's points (the code is repeated per sample, rendering.py:168).
+// One workgroup per ray: the ray's d_xin rows (fp32 [point][XR]: columns [0,in_xyz) position embedding, [t0, t0 + in_t)
+// time code; XR = 128 or 256) pass through LDS in 64-point chunks; d_xyz = derivative of PosEmbedding (reference
+// nerf.py:17-30: [x, sin(f0 x), cos(f0 x), ...]), d_t = sum over the ray's points (the code is repeated per sample,
+// rendering.py:168).
 struct InArgs {
     const float* d_xin; const float* xyz; float* d_xyz; float* d_t;
-    long long n_rays; int pts_per_ray, n_freqs, in_t;
+    long long n_rays; int pts_per_ray, n_freqs, in_t, t0;
     float freqs[NSFF_MAX_FREQS];
 };
+template <int XR>
 __global__ __launch_bounds__(256) void field_input_bwd_kernel(const InArgs a) {
-    constexpr int LDI = 132;                               // floats per LDS row (128 + 4: rows 16 B aligned, stride odd in 16-B units)
+    constexpr int LDI = XR + 4;                            // floats per LDS row (rows 16 B aligned, stride odd in 16-B units)
     __shared__ __attribute__((aligned(16))) float sD[64 * LDI];
     const long long ray = blockIdx.x;
     const int S = a.pts_per_ray, tid = threadIdx.x;
@@ -499,10 +515,10 @@ __global__ __launch_bounds__(256) void field_input_bwd_kernel(const InArgs a) {
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int cnt = S - s0 < 64 ? S - s0 : 64;
         __syncthreads();
-        for (int i = tid; i < cnt * 32; i += 256) {         // float4 chunks, coalesced
-            const int r = i >> 5, c4 = i & 31;
+        for (int i = tid; i < cnt * (XR / 4); i += 256) {   // float4 chunks, coalesced
+            const int r = i / (XR / 4), c4 = i % (XR / 4);
             *reinterpret_cast<float4*>(sD + r * LDI + 4 * c4) =
-                *reinterpret_cast<const float4*>(a.d_xin + (p_ray + s0 + r) * 128 + 4 * c4);
+                *reinterpret_cast<const float4*>(a.d_xin + (p_ray + s0 + r) * XR + 4 * c4);
         }
         __syncthreads();
         if (a.d_xyz != nullptr && tid < 192) {
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(256) void field_input_bwd_kernel(const InArgs a) {
             }
         }
         if (a.d_t != nullptr && tid < a.in_t) {
-            for (int r = 0; r < cnt; ++r) tsum += sD[r * LDI + 64 + tid];
+            for (int r = 0; r < cnt; ++r) tsum += sD[r * LDI + a.t0 + tid];
         }
     }
     if (a.d_t != nullptr && tid < a.in_t) a.d_t[ray * a.in_t + tid] = tsum;
@@ -823,14 +839,15 @@ int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params,
         PackSegB s{}; s.src[0] = w; s.dst = dst; s.kind = 1; s.ld = ld; s.c0 = c0; s.nks = 16; segs.push_back(s);
     };
     auto xrows = [&](const float* w, uint32_t dst, int ld, int in_t) {
-        PackSegB s{}; s.src[0] = w; s.dst = dst; s.kind = 3; s.ld = ld; s.nks = 16; s.in_xyz = d.in_xyz; s.in_t = in_t; segs.push_back(s);
+        PackSegB s{}; s.src[0] = w; s.dst = dst; s.kind = 3; s.ld = ld; s.nks = 16; s.in_xyz = d.in_xyz; s.in_t = in_t; s.k0s = L.k0s;
+        segs.push_back(s);
     };
     auto trunk = [&](int t, const TrunkLayoutB& T, int in_t) {
         const int in = d.in_xyz + in_t;
         for (int l = 0; l < d.D; ++l) {
             const float* w = params[pi]; pi += 2;
             if (l == 0) { if (T.x0 != NSFF_NONE) xrows(w, T.x0, in, in_t); }
-            else if (l == skip_of(d)) { lin(w, T.layer[l], in + NSFF_W, in); if (T.xskip != NSFF_NONE) xrows(w, T.xskip, in + NSFF_W, in_t); }
+            else if (is_skip(d, l)) { lin(w, T.layer[l], in + NSFF_W, in); if (T.xskip[l] != NSFF_NONE) xrows(w, T.xskip[l], in + NSFF_W, in_t); }
             else lin(w, T.layer[l], NSFF_W, 0);
         }
         const float* wf = params[pi]; pi += 2;
@@ -902,6 +919,7 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     k.d_side = d.use_viewdir ? g.d_side : nullptr;
     k.n_points = g.n_points; k.n_tiles = (g.n_points + 63) / 64;
     k.D = d.D; k.t_head_rows = d.has_flow ? 10 : 4; k.flow_scale = d.flow_scale;
+    k.xin_rows = L.xin_rows; k.side_rows = L.side_rows;
     if (k.n_tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
     int n = 0;
     auto push = [&](uint32_t w, int nks, int epi, int slot, int flags) {
@@ -915,17 +933,38 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
         if (t == 0 && d.use_viewdir) {
             // static_rgb reads static_dir_encoding = relu(W_dir . [*_final | dir | a]) (nerf.py:183-186)
             push(T.head, 4, EPI_MASK, 2 * d.D + 2, 0);
-            if (k.d_side != nullptr) push(L.dir_side, 16, EPI_DXIN, 0, F_HALF_ROWS | F_TO_SIDE);
+            if (k.d_side != nullptr) push(L.dir_side, 16, EPI_DXIN, 0, (L.side_rows == 128 ? F_HALF_ROWS : 0) | F_TO_SIDE);
             push(L.dir_h, 16, EPI_LINEAR, base + d.D, 0);
         } else {
             push(T.head, 4, EPI_LINEAR, base + d.D, 0);
         }
-        push(T.fin, 16, EPI_MASK, base + d.D - 1, (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == skip_of(d) && want_xin) ? F_STASH : 0));
-        for (int l = d.D - 1; l >= 1; --l)
-            push(T.layer[l], 16, EPI_MASK, base + l - 1, (l - 1 == skip_of(d) && want_xin) ? F_STASH : 0);
+        // Trunk-input gradient (dynamic trunk, want_xin): d_xin = Wx_0^T dpre_0 + sum over skip layers l of Wx_l^T dpre_l.
+        // The LOWEST skip layer's tile is stashed in LDS and multiplied last, into the accumulators layer 0 leaves (no
+        // memory traffic -- the reference's one-skip architecture); any further skip layer is multiplied right after its
+        // tile appears and goes to d_xin through memory (first one stores, later ones add).
+        const int xhalf = L.xin_rows == 128 ? F_HALF_ROWS : 0;
+        int stash_l = -1;
+        if (want_xin) for (int l = 1; l < d.D; ++l) if (is_skip(d, l)) { stash_l = l; break; }
+        bool wrote = false;
+        auto after_tile = [&](int l) {                       // the tile of layer l's pre-activation gradient just appeared
+            if (want_xin && l >= 1 && is_skip(d, l) && l != stash_l) {
+                push(T.xskip[l], 16, EPI_DXIN, 0, xhalf | (wrote ? F_ACCUM : 0));
+                wrote = true;
+            }
+        };
+        push(T.fin, 16, EPI_MASK, base + d.D - 1, (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == stash_l) ? F_STASH : 0));
+        after_tile(d.D - 1);
+        for (int l = d.D - 1; l >= 1; --l) {
+            push(T.layer[l], 16, EPI_MASK, base + l - 1, (l - 1 == stash_l) ? F_STASH : 0);
+            after_tile(l - 1);
+        }
         if (want_xin) {
-            push(T.x0, 16, EPI_KEEP, 0, F_HALF_ROWS);
-            push(T.xskip, 16, EPI_DXIN, 0, F_HALF_ROWS | F_CONTINUE | F_FROM_STASH);
+            if (stash_l >= 0) {
+                push(T.x0, 16, EPI_KEEP, 0, xhalf);
+                push(T.xskip[stash_l], 16, EPI_DXIN, 0, xhalf | F_CONTINUE | F_FROM_STASH | (wrote ? F_ACCUM : 0));
+            } else {
+                push(T.x0, 16, EPI_DXIN, 0, xhalf | (wrote ? F_ACCUM : 0));
+            }
         }
     };
     if (g.static_mode) trunk(L.st, 0, false);
@@ -937,19 +976,33 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     return nsff_launch_status();
 }
 
-int nsff_field_input_backward(const float* d_xin, const float* xyz, int64_t n_rays, int32_t pts_per_ray,
+int nsff_field_input_backward(const float* d_xin, int32_t xin_rows, int32_t t_row0, const float* xyz, int64_t n_rays, int32_t pts_per_ray,
                               const float* freqs_host, int32_t n_freqs, int32_t in_t, float* d_xyz, float* d_t, void* stream) {
-    if (n_rays < 0 || pts_per_ray < 1 || n_freqs < 0 || n_freqs > NSFF_MAX_FREQS || in_t < 0 || in_t > 64) return NSFF_ERR_INVALID;
+    if (n_rays < 0 || pts_per_ray < 1 || n_freqs < 0 || n_freqs > NSFF_MAX_FREQS || in_t < 0) return NSFF_ERR_INVALID;
+    if ((xin_rows != 128 && xin_rows != 256) || t_row0 < 0 || t_row0 + in_t > xin_rows || 3 + 6 * n_freqs > xin_rows) return NSFF_ERR_INVALID;
     if (n_rays == 0 || (!d_xyz && !d_t)) return NSFF_OK;
     if (!d_xin || (d_xyz && (!xyz || !freqs_host))) return NSFF_ERR_NULL;
     if ((uintptr_t)d_xin & 15) return NSFF_ERR_ALIGN;
     if (n_rays > 0x7fffffffLL) return NSFF_ERR_INVALID;
     InArgs a{};
     a.d_xin = d_xin; a.xyz = xyz; a.d_xyz = d_xyz; a.d_t = d_t;
-    a.n_rays = n_rays; a.pts_per_ray = pts_per_ray; a.n_freqs = n_freqs; a.in_t = in_t;
+    a.n_rays = n_rays; a.pts_per_ray = pts_per_ray; a.n_freqs = n_freqs; a.in_t = in_t; a.t0 = t_row0;
     for (int i = 0; i < n_freqs; ++i) a.freqs[i] = freqs_host[i];
-    hipLaunchKernelGGL(field_input_bwd_kernel, dim3((unsigned)n_rays), dim3(256), 0, (hipStream_t)stream, a);
+    if (xin_rows == 128) hipLaunchKernelGGL(field_input_bwd_kernel<128>, dim3((unsigned)n_rays), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(field_input_bwd_kernel<256>, dim3((unsigned)n_rays), dim3(256), 0, (hipStream_t)stream, a);
     return nsff_launch_status();
+}
+
+// Row geometry of the training buffers of a model (what save_xin / save_side / d_xin / d_side and the weight-gradient jobs of
+// their layers are sized by): trunk-input rows [0, t_row0) position embedding, [t_row0, ...) time code, xin_rows = 128 or 256 in
+// total; side_rows likewise for the [dir | a] input of static_dir_encoding.
+int nsff_train_dims(const NsffModelDesc* desc, int32_t* xin_rows, int32_t* t_row0, int32_t* side_rows) {
+    if (!desc || !xin_rows || !t_row0 || !side_rows) return NSFF_ERR_NULL;
+    LayoutB L;
+    const int rc = make_layout_b(*desc, L);
+    if (rc) return rc;
+    *xin_rows = L.xin_rows; *t_row0 = L.k0s; *side_rows = L.side_rows;
+    return NSFF_OK;
 }
 
 // Split-K factor of every job.  The two GEMM classes run one workgroup per CU (their LDS ring takes 96-128 KiB), so a

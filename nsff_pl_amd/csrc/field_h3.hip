@@ -97,6 +97,7 @@ struct H3KArgs {
     unsigned long long* save_masks;   // (slots, tiles, 256 threads) ReLU sign bits in accumulator order, or null
     _Float16* save_side;       // (tiles, 4 ks, 128 rows, 16 pts) fp16 [dir | a] input of static_dir_encoding, or null
     long long save_stride;     // halfs per activation slot = tiles * 64 * 256
+    int xin_rows, side_rows;   // rows of a save_xin / save_side tile (128 or 256)
     long long n_tiles;
     long long n_points;
     int pts_per_ray;
@@ -217,9 +218,15 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW
 // `side(j)` runs once per group of four k-steps (j = 0, 1, ...) right behind the group's last weight refill and
 // `side_rest(j)` once at the end: the training forward's HBM copy of the very tile this GEMM reads (see the kernel).
 struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
+// `next` (or null): the weight stream this wave multiplies NEXT (the following segment, or its share of a head tile); its
+// first four k-steps refill the ring slots of the last four k-steps as those are consumed, so the stream never stops at a
+// layer boundary (requested in one burst after the GEMM, 8 waves x 12 loads of 1 KiB serialise on the CU's 64 B/clk
+// vector-memory path for ~1.5k cycles in front of the barrier -- round-3 stamps).  Returns the pointer of k-step 4 of `next`.
+// NEXT_STRIDE: uint4s per k-step of that stream (256 trunk segments, 128 head tiles).
 template <int NT, int MTW, bool SPLIT, class Side = NoSide, class Rest = NoSide>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLIT>& ring, const uint4* __restrict__ wp,
-                                         BRows<NT> b, int nks, Side&& side = Side{}, Rest&& side_rest = Rest{}) {
+__device__ __forceinline__ const uint4* gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLIT>& ring, const uint4* __restrict__ wp,
+                                                 BRows<NT> b, int nks, Side&& side = Side{}, Rest&& side_rest = Rest{},
+                                                 const uint4* __restrict__ next = nullptr, int next_stride = 256) {
     // nks is a multiple of 4 (every K-segment is zero-padded to 64 columns): no per-step branches.
     XFrag<NT, SPLIT> x0, x1;
     load_x<NT, SPLIT>(x0, b, 0);
@@ -248,14 +255,28 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLI
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { b.h[nt] += 64; if constexpr (SPLIT) b.l[nt] += 64; }      // four k-steps of 16 halfs
     }
+    // (the refill of a slot is pinned behind the MFMAs that read it, like in the loop)
+    auto refill = [&](WFrag<MTW, SPLIT>& f) __attribute__((always_inline)) {
+        if (next != nullptr) {
+            const uint4* __restrict__ p = next;
+            load_w(f, p);                                       // (advances by a trunk segment's 256)
+            next += next_stride;
+        }
+        H3_PIN();
+    };
     load_x<NT, SPLIT>(x1, b, 1);
     mma_step<NT, MTW>(acc, ring.r[0], x0);
+    refill(ring.r[0]);
     load_x<NT, SPLIT>(x0, b, 2);
     mma_step<NT, MTW>(acc, ring.r[1], x1);
+    refill(ring.r[1]);
     load_x<NT, SPLIT>(x1, b, 3);
     mma_step<NT, MTW>(acc, ring.r[2], x0);
+    refill(ring.r[2]);
     mma_step<NT, MTW>(acc, ring.r[3], x1);
+    refill(ring.r[3]);
     if constexpr (!__is_same(Rest, NoSide)) side_rest(j);
+    return next;
 }
 
 // bias of row (neuron) 64w + 32mt + 8q + 4h + e, e = 0..3 -- loaded early, applied by acc_init
@@ -630,52 +651,84 @@ enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
 
 // Narrow heads as one zero-padded 32-row MFMA tile per 32 points.  The workgroup's NW waves split the NPT point
 // tiles AND (when NW > NPT) the K range: wave w takes point tile w % NPT and k-steps [16/KS * (w / NPT), ...), the
-// partial sums of the upper k ranges travel through `sRed` (one barrier).  One accumulator chain: separate chains per
-// product term shorten the dependent-MFMA latency but cost 14 spilled VGPRs (scratch = HBM traffic) -- measured 1.3 % slower.
+// partial sums of the upper k ranges travel through `sRed` (one barrier).
+// `pre` (use_pre): the wave's first head k-steps, already requested into the weight ring by the tail of the last GEMM
+// (gemm_seg `next`) -- four with 32-neuron waves, all eight with 64-neuron waves (a ring slot holds two head k-steps
+// there); `wrest` then points at the first k-step not in the ring.  With 32-neuron waves (registers to spare: no spills)
+// the three product terms run as three independent accumulator chains; one chain makes every MFMA wait for the one
+// before it (24 x the full MFMA latency), which the 64-neuron tilings accept: three chains spill 14 VGPRs there.
 // out row = (r&3) + 8*(r>>2) + 4*(lane>>5); only r < 8 (rows < 16) can be live.
-template <int NPT, int NW, bool SPLIT>
+template <int NPT, int NW, bool SPLIT, int MTW>
 __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, float* sRed, const uint32_t* __restrict__ pk,
                                       uint32_t w_off, uint32_t b_off, int n_rows, unsigned kinds, float flow_scale,
-                                      float* sRaw, int slot0, int wave, int lane) {
+                                      float* sRaw, int slot0, int wave, int lane,
+                                      const WRing<MTW, SPLIT>& pre, bool use_pre, const uint4* __restrict__ wrest) {
     constexpr int KS = NW / NPT;                 // k-splits (waves beyond NPT * KS idle)
     constexpr int NK = 16 / KS;                  // k-steps per wave
     static_assert(KS == 1 || KS == 2, "heads: 1 or 2 waves per point tile");
     const int pt = wave % NPT, kh = wave / NPT;
     if (KS == 1 && wave >= NPT) return;
-    f32x16 acc0;
+    constexpr int CH = (SPLIT && MTW == 1) ? 3 : 1;      // accumulator chains
+    f32x16 acc0[CH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[c][r] = 0.f;
     const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane + kh * NK * 2 * 64;
     const _Float16* bh = sXh + (32 * pt + (lane & 31)) * LDH + 8 * (lane >> 5) + kh * NK * 16;
     const _Float16* bl = sXl + (32 * pt + (lane & 31)) * LDH + 8 * (lane >> 5) + kh * NK * 16;
     // weights are requested eight k-steps (8 KiB per wave) at a time, ahead of their MFMAs
 #pragma unroll
     for (int half = 0; half < NK / 8; ++half) {
-        uint4 wr[8][2];
+        h8 whv[8], wlv[8];
+        bool have = false;
+        if constexpr (SPLIT) {
+            if (half == 0 && use_pre) {
+                have = true;
+                if constexpr (MTW == 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            wr[j][0] = w[((half * 8 + j) * 2 + 0) * 64];
-            wr[j][1] = w[((half * 8 + j) * 2 + 1) * 64];
+                    for (int j = 0; j < 4; ++j) { whv[j] = pre.r[j].wh[0]; wlv[j] = pre.r[j].wl[0]; }
+#pragma unroll
+                    for (int j = 4; j < 8; ++j) {
+                        whv[j] = __builtin_bit_cast(h8, wrest[((j - 4) * 2 + 0) * 64]);
+                        wlv[j] = __builtin_bit_cast(h8, wrest[((j - 4) * 2 + 1) * 64]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        whv[2 * j] = pre.r[j].wh[0]; wlv[2 * j] = pre.r[j].wl[0];
+                        whv[2 * j + 1] = pre.r[j].wh[1]; wlv[2 * j + 1] = pre.r[j].wl[1];
+                    }
+                }
+            }
+        }
+        if (!have) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                whv[j] = __builtin_bit_cast(h8, w[((half * 8 + j) * 2 + 0) * 64]);
+                wlv[j] = __builtin_bit_cast(h8, w[((half * 8 + j) * 2 + 1) * 64]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ks = half * 8 + j;
-            const h8 wh = __builtin_bit_cast(h8, wr[j][0]);
-            const h8 wl = __builtin_bit_cast(h8, wr[j][1]);
             const h8 xh = lds_h8(bh + ks * 16);
-            acc0 = MFMA_H(wl, xh, acc0);               // the narrow heads keep the weights' lo halfs in both modes
+            acc0[0] = MFMA_H(wlv[j], xh, acc0[0]);         // the narrow heads keep the weights' lo halfs in both modes
             if constexpr (SPLIT) {
                 const h8 xl = lds_h8(bl + ks * 16);
-                acc0 = MFMA_H(wh, xl, acc0);
-                acc0 = MFMA_H(wh, xh, acc0);
+                acc0[CH > 1 ? 1 : 0] = MFMA_H(whv[j], xl, acc0[CH > 1 ? 1 : 0]);
+                acc0[CH > 1 ? 2 : 0] = MFMA_H(whv[j], xh, acc0[CH > 1 ? 2 : 0]);
             } else {
-                acc0 = MFMA_H(wh, xh, acc0);
+                acc0[0] = MFMA_H(whv[j], xh, acc0[0]);
             }
         }
     }
     float part[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) part[r] = acc0[r];
+    for (int r = 0; r < 8; ++r) {
+        part[r] = acc0[0][r];
+        if constexpr (CH > 1) part[r] = (part[r] + acc0[1][r]) + acc0[2][r];
+    }
     if constexpr (KS == 2) {
         if (kh == 1) {
 #pragma unroll
@@ -789,6 +842,17 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             pend_dst = nullptr;
         }
     };
+    // static sigma reads the last trunk activation, before *_final (nerf.py:169);
+    // dynamic rows: rgb(3) sigmoid, sigma raw, fw(3)/bw(3) = flow_scale*tanh (nerf.py:197-208)
+    struct HeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
+    auto head_sel = [&](int head) {
+        HeadSel h{a.L.s_sigma_w, a.L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
+        if (head == HEAD_S_RGB) h = HeadSel{a.L.s_rgb_w, a.L.s_rgb_b, 3, 0, 0x15u};
+        if (head == HEAD_S_FOLD) h = HeadSel{a.L.s_fold_w, a.L.s_fold_b, 4, 0, 0x15u};
+        if (head == HEAD_T) h = HeadSel{a.L.t_head_w, a.L.t_head_b, (int)a.L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
+        if (head == HEAD_T_FOLD) h = HeadSel{a.L.t_fold_w, a.L.t_fold_b, (int)a.L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
+        return h;
+    };
     H3_SPAN(0);
     const H3Step s0 = step_at(s_begin);
     const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
@@ -809,20 +873,33 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             __syncthreads();
             if constexpr (SAVE) {
                 if (st.pre == PRE_SIDE) {
-                    if (a.save_side != nullptr) pend_set(a.save_side + tile64 * (64 * 128), 128, (int)a.L.side_k);
+                    if (a.save_side != nullptr) pend_set(a.save_side + tile64 * (64 * a.side_rows), a.side_rows, (int)a.L.side_k);
                 } else if (a.save_xin != nullptr && st.bias_off != NSFF_NONE && (st.pre == PRE_INPUT_T || a.transient_mode == 0)) {
-                    // trunk input of layer 0: columns [0,64) xyz embedding, [64,128) time code (zero when absent);
-                    // static only: rows 64.. stay unwritten
-                    pend_set(a.save_xin + tile64 * (64 * 128), 128, st.pre == PRE_INPUT_T ? 128 : 64);
+                    // trunk input of layer 0: columns [0, k0s) xyz embedding, [k0s, k0s + kt) time code; rows past what this
+                    // launch encodes stay unwritten (the caller zeroes the buffer then)
+                    pend_set(a.save_xin + tile64 * (64 * a.xin_rows), a.xin_rows,
+                             (int)a.L.k0s + (st.pre == PRE_INPUT_T ? (int)a.L.kt : 0));
                 }
             }
         }
         H3_STAMP(1);
         if (st.bias_off != NSFF_NONE) acc_init<NT, MTW>(acc, br);
+        // A step with output heads: this wave's share of the head tile is what it multiplies next -- the GEMM's last four
+        // k-steps request it into the ring slots they free (gemm_seg `next`), so the head starts with its weights on chip
+        // (stamps: heads + records 16.2k -> 11.9k cycles per trunk).  The same hand-over for the NEXT LAYER's weights was
+        // measured and dropped: the loads cost the GEMM what they save in front of the barrier (+1.3k / -0.9k cycles).
+        const bool has_next = i + 1 < s_end;
+        const H3Step nx = step_at(has_next ? i + 1 : i);
+        const HeadSel hs = head_sel(st.head);
+        constexpr bool HEAD_PREFETCH = SPLIT && NW / NPT == 2;           // (k-split heads of the f16x3 kernels)
+        const bool head_next = HEAD_PREFETCH && st.head != HEAD_NONE;
+        const uint4* nextp = nullptr;
+        if (head_next) nextp = reinterpret_cast<const uint4*>(pk + hs.w_off) + lane + (wave_id / NPT) * 8 * 2 * 64;
+        const int nstride = MTW == 1 ? 128 : 256;
         if constexpr (SAVE) {
             // (one instantiation of the GEMM loop; the copy is switched by a wave-uniform flag)
             const bool copy = H3_SAVE_INTERLEAVE && pend_dst != nullptr;
-            gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks,
+            const uint4* wafter = gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks,
                 [&](int j) {
                     const int task = (int)threadIdx.x + THREADS * j;
                     if (copy && task < pend_total) fragment_task(sXh, sXl, pend_dst, pend_rows, pend_pairs, task, pg_end);
@@ -835,15 +912,15 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                             H3_PIN();
                         }
                     }
-                });
+                }, nextp, nstride);
+            wnext = wafter;
             if (copy) pend_dst = nullptr;
         } else {
-            gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks);
+            wnext = gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks, NoSide{}, NoSide{}, nextp, nstride);
         }
         H3_STAMP(2);
-        if (i + 1 < s_end) {                       // next segment's weights + bias fly during the epilogue
-            const H3Step nx = step_at(i + 1);
-            wnext = prefetch_w<MTW, SPLIT>(ring, seg(nx.w_off, nx.nks));
+        if (has_next) {                            // next segment's weights + bias fly during the epilogue
+            if (!head_next) wnext = prefetch_w<MTW, SPLIT>(ring, seg(nx.w_off, nx.nks));
             if (nx.bias_off != NSFF_NONE) load_bias<MTW>(br, fbias(nx.bias_off), nb0, lane);
         }
         if (st.post != POST_NONE) {
@@ -870,20 +947,11 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                     pend_set(a.save_acts + (long long)(st.save - 1) * a.save_stride + tile64 * (64 * NSFF_W), NSFF_W, NSFF_W);
             }
             if (st.head != HEAD_NONE) {
-                // static sigma reads the last trunk activation, before *_final (nerf.py:169);
-                // dynamic rows: rgb(3) sigmoid, sigma raw, fw(3)/bw(3) = flow_scale*tanh (nerf.py:197-208)
-                uint32_t w_off = a.L.s_sigma_w, b_off = a.L.s_sigma_b;
-                int n_rows = 1, slot0 = 3;
-                unsigned kinds = ACT_NONE;
-                if (st.head == HEAD_S_RGB) { w_off = a.L.s_rgb_w; b_off = a.L.s_rgb_b; n_rows = 3; slot0 = 0; kinds = 0x15u; }
-                if (st.head == HEAD_S_FOLD) { w_off = a.L.s_fold_w; b_off = a.L.s_fold_b; n_rows = 4; slot0 = 0; kinds = 0x15u; }
-                if (st.head == HEAD_T || st.head == HEAD_T_FOLD) {
-                    w_off = st.head == HEAD_T ? a.L.t_head_w : a.L.t_fold_w;
-                    b_off = st.head == HEAD_T ? a.L.t_head_b : a.L.t_fold_b;
-                    n_rows = (int)a.L.t_head_rows; slot0 = 4;
-                    kinds = 0x15u | (0xAAAu << 8);
-                }
-                heads<NPT, NW, SPLIT>(sXh, sXl, sRed, pk, w_off, b_off, n_rows, kinds, a.flow_scale, sRaw, slot0, wave_id, lane);
+                heads<NPT, NW, SPLIT, MTW>(sXh, sXl, sRed, pk, hs.w_off, hs.b_off, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0,
+                                           wave_id, lane, ring, head_next, wnext);
+                // (a head in the middle of a trunk -- training forward, view directions: the ring carried its weights, so the
+                //  next segment's first k-steps are requested here, beside the head's activation arithmetic)
+                if (has_next && head_next) wnext = prefetch_w<MTW, SPLIT>(ring, seg(nx.w_off, nx.nks));
             }
         }
     }
@@ -1179,9 +1247,9 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.save_side = reinterpret_cast<_Float16*>(g.save_side);
     k.n_tiles = (g.n_points + 63) / 64;
     k.save_stride = k.n_tiles * 64 * NSFF_W;
-    if ((g.save_acts || g.save_xin || g.save_masks || g.save_side) &&
-        (!g.xyz || k.L.k0s != 64 || k.L.kt > 64 || k.L.side_k > 128 || __builtin_popcount(nsff_skip_layers(&d)) != 1))
-        return NSFF_ERR_INVALID;
+    if ((g.save_acts || g.save_xin || g.save_masks || g.save_side) && !g.xyz) return NSFF_ERR_INVALID;
+    k.xin_rows = (k.L.k0s + k.L.kt) <= 128 ? 128 : 256;          // row geometry of save_xin / save_side (nsff_train_dims)
+    k.side_rows = k.L.side_k <= 128 ? 128 : 256;
     k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
     k.D = d.D; k.skip = d.skip;   // (the step program below carries the skip layers)
     k.in_xyz = d.in_xyz; k.in_dir = d.in_dir; k.in_a = d.in_a; k.in_t = d.in_t;

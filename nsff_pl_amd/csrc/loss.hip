@@ -1,14 +1,18 @@
-// N1: the NSFF training objective as four small launches forward + one backward (reference losses.py:8-28 shiftscale_invariant_depthloss,
-// :31-171 NeRFWLoss) instead of the ~580 elementwise / reduction kernels the torch expression of its forward and
-// backward needs.  All eleven terms, train-mode NSFF configuration (flows + disocclusion present, topk == 1, no
-// per-ray weights, thickness == 1); every term is reduced to its scalar mean like the reference does.
+// N1: the NSFF training objective as six small launches forward + two backward (reference losses.py:8-28
+// shiftscale_invariant_depthloss, :31-171 NeRFWLoss) instead of the ~580 elementwise / reduction kernels the torch expression of
+// its forward and backward needs.  All eleven terms of the train-mode NSFF configuration (flows + disocclusion present), with
+// every reduction the reference's constructor can ask for: plain means, per-ray `weights` (hard sampling), top-k mining
+// (--topk < 1: mean of the int(topk * M) largest per-ray values, losses.py:162-169) and the dilated cross entropy
+// (--thickness > 1, losses.py:91-95).
 //
-//   loss_sums_kernel   grid-stride sums of the per-sample disocclusion weights (their means normalise cyc_l)
-//   loss_median_kernel medians of depth_fine / depth_coarse / -disp by rank counting in LDS (torch.median = lower median)
-//   loss_stats_kernel  ONE workgroup: mean absolute deviations around them, the second-level sums their gradients
-//                      need, means of the per-ray disocclusion weights, counts of valid flow projections
-//   loss_rays_kernel   one wavefront per ray, lane = sample: term sums (mode 1) or the gradient of
-//                      sum_k w_k * term_k w.r.t. every consumed render tensor (mode 2, w = upstream scalars)
+//   loss_sums_kernel    grid-stride sums of the per-sample disocclusion weights (their means normalise cyc_l)
+//   loss_median_kernel  medians of depth_fine / depth_coarse / -disp by rank counting in LDS (torch.median = lower median)
+//   loss_stats_kernel   ONE workgroup: mean absolute deviations around them, means of the per-ray disocclusion weights
+//   loss_rays_kernel<1> one wavefront per ray, lane = sample: the ray's value of every term (x its weight) -> per_ray
+//   loss_select_kernel  per term: rank of every ray's value inside the term's population (LDS rank counting), K = int(topk M),
+//                       coef[k][n] = weight_n [rank < K] / K, term_k = sum of the selected values / K
+//   loss_stats2_kernel  (backward) the second-level sums the gradient of the depth term needs, with those coefficients
+//   loss_rays_kernel<2> the gradient of sum_k w_k * term_k w.r.t. every consumed render tensor
 // Bound: HBM (reads ~70 B/sample, writes ~50 B/sample in mode 2); a few microseconds per launch at 1024 x 192.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -139,22 +143,7 @@ __global__ __launch_bounds__(1024) void loss_stats_kernel(const NsffLossArgs a) 
         }
     }
     __syncthreads();
-    // ---- second-level sums of the depth terms: y = (x - m) / s, target t = (-disp - m_t) / s_t, g = 2 (y - t) lambda / N ----
-    const float lam = a.hyper[0];
-    for (int v = 0; v < 2; ++v) {
-        const float* src = v == 0 ? a.depth_fine : a.depth_coarse;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (src != nullptr) {
-            for (int i = tid; i < N; i += 1024) {
-                const float y = (src[i] - sMed[v]) / sMad[v];
-                const float t = (-a.disps[i] - sMed[2]) / sMad[2];
-                const float g = 2.0f * (y - t) * lam / (float)N;
-                acc[0] += g; acc[1] += g * y; acc[2] += sgn(src[i] - sMed[v]);
-            }
-        }
-        block_sum4(acc, sRed);
-        if (tid == 0) { a.stats[ST_SG + v] = acc[0]; a.stats[ST_SGY + v] = acc[1]; a.stats[ST_SSGN + v] = acc[2]; }
-    }
+    (void)sMed; (void)sMad;
     // ---- means of the per-ray disocclusion weights, counts of valid projections ----
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < N; i += 1024) {
@@ -170,26 +159,99 @@ __global__ __launch_bounds__(1024) void loss_stats_kernel(const NsffLossArgs a) 
     }
 }
 
-// mode 1: term sums -> a.terms (11 floats, atomically accumulated; the buffer is zeroed by the host side)
-// mode 2: gradients of sum_k w[k] * term_k
+// Reduction of one term (blockIdx.y) over its population: rank counting like the medians (value descending, ties by
+// index), K = int(topk * M) (all M for topk >= 1), coef = weight [rank < K] / K, term = sum of the selected values / K.
+// per_ray holds the WEIGHTED values; a negative entry marks a ray outside the population (flow terms: invalid projection).
+__global__ __launch_bounds__(256) void loss_select_kernel(const NsffLossArgs a) {
+    __shared__ float sX[MAXN];
+    __shared__ float sRed[8];
+    const int N = (int)a.n_rays, k = blockIdx.y;
+    const bool masked = k == T_FLOW_FW || k == T_FLOW_BW;
+    const float* v = a.per_ray + (long long)k * N;
+    int m_loc = 0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float x = v[i];
+        sX[i] = x;
+        m_loc += (masked && x < 0.f) ? 0 : 1;
+    }
+    float mf = wave_sum((float)m_loc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = mf;
+    __syncthreads();
+    const int M = (int)(sRed[0] + sRed[1] + sRed[2] + sRed[3]);
+    const long long K = a.topk >= 1.0 ? (long long)M : (long long)(a.topk * (double)M);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float mine = 0.f;
+    if (i < N) {
+        const float x = sX[i];
+        const bool in_pop = !(masked && x < 0.f);
+        bool sel = in_pop && K > 0;
+        if (sel && K < M) {
+            int rank = 0;
+            for (int j = 0; j < N; ++j) {
+                const float y = sX[j];
+                if (masked && y < 0.f) continue;
+                rank += (y > x || (y == x && j < i)) ? 1 : 0;
+            }
+            sel = rank < K;
+        }
+        const float w = a.weights != nullptr ? a.weights[i] : 1.0f;
+        a.coef[(long long)k * N + i] = sel ? w / (float)K : 0.f;
+        mine = sel ? x / (float)K : 0.f;
+    }
+    mine = wave_sum(mine);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sRed[4 + (threadIdx.x >> 6)] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = sRed[4] + sRed[5] + sRed[6] + sRed[7];
+        if (t != 0.f) atomicAdd(a.terms + k, t);
+    }
+}
+
+// (backward) second-level sums of the depth term: y = (x - m) / s, target t = (-disp - m_t) / s_t, g_n = 2 (y - t) lambda c_n
+// with c_n = coef[disp_l][n] (1 / N for the plain mean)
+__global__ __launch_bounds__(1024) void loss_stats2_kernel(const NsffLossArgs a) {
+    __shared__ float sRed[64];
+    const int N = (int)a.n_rays, tid = threadIdx.x;
+    const float lam = a.hyper[0];
+    const float* cf = a.coef + (long long)T_DISP * N;
+    for (int v = 0; v < 2; ++v) {
+        const float* src = v == 0 ? a.depth_fine : a.depth_coarse;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (src != nullptr) {
+            const float med = a.stats[ST_MED + v], mad = a.stats[ST_MAD + v];
+            for (int i = tid; i < N; i += 1024) {
+                const float y = (src[i] - med) / mad;
+                const float t = (-a.disps[i] - a.stats[ST_MED + 2]) / a.stats[ST_MAD + 2];
+                const float g = 2.0f * (y - t) * lam * cf[i];
+                acc[0] += g; acc[1] += g * y; acc[2] += sgn(src[i] - med);
+            }
+        }
+        block_sum4(acc, sRed);
+        if (tid == 0) { a.stats[ST_SG + v] = acc[0]; a.stats[ST_SGY + v] = acc[1]; a.stats[ST_SSGN + v] = acc[2]; }
+    }
+}
+
+// mode 1: the ray's (weighted) value of every term -> a.per_ray (11, N)
+// mode 2: gradients of sum_k w[k] * term_k, term_k = sum_n coef[k][n] value_k[n] / weight_n
 template <int MODE>
 __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
     const int lane = threadIdx.x & 63;
     const int S = a.n_samples;
+    const long long NR = a.n_rays;
     const float N = (float)a.n_rays;
-    __shared__ float sPart[4][N_TERMS];
-    float tot[N_TERMS];
-#pragma unroll
-    for (int k = 0; k < N_TERMS; ++k) tot[k] = 0.f;
     for (long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.n_rays; n += (long long)gridDim.x * 4) {
     const float* st = a.stats;
     const float lam_d = a.hyper[0], lam_f = a.hyper[1], cross_w = a.hyper[2], lam_reg = a.hyper[3], lam_ent = a.hyper[4];
-    float w[N_TERMS];
+    // mode 2: c[k] = (upstream scalar of term k) * d term_k / d (this ray's value) -- weight, selection and 1 / K in one number
+    float c[N_TERMS];
 #pragma unroll
-    for (int k = 0; k < N_TERMS; ++k) w[k] = MODE == 2 ? a.term_w[k] : 1.0f;
+    for (int k = 0; k < N_TERMS; ++k) c[k] = MODE == 2 ? a.term_w[k] * a.coef[k * NR + n] : 0.f;
     float part[N_TERMS];
 #pragma unroll
     for (int k = 0; k < N_TERMS; ++k) part[k] = 0.f;
+    bool flow_ok[2] = {false, false};
     const Cam cam = ray_cam(a, n);
 
     // ---------------- per-ray terms (lane 0) ----------------
@@ -198,52 +260,52 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
         // col_l (losses.py:74-76)
         float e = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float d = a.rgb_fine[3 * n + c] - tg[c];
+        for (int ch = 0; ch < 3; ++ch) {
+            const float d = a.rgb_fine[3 * n + ch] - tg[ch];
             e += d * d;
-            if (MODE == 2) a.g_rgb_fine[3 * n + c] = w[T_COL] * 2.0f * d / (3.0f * N);
+            if (MODE == 2) a.g_rgb_fine[3 * n + ch] = c[T_COL] * 2.0f * d / 3.0f;
             if (a.rgb_coarse != nullptr) {
-                const float dc = a.rgb_coarse[3 * n + c] - tg[c];
+                const float dc = a.rgb_coarse[3 * n + ch] - tg[ch];
                 e += 0.1f * dc * dc;
-                if (MODE == 2) a.g_rgb_coarse[3 * n + c] = w[T_COL] * 0.2f * dc / (3.0f * N);
+                if (MODE == 2) a.g_rgb_coarse[3 * n + ch] = c[T_COL] * 0.2f * dc / 3.0f;
             }
         }
         part[T_COL] = e / 3.0f;
-        // disp_l (losses.py:8-28, 77-80): gradient through the median and the mean absolute deviation
+        // disp_l (losses.py:8-28, 77-80): gradient through the median and the mean absolute deviation (loss_stats2_kernel)
         const float t = (-a.disps[n] - st[ST_MED + 2]) / st[ST_MAD + 2];
         for (int v = 0; v < 2; ++v) {
             const float* src = v == 0 ? a.depth_fine : a.depth_coarse;
             if (src == nullptr) continue;
-            const float m = st[ST_MED + v], s = st[ST_MAD + v];
-            const float y = (src[n] - m) / s;
+            const float m = st[ST_MED + v], sd = st[ST_MAD + v];
+            const float y = (src[n] - m) / sd;
             part[T_DISP] += lam_d * (y - t) * (y - t);
             if (MODE == 2) {
-                const float g = 2.0f * (y - t) * lam_d / N;
+                const float g = 2.0f * (y - t) * lam_d * a.coef[T_DISP * NR + n];
                 const bool is_med = __float_as_int(st[ST_IDX + v]) == (int)n;
-                float d = g / s - st[ST_SGY + v] / s * (sgn(src[n] - m) / N);
-                if (is_med) d += -st[ST_SG + v] / s + st[ST_SGY + v] / s * (st[ST_SSGN + v] / N);
-                (v == 0 ? a.g_depth_fine : a.g_depth_coarse)[n] = w[T_DISP] * d;
+                float d = g / sd - st[ST_SGY + v] / sd * (sgn(src[n] - m) / N);
+                if (is_med) d += -st[ST_SG + v] / sd + st[ST_SGY + v] / sd * (st[ST_SSGN + v] / N);
+                (v == 0 ? a.g_depth_fine : a.g_depth_coarse)[n] = a.term_w[T_DISP] * d;
             }
         }
-        // flow_fw_l / flow_bw_l (losses.py:96-110), masked means
+        // flow_fw_l / flow_bw_l (losses.py:96-110): per-ray value lambda_f / 2 * mean |uv - uv_target| over the valid rays
         for (int dir = 0; dir < 2; ++dir) {
             const float* x = (dir == 0 ? a.xyz_fw : a.xyz_bw) + 3 * n;
             const float* uvt = (dir == 0 ? a.uv_fw : a.uv_bw) + 2 * n;
             const Proj p = project(a, n, x, cam, dir == 0);
-            const float cnt = fmaxf(st[ST_CNT + dir], 1.0f);
             float gx[3] = {0.f, 0.f, 0.f};
+            flow_ok[dir] = p.ok;
             if (p.ok) {
                 const float e0 = p.uv[0] - uvt[0], e1 = p.uv[1] - uvt[1];
-                part[T_FLOW_FW + dir] = (fabsf(e0) + fabsf(e1));           // scaled at the end
+                part[T_FLOW_FW + dir] = lam_f * 0.25f * (fabsf(e0) + fabsf(e1));
                 if (MODE == 2) {
-                    const float coef = w[T_FLOW_FW + dir] * lam_f / (4.0f * cnt);
+                    const float coef = c[T_FLOW_FW + dir] * lam_f * 0.25f;
                     const float gu0 = sgn(e0) * coef, gu1 = sgn(e1) * coef;
                     float guvd[3];
                     guvd[0] = gu0 / p.den; guvd[1] = gu1 / p.den;
                     guvd[2] = -(gu0 * p.uvd[0] + gu1 * p.uvd[1]) / (p.den * p.den) * sgn(p.uvd[2]);
                     float gw[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) gw[c] = p.P[c] * guvd[0] + p.P[4 + c] * guvd[1] + p.P[8 + c] * guvd[2];
+                    for (int ch = 0; ch < 3; ++ch) gw[ch] = p.P[ch] * guvd[0] + p.P[4 + ch] * guvd[1] + p.P[8 + ch] * guvd[2];
                     ndc2world_bwd(x, cam, gw, gx);
                 }
             }
@@ -251,7 +313,6 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
                 float* g = (dir == 0 ? a.g_xyz_fw : a.g_xyz_bw) + 3 * n;
                 g[0] = gx[0]; g[1] = gx[1]; g[2] = gx[2];
             }
-            part[T_FLOW_FW + dir] *= lam_f / (4.0f * cnt) * N;              // (the common 1/N is applied below)
         }
         // pho_l (losses.py:113-116)
         float ph = 0.f;
@@ -259,10 +320,10 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
             const float dc = (dir == 0 ? a.disocc_fw : a.disocc_bw)[n] / st[ST_DOCC + dir];
             const float* r = (dir == 0 ? a.rgb_fw : a.rgb_bw) + 3 * n;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float d = r[c] - tg[c];
+            for (int ch = 0; ch < 3; ++ch) {
+                const float d = r[ch] - tg[ch];
                 ph += dc * d * d;
-                if (MODE == 2) (dir == 0 ? a.g_rgb_fw : a.g_rgb_bw)[3 * n + c] = w[T_PHO] * 2.0f * dc * d / (3.0f * N);
+                if (MODE == 2) (dir == 0 ? a.g_rgb_fw : a.g_rgb_bw)[3 * n + ch] = c[T_PHO] * 2.0f * dc * d / 3.0f;
             }
         }
         part[T_PHO] = ph / 3.0f;
@@ -271,30 +332,37 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
     // ---------------- per-sample terms (lane = sample) ----------------
     const int n_keep = a.n_keep;
     const float c_cyc_fw = (N * S) / st[ST_DOCCS], c_cyc_bw = (N * S) / st[ST_DOCCS + 1];      // 1 / mean(disoccs)
-    const float c_reg = lam_reg / (3.0f * (float)n_keep);                                    // per ray; 1/N below
+    const float c_reg = lam_reg / (3.0f * (float)n_keep);
     const float c_sp = n_keep > 1 ? lam_reg / (3.0f * (float)(n_keep - 1)) : 0.f;
+    const int th = a.thickness, pad = (th - 1) / 2;
     const long long base = n * S;
     for (int s = lane; s < S; s += 64) {
         const long long e = base + s;
-        // entropy_l / cross_entropy_l (losses.py:83-95)
+        // entropy_l / cross_entropy_l (losses.py:83-95); the cross entropy sees the transient weights through a
+        // 1 x thickness box filter (zero padded, detached)
         const float tw = a.t_weights[e], sw = a.s_weights[e];
+        float dil = tw;
+        if (th > 1) {
+            dil = 0.f;
+            for (int j = s - pad; j <= s + th - 1 - pad; ++j) if (j >= 0 && j < S) dil += a.t_weights[base + j];
+        }
         part[T_ENT] += -tw * logf(tw + 1e-8f) * lam_ent;
-        part[T_CE] += cross_w * tw * logf(sw + 1e-8f);
+        part[T_CE] += cross_w * dil * logf(sw + 1e-8f);
         if (MODE == 2) {
-            a.g_t_weights[e] = w[T_ENT] * (-lam_ent / N) * (logf(tw + 1e-8f) + tw / (tw + 1e-8f));
-            a.g_s_weights[e] = w[T_CE] * (cross_w / N) * tw / (sw + 1e-8f);
+            a.g_t_weights[e] = c[T_ENT] * (-lam_ent) * (logf(tw + 1e-8f) + tw / (tw + 1e-8f));
+            a.g_s_weights[e] = c[T_CE] * cross_w * dil / (sw + 1e-8f);
         }
         // cyc_l (losses.py:117-120)
         const float* x0 = a.xyzs_fine + 3 * e;
         {
             const float df = a.disoccs_fw[e] * c_cyc_fw, db = a.disoccs_bw[e] * c_cyc_bw;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float ef = a.xyzs_fw_bw[3 * e + c] - x0[c], eb = a.xyzs_bw_fw[3 * e + c] - x0[c];
+            for (int ch = 0; ch < 3; ++ch) {
+                const float ef = a.xyzs_fw_bw[3 * e + ch] - x0[ch], eb = a.xyzs_bw_fw[3 * e + ch] - x0[ch];
                 part[T_CYC] += (df * fabsf(ef) + db * fabsf(eb)) / (3.0f * S);
                 if (MODE == 2) {
-                    a.g_xyzs_fw_bw[3 * e + c] = w[T_CYC] * df * sgn(ef) / (3.0f * S * N);
-                    a.g_xyzs_bw_fw[3 * e + c] = w[T_CYC] * db * sgn(eb) / (3.0f * S * N);
+                    a.g_xyzs_fw_bw[3 * e + ch] = c[T_CYC] * df * sgn(ef) / (3.0f * S);
+                    a.g_xyzs_bw_fw[3 * e + ch] = c[T_CYC] * db * sgn(eb) / (3.0f * S);
                 }
             }
         }
@@ -305,12 +373,12 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
             ndc2world(x0, cam, p0); ndc2world(a.xyzs_fw + 3 * e, cam, pf); ndc2world(a.xyzs_bw + 3 * e, cam, pb);
             float gwf[3], gwb[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float tsm = pf[c] + pb[c] - 2.0f * p0[c], mf = pf[c] - p0[c], mb = pb[c] - p0[c];
+            for (int ch = 0; ch < 3; ++ch) {
+                const float tsm = pf[ch] + pb[ch] - 2.0f * p0[ch], mf = pf[ch] - p0[ch], mb = pb[ch] - p0[ch];
                 part[T_TEMP] += c_reg * fabsf(tsm);
                 part[T_MIN] += c_reg * (fabsf(mf) + fabsf(mb));
-                gwf[c] = (w[T_TEMP] * sgn(tsm) + w[T_MIN] * sgn(mf)) * c_reg / N;
-                gwb[c] = (w[T_TEMP] * sgn(tsm) + w[T_MIN] * sgn(mb)) * c_reg / N;
+                gwf[ch] = (c[T_TEMP] * sgn(tsm) + c[T_MIN] * sgn(mf)) * c_reg;
+                gwb[ch] = (c[T_TEMP] * sgn(tsm) + c[T_MIN] * sgn(mb)) * c_reg;
             }
             // spatial smoothness: pairs (s-1, s) and (s, s+1)
             for (int side = 0; side < 2; ++side) {
@@ -325,11 +393,11 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
                 const float near = expf(-2.0f * sqrtf(dx * dx + dy * dy + dz * dz));
                 const float sg = side == 0 ? 1.0f : -1.0f;            // this sample is the second / the first of the pair
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float df = (f1[c] - a1[c]) - (f0[c] - a0[c]), db = (b1[c] - a1[c]) - (b0[c] - a0[c]);
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float df = (f1[ch] - a1[ch]) - (f0[ch] - a0[ch]), db = (b1[ch] - a1[ch]) - (b0[ch] - a0[ch]);
                     if (side == 1) part[T_SP] += c_sp * (fabsf(df) + fabsf(db)) * near;      // each pair counted once
-                    gwf[c] += w[T_SP] * sg * sgn(df) * near * c_sp / N;
-                    gwb[c] += w[T_SP] * sg * sgn(db) * near * c_sp / N;
+                    gwf[ch] += c[T_SP] * sg * sgn(df) * near * c_sp;
+                    gwb[ch] += c[T_SP] * sg * sgn(db) * near * c_sp;
                 }
             }
             if (MODE == 2) {
@@ -339,26 +407,21 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(const NsffLossArgs a) {
         }
         if (MODE == 2) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { a.g_xyzs_fw[3 * e + c] = gf[c]; a.g_xyzs_bw[3 * e + c] = gb[c]; }
+            for (int ch = 0; ch < 3; ++ch) { a.g_xyzs_fw[3 * e + ch] = gf[ch]; a.g_xyzs_bw[3 * e + ch] = gb[ch]; }
         }
     }
-    if (MODE == 1) {
-#pragma unroll
-        for (int k = 0; k < N_TERMS; ++k) tot[k] += part[k];
-    }
-    }   // rays of this wave
-    if (MODE == 1) {      // one atomic per term and WORKGROUP (they serialise in the L2: ~13 ns each)
+    if (MODE == 1) {      // this ray's value of every term, times its weight; a negative entry = outside a flow term's population
+        const float wn = a.weights != nullptr ? a.weights[n] : 1.0f;
+        const bool ok_fw = __shfl(flow_ok[0] ? 1 : 0, 0) != 0, ok_bw = __shfl(flow_ok[1] ? 1 : 0, 0) != 0;
 #pragma unroll
         for (int k = 0; k < N_TERMS; ++k) {
-            const float t = wave_sum(tot[k]) / N;
-            if (lane == 0) sPart[threadIdx.x >> 6][k] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x < N_TERMS) {
-            const float t = sPart[0][threadIdx.x] + sPart[1][threadIdx.x] + sPart[2][threadIdx.x] + sPart[3][threadIdx.x];
-            if (t != 0.f) atomicAdd(a.terms + threadIdx.x, t);
+            float v = wave_sum(part[k]) * wn;
+            if (k == T_FLOW_FW && !ok_fw) v = -1.0f;
+            if (k == T_FLOW_BW && !ok_bw) v = -1.0f;
+            if (lane == 0) a.per_ray[k * NR + n] = v;
         }
     }
+    }   // rays of this wave
 }
 
 }  // namespace
@@ -376,6 +439,7 @@ int nsff_nerfw_loss(const NsffLossArgs* args, int mode, void* stream) {
         !a.disoccs_fw || !a.disoccs_bw || !a.xyzs_fw_bw || !a.xyzs_bw_fw || !a.xyzs_fine || !a.xyzs_fw || !a.xyzs_bw ||
         !a.stats || !a.hyper) return NSFF_ERR_NULL;
     if ((a.rgb_coarse == nullptr) != (a.depth_coarse == nullptr)) return NSFF_ERR_INVALID;
+    if (!a.per_ray || !a.coef || a.thickness < 1 || !(a.topk > 0.0)) return NSFF_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const unsigned blocks = (unsigned)((a.n_rays + 3) / 4);
     if (mode == 1) {
@@ -387,11 +451,13 @@ int nsff_nerfw_loss(const NsffLossArgs* args, int mode, void* stream) {
         hipLaunchKernelGGL(loss_sums_kernel, dim3((unsigned)std::min<long long>((total + 2047) / 2048, 256)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(loss_median_kernel, dim3((unsigned)((a.n_rays + 255) / 256), 3), dim3(256), 0, st, a);
         hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(1024), 0, st, a);
-        hipLaunchKernelGGL(loss_rays_kernel<1>, dim3(std::min(blocks, 64u)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(loss_rays_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(loss_select_kernel, dim3((unsigned)((a.n_rays + 255) / 256), N_TERMS), dim3(256), 0, st, a);
     } else {
         if (!a.term_w || !a.g_rgb_fine || !a.g_depth_fine || !a.g_t_weights || !a.g_s_weights || !a.g_xyz_fw || !a.g_xyz_bw ||
             !a.g_rgb_fw || !a.g_rgb_bw || !a.g_xyzs_fw_bw || !a.g_xyzs_bw_fw || !a.g_xyzs_fw || !a.g_xyzs_bw) return NSFF_ERR_NULL;
         if (a.rgb_coarse && (!a.g_rgb_coarse || !a.g_depth_coarse)) return NSFF_ERR_NULL;
+        hipLaunchKernelGGL(loss_stats2_kernel, dim3(1), dim3(1024), 0, st, a);
         hipLaunchKernelGGL(loss_rays_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
     }
     return nsff_launch_status();

@@ -12,13 +12,16 @@ The field network (PosEmbedding + NeRF.forward, reference models/nerf.py:17-30,1
   bits) and ``nsff_weight_grad`` the batched split-K weight-gradient GEMMs (dW = dY^T.X, K = all points) over
   the fragment-major tiles both passes left in HBM.  Every point's gradient row carries its own power-of-two
   scale (block floating point); the positional-encoding derivative and the per-ray reduction of the time-code
-  gradient are a few torch ops on the (P,128) result.  ``NSFF_BWD_IMPL=torch`` selects an all-torch version of
-  the same arithmetic (debugging).
+  gradient are one more launch on the (P, xin_rows) result (``nsff_field_input_backward``).
 
 View-direction / appearance models (``static_dir_encoding``, reference nerf.py:83-91,183-185) are covered: the
 training forward also keeps that layer's input rows and activation, K1 differentiates it and returns the
-gradient of the per-ray appearance code.  Architectures the kernels are not built for (``why_unsupported``) are
-refused by name -- there is no torch fallback in the product.
+gradient of the per-ray appearance code.  Every architecture the inference kernels take trains as well: any list
+of skip layers (nerf.py:34-40,163-167; the lowest one's input share stays in LDS, further ones add theirs to d_xin
+through memory), position / time embeddings up to ceil64(in_xyz) + ceil64(in_t) <= 256 columns and [dir | a] inputs
+up to 256 (``_lib.train_dims``: the saved input tiles have 128 or 256 rows).  What is refused, by name
+(``why_unsupported``): widths other than 256, and the gradient with respect to the points of a STATIC trunk (never
+needed by ``render_rays``: only warped dynamic points carry gradients) -- there is no torch fallback in the product.
 """
 import os
 
@@ -28,7 +31,6 @@ import torch
 
 from . import _lib, config
 
-_F16_MAX = 65504.0
 
 
 def enabled():
@@ -36,16 +38,18 @@ def enabled():
 
 
 def why_unsupported(model):
-    """None, or what csrc/field_bwd.hip and the SAVE variant of csrc/field_h3.hip are not built for."""
-    if model.W != 256 or len(set(model.skips)) != 1:
-        return (f"W={model.W}, skips={list(model.skips)} (the backward kernels need W=256 and exactly one skip layer; "
-                "several or none run at inference only)")
-    if model.in_channels_xyz > 64:
-        return f"in_channels_xyz={model.in_channels_xyz} > 64 (the saved trunk input has 64 position columns)"
-    if model.encode_transient and model.in_channels_t > 64:
-        return f"in_channels_t={model.in_channels_t} > 64 (the saved trunk input has 64 time-code columns)"
-    if model.use_viewdir and model.in_channels_dir + model.in_channels_a > 128:
-        return f"in_channels_dir + in_channels_a = {model.in_channels_dir + model.in_channels_a} > 128"
+    """None, or what csrc/field_bwd.hip and the training forward of csrc/field_h3.hip are not built for."""
+    if model.W != 256:
+        return f"W={model.W} (the field kernels tile W=256 trunks)"
+    skips = sorted(set(int(v) for v in model.skips))
+    if not 2 <= model.D <= 8 or any(not 1 <= v < model.D for v in skips):
+        return f"D={model.D}, skips={list(model.skips)} (need 2 <= D <= 8 and skip layers among 1..D-1)"
+    pad = lambda n: (int(n) + 63) // 64 * 64
+    if pad(model.in_channels_xyz) + (pad(model.in_channels_t) if model.encode_transient else 0) > 256:
+        return (f"in_channels_xyz={model.in_channels_xyz}, in_channels_t={model.in_channels_t}: the trunk input is padded to "
+                "64-column segments and must fit 256 columns (inference has the same limit)")
+    if model.use_viewdir and model.in_channels_dir + model.in_channels_a > 256:
+        return f"in_channels_dir + in_channels_a = {model.in_channels_dir + model.in_channels_a} > 256"
     return None
 
 
@@ -70,16 +74,18 @@ def alloc_saves(model, n_points, device, transient, static=True):
     """Buffers the training forward fills for the backward kernels (layouts: include/nsff_render.h, NsffFieldArgs):
     (acts, xin, masks, side) -- side is None unless the launch evaluates static_dir_encoding."""
     tiles = (n_points + 63) // 64
+    xin_rows, t_row0, side_rows = _lib.train_dims(model)
     acts = torch.empty(n_slots(model), tiles, 64 * 256, device=device, dtype=torch.float16)
-    xin = torch.empty(tiles, 64 * 128, device=device, dtype=torch.float16)
+    xin = torch.empty(tiles, 64 * xin_rows, device=device, dtype=torch.float16)
     masks = torch.empty(n_slots(model), tiles, 256, device=device, dtype=torch.int64)
-    if not transient:
-        xin.zero_()                          # rows 64.. of a static-only launch are never written
+    written = t_row0 + ((model.in_channels_t + 63) // 64 * 64 if transient else 0)
+    if written < xin_rows:
+        xin.zero_()                          # rows the launch does not encode are never written
     side = None
     if model.use_viewdir and static:
-        side = torch.empty(tiles, 64 * 128, device=device, dtype=torch.float16)
-        if model.in_channels_dir + model.in_channels_a <= 64:
-            side.zero_()                     # rows 64.. are never written
+        side = torch.empty(tiles, 64 * side_rows, device=device, dtype=torch.float16)
+        if (model.in_channels_dir + model.in_channels_a + 63) // 64 * 64 < side_rows:
+            side.zero_()
     return acts, xin, masks, side
 
 
@@ -88,23 +94,6 @@ def forward_can_save(model, static_mode, transient_mode):
     re-run it): f16x3 arithmetic selected, no view directions, full (rgb+sigma) modes."""
     return (enabled() and _kernel_handles(model) and config.precision_code(model) == config.PRECISIONS["f16x3"]
             and static_mode in (0, 2) and transient_mode in (0, 2) and (static_mode or transient_mode))
-
-
-def _mm32(a16, b16):
-    """fp16 x fp16 -> fp32 (fp32 accumulate, fp32 result: a weight gradient summed over 1e5 points does not fit fp16)."""
-    try:
-        return torch.mm(a16, b16, out_dtype=torch.float32)
-    except (TypeError, RuntimeError):
-        return torch.mm(a16.float(), b16.float())
-
-
-def _h(x):
-    return x.clamp(-_F16_MAX, _F16_MAX).half()
-
-
-def _bmm(dpre16, w, out32=False):
-    """dX = dY . W with fp16 operands (fp32 accumulate), fp16 or fp32 result."""
-    return (_mm32 if out32 else torch.mm)(dpre16, w.detach().half())
 
 
 class _FieldFn(torch.autograd.Function):
@@ -138,16 +127,15 @@ class _FieldFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_raw):
         cfg = ctx.cfg
-        if os.environ.get("NSFF_BWD_IMPL", "hip") == "torch" or (cfg["static"] and ctx.needs_input_grad[1]):
-            if cfg["model"].use_viewdir and cfg["static"]:
-                raise NotImplementedError("gradient w.r.t. the points of a view-direction static trunk / NSFF_BWD_IMPL=torch: "
-                                          "only the HIP backward covers static_dir_encoding")
-            return _FieldFn._backward_torch(ctx, d_raw)
+        if cfg["static"] and ctx.needs_input_grad[1]:
+            raise NotImplementedError("field(): gradient w.r.t. the points of a STATIC trunk is not built (render_rays never "
+                                      "asks for it: only the warped points of the dynamic trunk carry gradients)")
         model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
         raw, acts, xin, masks, xyz = ctx.saved_tensors[:5]
         side = ctx.saved_tensors[5] if ctx.has_side else None
         params = ctx.saved_tensors[6 if ctx.has_side else 5:]
-        P, D, skip = ctx.P, model.D, model.skips[0]
+        P, D = ctx.P, model.D
+        xin_rows, t_row0, side_rows = _lib.train_dims(model)
         tiles, dev = acts.shape[1], d_raw.device
         if P == 0:                               # an empty batch contributes nothing
             return (None, None if not ctx.needs_input_grad[1] else torch.zeros_like(xyz), None, None, None) + (None,) * len(params)
@@ -160,9 +148,9 @@ class _FieldFn(torch.autograd.Function):
         dpre = torch.empty(n_slots(model), tiles, 64 * 256, device=dev, dtype=torch.float16)
         dhead = torch.empty(2, tiles, 64 * 32, device=dev, dtype=torch.float16)
         want_in = transient and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        d_xin = torch.empty(P, 128, device=dev) if want_in else None
+        d_xin = torch.empty(P, xin_rows, device=dev) if want_in else None
         want_a = viewdir and model.in_channels_a > 0 and ctx.needs_input_grad[4]
-        d_side = torch.empty(P, 128, device=dev) if want_a else None
+        d_side = torch.empty(P, side_rows, device=dev) if want_a else None
         _lib.field_backward(model, P, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side)
 
         # ---- weight-gradient GEMMs: one batched launch per output shape ----
@@ -171,13 +159,13 @@ class _FieldFn(torch.autograd.Function):
         for kind, t, l in meta:
             base = t * (D + 1)
             if kind == "x":
-                a_, b_, rows = dpre[base + l], xin, (256, 128)
+                a_, b_, rows = dpre[base + l], xin, (256, xin_rows)
             elif kind == "h":
                 a_, b_, rows = dpre[base + l], acts[base + l - 1], (256, 256)
             elif kind == "dir_h":
                 a_, b_, rows = dpre[S_DIR], acts[D], (256, 256)
             elif kind == "dir_x":
-                a_, b_, rows = dpre[S_DIR], side, (256, 128)
+                a_, b_, rows = dpre[S_DIR], side, (256, side_rows)
             elif l == 1:                                          # static sigma reads the trunk
                 a_, b_, rows = dhead[0], acts[base + D - 1], (32, 256)
             else:
@@ -218,7 +206,7 @@ class _FieldFn(torch.autograd.Function):
 
         d_xyz = d_t = d_a = None
         if d_xin is not None:              # derivative of the positional encoding + per-ray sum of the time-code rows
-            d_xyz, d_t = _lib.field_input_backward(d_xin, xyz, s, freqs, n_t, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            d_xyz, d_t = _lib.field_input_backward(d_xin, t_row0, xyz, s, freqs, n_t, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         if d_side is not None:               # per-ray appearance code: sum over the ray's points (rendering.py:168,172)
             c0 = model.in_channels_dir
             d_a = d_side[:, c0:c0 + model.in_channels_a].reshape(P // s, s, -1).sum(1)
@@ -231,122 +219,22 @@ class _FieldFn(torch.autograd.Function):
             return (None, d_xyz, d_t, None, d_a) + (None,) * len(params)
         return (None, d_xyz, d_t, None, d_a) + tuple(grads)
 
-    @staticmethod
-    def _backward_torch(ctx, d_raw):
-        """The same arithmetic with torch ops (fp16 GEMMs through rocBLAS): debugging aid, and the route for a
-        static trunk whose points require gradients (never the case inside render_pass)."""
-        cfg = ctx.cfg
-        model, freqs, s = cfg["model"], cfg["freqs"], cfg["pts_per_ray"]
-        raw, acts_f, xin_f, masks, xyz = ctx.saved_tensors[:5]
-        params = ctx.saved_tensors[5:]
-        P, D, skip = ctx.P, model.D, model.skips[0]
-        acts, xin = _unfragment(acts_f, 256), _unfragment(xin_f[None], 128)[0]
-        names = [id(p) for p in _lib.param_list(model)]
-        grads = [None] * len(params)
-        slot = {k: i for i, k in enumerate(names)}
 
-        # block floating point per point: every row of d_raw is normalised to max 2^10; the inverse scale is
-        # folded into the activation operand of the weight-gradient GEMMs, centred on the median exponent
-        amax = d_raw.abs().amax(1, keepdim=True).clamp_min(1e-30)
-        scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)))                  # (P,1)
-        ref = torch.median(scale)
-        scale = torch.minimum(scale, ref * 4096.0)
-        scale = torch.maximum(scale, ref / 1024.0)
-        d = d_raw * scale
-        inv = 1.0 / scale
-        rel = (ref * inv)                                                            # (P,1) exact powers of two
-        inv_ref = 1.0 / ref
-
-        def put(layer, dpre16, inp16):
-            grads[slot[id(layer.weight)]] = _mm32(dpre16.t(), (inp16.float() * rel).half()) * inv_ref
-            grads[slot[id(layer.bias)]] = (dpre16.float() * inv).sum(0)
-
-        def trunk(prefix, slot0, dh, in_t):
-            """dh: (P,256) fp16 gradient w.r.t. the last trunk activation.  Returns d(trunk input) (P, 63+in_t) fp32-ish."""
-            x_in = xin[:P, :model.in_channels_xyz] if in_t == 0 else \
-                torch.cat([xin[:P, :model.in_channels_xyz], xin[:P, 64:64 + in_t]], 1)
-            n_in = x_in.shape[1]
-            d_x = None
-            for l in range(D - 1, -1, -1):
-                layer = _lin(getattr(model, f"{prefix}_xyz_encoding_{l + 1}"))
-                dpre = dh * (acts[slot0 + l, :P] > 0).to(dh.dtype)
-                w = layer.weight
-                if l == 0:
-                    put(layer, dpre, x_in)
-                    d0 = _bmm(dpre, w, True)
-                    d_x = d0 if d_x is None else d_x + d0
-                elif l == skip:
-                    put(layer, dpre, torch.cat([x_in, acts[slot0 + l - 1, :P]], 1))
-                    d_x = _bmm(dpre, w[:, :n_in], True)
-                    dh = _h(_bmm(dpre, w[:, n_in:]))
-                else:
-                    put(layer, dpre, acts[slot0 + l - 1, :P])
-                    dh = _h(_bmm(dpre, w))
-            return d_x
-
-        d_xin = None
-        if cfg["static"]:
-            y = raw[:, 0:3]
-            dp_rgb = _h(d[:, 0:3] * y * (1 - y))
-            dp_sig = _h(d[:, 3:4])
-            feat, h_last = acts[D, :P], acts[D - 1, :P]
-            rgb, sig, fin = _lin(model.static_rgb), _lin(model.static_sigma), _lin(model.static_xyz_encoding_final)
-            put(rgb, dp_rgb, feat)
-            put(sig, dp_sig, h_last)
-            d_feat = _h(_bmm(dp_rgb, rgb.weight))
-            put(fin, d_feat, h_last)
-            dh = _h(_bmm(d_feat, fin.weight) + _bmm(dp_sig, sig.weight))
-            d_xs = trunk("static", 0, dh, 0)
-            if ctx.needs_input_grad[1]:                                 # (never the case inside render_pass)
-                d_xin = d_xs
-        if cfg["transient"]:
-            fs = getattr(model, "flow_scale", 0.0)
-            y = raw[:, 4:7]
-            heads = [(_lin(model.transient_rgb), _h(d[:, 4:7] * y * (1 - y))),
-                     (_lin(model.transient_sigma), _h(d[:, 7:8]))]
-            if model.output_flow:
-                for name, c0 in (("transient_flow_fw", 8), ("transient_flow_bw", 11)):
-                    yf = raw[:, c0:c0 + 3]
-                    heads.append((_lin(getattr(model, name)), _h(d[:, c0:c0 + 3] * (fs - yf * yf / fs))))
-            feat, h_last = acts[2 * D + 1, :P], acts[2 * D, :P]
-            d_feat = None
-            for layer, dp in heads:
-                put(layer, dp, feat)
-                term = _bmm(dp, layer.weight)
-                d_feat = term if d_feat is None else d_feat + term
-            d_feat = _h(d_feat)
-            fin = _lin(model.transient_xyz_encoding_final)
-            put(fin, d_feat, h_last)
-            dh = _h(_bmm(d_feat, fin.weight))
-            d_xt = trunk("transient", D + 1, dh, model.in_channels_t).float()
-            n_xyz = model.in_channels_xyz
-            if ctx.needs_input_grad[2]:
-                d_t_rows = d_xt[:, n_xyz:] * inv
-            d_xin = d_xt[:, :n_xyz] if d_xin is None else d_xin.float() + d_xt[:, :n_xyz]
-
-        d_xyz = d_t = None
-        if d_xin is not None:
-            d_xin = d_xin.float() * inv
-            n_xyz = model.in_channels_xyz
-            if cfg["transient"] and ctx.needs_input_grad[2]:
-                d_t = d_t_rows.reshape(P // s, s, -1).sum(1)
-            if ctx.needs_input_grad[1]:
-                de = d_xin[:, :n_xyz]
-                d_xyz = de[:, 0:3].clone()
-                for i, f in enumerate(freqs):
-                    ang = f * xyz
-                    d_xyz += f * (torch.cos(ang) * de[:, 3 + 6 * i:6 + 6 * i] - torch.sin(ang) * de[:, 6 + 6 * i:9 + 6 * i])
-        return (None, d_xyz, d_t, None, None) + tuple(grads)
+def job_shape(model, kind):
+    """(a_rows, b_rows) of a weight-gradient GEMM of `_wgrad_jobs`."""
+    xin_rows, _, side_rows = _lib.train_dims(model)
+    return {"x": (256, xin_rows), "h": (256, 256), "dir_h": (256, 256), "dir_x": (256, side_rows), "head": (32, 256)}[kind]
 
 
-_JOB_SHAPE = {"x": (256, 128), "h": (256, 256), "dir_h": (256, 256), "dir_x": (256, 128), "head": (32, 256)}
+def _skips(model):
+    return sorted(set(int(v) for v in model.skips))
 
 
 def _wgrad_jobs(model, static, transient):
-    """The weight-gradient GEMMs of one node as (kind, trunk, layer) tags: 'x' = trunk-input part of layer l, 'h' =
-    hidden part of layer l (l == D: *_final), 'dir_h' / 'dir_x' = the two parts of static_dir_encoding, 'head' =
-    the output heads (layer 1: static_sigma, which reads the trunk instead of *_final)."""
-    D, skip = model.D, model.skips[0]
+    """The weight-gradient GEMMs of one node as (kind, trunk, layer) tags: 'x' = trunk-input part of layer l (layer 0 and
+    every skip layer), 'h' = hidden part of layer l (l == D: *_final), 'dir_h' / 'dir_x' = the two parts of
+    static_dir_encoding, 'head' = the output heads (layer 1: static_sigma, which reads the trunk instead of *_final)."""
+    D, skips = model.D, _skips(model)
     viewdir = bool(model.use_viewdir and static)
     meta = []
     for t in ([0] if static else []) + ([1] if transient else []):
@@ -355,7 +243,7 @@ def _wgrad_jobs(model, static, transient):
                 meta.append(("x", t, 0))
             else:
                 meta.append(("h", t, l))
-                if l == skip:
+                if l in skips:
                     meta.append(("x", t, l))
         meta.append(("h", t, D))
         if t == 0 and viewdir:            # static_dir_encoding: [*_final | dir | a] -> 256, static_rgb reads it
@@ -370,9 +258,10 @@ def _assemble(model, static, transient, meta, plist, result, bias_of, cat):
     """Gradients of every parameter of `model` (order of `plist`) from the weight-gradient jobs of one node.
     result(i): the (a_rows, b_rows) matrix of job i; bias_of(i): its 256 row sums; `meta[i]` = (kind, trunk, layer).
     Works on tensors and on the index objects of :func:`_grad_map` alike (only slicing, `+` and `cat` are used)."""
-    D, skip = model.D, model.skips[0]
+    D, skips = model.D, _skips(model)
     viewdir = bool(model.use_viewdir and static)
     n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
+    _, t_row0, _ = _lib.train_dims(model)
     index = {id(q): i for i, q in enumerate(plist)}
     grads = [None] * len(plist)
     res = {tag: i for i, tag in enumerate(meta)}
@@ -381,8 +270,8 @@ def _assemble(model, static, transient, meta, plist, result, bias_of, cat):
         grads[index[id(layer.weight)]] = w
         grads[index[id(layer.bias)]] = b
 
-    def xcols(m, in_t):                       # (256,128) in trunk-input rows -> (256, in_dim) in Linear columns
-        return m[:, :n_xyz] if in_t == 0 else cat([m[:, :n_xyz], m[:, 64:64 + in_t]], 1)
+    def xcols(m, in_t):                       # (256, xin_rows) in trunk-input rows -> (256, in_dim) in Linear columns
+        return m[:, :n_xyz] if in_t == 0 else cat([m[:, :n_xyz], m[:, t_row0:t_row0 + in_t]], 1)
     for t in ([0] if static else []) + ([1] if transient else []):
         prefix, in_t = ("static", 0) if t == 0 else ("transient", n_t)
         for l in range(D):
@@ -390,7 +279,7 @@ def _assemble(model, static, transient, meta, plist, result, bias_of, cat):
             if l == 0:
                 i = res[("x", t, 0)]
                 put(layer, xcols(result(i), in_t), bias_of(i))
-            elif l == skip:
+            elif l in skips:
                 i = res[("h", t, l)]
                 put(layer, cat([xcols(result(res[("x", t, l)]), in_t), result(i)], 1), bias_of(i))
             else:
@@ -567,13 +456,6 @@ def _flush_weight_grads():
                     new.append(g)
             if have:
                 torch._foreach_add_(have, new)
-
-
-def _unfragment(frag, n_rows):
-    """(slots, tiles, 64*n_rows) fragment-major fp16 -> (slots, tiles*64, n_rows) point-major."""
-    slots, tiles = frag.shape[:2]
-    x = frag.view(slots, tiles, 4, n_rows // 32, 2, 32, 8)       # ks, row block, point-group parity, row, 8 points
-    return x.permute(0, 1, 2, 4, 6, 3, 5).reshape(slots, tiles * 64, n_rows)
 
 
 def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient, saved=None, dir_rows=None, a_rows=None):

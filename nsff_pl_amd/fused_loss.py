@@ -1,10 +1,12 @@
-"""``NeRFWLoss`` as three HIP launches forward + one backward (csrc/loss.hip, ``nsff_nerfw_loss``).
+"""``NeRFWLoss`` as six small HIP launches forward + two backward (csrc/loss.hip, ``nsff_nerfw_loss``).
 
 The torch expression in :mod:`nsff_pl_amd.losses` is ~280 small kernels forward and ~300 backward -- a quarter of the
-C4 training step's device time.  For the NSFF train-mode configuration (flows + disocclusion in the dict, topk == 1,
-no per-ray weights, thickness == 1, <= 4096 rays on the GPU) the same eleven scalars and their gradients w.r.t. the
-render dict come from the kernels instead; everything else keeps the torch expression (the two agree to fp32 rounding,
-tests/test_losses.py).  ``NSFF_FUSED_LOSS=0`` switches the kernels off.
+C4 training step's device time.  For the NSFF train-mode configuration (flows + disocclusion in the dict, <= 4096 rays on
+the GPU) the same eleven scalars and their gradients w.r.t. the render dict come from the kernels instead, for every
+reduction the reference's constructor can ask for: plain means, per-ray ``weights``, ``topk < 1`` (mean of the
+int(topk * M) largest per-ray values, losses.py:162-169) and ``thickness > 1`` (dilated cross entropy, losses.py:91-95).
+The torch expression stays what static-only models and CPU tensors use, and what the kernels are tested against
+(tests/test_losses.py).  ``NSFF_FUSED_LOSS=0`` switches the kernels off.
 """
 import os
 
@@ -33,11 +35,12 @@ def enabled():
 
 
 def applicable(loss, inputs, targets, kwargs):
-    if not enabled() or not kwargs.get("output_transient_flow") or "weights" in kwargs:
-        return False
-    if loss.topk < 1 or loss.thickness != 1:
+    if not enabled() or not kwargs.get("output_transient_flow"):
         return False
     x = inputs.get("rgb_fine")
+    w = kwargs.get("weights")
+    if w is not None and not (torch.is_tensor(w) and x is not None and w.numel() == x.shape[0]):
+        return False
     if x is None or not x.is_cuda or x.dtype != torch.float32 or not 1 <= x.shape[0] <= MAX_RAYS:
         return False
     need = [k for k, _, _ in _INPUTS if k not in _OPTIONAL]
@@ -54,7 +57,9 @@ class _LossFn(torch.autograd.Function):
         dev = tens[0].device
         stats = torch.empty(24, device=dev)
         terms = torch.empty(len(TERMS), device=dev)
-        common = dict(cfg["targets"], hyper=hyper, stats=stats)
+        common = dict(cfg["targets"], hyper=hyper, stats=stats, weights=cfg["weights"],
+                      per_ray=torch.empty(len(TERMS), cfg["n"], device=dev), coef=torch.empty(len(TERMS), cfg["n"], device=dev),
+                      topk=cfg["topk"], thickness=cfg["thickness"])
         _lib.nerfw_loss(1, cfg["n"], cfg["s"], cfg["n_keep"], cfg["n_frames"], cfg["max_t"], terms=terms, **args, **common)
         ctx.cfg, ctx.args, ctx.common = cfg, args, common
         return terms
@@ -97,8 +102,10 @@ def nerfw_loss(loss, inputs, targets, kwargs):
               ts=targets["ts"].contiguous().long(), cam_ids=targets["cam_ids"].contiguous().long(),
               uv_fw=targets["uv_fw"].contiguous().float(), uv_bw=targets["uv_bw"].contiguous().float(),
               Ks=loss.Ks.contiguous().float().reshape(-1, 3, 3), Ps=loss.Ps.contiguous().float())
+    w = kwargs.get("weights")
     cfg = dict(names=names, targets=tg, n=n, s=s, n_keep=int(s * loss.z_far), n_frames=int(loss.Ps.shape[1]),
-               max_t=int(loss.max_t))
+               max_t=int(loss.max_t), topk=float(loss.topk), thickness=int(loss.thickness),
+               weights=None if w is None else w.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous())
     terms = _LossFn.apply(cfg, hyper, *tens)
     return LossTerms(terms)
 

@@ -62,7 +62,7 @@ class NeRFWLoss(nn.Module):
         from . import fused_loss
         if fused_loss.applicable(self, inputs, targets, kwargs):      # NSFF train configuration on the GPU: csrc/loss.hip
             return fused_loss.nerfw_loss(self, inputs, targets, kwargs)
-        ret = {}
+        ret, population = {}, {}            # population: the rays a masked (flow) term's values belong to
         rgbs = targets['rgbs']
         ret['col_l'] = ((inputs['rgb_fine'] - rgbs) ** 2).mean(1)
         if 'rgb_coarse' in inputs:
@@ -100,8 +100,10 @@ class NeRFWLoss(nn.Module):
                     scalars[key] = self.lambda_geo_f / 2 * err.sum() / (2 * ok.sum().clamp_min(1))
             elif ok_fw.any():
                 ret['flow_fw_l'] = (self.lambda_geo_f / 2 * torch.abs(uv_fw[ok_fw] - targets['uv_fw'][ok_fw])).mean(1)
+                population['flow_fw_l'] = ok_fw
             if not self.static_shapes and ok_bw.any():
                 ret['flow_bw_l'] = (self.lambda_geo_f / 2 * torch.abs(uv_bw[ok_bw] - targets['uv_bw'][ok_bw])).mean(1)
+                population['flow_bw_l'] = ok_bw
 
             # photometric + cycle consistency of the warped renders, weighted by disocclusion
             pho = inputs['disocc_fw'] * (inputs['rgb_fw'] - rgbs) ** 2 / inputs['disocc_fw'].mean() + \
@@ -127,7 +129,10 @@ class NeRFWLoss(nn.Module):
             ret.update(scalars)             # already reduced (mean of a 0-d tensor is itself)
         for k, loss in ret.items():
             if 'weights' in kwargs:
-                loss = loss * kwargs['weights']
+                # (the reference multiplies every term by the (N,) weights, losses.py:163-164 -- which only broadcasts for the
+                #  masked flow terms when every ray is valid; here a masked term takes the weights of its own rays)
+                w = kwargs['weights']
+                loss = loss * (w[population[k]] if (k in population and torch.is_tensor(w) and w.dim() > 0) else w)
             if self.topk < 1:
                 loss, _ = torch.topk(loss.flatten(), int(self.topk * loss.numel()))
             ret[k] = loss.mean()

@@ -68,10 +68,14 @@ def oracle_render(cfg, models, emb, rays, ts, draws=None, dataset=None, zs_fine_
 
 
 def key_rtol(key, cfg):
-    """1e-4 everywhere; chained re-query keys of the gain-3 stress scene get 2e-3."""
+    """1e-4 everywhere; chained re-query keys (a second MLP pass at x + flow: the highest embedding frequency amplifies the
+    fp32 rounding of the first pass) get 2e-3 on the gain-3 stress scene and 4e-4 where the position embedding reaches 2^11
+    instead of the default 2^9 (four times the amplification; measured 1.05e-4 on the 12-frequency scene g18)."""
     import parity
     if key in CHAINED_KEYS and cfg["gain"] > 2.5:
         return 2e-3
+    if key in CHAINED_KEYS and cfg.get("xyz_emb", (9, 10))[0] > 9:
+        return 4e-4
     return parity.RTOL
 
 

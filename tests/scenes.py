@@ -44,12 +44,21 @@ CASES = {
     # view directions + appearance code in TRAIN mode (static_dir_encoding on the gradient path; ctor default use_viewdir=True)
     "g13_viewdir_train": dict(n_rays=16, N_samples=64, N_importance=64, transient=True, viewdir=True, appearance=True,
                               test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=13),
-    # the reference's `skips` is a list (nerf.py:34-40,163-167): two skip layers / none at all (test-time: the backward kernels
-    # want exactly one skip layer, these architectures run at inference only)
+    # the reference's `skips` is a list (nerf.py:34-40,163-167): two skip layers / none at all, at test time ...
     "g14_two_skips": dict(n_rays=10, N_samples=32, N_importance=24, transient=True, viewdir=False, appearance=False,
                           test_time=True, flow=['fw', 'bw'], gain=2.5, seed=14, D=8, skips=[2, 5]),
     "g15_no_skip": dict(n_rays=10, N_samples=48, N_importance=0, transient=True, viewdir=True, appearance=False,
                         test_time=True, flow=[], gain=2.5, seed=15, D=4, skips=[]),
+    # ... and in TRAIN mode (gradient goldens g9_*): two skip layers, no skip layer, and the widths the reference's CLI can
+    # reach beyond the defaults (opt.py:25 --N_emb_xyz, :45 --N_tau; a 16-frequency direction embedding + appearance code):
+    # in_xyz = 75 > 64, in_t = 96 > 64, in_dir + in_a = 147 > 128 -- the saved input tiles of the backward pass get 256 rows
+    "g16_two_skips_train": dict(n_rays=12, N_samples=32, N_importance=24, transient=True, viewdir=False, appearance=False,
+                                test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=16, D=8, skips=[2, 5]),
+    "g17_no_skip_train": dict(n_rays=12, N_samples=32, N_importance=24, transient=True, viewdir=False, appearance=False,
+                              test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=17, D=4, skips=[]),
+    "g18_wide_inputs_train": dict(n_rays=12, N_samples=32, N_importance=24, transient=True, viewdir=True, appearance=True,
+                                  test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=18,
+                                  n_tau=96, xyz_emb=(11, 12), dir_emb=(15, 16)),
     "g7b_static_noise_odd": dict(n_rays=9, N_samples=48, N_importance=40, transient=False, viewdir=True,
                                  appearance=False, test_time=False, flow=[], gain=2.5, seed=8,
                                  perturb=0.5, noise_std=0.7),
@@ -188,7 +197,8 @@ def replay_draws(cfg, seed):
 
 
 # ---- gradient goldens (G9): a fixed random cotangent per differentiable output key ----
-GRAD_CASES = ("g3_nsff_train", "g7_nsff_train_noise", "g2_static_c2f", "g13_viewdir_train")
+GRAD_CASES = ("g3_nsff_train", "g7_nsff_train_noise", "g2_static_c2f", "g13_viewdir_train",
+              "g16_two_skips_train", "g17_no_skip_train", "g18_wide_inputs_train")
 NON_DIFF_KEYS = ("zs_coarse", "xyzs_coarse", "zs_fine", "xyzs_fine")
 FULL_GRAD_PARAMS = ("t.weight", "fine.transient_flow_fw.0.weight", "fine.static_sigma.weight",
                     "fine.static_xyz_encoding_5.0.bias", "coarse.transient_rgb.0.bias", "coarse.static_rgb.0.weight",

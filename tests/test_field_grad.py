@@ -51,9 +51,8 @@ def test_field_node_gradients(static, transient, spread, hip_lib):
 
     for p in model.parameters():
         p.grad = None
-    # inside render_pass the static trunk only ever sees points without gradient: that is the native route;
-    # static + d(points) takes the torch fallback of field_grad, covered by spread == 0 here
-    x = xyz.detach().clone().requires_grad_(not static or spread == 0.0)
+    # inside render_pass the static trunk only ever sees points without gradient: static + d(points) is not built
+    x = xyz.detach().clone().requires_grad_(not static)
     t = t_rows.detach().clone().requires_grad_(True)
     raw = field_grad.field(model, x, freqs, t, s, static, transient)
     (raw * cot).sum().backward()

@@ -202,19 +202,21 @@ def test_nerf_forward_rejects_cpu_and_bad_shapes(hip_lib):
     assert m(torch.zeros(0, 63 + 27, device=DEV), output_transient=False).shape == (0, 4)
 
 
-def test_skip_lists_render_but_refuse_to_train_by_name(hip_lib):
-    """Several skip layers (nerf.py:34-40) run through the inference kernels (goldens g14 / g15); a call that would be
-    differentiated is refused with the reason, not served by a fallback."""
-    cfg = dict(scenes.CASES["g14_two_skips"], test_time=False)
-    rays, ts = scenes.synthetic_rays(cfg["n_rays"], cfg["seed"])
-    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
-    _to_dev(models, emb)
-    args = (models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, 32, 0, 0, 24, 32768)
-    with pytest.raises(RuntimeError, match="cannot be differentiated.*exactly one skip"):
-        A.render_rays(*args, test_time=False, output_transient_flow=['fw', 'bw', 'disocc'])
-    with torch.no_grad():
-        out = A.render_rays(*args, test_time=False, output_transient_flow=['fw', 'bw', 'disocc'])
-    assert torch.isfinite(out["rgb_fine"]).all() and "transient_flow_fw" in out
+def test_skip_lists_render_and_train(hip_lib):
+    """Several skip layers / none (nerf.py:34-40,163-167) run through the inference kernels (goldens g14 / g15) and through
+    the training kernels (gradient goldens g16 / g17, tests/test_gradients.py): a differentiated call carries a graph."""
+    for name in ("g14_two_skips", "g15_no_skip"):
+        cfg = dict(scenes.CASES[name], test_time=False)
+        rays, ts = scenes.synthetic_rays(cfg["n_rays"], cfg["seed"])
+        models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+        _to_dev(models, emb)
+        res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0,
+                            cfg["N_importance"], 32768, test_time=False, **scenes.render_kwargs(cfg))
+        assert res["rgb_fine"].requires_grad
+        res["rgb_fine"].sum().backward()
+        torch.cuda.synchronize()
+        g = models["fine"].transient_xyz_encoding_1[0].weight.grad
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
 
 
 def test_weight_repack_follows_parameter_updates(hip_lib):

@@ -56,16 +56,16 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 17
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 18
 
 
 def test_struct_layouts_match_the_header_sizes():
     # natural-alignment layout of the C structs (pointer = 8 bytes)
     assert C.sizeof(_lib.ModelDesc) == 48
-    assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 64 + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8
+    assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 4 * _lib.MAX_FREQS + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8 and _lib.MAX_FREQS == 24
     assert C.sizeof(_lib.FieldBwdArgs) == 16 + 8 * 8 and C.sizeof(_lib.WgradJob) == 32
     assert C.sizeof(_lib.SplatArgs) == 12 + 16 + 48 + 4 + 5 * 8 and C.sizeof(_lib.MpiArgs) == 16 + 7 * 8
-    assert C.sizeof(_lib.LossArgs) == 24 + 8 * (len(_lib._LOSS_IN) + len(_lib.LOSS_GRADS))
+    assert C.sizeof(_lib.LossArgs) == 24 + 8 + 8 + 8 * (len(_lib._LOSS_IN) + 3 + len(_lib.LOSS_GRADS))
     n_ptr = len(_lib._COMPOSITE_PTRS_IN) + len(_lib._COMPOSITE_PTRS_OUT)
     assert C.sizeof(_lib.FrustumArgs) == 16 + 16 + 16
     assert C.sizeof(_lib.CompositeArgs) == 40 + 8 * n_ptr + C.sizeof(_lib.FrustumArgs)
@@ -158,31 +158,42 @@ def test_compositing_node_outputs_are_result_keys_of_the_reference():
 
 def test_unsupported_architectures_are_refused_by_name():
     """models/nerf.py:34-40 accepts any W and a list of skips; the kernels take W = 256 and any skip layers among
-    1..D-1 (the backward kernels exactly one) -- the error must say which field."""
+    1..D-1, for inference and training alike -- the error must say which field."""
     from nsff_pl_amd import field_grad
     for kw, needle in ((dict(W=128), "W=128"), (dict(D=8, skips=[8]), "skips="), (dict(D=8, skips=[0, 4]), "skips="),
                        (dict(D=1, skips=[]), "D=1")):
         m = A.NeRF('fine', use_viewdir=False, **kw)
         with pytest.raises(RuntimeError, match="unsupported NeRF architecture.*" + needle):
             _lib.model_desc(m)
+        assert needle.rstrip("=") in field_grad.why_unsupported(m)
     for skips, mask in (([2, 5], 0b100100), ([], 0), ([1, 2, 3], 0b1110)):
-        m = A.NeRF('fine', D=6, skips=skips, use_viewdir=False)
-        d = _lib.model_desc(m)                                                 # several / no skip layers: inference only
+        m = A.NeRF('fine', D=6, skips=skips, use_viewdir=False, encode_transient=True)
+        d = _lib.model_desc(m)                                                 # several / no skip layers
         assert (d.skip, d.skip_mask) == (0, mask)
-        assert "exactly one skip" in field_grad.why_unsupported(m)
+        assert field_grad.why_unsupported(m) is None
         n = C.c_size_t(0)
         assert _lib.load().nsff_packed_bytes(C.byref(d), 1, C.byref(n)) == 0 and n.value > 0
-        assert _lib.load().nsff_bwd_packed_bytes(C.byref(d), C.byref(n)) != 0          # the backward pack refuses
+        assert _lib.load().nsff_bwd_packed_bytes(C.byref(d), C.byref(n)) == 0 and n.value > 0      # ... train as well
     d = _lib.model_desc(A.NeRF('fine', D=6, skips=[2], use_viewdir=False))
     assert (d.skip, d.skip_mask) == (2, 0)
-    _lib.model_desc(A.NeRF('fine', D=6, skips=[2], use_viewdir=False))       # fine
+    # the reference's CLI can widen the embeddings (opt.py:25,41,45): the saved input tiles then have 256 rows
+    assert _lib.train_dims(A.NeRF('fine', use_viewdir=False, encode_transient=True)) == (128, 64, 128)
+    assert _lib.train_dims(A.NeRF('fine', use_viewdir=False, in_channels_xyz=3 + 6 * 12, encode_transient=True, in_channels_t=96)) == (256, 128, 128)
+    assert _lib.train_dims(A.NeRF('fine', use_viewdir=True, in_channels_dir=99, encode_appearance=True, in_channels_a=48)) == (128, 64, 256)
+    assert _lib.train_dims(A.NeRF("fine", use_viewdir=False, in_channels_xyz=3 + 6 * 20, encode_transient=True, in_channels_t=128)) == (256, 128, 128)
+    too_wide = A.NeRF("fine", use_viewdir=False, in_channels_xyz=3 + 6 * 20, encode_transient=True, in_channels_t=192)   # 128 + 192 > 256
+    assert "must fit 256 columns" in field_grad.why_unsupported(too_wide)
 
 
 @pytest.mark.parametrize("kw,static,transient", [
     (dict(use_viewdir=False, encode_transient=True, output_flow=True), True, True),
     (dict(use_viewdir=False, encode_transient=True, output_flow=True), False, True),
     (dict(use_viewdir=True, encode_appearance=True, in_channels_a=48, encode_transient=True, output_flow=True), True, True),
-    (dict(use_viewdir=True, encode_transient=False, D=5, skips=[2]), True, False)])
+    (dict(use_viewdir=True, encode_transient=False, D=5, skips=[2]), True, False),
+    (dict(use_viewdir=False, encode_transient=True, output_flow=True, skips=[2, 5]), True, True),
+    (dict(use_viewdir=False, encode_transient=True, output_flow=True, D=4, skips=[]), True, True),
+    (dict(use_viewdir=True, encode_appearance=True, in_channels_a=48, in_channels_dir=99, in_channels_xyz=75,
+          encode_transient=True, in_channels_t=96, output_flow=True), True, True)])
 def test_gradient_map_names_the_same_elements_as_the_tensor_assembly(kw, static, transient):
     """nsff_weight_grad_accumulate's map (field_grad._grad_map) is built by running the tensor assembly on index
     objects: gathering through those indices must reproduce the tensors, element for element, with one owner each."""
@@ -191,7 +202,7 @@ def test_gradient_map_names_the_same_elements_as_the_tensor_assembly(kw, static,
     plist = _lib.param_list(model)
     meta = fg._wgrad_jobs(model, static, transient)
     rng = np.random.default_rng(5)
-    mats = [rng.standard_normal(fg._JOB_SHAPE[k]).astype(np.float32) for k, _, _ in meta]
+    mats = [rng.standard_normal(fg.job_shape(model, k)).astype(np.float32) for k, _, _ in meta]
     rows = [rng.standard_normal(256).astype(np.float32) for _ in meta]
     sizes = [m.size for m in mats]
     tens = fg._assemble(model, static, transient, meta, plist, lambda i: torch.from_numpy(mats[i]),

@@ -242,10 +242,15 @@ def test_trainer_steps_reduce_the_loss(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_rays,coarse", [(64, True), (333, True), (1024, False)])
-def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, hip_lib, monkeypatch):
+@pytest.mark.parametrize("n_rays,coarse,topk,thickness,weighted", [
+    (64, True, 1.0, 1, False), (333, True, 1.0, 1, False), (1024, False, 1.0, 1, False),
+    (333, True, 0.3, 1, False), (256, True, 1.0, 3, False), (200, False, 1.0, 4, True), (333, True, 0.7, 5, True)])
+def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, topk, thickness, weighted, hip_lib, monkeypatch):
     """csrc/loss.hip (terms + gradients w.r.t. every consumed render tensor, arbitrary upstream weights per term)
-    against autograd of the torch NeRFWLoss on the same render dict."""
+    against autograd of the torch NeRFWLoss on the same render dict -- plain means and the reference's other reductions:
+    --topk < 1 (losses.py:162-169), --thickness > 1 (:91-95; kornia's filter2d is absent here, so that golden is unpinned:
+    the torch side is the conv1d restatement, itself checked against a hand-written box filter in test_loss_options) and
+    per-ray weights (:163-164)."""
     from test_gpu_parity import _to_dev, DEV
     from nsff_pl_amd import fused_loss
     cfg = dict(scenes.CASES["g7_nsff_train_noise"], n_rays=n_rays)
@@ -259,13 +264,16 @@ def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, hip_lib, 
                             test_time=False, **kw)
     if not coarse:
         res = {k: v for k, v in res.items() if not k.endswith("_coarse")}
-    loss_fn = NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0, static_shapes=True)
+    plain = topk >= 1 and not weighted
+    loss_fn = NeRFWLoss(lambda_geo=0.04, thickness=thickness, topk=topk, static_shapes=plain)
     Ks, Ps, max_t = scenes.camera_buffers()
     loss_fn.register_buffer("Ks", Ks); loss_fn.register_buffer("Ps", Ps); loss_fn.max_t = max_t
     loss_fn.to(DEV)
     targets = {k: v.to(DEV) for k, v in scenes.synthetic_targets(n_rays, ts, 5).items()}
     g = torch.Generator().manual_seed(11)
     upstream = {k: float(torch.rand(1, generator=g)) + 0.5 for k in fused_loss.TERMS}
+    if weighted:
+        kw = dict(kw, weights=(torch.rand(n_rays, generator=g) + 0.25).to(DEV))
     out = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("NSFF_FUSED_LOSS", fused)
