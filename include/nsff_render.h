@@ -399,7 +399,13 @@ typedef struct NsffSplatArgs {
     const float* rgb;           /* (H*W, S, 3) transient_rgbs_fine                                           */
     const float* alpha;         /* (H*W, S)    transient_alphas_fine                                         */
     float*       accum;         /* (H*W, S, 8) OUT; cleared by this call                                     */
+    void*        work;          /* device workspace of the binned far path (32-byte aligned) or NULL: samples that land
+                                   farther than 4 pixels from their own pixel are then added with device-scope atomics */
+    int64_t      work_bytes;    /* nsff_splat_work_bytes(H, W, S) holds every far sample twice (a sample makes one record
+                                   per 32 x 8 output block it touches, 1.16 on average); what does not fit takes the
+                                   atomic route                                                                       */
 } NsffSplatArgs;
+int64_t nsff_splat_work_bytes(int32_t H, int32_t W, int32_t n_planes);
 int nsff_splat_planes(const NsffSplatArgs* args, void* stream);
 
 typedef struct NsffMpiArgs {

@@ -98,7 +98,8 @@ class WgradJob(C.Structure):
 class SplatArgs(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("n_planes", C.c_int32), ("K4", C.c_float * 4),
                 ("P", C.c_float * 12), ("scale", C.c_float),
-                ("xyz", _fp), ("flow", _fp), ("rgb", _fp), ("alpha", _fp), ("accum", _fp)]
+                ("xyz", _fp), ("flow", _fp), ("rgb", _fp), ("alpha", _fp), ("accum", _fp), ("work", _fp),
+                ("work_bytes", C.c_int64)]
 
 
 class MpiArgs(C.Structure):
@@ -159,6 +160,7 @@ _SIGNATURES = {
     "nsff_composite_backward": (C.c_int, [C.POINTER(CompositeBwdArgs), _fp]),
     "nsff_nerfw_loss": (C.c_int, [C.POINTER(LossArgs), C.c_int, _fp]),
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
+    "nsff_splat_work_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
     "nsff_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -507,9 +509,17 @@ def nerfw_loss(mode, n_rays, n_samples, n_keep, n_frames, max_t, topk=1.0, thick
     _check(load().nsff_nerfw_loss(C.byref(a), int(mode), _stream()), "nsff_nerfw_loss")
 
 
-def splat_planes(H, W, S, K4, P12, scale, xyz, flow, rgb, alpha, accum):
+def splat_work_bytes(H, W, S):
+    return int(load().nsff_splat_work_bytes(int(H), int(W), int(S)))
+
+
+def splat_planes(H, W, S, K4, P12, scale, xyz, flow, rgb, alpha, accum, work=None):
+    """work: uint8 device tensor of splat_work_bytes(H, W, S) bytes (binned far path) or None (device-scope atomics)."""
     a = SplatArgs(H=int(H), W=int(W), n_planes=int(S), scale=float(scale), xyz=_ptr(xyz), flow=_ptr(flow),
                   rgb=_ptr(rgb), alpha=_ptr(alpha), accum=_ptr(accum))
+    if work is not None:
+        assert work.is_cuda and work.is_contiguous() and work.dtype == torch.uint8
+        a.work, a.work_bytes = work.data_ptr(), work.numel()
     a.K4[:] = [float(v) for v in K4]
     a.P[:] = [float(v) for v in P12]
     _check(load().nsff_splat_planes(C.byref(a), _stream()), "nsff_splat_planes")

@@ -1,8 +1,20 @@
 // N2: plane splatting + MPI compositing for time interpolation (reference models/rendering.py:365-460,
-// models/softsplat.py:6-44,303-326).  Scatter work: output tiles are OWNED by workgroups that accumulate the
-// samples landing in them in LDS (ds_add_f32) and write them with plain stores; only samples that move farther
-// than the halo use global atomics.  Compositing is one wavefront per pixel with a segmented product scan over
-// the planes (same scheme as composite_kernel in rays.hip).
+// models/softsplat.py:6-44,303-326).  Scatter work without global atomics: output blocks (32 x 8 pixels x 8 planes) are OWNED
+// by workgroups.
+//   splat_tiles_kernel   accumulates the NEAR samples (landing within a 4-pixel halo of their own pixel) of the block's
+//                        surroundings in LDS (ds_add_f32) and writes the block with plain stores; while it projects its own
+//                        samples anyway it counts the FAR ones per destination block (LDS histogram -> one global add per
+//                        (workgroup, destination));
+//   splat_scan_kernel    exclusive scan of the destination counts -> where each block's records start;
+//   splat_bin_kernel     workgroups that own far samples re-project them and append one 32-byte record {landing, plane,
+//                        rgba} per (sample, destination block) to the destination's range;
+//   splat_gather_kernel  one workgroup per destination block with records: LDS accumulate, then add to the block.
+// Samples that move farther than the halo are rare for a trained flow field (the last three kernels then return at once);
+// random-init flow heads move EVERY sample ~50 px, which the first version paid for with 20 device-scope atomics per sample
+// (49 ms per 512 x 288 x 256 frame at ~15 G atomics/s).  Without a workspace (or on frames of more than MAX_TILES blocks)
+// the far samples still take that route (splat_far_kernel).
+// Compositing is one wavefront per pixel with a segmented product scan over the planes (same scheme as composite_kernel
+// in rays.hip).
 #include "nsff_common.h"
 
 namespace {
@@ -32,7 +44,7 @@ __device__ __forceinline__ void ndc2world(const float x, const float y, const fl
 }
 
 // Where sample (pixel px,py; plane s) of the source frame lands: bilinear corner (nwx, nwy) and the four weights.
-struct Landing { int nwx, nwy; float w[4]; bool finite; };
+struct Landing { int nwx, nwy; float w[4]; float ox, oy; bool finite; };
 
 __device__ __forceinline__ Landing project_sample(const NsffSplatArgs& a, long long idx, int px, int py) {
     const float* xp = a.xyz + idx * 3;
@@ -52,6 +64,7 @@ __device__ __forceinline__ Landing project_sample(const NsffSplatArgs& a, long l
     const float oy = (float)py + (uvd[1] / uvd[2] - (float)py);
     const float flx = floorf(ox), fly = floorf(oy);
     Landing L;
+    L.ox = ox; L.oy = oy;
     L.finite = flx >= -2.0f && flx <= (float)a.W && fly >= -2.0f && fly <= (float)a.H;   // false for NaN / far outside
     L.nwx = L.finite ? (int)flx : -4;
     L.nwy = L.finite ? (int)fly : -4;
@@ -61,6 +74,15 @@ __device__ __forceinline__ Landing project_sample(const NsffSplatArgs& a, long l
     L.w[2] = (sex - ox) * (oy - (float)L.nwy);        // south-west
     L.w[3] = (ox - (float)L.nwx) * (oy - (float)L.nwy);
     return L;
+}
+
+// the four bilinear weights of a landing, exactly as project_sample forms them
+__device__ __forceinline__ void landing_weights(Landing& L) {
+    const float sex = (float)(L.nwx + 1), sey = (float)(L.nwy + 1);
+    L.w[0] = (sex - L.ox) * (sey - L.oy);
+    L.w[1] = (L.ox - (float)L.nwx) * (sey - L.oy);
+    L.w[2] = (sex - L.ox) * (L.oy - (float)L.nwy);
+    L.w[3] = (L.ox - (float)L.nwx) * (L.oy - (float)L.nwy);
 }
 
 // A sample is "near" when its landing cell is within HALO pixels of its own pixel: then every output tile it
@@ -75,13 +97,59 @@ __device__ __forceinline__ bool is_near(const Landing& L, int px, int py) {
 // Pass 1: each workgroup OWNS a TILE_X x TILE_Y block of output pixels for PL consecutive planes, accumulates the
 // near samples of the surrounding (tile + halo) source region in LDS (ds_add_f32) and writes the block with plain
 // stores -- no global atomics, no memset; the 2.5x redundant projection work is cheap next to the atomics it saves.
+// Workspace of the binned far path (ints, then 32-byte records): per block b = tile + n_tiles * plane group
+struct FarWork {
+    int* count;        // [n_blocks] far records destined for block b
+    int* start;        // [n_blocks + 1] exclusive scan of count
+    int* cursor;       // [n_blocks] next free record of block b (splat_bin_kernel)
+    int* own;          // [n_blocks] far records the samples OWNED by block b produce
+    float* records;    // capacity x 8 floats: {ox, oy, plane in group (int bits), r | g, b, a, -} (landing as project_sample left it)
+    long long capacity;
+    int n_tiles, tiles_x, n_blocks;
+};
+constexpr int MAX_TILES = 6144;      // LDS histogram of destination tiles (24 KiB) next to the 40 KiB accumulator
+
+__device__ __forceinline__ FarWork far_work(const NsffSplatArgs& a) {
+    FarWork w{};
+    w.tiles_x = (a.W + TILE_X - 1) / TILE_X;
+    w.n_tiles = w.tiles_x * ((a.H + TILE_Y - 1) / TILE_Y);
+    w.n_blocks = w.n_tiles * ((a.n_planes + PL - 1) / PL);
+    if (a.work == nullptr || w.n_tiles > MAX_TILES) return w;
+    int* p = reinterpret_cast<int*>(a.work);
+    const long long ints = 4LL * w.n_blocks + 8;
+    w.count = p; w.start = p + w.n_blocks; w.cursor = w.start + w.n_blocks + 1; w.own = w.cursor + w.n_blocks;
+    const long long head = (ints * 4 + 31) / 32 * 32;
+    w.records = reinterpret_cast<float*>(reinterpret_cast<char*>(a.work) + head);
+    w.capacity = (a.work_bytes - head) / 32;
+    if (w.capacity < 1) w.count = nullptr;
+    return w;
+}
+
+// the (up to four) distinct destination tiles of a far landing: calls f(tile) once per tile that holds a corner inside the frame
+template <class F>
+__device__ __forceinline__ void for_each_dest_tile(const NsffSplatArgs& a, const Landing& L, int tiles_x, F&& f) {
+    int seen[4], n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cx = L.nwx + (k & 1), cy = L.nwy + (k >> 1);
+        if (cx < 0 || cx >= a.W || cy < 0 || cy >= a.H) continue;
+        const int t = (cy / TILE_Y) * tiles_x + cx / TILE_X;
+        bool dup = false;
+        for (int j = 0; j < n; ++j) dup = dup || seen[j] == t;
+        if (!dup) { seen[n++] = t; f(t); }
+    }
+}
+
 __global__ __launch_bounds__(256) void splat_tiles_kernel(const NsffSplatArgs a) {
     __shared__ float sAcc[TILE_X * TILE_Y * PL * 5];
+    __shared__ int sHist[MAX_TILES];
     const int S = a.n_planes;
     const int tiles_x = (a.W + TILE_X - 1) / TILE_X;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blockIdx.y * PL;
+    const FarWork fw = far_work(a);
     for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL * 5; i += 256) sAcc[i] = 0.f;
+    if (fw.count != nullptr) for (int i = threadIdx.x; i < fw.n_tiles; i += 256) sHist[i] = 0;
     __syncthreads();
     for (int item = threadIdx.x; item < REG_X * REG_Y * PL; item += 256) {
         const int j = item % PL, rp = item / PL;
@@ -89,7 +157,13 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(const NsffSplatArgs a)
         if (px < 0 || px >= a.W || py < 0 || py >= a.H || s >= S) continue;
         const long long idx = ((long long)py * a.W + px) * S + s;
         const Landing L = project_sample(a, idx, px, py);
-        if (!is_near(L, px, py)) continue;
+        if (!is_near(L, px, py)) {
+            // a far sample of this block's OWN pixels: one record per destination tile it touches (binned far path)
+            const bool own = px >= x0 && px < x0 + TILE_X && py >= y0 && py < y0 + TILE_Y;
+            if (own && L.finite && fw.count != nullptr)
+                for_each_dest_tile(a, L, tiles_x, [&](int t) { atomicAdd(&sHist[t], 1); });
+            continue;
+        }
         const float* cp = a.rgb + idx * 3;
         const float src[5] = {cp[0], cp[1], cp[2], a.alpha[idx], 1.0f};
 #pragma unroll
@@ -112,9 +186,156 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(const NsffSplatArgs a)
         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
         dst[1] = make_float4(v[4], 0.f, 0.f, 0.f);
     }
+    if (fw.count != nullptr) {
+        int mine = 0;
+        for (int t = threadIdx.x; t < fw.n_tiles; t += 256) {
+            const int c = sHist[t];
+            if (c) { atomicAdd(fw.count + t + fw.n_tiles * blockIdx.y, c); mine += c; }
+        }
+        if (mine) atomicAdd(fw.own + blockIdx.x + fw.n_tiles * blockIdx.y, mine);
+    }
 }
 
-// Pass 2: samples that move farther than the halo (rare for a trained flow field) are added with global atomics.
+// exclusive scan of the per-block record counts (one workgroup; n_blocks is a few tens of thousands at most)
+__global__ __launch_bounds__(1024) void splat_scan_kernel(const NsffSplatArgs a) {
+    __shared__ int sWave[16];
+    __shared__ int sCarry;
+    const FarWork fw = far_work(a);
+    if (fw.count == nullptr) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sCarry = 0;
+    __syncthreads();
+    for (int base = 0; base < fw.n_blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < fw.n_blocks ? fw.count[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+        if (lane == 63) sWave[wave] = incl;
+        __syncthreads();
+        int before = sCarry;
+        for (int w = 0; w < wave; ++w) before += sWave[w];
+        if (i < fw.n_blocks) { fw.start[i] = before + incl - v; fw.cursor[i] = before + incl - v; }
+        __syncthreads();
+        if (threadIdx.x == 1023) sCarry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fw.start[fw.n_blocks] = sCarry;
+}
+
+// add one (sample, destination tile) contribution straight to the accumulator (fallback: no workspace / records overflow)
+__device__ __forceinline__ void far_atomic_add(const NsffSplatArgs& a, const Landing& L, int s, const float (&src)[5], int only_tile,
+                                               int tiles_x) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cx = L.nwx + (k & 1), cy = L.nwy + (k >> 1);
+        if (cx < 0 || cx >= a.W || cy < 0 || cy >= a.H) continue;
+        if (only_tile >= 0 && (cy / TILE_Y) * tiles_x + cx / TILE_X != only_tile) continue;
+        float* dst = a.accum + (((long long)cy * a.W + cx) * a.n_planes + s) * 8;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) unsafeAtomicAdd(dst + c, src[c] * L.w[k]);
+    }
+}
+
+// workgroups whose own samples include far ones: re-project them and append one record per destination tile
+__global__ __launch_bounds__(256) void splat_bin_kernel(const NsffSplatArgs a) {
+    __shared__ int sHist[MAX_TILES];      // records of this workgroup per destination tile: count, then slots handed out
+    __shared__ int sBase[MAX_TILES];      // first record of this workgroup's range in that destination
+    const FarWork fw = far_work(a);
+    if (fw.count == nullptr) return;
+    const int blk = blockIdx.x + fw.n_tiles * blockIdx.y;
+    if (fw.own[blk] == 0) return;                         // (the usual case for a trained flow field)
+    const int S = a.n_planes;
+    const int tx = blockIdx.x % fw.tiles_x, ty = blockIdx.x / fw.tiles_x;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blockIdx.y * PL;
+    for (int i = threadIdx.x; i < fw.n_tiles; i += 256) sHist[i] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int item = threadIdx.x; item < TILE_X * TILE_Y * PL; item += 256) {
+            const int j = item % PL, rp = item / PL;
+            const int px = x0 + rp % TILE_X, py = y0 + rp / TILE_X, sp = s0 + j;
+            if (px >= a.W || py >= a.H || sp >= S) continue;
+            const long long idx = ((long long)py * a.W + px) * S + sp;
+            const Landing L = project_sample(a, idx, px, py);
+            if (!L.finite || is_near(L, px, py)) continue;
+            if (pass == 0) {
+                for_each_dest_tile(a, L, fw.tiles_x, [&](int t) { atomicAdd(&sHist[t], 1); });
+            } else {
+                const float* cp = a.rgb + idx * 3;
+                const float src[5] = {cp[0], cp[1], cp[2], a.alpha[idx], 1.0f};
+                for_each_dest_tile(a, L, fw.tiles_x, [&](int t) {
+                    const long long slot = (long long)sBase[t] + atomicAdd(&sHist[t], 1);
+                    if (slot < fw.capacity) {
+                        float4* r = reinterpret_cast<float4*>(fw.records + slot * 8);
+                        r[0] = make_float4(L.ox, L.oy, __int_as_float(j), src[0]);
+                        r[1] = make_float4(src[1], src[2], src[3], 0.f);
+                    } else {                                 // workspace too small for this frame: the old route for the rest
+                        far_atomic_add(a, L, sp, src, t, fw.tiles_x);
+                    }
+                });
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {                                      // reserve this workgroup's range in every destination it feeds
+            for (int t = threadIdx.x; t < fw.n_tiles; t += 256) {
+                const int c = sHist[t];
+                sBase[t] = c ? atomicAdd(fw.cursor + t + fw.n_tiles * blockIdx.y, c) : 0;
+                sHist[t] = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// one workgroup per destination block: its records -> LDS accumulator -> added to the block splat_tiles_kernel wrote
+__global__ __launch_bounds__(256) void splat_gather_kernel(const NsffSplatArgs a) {
+    __shared__ float sAcc[TILE_X * TILE_Y * PL * 5];
+    const FarWork fw = far_work(a);
+    if (fw.count == nullptr) return;
+    const int blk = blockIdx.x + fw.n_tiles * blockIdx.y;
+    const long long first = fw.start[blk];
+    long long n = fw.count[blk];
+    if (first + n > fw.capacity) n = fw.capacity > first ? fw.capacity - first : 0;     // (the overflow went through atomics)
+    if (n <= 0) return;
+    const int S = a.n_planes;
+    const int tx = blockIdx.x % fw.tiles_x, ty = blockIdx.x / fw.tiles_x;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blockIdx.y * PL;
+    for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL * 5; i += 256) sAcc[i] = 0.f;
+    __syncthreads();
+    for (long long r = threadIdx.x; r < n; r += 256) {
+        const float4* rec = reinterpret_cast<const float4*>(fw.records + (first + r) * 8);
+        const float4 r0 = rec[0], r1 = rec[1];
+        Landing L;
+        L.ox = r0.x; L.oy = r0.y; L.finite = true;
+        L.nwx = (int)floorf(r0.x); L.nwy = (int)floorf(r0.y);
+        landing_weights(L);
+        const int j = __float_as_int(r0.z);
+        const float src[5] = {r0.w, r1.x, r1.y, r1.z, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = L.nwx + (k & 1) - x0, cy = L.nwy + (k >> 1) - y0;
+            if (cx < 0 || cx >= TILE_X || cy < 0 || cy >= TILE_Y) continue;
+            if (L.nwx + (k & 1) >= a.W || L.nwy + (k >> 1) >= a.H) continue;
+            float* dst = sAcc + ((cy * TILE_X + cx) * PL + j) * 5;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) atomicAdd(dst + c, src[c] * L.w[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL; i += 256) {
+        const int j = i % PL, pix = i / PL;
+        const int px = x0 + pix % TILE_X, py = y0 + pix / TILE_X, sp = s0 + j;
+        if (px >= a.W || py >= a.H || sp >= S) continue;
+        const float* v = sAcc + i * 5;
+        if (v[4] == 0.f) continue;                            // nothing landed in this cell
+        float4* dst = reinterpret_cast<float4*>(a.accum + (((long long)py * a.W + px) * S + sp) * 8);
+        float4 d0 = dst[0], d1 = dst[1];
+        d0.x += v[0]; d0.y += v[1]; d0.z += v[2]; d0.w += v[3]; d1.x += v[4];
+        dst[0] = d0; dst[1] = d1;
+    }
+}
+
+// Far samples without a workspace (or on frames of more than MAX_TILES blocks): device-scope atomics.
 __global__ __launch_bounds__(256) void splat_far_kernel(const NsffSplatArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;       // (pixel, plane), plane fastest
     const long long total = (long long)a.H * a.W * a.n_planes;
@@ -127,14 +348,7 @@ __global__ __launch_bounds__(256) void splat_far_kernel(const NsffSplatArgs a) {
     if (!L.finite || is_near(L, px, py)) return;
     const float* cp = a.rgb + idx * 3;
     const float src[5] = {cp[0], cp[1], cp[2], a.alpha[idx], 1.0f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int cx = L.nwx + (k & 1), cy = L.nwy + (k >> 1);
-        if (cx < 0 || cx >= a.W || cy < 0 || cy >= a.H) continue;
-        float* dst = a.accum + (((long long)cy * a.W + cx) * S + s) * 8;
-#pragma unroll
-        for (int c = 0; c < 5; ++c) unsafeAtomicAdd(dst + c, src[c] * L.w[k]);
-    }
+    far_atomic_add(a, L, s, src, -1, 0);
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void mpi_composite_kernel(const NsffMpiArgs a) {
@@ -187,6 +401,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void mpi_composite_kernel(con
 
 extern "C" {
 
+int64_t nsff_splat_work_bytes(int32_t H, int32_t W, int32_t n_planes) {
+    if (H < 1 || W < 1 || n_planes < 1) return -1;
+    const long long tiles = (long long)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    const long long n_blocks = tiles * ((n_planes + PL - 1) / PL);
+    const long long head = ((4 * n_blocks + 8) * 4 + 31) / 32 * 32;
+    return head + 2LL * H * W * n_planes * 32;
+}
+
 int nsff_splat_planes(const NsffSplatArgs* args, void* stream) {
     if (!args) return NSFF_ERR_NULL;
     const NsffSplatArgs& a = *args;
@@ -195,9 +417,23 @@ int nsff_splat_planes(const NsffSplatArgs* args, void* stream) {
     if (reinterpret_cast<uintptr_t>(a.accum) & 15) return NSFF_ERR_ALIGN;
     const long long total = (long long)a.H * a.W * a.n_planes;
     const unsigned tiles = (unsigned)(((a.W + TILE_X - 1) / TILE_X) * ((a.H + TILE_Y - 1) / TILE_Y));
-    hipLaunchKernelGGL(splat_tiles_kernel, dim3(tiles, (unsigned)((a.n_planes + PL - 1) / PL)), dim3(256), 0,
-                       (hipStream_t)stream, a);
-    hipLaunchKernelGGL(splat_far_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid(tiles, (unsigned)((a.n_planes + PL - 1) / PL));
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_blocks = (long long)grid.x * grid.y;
+    const long long head = ((4 * n_blocks + 8) * 4 + 31) / 32 * 32;
+    const bool binned = a.work != nullptr && (int)tiles <= MAX_TILES && a.work_bytes >= head + 32 &&
+                        !(reinterpret_cast<uintptr_t>(a.work) & 31);
+    NsffSplatArgs k = a;
+    if (!binned) { k.work = nullptr; k.work_bytes = 0; }
+    else if (hipMemsetAsync(a.work, 0, (size_t)head, st) != hipSuccess) return nsff_launch_status();
+    hipLaunchKernelGGL(splat_tiles_kernel, grid, dim3(256), 0, st, k);
+    if (binned) {
+        hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, st, k);
+        hipLaunchKernelGGL(splat_bin_kernel, grid, dim3(256), 0, st, k);
+        hipLaunchKernelGGL(splat_gather_kernel, grid, dim3(256), 0, st, k);
+    } else {
+        hipLaunchKernelGGL(splat_far_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k);
+    }
     return nsff_launch_status();
 }
 

@@ -3,12 +3,18 @@
 ``interpolate`` has the signature of the reference's ``models/rendering.py:365-460``.  The reference splats
 each of the S sample planes separately (2*S cupy launches, each with a ``.cuda()``/``.cpu()`` round trip,
 ``rendering.py:439-449``); here the whole frame is two ``nsff_splat_planes`` launches (t forward by dt, t+1
-backward by 1-dt) into (pixel, plane, 8) fp32 accumulators with hardware atomic adds, and one
-``nsff_mpi_composite`` launch (wavefront per pixel, product scan over the planes).
+backward by 1-dt) into (pixel, plane, 8) fp32 accumulators -- output blocks owned by workgroups, LDS adds, far samples
+binned per destination block (csrc/interp.hip) -- and one ``nsff_mpi_composite`` launch (wavefront per pixel, product scan
+over the planes).
 """
+import os
+
 import torch
 
 from . import _lib
+
+
+_FAR_BINNING = os.environ.get("NSFF_SPLAT_BINNING", "1") != "0"      # 0: far samples through device-scope atomics (A/B)
 
 
 def _dev(t, device):
@@ -37,12 +43,15 @@ def interpolate(results_t, results_tp1, dt, K, c2w, img_wh):
 
     xyz = _dev(xyzs, device)
     accum = torch.empty(2, n_rays, S, 8, device=device)
+    # workspace of the binned far path (samples that move more than 4 pixels): one allocation serves both splats, and the
+    # caching allocator hands the same block back frame after frame
+    work = torch.empty(_lib.splat_work_bytes(h, w, S), device=device, dtype=torch.uint8) if _FAR_BINNING else None
     _lib.splat_planes(h, w, S, K4, P, dt, xyz, _dev(results_t['transient_flows_fw'], device),
                       _dev(results_t['transient_rgbs_fine'], device), _dev(results_t['transient_alphas_fine'], device),
-                      accum[0])
+                      accum[0], work)
     _lib.splat_planes(h, w, S, K4, P, 1 - dt, xyz, _dev(results_tp1['transient_flows_bw'], device),
                       _dev(results_tp1['transient_rgbs_fine'], device),
-                      _dev(results_tp1['transient_alphas_fine'], device), accum[1])
+                      _dev(results_tp1['transient_alphas_fine'], device), accum[1], work)
     rgb = torch.empty(h, w, 3, device=device)
     depth = torch.empty(h, w, device=device)
     _lib.mpi_composite(h, w, S, dt, accum[0], accum[1], _dev(results_t['static_rgbs_fine'], device),

@@ -266,8 +266,13 @@ def test_multi_tile_case_exercises_every_splat_path():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(96, 40, 24), (70, 19, 11)])        # whole tiles / ragged tiles and plane groups
-def test_hip_interpolate_multi_tile_matches_oracle(shape, hip_lib):
+@pytest.mark.parametrize("shape,binning", [((96, 40, 24), True), ((70, 19, 11), True), ((96, 40, 24), False),
+                                           ((512, 288, 64), True)])
+def test_hip_interpolate_multi_tile_matches_oracle(shape, binning, hip_lib, monkeypatch):
+    """whole tiles / ragged tiles and plane groups / the atomic far route / the C5 frame size (BASELINE.json configs[4]:
+    512 x 288, 64 planes here -- the oracle's numpy scatter-add needs ~20 s for it)."""
+    import nsff_pl_amd.interpolation as I
+    monkeypatch.setattr(I, "_FAR_BINNING", binning)
     W, H, S = shape
     res_t, res_tp1, dt, K, c2w, wh, _ = multi_tile_case(W, H, S)
     dev = torch.device("cuda:0")
