@@ -238,42 +238,43 @@ __device__ __forceinline__ float pow2_scale(float amax) {      // 2^k with amax 
 
 // LDS tile (fp16, [point][LDH]) -> HBM fragments dst[ks][row block][lane][8 pts] (layout of field_h3.hip's
 // tile_to_fragments), every point scaled by rel[p] = G / s_p, a power of two <= 1 that reaches down to 2^-40: it is applied
-// as two packed fp16 factors r1 = max(rel, 2^-14) and r2 = rel / r1 (sRel1 / sRel2 hold them duplicated in both halfs of a
-// dword).  The first product is exact unless it is subnormal, the second only ever shrinks it -- what comes out is the
-// fp16 rounding of v * rel up to a second rounding in the subnormal range (2^-25 absolute on a scale whose maximum is
-// 2^10), and no clamp is needed since |v * rel| <= |v|.  One task = (row pair, 8-point group) = two 16-byte stores; a
-// 256-row tile is 1024 tasks = four per thread.
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void fragment_task(const _Float16* sB, const unsigned* sRel1, const unsigned* sRel2, _Float16* dst,
-                                              int n_rows, int task) {
-    const int pairs = n_rows >> 1;                                         // two neurons per 4-byte LDS read
-    const int row = 2 * (task % pairs), pg = task / pairs;
-    const u4 a0 = *reinterpret_cast<const u4*>(sRel1 + 8 * pg), a1 = *reinterpret_cast<const u4*>(sRel1 + 8 * pg + 4);
-    const u4 b0 = *reinterpret_cast<const u4*>(sRel2 + 8 * pg), b1 = *reinterpret_cast<const u4*>(sRel2 + 8 * pg + 4);
-    const unsigned r1[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    const unsigned r2[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-    h8 out0, out1;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const h2 v = *reinterpret_cast<const h2*>(sB + (8 * pg + t) * LDH + row);
-        const h2 p = (v * __builtin_bit_cast(h2, r1[t])) * __builtin_bit_cast(h2, r2[t]);
-        out0[t] = p[0];
-        out1[t] = p[1];
-    }
-    _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
-    __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad:
-    __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));     // keep the weights' L2 lines (-17 % per launch)
+// as two packed fp16 factors r1 = max(rel, 2^-14) and r2 = rel / r1 (sRel1 / sRel2, one half per point).  The first product
+// is exact unless it is subnormal, the second only ever shrinks it -- what comes out is the fp16 rounding of v * rel up to a
+// second rounding in the subnormal range (2^-25 absolute on a scale whose maximum is 2^10), and no clamp is needed since
+// |v * rel| <= |v|.  One unit of work = one 1 KiB block (16 points x 32 rows) = one wave-wide contiguous 16-byte store: two
+// transposing LDS reads (ds_read_b64_tr_b16: lane i of a 16-lane group addresses four rows of point i / 4 and receives row
+// i % 16 at the group's four points -- see field_h3.hip), two 8-byte reads per factor array, four packed multiplies.  A
+// 256-row tile is 32 blocks = eight per wave.
+typedef __fp16 fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h4 lds_tr4(const _Float16* p) {
+    return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp4*)p));
 }
-__device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const unsigned* sRel1, const unsigned* sRel2,
+__device__ __forceinline__ void fragment_block(const _Float16* sB, const _Float16* sRel1, const _Float16* sRel2, _Float16* dst,
+                                               int n_rows, int blk, int lane) {
+    const int rblocks = n_rows >> 5;
+    const int rb = blk % rblocks, ks = blk / rblocks;
+    const int i = lane & 15, g = lane >> 4;
+    const int pt0 = 16 * ks + 8 * (g >> 1);                                  // first of this lane's eight points
+    const int at = (pt0 + (i >> 2)) * LDH + 32 * rb + 16 * (g & 1) + 4 * (i & 3);
+    const h4 v03 = lds_tr4(sB + at), v47 = lds_tr4(sB + at + 4 * LDH);
+    const h4 p03 = (v03 * *reinterpret_cast<const h4*>(sRel1 + pt0)) * *reinterpret_cast<const h4*>(sRel2 + pt0);
+    const h4 p47 = (v47 * *reinterpret_cast<const h4*>(sRel1 + pt0 + 4)) * *reinterpret_cast<const h4*>(sRel2 + pt0 + 4);
+    h8 out;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { out[t] = p03[t]; out[4 + t] = p47[t]; }
+    // written once, read once by nsff_weight_grad: keep the weights' L2 lines (-17 % per launch)
+    __builtin_nontemporal_store(out, reinterpret_cast<h8*>(dst + (((long long)ks * rblocks + rb) * 64 + lane) * 8));
+}
+__device__ __forceinline__ void tile_to_fragments_scaled(const _Float16* sB, const _Float16* sRel1, const _Float16* sRel2,
                                                          _Float16* dst, int n_rows) {
-    for (int task = threadIdx.x; task < (n_rows >> 1) * 8; task += 256) fragment_task(sB, sRel1, sRel2, dst, n_rows, task);
+    for (int blk = threadIdx.x >> 6; blk < (n_rows >> 5) * 4; blk += 4) fragment_block(sB, sRel1, sRel2, dst, n_rows, blk, threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 sB[64 * LDH];
     __shared__ __attribute__((aligned(16))) _Float16 sStash[64 * LDH];
     __shared__ __attribute__((aligned(16))) float sInv[64], sSig[64];
-    __shared__ __attribute__((aligned(16))) unsigned sRel1[64], sRel2[64];      // G / s as two packed fp16 factors (fragment_task)
+    __shared__ __attribute__((aligned(16))) _Float16 sRel1[64], sRel2[64];     // G / s as two fp16 factors (fragment_block)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long tile = blockIdx.x;
@@ -345,9 +346,8 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
                 sInv[pt] = 1.0f / s;
                 const float rel = fminf(G / s, 1.0f);                // (> 1 only for an all-zero row: any factor will do)
                 const float f1 = fmaxf(rel, 6.103515625e-05f);       // 2^-14: the smallest normal fp16
-                const h2 p1 = {(_Float16)f1, (_Float16)f1}, p2 = {(_Float16)(rel / f1), (_Float16)(rel / f1)};
-                sRel1[pt] = __builtin_bit_cast(unsigned, p1);
-                sRel2[pt] = __builtin_bit_cast(unsigned, p2);
+                sRel1[pt] = (_Float16)f1;
+                sRel2[pt] = (_Float16)(rel / f1);
                 sSig[pt] = is_static ? hv[3] * s : 0.f;     // the static sigma head reads the trunk, not *_final
                 h8 lo, hi;
 #pragma unroll
@@ -392,11 +392,16 @@ __global__ __launch_bounds__(256, 2) void nsff_field_bwd_kernel(const BKArgs a) 
             const bool copy = BWD_STORE_INTERLEAVE && pending_slot >= 0;
             _Float16* dst = pending_dst();
             gemm1(acc, ring, wnext, (st.flags & F_FROM_STASH) ? sSw : sBw, st.nks,
-                  [&](int j) { if (copy) fragment_task(sB, sRel1, sRel2, dst, NSFF_W, (int)threadIdx.x + 256 * j); },
+                  [&](int j) {                       // two of the wave's eight blocks behind each group of four k-steps
+                      if (copy) {
+                          fragment_block(sB, sRel1, sRel2, dst, NSFF_W, wave + 4 * (2 * j), lane);
+                          fragment_block(sB, sRel1, sRel2, dst, NSFF_W, wave + 4 * (2 * j + 1), lane);
+                      }
+                  },
                   [&](int j) {
                       if (copy) {
 #pragma unroll 1
-                          for (; j < 4; ++j) { fragment_task(sB, sRel1, sRel2, dst, NSFF_W, (int)threadIdx.x + 256 * j); B_PIN(); }
+                          for (int u = 2 * j; u < 8; ++u) { fragment_block(sB, sRel1, sRel2, dst, NSFF_W, wave + 4 * u, lane); B_PIN(); }
                       }
                   });
             if (copy) pending_slot = -1;

@@ -441,34 +441,48 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
 
 // Copy the tile's activations (hi + lo planes, rounded to nearest) to HBM in the fragment order of the
 // weight-gradient GEMM (K = points): dst[ks][row block][lane][8 pts] -- every 1 KiB block is exactly one MFMA
-// operand fragment (32 rows x 16 points) in lane order; rows = neurons (n_rows, a multiple of 32), ks = 16-point groups
-// (four per 64-point tile of the backward kernels; a 128-point workgroup writes two consecutive tiles).
-// One task = (row pair, 8-point group) = two 16-byte stores; hi + lo is one packed fp16 add (the sum of the two halfs
-// rounded to nearest even -- what the fp32 sum followed by a conversion gives, the fp32 sum being exact).
-// pg_end: 8-point groups that exist (the second 64-point tile of the last 128-point workgroup may not).
-__device__ __forceinline__ void fragment_task(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows, int pairs,
-                                              int task, int pg_end) {
-    const int row = 2 * (task % pairs), pg = task / pairs;
-    if (pg >= pg_end) return;
-    h8 out0, out1;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int idx = (8 * pg + t) * LDH + row;
-        const h2f sum = *reinterpret_cast<const h2f*>(sXh + idx) + *reinterpret_cast<const h2f*>(sXl + idx);
-        out0[t] = sum[0];
-        out1[t] = sum[1];
-    }
-    // 1 KiB blocks of 32 rows, lane-linear inside: [ks][row/32][(row&31) + 32*(point group&1)][8 points]
-    _Float16* d = dst + ((((pg >> 1) * (n_rows >> 5) + (row >> 5)) * 64) + (row & 31) + 32 * (pg & 1)) * 8;
-    __builtin_nontemporal_store(out0, reinterpret_cast<h8*>(d));         // written once, read once by nsff_weight_grad
-    __builtin_nontemporal_store(out1, reinterpret_cast<h8*>(d + 8));
+// operand fragment (32 rows x 16 points) in lane order, lane = (row & 31) + 32 * (8-point group & 1); rows = neurons (n_rows,
+// a multiple of 32), ks = 16-point groups (four per 64-point tile of the backward kernels; a 128-point workgroup writes two
+// consecutive tiles).
+// One unit of work = one such block = one wave-wide, fully contiguous 16-byte store: the LDS image is point-major, the
+// fragment wants 8 consecutive POINTS of one row per lane, and ds_read_b64_tr_b16 does that transposition in the read -- lane
+// i of a 16-lane group addresses four consecutive rows (neurons) of point i / 4, and receives row i % 16 of the group's
+// sixteen at its four points (tools/debug/probes/tr_read_probe.hip prints the mapping).  Four reads (two per plane), four
+// packed adds (hi + lo: the sum of the two halfs rounded to nearest even -- what the fp32 sum followed by a conversion
+// gives, the fp32 sum being exact) and one store per block instead of 16 four-byte reads, 16 element inserts and two
+// strided stores per (row pair, 8 points).  Same box, 131 072 points, both trunks: training forward 1000 -> 988 us, field
+// backward (same scheme, field_bwd.hip) 492 -> 464 us.  What the copy costs the training forward is mostly not instructions:
+// with its stores compiled out 963 -> 885 us, without the copy 792 us, without the sign words 934 us (inference kernel: 736);
+// reading the tile a GEMM group ahead of the adds changed nothing -- the eight waves' B-operand reads already keep the LDS
+// ~2/3 busy during a layer and every copied tile is one more pass over it.
+// ks_end: 16-point groups that exist (the second 64-point tile of the last 128-point workgroup may not).
+typedef __fp16 fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h4 lds_tr4(const _Float16* p) {
+    return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp4*)p));
 }
+__device__ __forceinline__ void fragment_block(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows, int rows_copied,
+                                               int rblocks, int blk, int ks_end, int lane) {
+    const int rb = blk % rblocks, ks = blk / rblocks;
+    if (ks >= ks_end) return;
+    const int i = lane & 15, g = lane >> 4;
+    const int at = (16 * ks + 8 * (g >> 1) + (i >> 2)) * LDH + 32 * rb + 16 * (g & 1) + 4 * (i & 3);
+    const h4 lo03 = lds_tr4(sXh + at) + lds_tr4(sXl + at);                           // points 0..3 of the lane's eight
+    const h4 lo47 = lds_tr4(sXh + at + 4 * LDH) + lds_tr4(sXl + at + 4 * LDH);       // points 4..7
+    h8 out;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { out[t] = lo03[t]; out[4 + t] = lo47[t]; }
+    _Float16* d = dst + (((long long)ks * (n_rows >> 5) + rb) * 64 + lane) * 8;
+    if (32 * rb + (lane & 31) < rows_copied)
+        __builtin_nontemporal_store(out, reinterpret_cast<h8*>(d));          // written once, read once by nsff_weight_grad
+}
+// blocks of a tile: (16-point group, 32-row block), row block fastest
+template <int M> __device__ __forceinline__ int fragment_blocks(int rows_copied) { return ((rows_copied + 31) >> 5) * (M / 16); }
 template <int THREADS, int M>
 __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows,
-                                                  int rows_copied, int pg_end) {
-    const int pairs = rows_copied >> 1;                                    // two neurons per 4-byte LDS read
-    for (int task = threadIdx.x; task < pairs * (M / 8); task += THREADS)  // (8-point group, row pair), pair fastest
-        fragment_task(sXh, sXl, dst, n_rows, pairs, task, pg_end);
+                                                  int rows_copied, int ks_end) {
+    const int rblocks = (rows_copied + 31) >> 5;
+    for (int blk = threadIdx.x >> 6; blk < rblocks * (M / 16); blk += THREADS / 64)
+        fragment_block(sXh, sXl, dst, n_rows, rows_copied, rblocks, blk, ks_end, threadIdx.x & 63);
 }
 
 // four consecutive columns of one row -> one 8-byte store per plane
@@ -830,15 +844,16 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     // (vmcnt counts loads and stores in one in-order queue: a burst of stores in front of a GEMM holds its refills
     // back until every store is acknowledged).  A tile that is rebuilt or abandoned first is flushed on the spot.
     [[maybe_unused]] _Float16* pend_dst = nullptr;
-    [[maybe_unused]] int pend_rows = 0, pend_pairs = 0, pend_total = 0;
+    [[maybe_unused]] int pend_rows = 0, pend_copied = 0, pend_rblocks = 1, pend_total = 0;
     [[maybe_unused]] const long long tile64 = tile * (M / 64);
-    [[maybe_unused]] const int pg_end = (M == 128 && tile64 + 1 >= a.n_tiles) ? 8 : M / 8;
+    [[maybe_unused]] const int ks_end = (M == 128 && tile64 + 1 >= a.n_tiles) ? 4 : M / 16;
     auto pend_set = [&](_Float16* dst, int n_rows, int rows_copied) {
-        pend_dst = dst; pend_rows = n_rows; pend_pairs = rows_copied >> 1; pend_total = pend_pairs * (M / 8);
+        pend_dst = dst; pend_rows = n_rows; pend_copied = rows_copied; pend_rblocks = (rows_copied + 31) >> 5;
+        pend_total = fragment_blocks<M>(rows_copied);
     };
     auto pend_flush = [&]() {
         if constexpr (SAVE) {
-            if (pend_dst != nullptr) tile_to_fragments<THREADS, M>(sXh, sXl, pend_dst, pend_rows, 2 * pend_pairs, pg_end);
+            if (pend_dst != nullptr) tile_to_fragments<THREADS, M>(sXh, sXl, pend_dst, pend_rows, pend_copied, ks_end);
             pend_dst = nullptr;
         }
     };
@@ -900,15 +915,19 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             // (one instantiation of the GEMM loop; the copy is switched by a wave-uniform flag)
             const bool copy = H3_SAVE_INTERLEAVE && pend_dst != nullptr;
             const uint4* wafter = gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks,
-                [&](int j) {
-                    const int task = (int)threadIdx.x + THREADS * j;
-                    if (copy && task < pend_total) fragment_task(sXh, sXl, pend_dst, pend_rows, pend_pairs, task, pg_end);
+                [&](int j) {                     // two blocks per wave behind each group of four k-steps (64 blocks, NW * 4 calls)
+#pragma unroll
+                    for (int u = 2 * j; u < 2 * j + 2; ++u) {
+                        const int blk = wave_id + NW * u;
+                        if (copy && blk < pend_total)
+                            fragment_block(sXh, sXl, pend_dst, pend_rows, pend_copied, pend_rblocks, blk, ks_end, lane);
+                    }
                 },
                 [&](int j) {
                     if (copy) {
 #pragma unroll 1
-                        for (int task = (int)threadIdx.x + THREADS * j; task < pend_total; task += THREADS) {
-                            fragment_task(sXh, sXl, pend_dst, pend_rows, pend_pairs, task, pg_end);
+                        for (int blk = wave_id + NW * 2 * j; blk < pend_total; blk += NW) {
+                            fragment_block(sXh, sXl, pend_dst, pend_rows, pend_copied, pend_rblocks, blk, ks_end, lane);
                             H3_PIN();
                         }
                     }
@@ -936,7 +955,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                 if (st.post == POST_RELU) acc_store_f16<NT, true, MTW>(sXh, acc, nb0, nt0, lane);
                 else acc_store_f16<NT, false, MTW>(sXh, acc, nb0, nt0, lane);
             } else if (st.post == POST_RELU) {
-                if (SAVE && mk != nullptr) acc_store<NT, true, MTW, SAVE>(sXh, sXl, acc, nb0, nt0, lane, mk, pg_end > 8);
+                if (SAVE && mk != nullptr) acc_store<NT, true, MTW, SAVE>(sXh, sXl, acc, nb0, nt0, lane, mk, ks_end > 4);
                 else acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane);
             } else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane);
             H3_STAMP(4);
