@@ -453,8 +453,7 @@ __device__ __forceinline__ void acc_store(_Float16* sXh, _Float16* sXl, const f3
 // strided stores per (row pair, 8 points).  Same box, 131 072 points, both trunks: training forward 1000 -> 988 us, field
 // backward (same scheme, field_bwd.hip) 492 -> 464 us.  What the copy costs the training forward is mostly not instructions:
 // with its stores compiled out 963 -> 885 us, without the copy 792 us, without the sign words 934 us (inference kernel: 736);
-// reading the tile a GEMM group ahead of the adds changed nothing -- the eight waves' B-operand reads already keep the LDS
-// ~2/3 busy during a layer and every copied tile is one more pass over it.
+// reading the tile a GEMM group ahead of the adds (so that a group of MFMAs hides the LDS latency) changed nothing.
 // ks_end: 16-point groups that exist (the second 64-point tile of the last 128-point workgroup may not).
 typedef __fp16 fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ h4 lds_tr4(const _Float16* p) {
