@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      18
+#define NSFF_ABI_VERSION      19
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -114,6 +114,12 @@ int nsff_posenc(const float* x, int64_t n_rows, const float* freqs_host, int n_f
  * table (n_table, width) fp32, ts (n) int64 on the device; next / prev (n, width), either may be NULL. */
 int nsff_time_rows(const float* table, int64_t n_table, int32_t width, const int64_t* ts, int64_t n, int64_t max_t,
                    float* next, float* prev, void* stream);
+
+/* N1: gradient of those gathers and of embedding_t(ts) itself (rendering.py:162) w.r.t. the table: d_table (n_table, width),
+ * every row written, = the rows of g_cur / g_next / g_prev (each (n, width) or NULL) summed by their (clamped) frame index.
+ * Replaces three embedding backwards (torch: atomics on ~30 distinct rows) with one deterministic launch. */
+int nsff_time_rows_backward(const float* g_cur, const float* g_next, const float* g_prev, const int64_t* ts, int64_t n,
+                            int64_t max_t, int64_t n_table, int32_t width, float* d_table, void* stream);
 
 /* ---- a3/a5: fused field query = encode -> trunk(s) -> heads (NeRF.forward) ---- */
 typedef struct NsffFieldArgs {
@@ -446,6 +452,27 @@ typedef struct NsffCompositeBwdArgs {
     float* d_raw;  float* d_raw_fw;  float* d_raw_bw;  float* d_f_fw;  float* d_f_bw;
 } NsffCompositeBwdArgs;
 int nsff_composite_backward(const NsffCompositeBwdArgs* args, void* stream);
+
+/* ---- N1: gradient of the scene-flow glue of `inference` (reference models/rendering.py:187-188 flows zeroed beyond
+ * z = 0.95, :218/:224 warped points xyz + flow, :226-232 cycle points xyz_fw + flow_bw(xyz_fw)) w.r.t. the field record it
+ * reads.  For every point p (depth zs[p]):
+ *     out[p][col_a .. col_a+2] (+)= m * sum_k g_a[k][p][0..2],   out[p][col_b .. col_b+2] (+)= m * sum_k g_b[k][p][0..2],
+ * m = zs[p] > z_far ? 0 : 1; accumulate = 0 also writes zeros to the other 10 columns of the (P,16) record (a whole-record
+ * store), accumulate = 1 adds into the named columns only.  g_a / g_b: up to four (P,3) cotangents each (NULL = absent) -- the
+ * consumers of one flow: the compositing node, the warped query, the loss.  col_a / col_b < 0 disables a group.  One launch
+ * replaces autograd's where / slice / zeros / add chain (~12 small kernels per flow direction). */
+typedef struct {
+    int64_t n_points;
+    const float* zs;            /* (P) sample depths                                          */
+    float z_far;                /* 0.95 (rendering.py:187)                                    */
+    int32_t accumulate;
+    int32_t col_a, col_b;       /* first column of each 3-wide group in the 16-float record   */
+    int32_t pad_;
+    const float* g_a[4];
+    const float* g_b[4];
+    float* out;                 /* (P,16), 16-byte aligned                                    */
+} NsffFlowGradArgs;
+int nsff_flow_grad(const NsffFlowGradArgs* args, void* stream);
 
 /* ---- profiling hooks used by bench.py (HIP events around field-query launches) ---- */
 int nsff_prof_enable(int on);

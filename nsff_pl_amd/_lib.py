@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -123,6 +123,11 @@ class LossArgs(C.Structure):
                 + [(n, _fp) for n in LOSS_GRADS])
 
 
+class FlowGradArgs(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("zs", _fp), ("z_far", C.c_float), ("accumulate", C.c_int32), ("col_a", C.c_int32),
+                ("col_b", C.c_int32), ("pad_", C.c_int32), ("g_a", _fp * 4), ("g_b", _fp * 4), ("out", _fp)]
+
+
 # name -> (restype, argtypes); also the list of symbols the header declares
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
@@ -134,6 +139,7 @@ _SIGNATURES = {
     "nsff_fold_heads": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_fp), _fp, _fp]),
     "nsff_posenc": (C.c_int, [_fp, C.c_int64, C.POINTER(C.c_float), C.c_int, _fp, _fp]),
     "nsff_time_rows": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, C.c_int64, C.c_int64, _fp, _fp, _fp]),
+    "nsff_time_rows_backward": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp]),
     "nsff_field_query": (C.c_int, [C.POINTER(ModelDesc), _fp, C.POINTER(FieldArgs), _fp]),
     "nsff_coarse_samples": (C.c_int, [_fp, C.c_int64, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, _fp]),
     "nsff_fine_samples": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp,
@@ -158,6 +164,7 @@ _SIGNATURES = {
     "nsff_absmax": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "nsff_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double, _fp]),
     "nsff_composite_backward": (C.c_int, [C.POINTER(CompositeBwdArgs), _fp]),
+    "nsff_flow_grad": (C.c_int, [C.POINTER(FlowGradArgs), _fp]),
     "nsff_nerfw_loss": (C.c_int, [C.POINTER(LossArgs), C.c_int, _fp]),
     "nsff_splat_planes": (C.c_int, [C.POINTER(SplatArgs), _fp]),
     "nsff_splat_work_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
@@ -287,6 +294,17 @@ def fold_heads(desc, params, packed, precision):
     arr = (_fp * len(keep))(*[p.data_ptr() for p in keep])
     _check(load().nsff_fold_heads(C.byref(desc), int(precision), arr, _ptr(packed), _stream()), "nsff_fold_heads")
     return keep
+
+
+def time_rows_backward(g_cur, g_next, g_prev, ts, max_t, n_table):
+    """d_table (n_table, width) of E[ts], E[clamp(ts + 1)], E[clamp(ts - 1)] for the (n, width) cotangents given (None = absent)."""
+    gs = [None if g is None else g.contiguous() for g in (g_cur, g_next, g_prev)]
+    width = next(g for g in gs if g is not None).shape[1]
+    assert ts.dtype == torch.int64 and ts.is_cuda and ts.is_contiguous()
+    d = torch.empty(int(n_table), width, device=ts.device)
+    _check(load().nsff_time_rows_backward(_ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), C.c_void_p(ts.data_ptr()), ts.shape[0],
+                                          int(max_t), int(n_table), width, _ptr(d), _stream()), "nsff_time_rows_backward")
+    return d
 
 
 def time_rows(table, ts, max_t, want_next=True, want_prev=True):
@@ -490,6 +508,20 @@ def composite_backward(n_rays, n_samples, has_transient, flow_mode, noise_std, *
     for k, v in tensors.items():
         setattr(a, k, _ptr(v))
     _check(load().nsff_composite_backward(C.byref(a), _stream()), "nsff_composite_backward")
+
+
+def flow_grad(zs, z_far, out, accumulate, col_a=-1, g_a=(), col_b=-1, g_b=()):
+    """out (P,16) (+)= masked sums of the (P,3) cotangents g_a into columns col_a.., g_b into col_b.. (nsff_flow_grad)."""
+    a = FlowGradArgs(n_points=int(out.shape[0]), zs=_ptr(zs), z_far=float(z_far), accumulate=int(bool(accumulate)),
+                     col_a=int(col_a), col_b=int(col_b), out=_ptr(out))
+    if len(g_a) > 4 or len(g_b) > 4:
+        raise ValueError("flow_grad: at most four cotangents per group")
+    keep = [g.contiguous() for g in list(g_a) + list(g_b)]          # (alive until the launch is enqueued)
+    for i, g in enumerate(keep[:len(g_a)]):
+        a.g_a[i] = _ptr(g)
+    for i, g in enumerate(keep[len(g_a):]):
+        a.g_b[i] = _ptr(g)
+    _check(load().nsff_flow_grad(C.byref(a), _stream()), "nsff_flow_grad")
 
 
 def nerfw_loss(mode, n_rays, n_samples, n_keep, n_frames, max_t, topk=1.0, thickness=1, **tensors):

@@ -8,8 +8,9 @@ built from two kinds of native nodes:
   ``nsff_field_backward`` + ``nsff_weight_grad``), one node per field launch;
 * the compositing of a pass (:mod:`nsff_pl_amd.composite_grad`: backward = ``nsff_composite_backward``).
 
-What stays in torch between the nodes is glue -- far-masking of the flows, the warped query points, sums of node
-outputs.  Every returned tensor keeps the kernel's value and takes its gradient route from that graph
+The glue between them -- far-masking of the flows, the warped query points, the cycle points -- is a third node
+(:class:`_FlowFn`, backward = ``nsff_flow_grad``) and a tail of the compositing node; what stays in torch is the per-ray
+``xyz + expected flow`` sums and the embedding gathers.  Every returned tensor keeps the kernel's value and takes its gradient route from that graph
 (:class:`_Graft`).  ``sample_pdf`` and the disocclusion weights carry no gradient in the reference either
 (``.detach()`` at rendering.py:336,343,290-291).
 
@@ -19,7 +20,7 @@ There is no torch fallback: a model or call the native nodes do not cover is ref
 """
 import torch
 
-from . import composite_grad, field_grad
+from . import _lib, composite_grad, field_grad
 
 Z_FAR = 0.95
 # outputs that do not depend on any parameter
@@ -55,6 +56,44 @@ class _EmbedRows(torch.autograd.Function):
         return onehot @ grad, None
 
 
+class _TimeRows(torch.autograd.Function):
+    """(E[ts], E[clamp(ts + 1, max=max_t)], E[clamp(ts - 1, min=0)]) of the time-code table -- the three gathers of a training
+    step (rendering.py:162,218,224) -- as one node: forward = one index_select + ``nsff_time_rows``, backward = one
+    ``nsff_time_rows_backward`` launch (deterministic) instead of three one-hot GEMMs and two adds."""
+
+    @staticmethod
+    def forward(ctx, weight, ts, max_t):
+        ts = ts.contiguous()
+        ctx.save_for_backward(ts)
+        ctx.max_t, ctx.n_table = int(max_t), weight.shape[0]
+        ctx.set_materialize_grads(False)
+        w = weight.detach()
+        nxt, prv = _lib.time_rows(w, ts, max_t)
+        return w.index_select(0, ts), nxt, prv
+
+    @staticmethod
+    def backward(ctx, g_cur, g_next, g_prev):
+        if g_cur is None and g_next is None and g_prev is None:
+            return None, None, None
+        (ts,) = ctx.saved_tensors
+        return _lib.time_rows_backward(g_cur, g_next, g_prev, ts, ctx.max_t, ctx.n_table), None, None
+
+
+def _plain_table(module, idx):
+    return (isinstance(module, torch.nn.Embedding) and module.padding_idx is None and module.max_norm is None
+            and not module.sparse and module.weight.is_cuda and module.weight.dtype == torch.float32 and idx.dim() == 1)
+
+
+def time_rows(module, ts, max_t, neighbours):
+    """(module(ts), module(clamp(ts + 1, max=max_t)), module(clamp(ts - 1, min=0))) -- the last two None unless `neighbours`."""
+    if _plain_table(module, ts) and neighbours and ts.dtype == torch.int64:
+        return _TimeRows.apply(module.weight, ts, max_t)
+    cur = embed_rows(module, ts)
+    if not neighbours:
+        return cur, None, None
+    return cur, embed_rows(module, torch.clamp(ts + 1, max=max_t)), embed_rows(module, torch.clamp(ts - 1, min=0))
+
+
 def embed_rows(module, idx):
     """module(idx) -- through the dense-backward gather when `module` is a plain nn.Embedding on the GPU."""
     if (isinstance(module, torch.nn.Embedding) and module.padding_idx is None and module.max_norm is None
@@ -78,6 +117,35 @@ def why_not_differentiable(models, rays, flows):
     return None
 
 
+class _FlowFn(torch.autograd.Function):
+    """The scene-flow glue between the fine field query and its warped re-queries (reference rendering.py:187-188, 218, 224) as
+    ONE node: forward hands out the flows (zeroed beyond z = 0.95) and the warped points the HIP forward already wrote
+    (nothing is launched) -- the warped points three times, once per consumer (result key, re-query, cycle point), so that
+    the engine never has to add their cotangents; backward is one ``nsff_flow_grad`` launch that sums whatever arrived,
+    masks it and writes the (P,16) record gradient.  As torch ops (where / slice / add and their backward: zeros, copy,
+    where, add) the same glue was ~35 small kernels per step."""
+
+    @staticmethod
+    def forward(ctx, cfg, raw):
+        v = cfg["values"]
+        ctx.cfg = cfg
+        ctx.set_materialize_grads(False)
+        again = lambda t: t.detach().view_as(t)
+        return ((again(v["transient_flows_fw"]), again(v["transient_flows_bw"]))
+                + tuple(again(v["xyzs_fw"]) for _ in range(3)) + tuple(again(v["xyzs_bw"]) for _ in range(3)))
+
+    @staticmethod
+    def backward(ctx, g_f_fw, g_f_bw, *gx):
+        g_fw = [g for g in (g_f_fw,) + tuple(gx[:3]) if g is not None]
+        g_bw = [g for g in (g_f_bw,) + tuple(gx[3:]) if g is not None]
+        if not g_fw and not g_bw:
+            return None, None
+        zs = ctx.cfg["zs"]
+        d_raw = torch.empty(zs.numel(), 16, device=zs.device)
+        _lib.flow_grad(zs, Z_FAR, d_raw, False, 8 if g_fw else -1, g_fw, 11 if g_bw else -1, g_bw)
+        return None, d_raw
+
+
 def _render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded, t_next, t_prev,
                  output_transient, flows, noise_std, noise, saved, values):
     """One model pass (reference ``inference``, rendering.py:83-300) as native nodes + glue.  `values`: the result
@@ -91,24 +159,20 @@ def _render_pass(results, model, typ, freqs_xyz, rays, zs, dir_embedded, a_embed
     raw = field_grad.field(model, xyz.reshape(-1, 3), freqs_xyz, t_embedded if output_transient else None, s,
                            True, output_transient, saved.get(typ), **side)
     results[f"static_rgbs_{typ}"] = raw[:, 0:3].view(n, s, 3)
-    raw_fw = raw_bw = f_fw = f_bw = None
+    raw_fw = raw_bw = f_fw = f_bw = cyc_fw = cyc_bw = None
     if output_transient:
         results[f"transient_rgbs_{typ}"] = raw[:, 4:7].view(n, s, 3)
         if flows:
-            far = (zs > Z_FAR)[..., None]
-            zero = torch.zeros((), device=zs.device)
-            f_fw = results["transient_flows_fw"] = torch.where(far, zero, raw[:, 8:11].view(n, s, 3))
-            f_bw = results["transient_flows_bw"] = torch.where(far, zero, raw[:, 11:14].view(n, s, 3))
-            xyz_fw = results["xyzs_fw"] = xyz + f_fw
-            xyz_bw = results["xyzs_bw"] = xyz + f_bw
+            (f_fw, f_bw, results["xyzs_fw"], xyz_fw, cyc_fw, results["xyzs_bw"], xyz_bw, cyc_bw) = \
+                _FlowFn.apply(dict(values=values, zs=zs.contiguous()), raw)
+            results["transient_flows_fw"], results["transient_flows_bw"] = f_fw, f_bw
             raw_fw = field_grad.field(model, xyz_fw.reshape(-1, 3), freqs_xyz, t_next, s, False, True,
                                       saved.get(f"{typ}_warp_fw"))
             raw_bw = field_grad.field(model, xyz_bw.reshape(-1, 3), freqs_xyz, t_prev, s, False, True,
                                       saved.get(f"{typ}_warp_bw"))
-            results["xyzs_fw_bw"] = xyz_fw + torch.where(far, zero, raw_fw[:, 11:14].view(n, s, 3))
-            results["xyzs_bw_fw"] = xyz_bw + torch.where(far, zero, raw_bw[:, 8:11].view(n, s, 3))
+    # (the cycle points xyzs_fw_bw / xyzs_bw_fw = warped point + masked flow of the re-query come out of the compositing node)
     results.update(composite_grad.composite(values, typ, raw, raw_fw, raw_bw, f_fw, f_bw, zs, xyz if flows else None,
-                                            output_transient, noise_std, noise))
+                                            output_transient, noise_std, noise, cyc_fw, cyc_bw))
     if output_transient and flows:
         results["xyz_fw"] = results["xyz_fine"] + results["transient_flow_fw"]
         results["xyz_bw"] = results["xyz_fine"] + results["transient_flow_bw"]
@@ -123,10 +187,12 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
     results = {}
     freqs_xyz = [float(f) for f in embeddings["xyz"].freqs]
     dir_embedded = rec.get("dir_embedded")        # the rows render_rays' forward used (view directions carry no gradient)
-    t_embedded = None
+    t_embedded = t_next = t_prev = None
     out_t = rec["output_transient"]
     if out_t:
-        t_embedded = rec["t_embedded_override"] if rec["t_embedded_override"] is not None else embed_rows(embeddings["t"], ts)
+        t_embedded, t_next, t_prev = time_rows(embeddings["t"], ts, max_t, bool(rec["flows"]))
+        if rec["t_embedded_override"] is not None:
+            t_embedded = rec["t_embedded_override"]
     if rec["N_importance"] > 0:
         _render_pass(results, models["coarse"], "coarse", freqs_xyz, rays, rec["zs_coarse"], dir_embedded,
                      None, t_embedded, None, None, out_t, [], rec["noise_std"],
@@ -137,10 +203,6 @@ def recompute(models, embeddings, rays, ts, max_t, rec):
     if fine.encode_appearance:
         a_embedded = rec["a_embedded_override"] if rec["a_embedded_override"] is not None else embed_rows(embeddings["a"], ts)
     flows = rec["flows"]
-    t_next = t_prev = None
-    if out_t and flows:
-        t_next = embed_rows(embeddings["t"], torch.clamp(ts + 1, max=max_t))
-        t_prev = embed_rows(embeddings["t"], torch.clamp(ts - 1, min=0))
     zs = rec["zs_fine"] if rec["N_importance"] > 0 else rec["zs_coarse"]
     _render_pass(results, fine, "fine", freqs_xyz, rays, zs, dir_embedded, a_embedded, t_embedded,
                  t_next, t_prev, out_t, flows, rec["noise_std"],

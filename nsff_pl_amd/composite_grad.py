@@ -23,6 +23,10 @@ _OUTS_FLOW = [("xyz_fine", "g_xyz_exp"), ("transient_flow_fw", "g_flow_fw_exp"),
 _OUTS_WARP = [("rgb_fw", "g_rgb_fw"), ("rgb_bw", "g_rgb_bw")]
 
 
+CYCLE_KEYS = ("xyzs_fw_bw", "xyzs_bw_fw")
+Z_FAR = 0.95
+
+
 def enabled():
     return os.environ.get("NSFF_NATIVE_COMPOSITE_BWD", "1") != "0"
 
@@ -38,19 +42,24 @@ def output_spec(typ, transient, flows, warps):
 
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg, raw, raw_fw, raw_bw, f_fw, f_bw):
+    def forward(ctx, cfg, raw, raw_fw, raw_bw, f_fw, f_bw, cyc_fw, cyc_bw):
         values = cfg["values"]
         ctx.cfg = cfg
         ctx.set_materialize_grads(False)         # outputs nobody differentiates arrive as None -> NULL, not as zero tensors
         ctx.save_for_backward(*[t for t in (raw, raw_fw, raw_bw, f_fw, f_bw) if t is not None])
         ctx.present = [t is not None for t in (raw, raw_fw, raw_bw, f_fw, f_bw)]
-        return tuple(values[k].detach().view_as(values[k]) for k, _ in cfg["spec"])
+        ctx.cycle = cyc_fw is not None
+        keys = [k for k, _ in cfg["spec"]] + (list(CYCLE_KEYS) if ctx.cycle else [])
+        return tuple(values[k].detach().view_as(values[k]) for k in keys)
 
     @staticmethod
     def backward(ctx, *grads):
         cfg = ctx.cfg
         if all(g is None for g in grads):
-            return (None,) * 6
+            return (None,) * 8
+        g_cyc_fw = g_cyc_bw = None
+        if ctx.cycle:
+            grads, (g_cyc_fw, g_cyc_bw) = grads[:-2], grads[-2:]
         it = iter(ctx.saved_tensors)
         raw, raw_fw, raw_bw, f_fw, f_bw = [next(it) if p else None for p in ctx.present]
         n, s = cfg["zs"].shape
@@ -77,13 +86,24 @@ class _CompositeFn(torch.autograd.Function):
             tens.update(d_f_fw=d_f_fw, d_f_bw=d_f_bw)
         flow_mode = 0 if f_fw is None else (2 if raw_fw is not None else 1)
         _lib.composite_backward(n, s, cfg["transient"], flow_mode, cfg["noise_std"], **tens)
-        return None, d_raw, d_raw_fw, d_raw_bw, d_f_fw, d_f_bw
+        # cycle points (rendering.py:226-232): xyzs_fw_bw = x_fw + [z <= 0.95] bw(x_fw), xyzs_bw_fw = x_bw + [z <= 0.95] fw(x_bw):
+        # the cotangent goes to the warped point as it is and, masked, into the flow columns of the re-query's record
+        if g_cyc_fw is not None:
+            _lib.flow_grad(cfg["zs"], Z_FAR, d_raw_fw, True, 11, [g_cyc_fw.reshape(-1, 3)])
+        if g_cyc_bw is not None:
+            _lib.flow_grad(cfg["zs"], Z_FAR, d_raw_bw, True, 8, [g_cyc_bw.reshape(-1, 3)])
+        return None, d_raw, d_raw_fw, d_raw_bw, d_f_fw, d_f_bw, g_cyc_fw, g_cyc_bw
 
 
-def composite(values, typ, raw, raw_fw, raw_bw, f_fw, f_bw, zs, xyz, transient, noise_std, noise):
-    """Differentiable per-ray / per-sample compositing outputs of one pass, as a dict keyed like render_rays."""
+def composite(values, typ, raw, raw_fw, raw_bw, f_fw, f_bw, zs, xyz, transient, noise_std, noise, cyc_fw=None, cyc_bw=None):
+    """Differentiable per-ray / per-sample compositing outputs of one pass, as a dict keyed like render_rays.
+    cyc_fw / cyc_bw: the warped points (their own copies out of autograd._FlowFn); with them the node also hands out the
+    cycle points ``xyzs_fw_bw`` / ``xyzs_bw_fw``."""
     spec = output_spec(typ, transient, f_fw is not None, raw_fw is not None)
+    if cyc_fw is not None and raw_fw is None:
+        raise ValueError("cycle points need the warped re-queries")
     cfg = dict(values=values, spec=spec, zs=zs.contiguous(), xyz=None if xyz is None else xyz.contiguous(),
                transient=bool(transient), noise_std=float(noise_std), noise=noise)
-    outs = _CompositeFn.apply(cfg, raw, raw_fw, raw_bw, f_fw, f_bw)
-    return {k: o for (k, _), o in zip(spec, outs)}
+    outs = _CompositeFn.apply(cfg, raw, raw_fw, raw_bw, f_fw, f_bw, cyc_fw, cyc_bw)
+    keys = [k for k, _ in spec] + (list(CYCLE_KEYS) if cyc_fw is not None else [])
+    return dict(zip(keys, outs))

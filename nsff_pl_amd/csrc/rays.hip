@@ -500,9 +500,50 @@ __global__ __launch_bounds__(256) void time_rows_kernel(const float* __restrict_
     }
 }
 
+// Gradient of the three time-code gathers of a training step, E[ts], E[min(ts + 1, max_t)], E[max(ts - 1, 0)], w.r.t. the table:
+// d_table[r] = sum of the rows of g_cur / g_next / g_prev whose (clamped) index is r.  One workgroup per table row, the rays in
+// four interleaved slices, fixed summation order (deterministic).  A batch hits ~30 distinct rows: torch's embedding backward
+// serialises on atomics (~200 us per gather), the one-hot GEMM that replaced it in round 1 was 4 kernels per gather.
+__global__ __launch_bounds__(256) void time_rows_bwd_kernel(const float* __restrict__ g_cur, const float* __restrict__ g_next,
+                                                             const float* __restrict__ g_prev, const long long* __restrict__ ts,
+                                                             long long n, long long max_t, long long n_table, int width,
+                                                             float* __restrict__ d_table) {
+    __shared__ float sPart[4][64];
+    const long long r = blockIdx.x;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < width; c0 += 64) {
+        const int c = c0 + lane;
+        float acc = 0.f;
+        if (c < width)
+            for (long long i = part; i < n; i += 4) {
+                const long long t = ts[i];
+                long long tn = t + 1 < max_t ? t + 1 : max_t, tp = t - 1 > 0 ? t - 1 : 0;      // (nsff_time_rows' own index arithmetic)
+                tn = tn < 0 ? 0 : (tn > n_table - 1 ? n_table - 1 : tn);
+                tp = tp > n_table - 1 ? n_table - 1 : tp;
+                if (g_cur != nullptr && t == r) acc += g_cur[i * width + c];
+                if (g_next != nullptr && tn == r) acc += g_next[i * width + c];
+                if (g_prev != nullptr && tp == r) acc += g_prev[i * width + c];
+            }
+        sPart[part][lane] = acc;
+        __syncthreads();
+        if (part == 0 && c < width) d_table[r * width + c] = (sPart[0][lane] + sPart[1][lane]) + (sPart[2][lane] + sPart[3][lane]);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int nsff_time_rows_backward(const float* g_cur, const float* g_next, const float* g_prev, const int64_t* ts, int64_t n,
+                            int64_t max_t, int64_t n_table, int32_t width, float* d_table, void* stream) {
+    if (n < 0 || n_table < 1 || n_table > 0x7fffffffLL || width < 1) return NSFF_ERR_INVALID;
+    if (!d_table || (n > 0 && !ts)) return NSFF_ERR_NULL;
+    hipLaunchKernelGGL(time_rows_bwd_kernel, dim3((unsigned)n_table), dim3(256), 0, (hipStream_t)stream, g_cur, g_next, g_prev,
+                       reinterpret_cast<const long long*>(ts), (long long)n, (long long)max_t, (long long)n_table, (int)width,
+                       d_table);
+    return nsff_launch_status();
+}
 
 int nsff_time_rows(const float* table, int64_t n_table, int32_t width, const int64_t* ts, int64_t n, int64_t max_t,
                    float* next, float* prev, void* stream) {

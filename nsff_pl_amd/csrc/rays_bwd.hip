@@ -278,6 +278,50 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_bwd_kernel(con
 
 }  // namespace
 
+// Gradient of the flow glue (see the header): thread = point, the record leaves as four 16-byte stores (accumulate: the named
+// columns are read-modify-written).
+__global__ __launch_bounds__(256) void flow_grad_kernel(const NsffFlowGradArgs a) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n_points) return;
+    const float m = a.zs[p] > a.z_far ? 0.f : 1.f;
+    float va[3] = {0.f, 0.f, 0.f}, vb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (a.col_a >= 0 && a.g_a[k] != nullptr) { const float* g = a.g_a[k] + 3 * p; va[0] += g[0]; va[1] += g[1]; va[2] += g[2]; }
+        if (a.col_b >= 0 && a.g_b[k] != nullptr) { const float* g = a.g_b[k] + 3 * p; vb[0] += g[0]; vb[1] += g[1]; vb[2] += g[2]; }
+    }
+    float* o = a.out + 16 * p;
+    if (a.accumulate) {
+        if (a.col_a >= 0) for (int c = 0; c < 3; ++c) o[a.col_a + c] += m * va[c];
+        if (a.col_b >= 0) for (int c = 0; c < 3; ++c) o[a.col_b + c] += m * vb[c];
+    } else {
+        float rec[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = 0.f;
+            if (a.col_a >= 0 && c >= a.col_a && c < a.col_a + 3) v = m * va[c - a.col_a];
+            if (a.col_b >= 0 && c >= a.col_b && c < a.col_b + 3) v = m * vb[c - a.col_b];
+            rec[c] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            reinterpret_cast<float4*>(o)[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+    }
+}
+
+extern "C" int nsff_flow_grad(const NsffFlowGradArgs* args, void* stream) {
+    if (!args) return NSFF_ERR_NULL;
+    const NsffFlowGradArgs& a = *args;
+    if (a.n_points < 0 || a.col_a > 13 || a.col_b > 13 || (a.col_a < 0 && a.col_b < 0)) return NSFF_ERR_INVALID;
+    if (a.col_a >= 0 && a.col_b >= 0 && a.col_a + 3 > a.col_b && a.col_b + 3 > a.col_a) return NSFF_ERR_INVALID;     // overlapping groups
+    if (a.n_points == 0) return NSFF_OK;
+    if (!a.zs || !a.out) return NSFF_ERR_NULL;
+    if ((uintptr_t)a.out & 15) return NSFF_ERR_ALIGN;
+    const unsigned blocks = (unsigned)((a.n_points + 255) / 256);
+    hipLaunchKernelGGL(flow_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return nsff_launch_status();
+}
+
 extern "C" int nsff_composite_backward(const NsffCompositeBwdArgs* args, void* stream) {
     if (!args) return NSFF_ERR_NULL;
     const NsffCompositeBwdArgs& a = *args;

@@ -225,3 +225,64 @@ def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_
             expect = t if w is None else (t + w) + w
             assert torch.equal(p.grad, expect), (layout, tuple(p.shape))
     assert field_grad._GRAD_MAPS, "the in-place path was not taken"
+
+
+@pytest.mark.gpu
+def test_flow_grad_matches_the_torch_expression(hip_lib):
+    """nsff_flow_grad (the backward of the flow glue, rendering.py:187-188,218,224,226-232) against autograd of the torch ops
+    it replaces: where(z > 0.95, 0, raw[:, c:c+3]) consumed by several users, overwrite and accumulate form."""
+    from nsff_pl_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    P = 1000                                               # not a multiple of the block size
+    zs = torch.rand(P, generator=g).to(dev)
+    raw = torch.randn(P, 16, generator=g).to(dev).requires_grad_(True)
+    cot = [torch.randn(P, 3, generator=g).to(dev) for _ in range(5)]
+    far = (zs > 0.95)[:, None]
+    assert 0 < int(far.sum()) < P
+    f_fw = torch.where(far, torch.zeros((), device=dev), raw[:, 8:11])
+    f_bw = torch.where(far, torch.zeros((), device=dev), raw[:, 11:14])
+    want, = torch.autograd.grad((f_fw * (cot[0] + cot[1] + cot[2])).sum() + (f_bw * (cot[3] + cot[4])).sum(), raw)
+    got = torch.full((P, 16), float("nan"), device=dev)
+    _lib.flow_grad(zs, 0.95, got, False, 8, cot[:3], 11, cot[3:])
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+    # accumulate: only the named columns change
+    base = torch.randn(P, 16, generator=g).to(dev)
+    acc = base.clone()
+    _lib.flow_grad(zs, 0.95, acc, True, 11, [cot[0]])
+    want2 = base.clone()
+    want2[:, 11:14] += torch.where(far, torch.zeros((), device=dev), cot[0])
+    assert torch.allclose(acc, want2, rtol=1e-6, atol=1e-6)
+    # one group only, overwrite: the other group's columns are zero
+    one = torch.full((P, 16), float("nan"), device=dev)
+    _lib.flow_grad(zs, 0.95, one, False, -1, [], 11, [cot[3]])
+    assert torch.equal(one[:, :11], torch.zeros(P, 11, device=dev)) and torch.equal(one[:, 14:], torch.zeros(P, 2, device=dev))
+
+
+@pytest.mark.gpu
+def test_time_rows_node_matches_embedding_autograd(hip_lib):
+    """autograd._TimeRows (E[ts], E[clamp(ts+1)], E[clamp(ts-1)] with one native backward) against nn.Embedding autograd, frames
+    at both ends of the clamp included, one cotangent absent."""
+    from nsff_pl_amd import autograd as ag
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    n_frames, width, n = 12, 48, 700
+    emb = torch.nn.Embedding(n_frames, width).to(dev)
+    ts = torch.randint(0, n_frames, (n,), generator=g).to(dev)
+    ts[:3] = torch.tensor([0, n_frames - 1, n_frames - 2], device=dev)
+    max_t = n_frames - 1
+    cots = [torch.randn(n, width, generator=g).to(dev) for _ in range(3)]
+    cur, nxt, prv = ag.time_rows(emb, ts, max_t, True)
+    ref = [emb(ts), emb(torch.clamp(ts + 1, max=max_t)), emb(torch.clamp(ts - 1, min=0))]
+    for a, b in zip((cur, nxt, prv), ref):
+        assert torch.equal(a, b)
+    want, = torch.autograd.grad(sum((r * c).sum() for r, c in zip(ref, cots)), emb.weight)
+    got, = torch.autograd.grad(sum((r * c).sum() for r, c in zip((cur, nxt, prv), cots)), emb.weight)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    cur, nxt, prv = ag.time_rows(emb, ts, max_t, True)
+    ref = [emb(ts), None, emb(torch.clamp(ts - 1, min=0))]
+    want, = torch.autograd.grad((ref[0] * cots[0]).sum() + (ref[2] * cots[2]).sum(), emb.weight)
+    got, = torch.autograd.grad((cur * cots[0]).sum() + (prv * cots[2]).sum(), emb.weight)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    only, _, _ = ag.time_rows(emb, ts, max_t, False)                     # no neighbours: the plain gather
+    assert torch.equal(only, emb(ts))

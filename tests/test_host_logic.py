@@ -56,7 +56,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 18
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_struct_layouts_match_the_header_sizes():
@@ -98,6 +98,13 @@ def test_layout_and_argument_validation_without_gpu():
     c.n_rays, c.n_samples = 4, 0
     assert lib.nsff_composite(C.byref(c), None) == -1
     assert lib.nsff_coarse_samples(None, 4, None, 0, 0.0, None, None, None, None) == -1
+    fg = _lib.FlowGradArgs(n_points=8, col_a=8, col_b=11)
+    assert C.sizeof(_lib.FlowGradArgs) == 8 + 8 + 4 * 5 + 4 + 8 * 9
+    assert lib.nsff_flow_grad(None, None) == -2 and lib.nsff_flow_grad(C.byref(fg), None) == -2      # zs / out missing
+    fg.col_b = 9                                                                                     # overlapping groups
+    assert lib.nsff_flow_grad(C.byref(fg), None) == -1
+    fg.col_a = fg.col_b = -1
+    assert lib.nsff_flow_grad(C.byref(fg), None) == -1
     assert lib.nsff_coarse_samples(None, 0, None, 8, 0.0, None, None, None, None) == 0   # empty batch is ok
 
 
