@@ -501,33 +501,88 @@ __global__ __launch_bounds__(256) void time_rows_kernel(const float* __restrict_
 }
 
 // Gradient of the three time-code gathers of a training step, E[ts], E[min(ts + 1, max_t)], E[max(ts - 1, 0)], w.r.t. the table:
-// d_table[r] = sum of the rows of g_cur / g_next / g_prev whose (clamped) index is r.  One workgroup per table row, the rays in
-// four interleaved slices, fixed summation order (deterministic).  A batch hits ~30 distinct rows: torch's embedding backward
-// serialises on atomics (~200 us per gather), the one-hot GEMM that replaced it in round 1 was 4 kernels per gather.
+// d_table[r] = sum of the rows of g_cur / g_next / g_prev whose (clamped) index is r.  One workgroup per table row: wave 0
+// compacts, per gather, the rays that hit the row into an LDS list in ascending order (ballot + popcount), the four waves then
+// add the listed rows -- wave w the entries w, w + 4, ... -- and their partial sums are added in a fixed order: deterministic.
+// (A batch hits ~30 distinct rows: torch's embedding backward serialises on atomics, ~200 us per gather; the one-hot GEMM that
+// replaced it in round 1 was 4 kernels per gather; a first form of this kernel that let every thread walk all rays took 110 us.)
+constexpr int TRB_CHUNK = 2048;          // rays per compaction pass
+constexpr int TRB_COLS = 4;              // 64-column groups held in registers (width <= 256; wider tables loop over groups of 4)
 __global__ __launch_bounds__(256) void time_rows_bwd_kernel(const float* __restrict__ g_cur, const float* __restrict__ g_next,
                                                              const float* __restrict__ g_prev, const long long* __restrict__ ts,
                                                              long long n, long long max_t, long long n_table, int width,
                                                              float* __restrict__ d_table) {
+    __shared__ int sList[3][TRB_CHUNK];
+    __shared__ int sTs[TRB_CHUNK];           // the chunk's frame indices (clamped to int range), staged by all four waves
+    __shared__ int sCnt[3];
     __shared__ float sPart[4][64];
     const long long r = blockIdx.x;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < width; c0 += 64) {
-        const int c = c0 + lane;
-        float acc = 0.f;
-        if (c < width)
-            for (long long i = part; i < n; i += 4) {
+    const float* gs[3] = {g_cur, g_next, g_prev};
+    for (int cg = 0; cg < width; cg += 64 * TRB_COLS) {
+        float acc[TRB_COLS];
+#pragma unroll
+        for (int j = 0; j < TRB_COLS; ++j) acc[j] = 0.f;
+        for (long long base = 0; base < n; base += TRB_CHUNK) {
+            const long long end = base + TRB_CHUNK < n ? base + TRB_CHUNK : n;
+            for (long long i = base + threadIdx.x; i < end; i += 256) {
                 const long long t = ts[i];
-                long long tn = t + 1 < max_t ? t + 1 : max_t, tp = t - 1 > 0 ? t - 1 : 0;      // (nsff_time_rows' own index arithmetic)
-                tn = tn < 0 ? 0 : (tn > n_table - 1 ? n_table - 1 : tn);
-                tp = tp > n_table - 1 ? n_table - 1 : tp;
-                if (g_cur != nullptr && t == r) acc += g_cur[i * width + c];
-                if (g_next != nullptr && tn == r) acc += g_next[i * width + c];
-                if (g_prev != nullptr && tp == r) acc += g_prev[i * width + c];
+                sTs[i - base] = (int)(t < -2 ? -2 : (t > 0x7ffffff0LL ? 0x7ffffff0LL : t));
             }
-        sPart[part][lane] = acc;
-        __syncthreads();
-        if (part == 0 && c < width) d_table[r * width + c] = (sPart[0][lane] + sPart[1][lane]) + (sPart[2][lane] + sPart[3][lane]);
-        __syncthreads();
+            __syncthreads();
+            if (part == 0) {
+                int cnt[3] = {0, 0, 0};
+                for (long long i0 = base; i0 < end; i0 += 64) {
+                    const long long i = i0 + lane;
+                    bool hit[3] = {false, false, false};
+                    if (i < end) {
+                        const long long t = sTs[i - base];
+                        long long tn = t + 1 < max_t ? t + 1 : max_t, tp = t - 1 > 0 ? t - 1 : 0;    // (nsff_time_rows' own index arithmetic)
+                        tn = tn < 0 ? 0 : (tn > n_table - 1 ? n_table - 1 : tn);
+                        tp = tp > n_table - 1 ? n_table - 1 : tp;
+                        hit[0] = t == r; hit[1] = tn == r; hit[2] = tp == r;
+                    }
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        const unsigned long long m = __ballot(hit[l] && gs[l] != nullptr);
+                        if (hit[l] && gs[l] != nullptr) sList[l][cnt[l] + __popcll(m & ((1ull << lane) - 1ull))] = (int)(i - base);
+                        cnt[l] += __popcll(m);
+                    }
+                }
+                if (lane == 0) { sCnt[0] = cnt[0]; sCnt[1] = cnt[1]; sCnt[2] = cnt[2]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const float* __restrict__ g = gs[l];
+                const int cnt = sCnt[l];
+                for (int k0 = part; k0 < cnt; k0 += 16) {            // four rows requested before the first add (fixed order)
+                    float v[4][TRB_COLS];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + 4 * u;
+                        const float* row = g + (base + sList[l][k < cnt ? k : k0]) * width + cg + lane;
+#pragma unroll
+                        for (int j = 0; j < TRB_COLS; ++j)
+                            v[u][j] = (k < cnt && cg + 64 * j + lane < width) ? row[64 * j] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < TRB_COLS; ++j) acc[j] += v[u][j];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < TRB_COLS; ++j) {
+            const int c = cg + 64 * j + lane;
+            if (cg + 64 * j >= width) break;
+            sPart[part][lane] = acc[j];
+            __syncthreads();
+            if (part == 0 && c < width) d_table[r * width + c] = (sPart[0][lane] + sPart[1][lane]) + (sPart[2][lane] + sPart[3][lane]);
+            __syncthreads();
+        }
     }
 }
 
