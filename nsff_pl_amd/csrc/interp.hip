@@ -46,9 +46,8 @@ __device__ __forceinline__ void ndc2world(const float x, const float y, const fl
 // Where sample (pixel px,py; plane s) of the source frame lands: bilinear corner (nwx, nwy) and the four weights.
 struct Landing { int nwx, nwy; float w[4]; float ox, oy; bool finite; };
 
-__device__ __forceinline__ Landing project_sample(const NsffSplatArgs& a, long long idx, int px, int py) {
-    const float* xp = a.xyz + idx * 3;
-    const float* fp = a.flow + idx * 3;
+// (xp: the sample's NDC point, fp: its scene flow -- already in registers)
+__device__ __forceinline__ Landing project_values(const NsffSplatArgs& a, const float (&xp)[3], const float (&fp)[3], int px, int py) {
     const float x = xp[0], y = xp[1], z = xp[2];
     float pw[3], qw[3];
     ndc2world(x, y, z, a.K4, pw);
@@ -76,6 +75,13 @@ __device__ __forceinline__ Landing project_sample(const NsffSplatArgs& a, long l
     return L;
 }
 
+__device__ __forceinline__ Landing project_sample(const NsffSplatArgs& a, long long idx, int px, int py) {
+    const float* xq = a.xyz + idx * 3;
+    const float* fq = a.flow + idx * 3;
+    const float xp[3] = {xq[0], xq[1], xq[2]}, fp[3] = {fq[0], fq[1], fq[2]};
+    return project_values(a, xp, fp, px, py);
+}
+
 // the four bilinear weights of a landing, exactly as project_sample forms them
 __device__ __forceinline__ void landing_weights(Landing& L) {
     const float sex = (float)(L.nwx + 1), sey = (float)(L.nwy + 1);
@@ -87,7 +93,19 @@ __device__ __forceinline__ void landing_weights(Landing& L) {
 
 // A sample is "near" when its landing cell is within HALO pixels of its own pixel: then every output tile it
 // touches sees it inside its halo and accumulates it in LDS.  Everything else goes through global atomics.
-constexpr int TILE_X = 32, TILE_Y = 8, HALO = 4, PL = 8;           // output tile, halo, planes per workgroup
+// LDS accumulators are DOUBLES: on gfx950 ds_add_f32 retires ~0.4 lanes per clock per CU while ds_add_f64 does 8.6 and
+// ds_add_u32 16 (tools/debug/probes/lds_atomic_rate*.hip) -- the f32 form made this pass atomic-bound at exactly that rate
+// (174 G lane-adds/s).  The products are formed in fp32 as the reference's kernel forms them (softsplat.py:27-43); their sum in
+// double is the exact-order-independent one, rounded once when the block is written.  Twice the bytes per cell: four planes
+// per workgroup instead of eight keep the accumulator at 40 KiB.
+__device__ __forceinline__ void lds_add(double* cell, float v) { atomicAdd(cell, (double)v); }
+#ifndef SPLAT_PL
+#define SPLAT_PL 4
+#endif
+#ifndef SPLAT_MAX_TILES
+#define SPLAT_MAX_TILES 3072
+#endif
+constexpr int TILE_X = 32, TILE_Y = 8, HALO = 4, PL = SPLAT_PL;     // output tile, halo, planes per workgroup
 constexpr int REG_X = TILE_X + 2 * HALO, REG_Y = TILE_Y + 2 * HALO;
 __device__ __forceinline__ bool is_near(const Landing& L, int px, int py) {
     const int dx = L.nwx - px, dy = L.nwy - py;
@@ -107,7 +125,7 @@ struct FarWork {
     long long capacity;
     int n_tiles, tiles_x, n_blocks;
 };
-constexpr int MAX_TILES = 6144;      // LDS histogram of destination tiles (24 KiB) next to the 40 KiB accumulator
+constexpr int MAX_TILES = SPLAT_MAX_TILES;      // LDS histogram of destination tiles (12 KiB) next to the 40 KiB accumulator: three workgroups per CU
 
 __device__ __forceinline__ FarWork far_work(const NsffSplatArgs& a) {
     FarWork w{};
@@ -140,23 +158,72 @@ __device__ __forceinline__ void for_each_dest_tile(const NsffSplatArgs& a, const
     }
 }
 
+// Workgroup -> (output tile, plane group).  The hardware deals workgroups to the eight XCDs round-robin, each XCD has its own
+// L2, and what this pass re-reads is spatially local: the 4-pixel halo overlaps the neighbouring tiles, and an 8-plane group
+// of one pixel is a 96-byte piece of the 128-byte lines its neighbouring plane groups also touch.  So every XCD gets one
+// CONTIGUOUS eighth of the (tile, plane group) sequence, plane groups fastest: neighbours in space are neighbours in
+// dispatch order on the same L2.  (SPLAT_XCD=0: the plain 2-D grid order, tiles fastest.)
+#ifndef SPLAT_XCD
+#define SPLAT_XCD 1
+#endif
+struct SplatBlock { int tile, pg; bool live; };
+__device__ __forceinline__ SplatBlock splat_block(int n_tiles, int n_pg) {
+    SplatBlock b;
+#if SPLAT_XCD
+    const long long total = (long long)n_tiles * n_pg, chunk = (total + 7) / 8;
+    const long long k = blockIdx.x >> 3, l = (long long)(blockIdx.x & 7) * chunk + k;
+    b.live = k < chunk && l < total;
+    b.pg = (int)(l % n_pg); b.tile = (int)(l / n_pg);
+#else
+    b.live = true; b.tile = blockIdx.x % n_tiles; b.pg = blockIdx.x / n_tiles;
+#endif
+    return b;
+}
+__host__ __device__ __forceinline__ int splat_tiles_total(int W, int H) { return ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y); }
+
 __global__ __launch_bounds__(256) void splat_tiles_kernel(const NsffSplatArgs a) {
-    __shared__ float sAcc[TILE_X * TILE_Y * PL * 5];
+    __shared__ double sAcc[TILE_X * TILE_Y * PL * 5];          // (double: see lds_add)
     __shared__ int sHist[MAX_TILES];
     const int S = a.n_planes;
     const int tiles_x = (a.W + TILE_X - 1) / TILE_X;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blockIdx.y * PL;
+    const SplatBlock blk_ = splat_block(splat_tiles_total(a.W, a.H), (S + PL - 1) / PL);
+    if (!blk_.live) return;
+    const int tx = blk_.tile % tiles_x, ty = blk_.tile / tiles_x;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blk_.pg * PL;
     const FarWork fw = far_work(a);
-    for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL * 5; i += 256) sAcc[i] = 0.f;
+    for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL * 5; i += 256) sAcc[i] = 0.0;
     if (fw.count != nullptr) for (int i = threadIdx.x; i < fw.n_tiles; i += 256) sHist[i] = 0;
     __syncthreads();
-    for (int item = threadIdx.x; item < REG_X * REG_Y * PL; item += 256) {
+    // Four samples per thread and trip: their 16 + 24 bytes each are requested before the first projection -- the pass is a chain
+    // of dependent round trips (point + flow, then colour) with three workgroups per CU to hide them, not a bandwidth problem
+    // (halving its HBM reads with the XCD order above left its time where it was).
+    constexpr int UN = 4, N_ITEMS = REG_X * REG_Y * PL;
+    for (int base = threadIdx.x; base < N_ITEMS; base += 256 * UN) {
+      float xq[UN][3], fq[UN][3], cq[UN][4];
+      long long idxs[UN];
+      bool ok[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int item = base + 256 * u;
         const int j = item % PL, rp = item / PL;
         const int px = x0 - HALO + rp % REG_X, py = y0 - HALO + rp / REG_X, s = s0 + j;
-        if (px < 0 || px >= a.W || py < 0 || py >= a.H || s >= S) continue;
-        const long long idx = ((long long)py * a.W + px) * S + s;
-        const Landing L = project_sample(a, idx, px, py);
+        ok[u] = item < N_ITEMS && !(px < 0 || px >= a.W || py < 0 || py >= a.H || s >= S);
+        idxs[u] = ok[u] ? ((long long)py * a.W + px) * S + s : 0;
+        const float* xg = a.xyz + idxs[u] * 3;
+        const float* fg = a.flow + idxs[u] * 3;
+        const float* cg = a.rgb + idxs[u] * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xq[u][c] = xg[c]; fq[u][c] = fg[c]; cq[u][c] = cg[c]; }
+        cq[u][3] = a.alpha[idxs[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (!ok[u]) continue;
+        const int item = base + 256 * u;
+        const int j = item % PL, rp = item / PL;
+        const int px = x0 - HALO + rp % REG_X, py = y0 - HALO + rp / REG_X;
+        const long long idx = idxs[u];
+        const Landing L = project_values(a, xq[u], fq[u], px, py);
         if (!is_near(L, px, py)) {
             // a far sample of this block's OWN pixels: one record per destination tile it touches (binned far path)
             const bool own = px >= x0 && px < x0 + TILE_X && py >= y0 && py < y0 + TILE_Y;
@@ -164,35 +231,36 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(const NsffSplatArgs a)
                 for_each_dest_tile(a, L, tiles_x, [&](int t) { atomicAdd(&sHist[t], 1); });
             continue;
         }
-        const float* cp = a.rgb + idx * 3;
-        const float src[5] = {cp[0], cp[1], cp[2], a.alpha[idx], 1.0f};
+        (void)idx;
+        const float src[5] = {cq[u][0], cq[u][1], cq[u][2], cq[u][3], 1.0f};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cx = L.nwx + (k & 1) - x0, cy = L.nwy + (k >> 1) - y0;        // inside the owned tile?
             if (cx < 0 || cx >= TILE_X || cy < 0 || cy >= TILE_Y) continue;
             if (L.nwx + (k & 1) >= a.W || L.nwy + (k >> 1) >= a.H) continue;        // (tile may overhang the image)
-            float* dst = sAcc + ((cy * TILE_X + cx) * PL + j) * 5;
+            double* dst = sAcc + ((cy * TILE_X + cx) * PL + j) * 5;
 #pragma unroll
-            for (int c = 0; c < 5; ++c) atomicAdd(dst + c, src[c] * L.w[k]);
+            for (int c = 0; c < 5; ++c) lds_add(dst + c, src[c] * L.w[k]);
         }
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL; i += 256) {
         const int j = i % PL, pix = i / PL;
         const int px = x0 + pix % TILE_X, py = y0 + pix / TILE_X, s = s0 + j;
         if (px >= a.W || py >= a.H || s >= S) continue;
-        const float* v = sAcc + i * 5;
+        const double* v = sAcc + i * 5;
         float4* dst = reinterpret_cast<float4*>(a.accum + (((long long)py * a.W + px) * S + s) * 8);
-        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_float4(v[4], 0.f, 0.f, 0.f);
+        dst[0] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        dst[1] = make_float4((float)v[4], 0.f, 0.f, 0.f);
     }
     if (fw.count != nullptr) {
         int mine = 0;
         for (int t = threadIdx.x; t < fw.n_tiles; t += 256) {
             const int c = sHist[t];
-            if (c) { atomicAdd(fw.count + t + fw.n_tiles * blockIdx.y, c); mine += c; }
+            if (c) { atomicAdd(fw.count + t + fw.n_tiles * blk_.pg, c); mine += c; }
         }
-        if (mine) atomicAdd(fw.own + blockIdx.x + fw.n_tiles * blockIdx.y, mine);
+        if (mine) atomicAdd(fw.own + blk_.tile + fw.n_tiles * blk_.pg, mine);
     }
 }
 
@@ -243,11 +311,13 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const NsffSplatArgs a) {
     __shared__ int sBase[MAX_TILES];      // first record of this workgroup's range in that destination
     const FarWork fw = far_work(a);
     if (fw.count == nullptr) return;
-    const int blk = blockIdx.x + fw.n_tiles * blockIdx.y;
+    const SplatBlock blk_ = splat_block(fw.n_tiles, (a.n_planes + PL - 1) / PL);
+    if (!blk_.live) return;
+    const int blk = blk_.tile + fw.n_tiles * blk_.pg;
     if (fw.own[blk] == 0) return;                         // (the usual case for a trained flow field)
     const int S = a.n_planes;
-    const int tx = blockIdx.x % fw.tiles_x, ty = blockIdx.x / fw.tiles_x;
-    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blockIdx.y * PL;
+    const int tx = blk_.tile % fw.tiles_x, ty = blk_.tile / fw.tiles_x;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blk_.pg * PL;
     for (int i = threadIdx.x; i < fw.n_tiles; i += 256) sHist[i] = 0;
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
@@ -279,7 +349,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const NsffSplatArgs a) {
         if (pass == 0) {                                      // reserve this workgroup's range in every destination it feeds
             for (int t = threadIdx.x; t < fw.n_tiles; t += 256) {
                 const int c = sHist[t];
-                sBase[t] = c ? atomicAdd(fw.cursor + t + fw.n_tiles * blockIdx.y, c) : 0;
+                sBase[t] = c ? atomicAdd(fw.cursor + t + fw.n_tiles * blk_.pg, c) : 0;
                 sHist[t] = 0;
             }
             __syncthreads();
@@ -289,18 +359,20 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const NsffSplatArgs a) {
 
 // one workgroup per destination block: its records -> LDS accumulator -> added to the block splat_tiles_kernel wrote
 __global__ __launch_bounds__(256) void splat_gather_kernel(const NsffSplatArgs a) {
-    __shared__ float sAcc[TILE_X * TILE_Y * PL * 5];
+    __shared__ double sAcc[TILE_X * TILE_Y * PL * 5];          // (double: see lds_add)
     const FarWork fw = far_work(a);
     if (fw.count == nullptr) return;
-    const int blk = blockIdx.x + fw.n_tiles * blockIdx.y;
+    const SplatBlock blk_ = splat_block(fw.n_tiles, (a.n_planes + PL - 1) / PL);
+    if (!blk_.live) return;
+    const int blk = blk_.tile + fw.n_tiles * blk_.pg;
     const long long first = fw.start[blk];
     long long n = fw.count[blk];
     if (first + n > fw.capacity) n = fw.capacity > first ? fw.capacity - first : 0;     // (the overflow went through atomics)
     if (n <= 0) return;
     const int S = a.n_planes;
-    const int tx = blockIdx.x % fw.tiles_x, ty = blockIdx.x / fw.tiles_x;
-    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blockIdx.y * PL;
-    for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL * 5; i += 256) sAcc[i] = 0.f;
+    const int tx = blk_.tile % fw.tiles_x, ty = blk_.tile / fw.tiles_x;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, s0 = blk_.pg * PL;
+    for (int i = threadIdx.x; i < TILE_X * TILE_Y * PL * 5; i += 256) sAcc[i] = 0.0;
     __syncthreads();
     for (long long r = threadIdx.x; r < n; r += 256) {
         const float4* rec = reinterpret_cast<const float4*>(fw.records + (first + r) * 8);
@@ -316,9 +388,9 @@ __global__ __launch_bounds__(256) void splat_gather_kernel(const NsffSplatArgs a
             const int cx = L.nwx + (k & 1) - x0, cy = L.nwy + (k >> 1) - y0;
             if (cx < 0 || cx >= TILE_X || cy < 0 || cy >= TILE_Y) continue;
             if (L.nwx + (k & 1) >= a.W || L.nwy + (k >> 1) >= a.H) continue;
-            float* dst = sAcc + ((cy * TILE_X + cx) * PL + j) * 5;
+            double* dst = sAcc + ((cy * TILE_X + cx) * PL + j) * 5;
 #pragma unroll
-            for (int c = 0; c < 5; ++c) atomicAdd(dst + c, src[c] * L.w[k]);
+            for (int c = 0; c < 5; ++c) lds_add(dst + c, src[c] * L.w[k]);
         }
     }
     __syncthreads();
@@ -326,11 +398,11 @@ __global__ __launch_bounds__(256) void splat_gather_kernel(const NsffSplatArgs a
         const int j = i % PL, pix = i / PL;
         const int px = x0 + pix % TILE_X, py = y0 + pix / TILE_X, sp = s0 + j;
         if (px >= a.W || py >= a.H || sp >= S) continue;
-        const float* v = sAcc + i * 5;
-        if (v[4] == 0.f) continue;                            // nothing landed in this cell
+        const double* v = sAcc + i * 5;
+        if (v[4] == 0.0) continue;                            // nothing landed in this cell
         float4* dst = reinterpret_cast<float4*>(a.accum + (((long long)py * a.W + px) * S + sp) * 8);
         float4 d0 = dst[0], d1 = dst[1];
-        d0.x += v[0]; d0.y += v[1]; d0.z += v[2]; d0.w += v[3]; d1.x += v[4];
+        d0.x += (float)v[0]; d0.y += (float)v[1]; d0.z += (float)v[2]; d0.w += (float)v[3]; d1.x += (float)v[4];
         dst[0] = d0; dst[1] = d1;
     }
 }
@@ -417,9 +489,10 @@ int nsff_splat_planes(const NsffSplatArgs* args, void* stream) {
     if (reinterpret_cast<uintptr_t>(a.accum) & 15) return NSFF_ERR_ALIGN;
     const long long total = (long long)a.H * a.W * a.n_planes;
     const unsigned tiles = (unsigned)(((a.W + TILE_X - 1) / TILE_X) * ((a.H + TILE_Y - 1) / TILE_Y));
-    const dim3 grid(tiles, (unsigned)((a.n_planes + PL - 1) / PL));
+    const long long n_blocks = (long long)tiles * ((a.n_planes + PL - 1) / PL);
+    if (n_blocks > 0x7ffffff0LL) return NSFF_ERR_INVALID;
+    const dim3 grid((unsigned)(SPLAT_XCD ? 8 * ((n_blocks + 7) / 8) : n_blocks));          // (see splat_block)
     hipStream_t st = (hipStream_t)stream;
-    const long long n_blocks = (long long)grid.x * grid.y;
     const long long head = ((4 * n_blocks + 8) * 4 + 31) / 32 * 32;
     const bool binned = a.work != nullptr && (int)tiles <= MAX_TILES && a.work_bytes >= head + 32 &&
                         !(reinterpret_cast<uintptr_t>(a.work) & 31);

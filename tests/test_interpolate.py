@@ -190,7 +190,7 @@ def test_render_sequence_mirrors_the_eval_loop(hip_lib):
 
 # ---- multi-tile frame: the splat's tile ownership, halo and far path (csrc/interp.hip: TILE 32x8, HALO 4, 8 planes
 # per workgroup) against the oracle's scatter-add restatement of softsplat.py:6-44 / :303-326 ----
-SPLAT_TILE_X, SPLAT_TILE_Y, SPLAT_HALO, SPLAT_PLANES = 32, 8, 4, 8
+SPLAT_TILE_X, SPLAT_TILE_Y, SPLAT_HALO, SPLAT_PLANES = 32, 8, 4, 4
 # landing-cell offsets (pixels, after the dt scaling): inside the halo, on its last cell (3.75 -> +3, -3.75 -> -4),
 # first cell beyond it (4.25 -> +4, -4.25 -> -5), far, several tiles away, out of the frame.  No value is near an
 # integer: a cell that only receives an epsilon weight is normalised to a full value ('average'), i.e. the floor of a
