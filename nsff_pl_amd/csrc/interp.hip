@@ -1,8 +1,8 @@
 // N2: plane splatting + MPI compositing for time interpolation (reference models/rendering.py:365-460,
-// models/softsplat.py:6-44,303-326).  Scatter work without global atomics: output blocks (32 x 8 pixels x 8 planes) are OWNED
+// models/softsplat.py:6-44,303-326).  Scatter work without global atomics: output blocks (32 x 8 pixels x 4 planes) are OWNED
 // by workgroups.
 //   splat_tiles_kernel   accumulates the NEAR samples (landing within a 4-pixel halo of their own pixel) of the block's
-//                        surroundings in LDS (ds_add_f32) and writes the block with plain stores; while it projects its own
+//                        surroundings in LDS (ds_add_f64: see lds_add) and writes the block with plain stores; while it projects its own
 //                        samples anyway it counts the FAR ones per destination block (LDS histogram -> one global add per
 //                        (workgroup, destination));
 //   splat_scan_kernel    exclusive scan of the destination counts -> where each block's records start;
@@ -113,7 +113,7 @@ __device__ __forceinline__ bool is_near(const Landing& L, int px, int py) {
 }
 
 // Pass 1: each workgroup OWNS a TILE_X x TILE_Y block of output pixels for PL consecutive planes, accumulates the
-// near samples of the surrounding (tile + halo) source region in LDS (ds_add_f32) and writes the block with plain
+// near samples of the surrounding (tile + halo) source region in LDS (ds_add_f64) and writes the block with plain
 // stores -- no global atomics, no memset; the 2.5x redundant projection work is cheap next to the atomics it saves.
 // Workspace of the binned far path (ints, then 32-byte records): per block b = tile + n_tiles * plane group
 struct FarWork {
