@@ -172,7 +172,9 @@ class _FieldFn(torch.autograd.Function):
                 a_, b_, rows = dhead[t], acts[S_DIR if (t == 0 and viewdir) else base + D], (32, 256)
             jobs.append([a_.data_ptr(), b_.data_ptr(), rows[0], rows[1], 0])
             sizes.append(rows[0] * rows[1])
-        n_splits = max(1, min(int(os.environ.get("NSFF_WGRAD_SPLITS", "32")), tiles // 4))
+        # requested split-K factor; the library rounds it to whole rounds of the 256 CUs (16 -> one round of 14 splits x 18 jobs:
+        # 7.52 ms per C2 step against 7.63 at 32 = two rounds, 7.79 at 48: fewer partial sums for the accumulate pass to read)
+        n_splits = max(1, min(int(os.environ.get("NSFF_WGRAD_SPLITS", "16")), tiles // 4))
         off = 0
         for j, sz in zip(jobs, sizes):
             j[4] = off
