@@ -118,6 +118,11 @@ def test_render_rays_matches_reference_goldens(name, hip_lib, monkeypatch):
             tol = np.maximum(tol, tol_t.max(1, keepdims=True))
         parity.assert_samples_close("zs_fine", got["zs_fine"], want["zs_fine"], tol)
         assert (np.diff(got["zs_fine"], axis=1) >= 0).all(), "zs_fine not sorted"
+        # merge + sort (rendering.py:346-348), bit for bit and independent of the sampling's conditioning: the merged depths
+        # are exactly the kernel's own coarse depths and inverse-CDF samples, sorted -- on every ray, near-empty ones included
+        parts = [got["zs_coarse"]] + [got[k] for k in ("static_zs_fine", "transient_zs_fine") if k in got and k in want]
+        if len(parts) > 1 and sum(p.shape[1] for p in parts) == got["zs_fine"].shape[1]:
+            assert np.array_equal(got["zs_fine"], np.sort(np.concatenate(parts, 1), 1)), "zs_fine is not sort(cat(coarse, samples))"
 
         got = _render(cfg, models, emb, rays, ts, dataset, monkeypatch, use_draws, zs_fine=want["zs_fine"])
         for k in want:
@@ -475,6 +480,9 @@ def test_frame_egress_to_pinned_host_buffers(hip_lib, precision):
         return (time.perf_counter() - t0) / 3
     pool = evaluate.PinnedPool(depth=2)
     timed(); timed(to_host=pool)                              # warm both paths
-    t_gpu, t_host, t_block = timed(), timed(to_host=pool), timed(to_cpu=True)
+    # best of three alternating measurements (a wall-clock comparison on a shared host: one slow repetition must not fail it)
+    t_gpu, t_host = min(timed() for _ in range(3)), min(timed(to_host=pool) for _ in range(3))
+    t_gpu = min(t_gpu, timed())
+    t_block = timed(to_cpu=True)
     print(f"frame {H}x{W}: resident {t_gpu * 1e3:.1f} ms, async pinned egress {t_host * 1e3:.1f} ms, blocking .cpu() {t_block * 1e3:.1f} ms")
     assert t_host <= 1.05 * t_gpu + 2e-3, (t_host, t_gpu)
