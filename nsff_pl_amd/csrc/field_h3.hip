@@ -45,9 +45,13 @@ __device__ unsigned long long g_h3_span[2] = {~0ull, 0ull};     // first / last 
     if (k) atomicMax(&g_h3_span[1], t_); else atomicMin(&g_h3_span[0], t_); } } while (0)
 #define H3_STAMP(k) do { if (lane == 0 && blockIdx.x < 256 && i < 32) \
     g_h3_timing[((blockIdx.x * 8 + wave_id) * 32 + i) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+// stamps inside the LAST head call of a workgroup and behind it: slot 30
+#define H3_HSTAMP(k) do { if (lane == 0 && blockIdx.x < 256) \
+    g_h3_timing[((blockIdx.x * 8 + wave) * 32 + 30) * 6 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define H3_STAMP(k) do {} while (0)
 #define H3_SPAN(k) do {} while (0)
+#define H3_HSTAMP(k) do {} while (0)
 #endif
 
 namespace {
@@ -683,6 +687,22 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
     if (KS == 1 && wave >= NPT) return;
     constexpr int CH = (SPLIT && MTW == 1) ? 3 : 1;      // accumulator chains
     f32x16 acc0[CH];
+    H3_HSTAMP(0);
+    // the biases of this lane's (up to) eight rows: requested now, used behind the MFMAs and the k-split exchange (round-3 head
+    // stamps of the last head call: weights + MFMAs 3.4 k cycles, k-split exchange 1.0 k, bias + activations + record image 2.4 k,
+    // final barrier 1.7 k, records 0.8 k; -1.7 % per launch on one box, +-0 on another.  Requesting the second half of the
+    // head weights behind the last GEMM as well costs 19 spilled registers: +2.5 %, not kept)
+    // (32-neuron waves only: the 64-neuron tilings have no registers to spare -- the fast mode lost 3.7 % to 12 more spills)
+    constexpr bool EARLY_BIAS = SPLIT && MTW == 1;
+    const float* bias = reinterpret_cast<const float*>(pk + b_off);
+    [[maybe_unused]] float bv[8];
+    if constexpr (EARLY_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            bv[r] = row < n_rows ? bias[row] : 0.f;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -742,6 +762,7 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
         part[r] = acc0[0][r];
         if constexpr (CH > 1) part[r] = (part[r] + acc0[1][r]) + acc0[2][r];
     }
+    H3_HSTAMP(1);
     if constexpr (KS == 2) {
         if (kh == 1) {
 #pragma unroll
@@ -752,20 +773,21 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
 #pragma unroll
         for (int r = 0; r < 8; ++r) part[r] += sRed[(pt * 8 + r) * 64 + lane];
     }
+    H3_HSTAMP(2);
     // the values go to the tile's raw-record image in LDS; the kernel writes whole 64-byte records at its end
     float* rec = sRaw + (32 * pt + (lane & 31)) * NSFF_RAW_STRIDE + slot0;
-    const float* bias = reinterpret_cast<const float*>(pk + b_off);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < n_rows) {
-            float v = part[r] + bias[row];
+            float v = part[r] + (EARLY_BIAS ? bv[r] : bias[row]);
             const unsigned kind = (kinds >> (2 * row)) & 3u;
             if (kind == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
             else if (kind == ACT_FLOW) v = flow_scale * tanhf(v);
             rec[row] = v;
         }
     }
+    H3_HSTAMP(3);
 }
 
 // NT = point tiles (of 32) per wave, WM = wave rows: the workgroup has 4*WM waves and 32*NT*WM points.
@@ -974,7 +996,9 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         }
     }
     pend_flush();
+    { [[maybe_unused]] const int wave = wave_id; H3_HSTAMP(4); }
     __syncthreads();
+    { [[maybe_unused]] const int wave = wave_id; H3_HSTAMP(5); }
     for (int i = threadIdx.x; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
         const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
         const int q4 = i % (NSFF_RAW_STRIDE / 4);                   // 16-byte quarter of the record

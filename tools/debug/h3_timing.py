@@ -74,3 +74,17 @@ for s_ in range(nsteps):
     gaps.append((((nxt_t - t[:, :, s_, last[s_]]) & 0xffffffff).astype(np.float64)).mean())
 print("after each step (heads / next pre-barrier / end of kernel): " + " ".join(f"{v:6.0f}" for v in gaps))
 print(f"{'heads, raw records, rest':26s} share {(tot.sum() - acc) / tot.sum() * 100:5.1f}%")
+
+# ---- inside / behind the last head call of each workgroup (slot 30: 0 entry, 1 MFMAs done, 2 k-split exchange done,
+# 3 activations written to the record image, 4 before the final barrier, 5 after it; slot 31 stamp 0 = records stored) ----
+h = t[:, :, 30, :]
+last5 = ((t[:, :, nsteps - 1, 5] if post[nsteps - 1] else t[:, :, nsteps - 1, 2]))
+seg = lambda a_, b_: ((b_ - a_) & 0xffffffff).astype(np.float64)
+kh0 = slice(0, waves // 2)                                   # waves of the lower k half run the whole head
+print("last head call, waves of the lower k half (mean cycles):",
+      f"barrier-2 of the last layer -> head entry {seg(last5, h[..., 0])[:, kh0].mean():.0f} |",
+      f"weights + MFMAs {seg(h[..., 0], h[..., 1])[:, kh0].mean():.0f} |",
+      f"k-split exchange (barrier) {seg(h[..., 1], h[..., 2])[:, kh0].mean():.0f} |",
+      f"bias + activations + record image {seg(h[..., 2], h[..., 3])[:, kh0].mean():.0f} |",
+      f"-> final barrier entered {seg(h[..., 3], h[..., 4])[:, kh0].mean():.0f} | barrier {seg(h[..., 4], h[..., 5]).mean():.0f} |",
+      f"records to HBM {seg(h[..., 5], t[:, :, 31, 0]).mean():.0f}")
