@@ -4,6 +4,7 @@
 #   pmc     counter passes (one rocprofv3 run per group, --kernel-trace only) of the default bench (f16x3 field
 #           kernel + the per-ray kernels) and of the f16 fast mode
 #   interp  FETCH / WRITE passes of the time-interpolation kernels (tools/bench_interp.py)
+#   eval    kernel stats + FETCH / WRITE of one 512x288 test-time frame with the visibility branch on (C3)
 #   train   kernel stats + FETCH / WRITE / mfma passes of the training step
 # Summaries: python profiles/summarize_r03.py gpurun_out/r03_<tag>  > profiles/r03_<tag>_summary.txt
 set -u
@@ -36,6 +37,10 @@ for w in $WHAT; do
     interp)
       pmc interp_pmc fetch "python $ROOT/tools/bench_interp.py --reps 2" FETCH_SIZE
       pmc interp_pmc write "python $ROOT/tools/bench_interp.py --reps 2" WRITE_SIZE ;;
+    eval)
+      rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eval_stats -o eval -- python $ROOT/bench.py --workload eval --steps 2 --warmup 1 --no-cpu-baseline --no-aux > $OUT/eval_stats.log 2>&1
+      pmc eval_pmc fetch "python $ROOT/bench.py --workload eval --steps 1 --warmup 1 --no-cpu-baseline --no-aux" FETCH_SIZE
+      pmc eval_pmc write "python $ROOT/bench.py --workload eval --steps 1 --warmup 1 --no-cpu-baseline --no-aux" WRITE_SIZE ;;
     train)
       rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o train -- python $ROOT/bench.py --workload train --graph --steps 10 --warmup 3 --no-cpu-baseline > $OUT/train_stats.log 2>&1
       T="python $ROOT/bench.py --workload train --steps 2 --warmup 2 --no-cpu-baseline"

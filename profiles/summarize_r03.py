@@ -68,9 +68,9 @@ def stats_table(dirname):
                 print(f"  {int(row['Calls']):5d} x  avg {float(row['AverageNs']) / 1e3:9.1f} us  {float(row['Percentage']):6.2f} %  {row['Name'][:110]}")
 
 
-for d in ("bench_stats", "fast_stats", "train_stats"):
+for d in ("bench_stats", "fast_stats", "eval_stats", "train_stats"):
     stats_table(d)
-for d in ("bench_pmc", "fast_pmc", "interp_pmc", "train_pmc"):
+for d in ("bench_pmc", "fast_pmc", "interp_pmc", "eval_pmc", "train_pmc"):
     passes = load(d)
     if not passes:
         continue
