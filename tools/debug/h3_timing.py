@@ -88,3 +88,10 @@ print("last head call, waves of the lower k half (mean cycles):",
       f"bias + activations + record image {seg(h[..., 2], h[..., 3])[:, kh0].mean():.0f} |",
       f"-> final barrier entered {seg(h[..., 3], h[..., 4])[:, kh0].mean():.0f} | barrier {seg(h[..., 4], h[..., 5]).mean():.0f} |",
       f"records to HBM {seg(h[..., 5], t[:, :, 31, 0]).mean():.0f}")
+
+# ---- per-wave view of one mid-trunk layer (step 2) of a few workgroups: when does each wave start / finish issuing its GEMM,
+# how long does it wait at the barrier behind it? ----
+for wg in (0, 97, 200):
+    base = t[wg, :, 2, 1].min()
+    rel = lambda k: ((t[wg, :, 2, k] - base) & 0xffffffff)
+    print(f"workgroup {wg:3d} layer step 2: GEMM start {rel(1).tolist()}  GEMM issued {rel(2).tolist()}  past barrier 1 {rel(3).tolist()}")
