@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      19
+#define NSFF_ABI_VERSION      20
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -251,6 +251,16 @@ int nsff_absmax(const float* x, int64_t n, float* out, void* stream);
 int nsff_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                    const float* lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
+/* The same step with torch.optim.Adam's treatment of parameters that receive no gradient (`if p.grad is None: continue`,
+ * what train.py's optimizer does for a head the step never used): the flat buffers are n_seg consecutive parameter tensors,
+ * tensor k = elements [seg_start[k], seg_start[k+1]) (DEVICE int64[n_seg + 1], ascending, seg_start[0] = 0); a tensor whose
+ * gradient slice is identically zero this step keeps its values AND its moments (no weight decay, no moment decay);
+ * seg_used: DEVICE int32[n_seg] scratch (receives the per-tensor flags).  One memset + three launches, capturable.
+ * seg_start == NULL (with seg_used == NULL): every element is updated, exactly nsff_adam_step.                          */
+int nsff_adam_step_segments(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                            const float* lr, double beta1, double beta2, double eps, double weight_decay,
+                            const int64_t* seg_start, int n_seg, int32_t* seg_used, void* stream);
+
 /* ---- N1: the training objective NeRFWLoss (reference losses.py:8-28, 31-171) on the render dict, NSFF train-mode
  * configuration (flows + disocclusion present, topk == 1, no per-ray weights, thickness == 1), every term reduced to
  * its scalar.  mode 1: terms[11] = col_l, disp_l, entropy_l, cross_entropy_l, flow_fw_l, flow_bw_l, pho_l, cyc_l,
@@ -337,7 +347,8 @@ int nsff_frame_rays(const float* K4_host, const float* c2w_host, int32_t H, int3
 typedef struct NsffFrustumArgs {
     const float*   w2c;         /* device (n_cams * n_frames, 12): row-major first three rows of inverse([c2w; 0 0 0 1]),
                                    camera i of frame f at row i * n_frames + f (dataset.poses order, rendering.py:199)  */
-    const int64_t* ts;          /* device: the frame is ts[0] (read on the device: no host synchronisation)            */
+    const int64_t* ts;          /* device: the frame is ts[0] (read on the device: no host synchronisation); a frame outside
+                                   [0, n_frames) is treated as seen by no camera (count 0), never read out of bounds      */
     float   K4[4];              /* fx, fy, cx, cy of dataset.Ks[0]                                                     */
     int32_t n_cams, n_frames, H, W;
 } NsffFrustumArgs;

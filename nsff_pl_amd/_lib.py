@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 19
+ABI_VERSION = 20
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -163,6 +163,8 @@ _SIGNATURES = {
                                               _fp, _fp, _fp]),
     "nsff_absmax": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "nsff_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double, _fp]),
+    "nsff_adam_step_segments": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                          _fp, C.c_int, _fp, _fp]),
     "nsff_composite_backward": (C.c_int, [C.POINTER(CompositeBwdArgs), _fp]),
     "nsff_flow_grad": (C.c_int, [C.POINTER(FlowGradArgs), _fp]),
     "nsff_nerfw_loss": (C.c_int, [C.POINTER(LossArgs), C.c_int, _fp]),
@@ -496,10 +498,19 @@ def absmax(x):
     return out
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay):
-    """One Adam step on flat buffers (include/nsff_render.h: nsff_adam_step); state / lr are device tensors."""
-    _check(load().nsff_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(state), _ptr(lr),
-                                 float(beta1), float(beta2), float(eps), float(weight_decay), _stream()), "nsff_adam_step")
+def adam_step(param, grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, seg_start=None, seg_used=None):
+    """One Adam step on flat buffers (include/nsff_render.h: nsff_adam_step); state / lr are device tensors.  With
+    ``seg_start`` (int64, n_seg + 1 offsets) and ``seg_used`` (int32, n_seg): parameter tensors whose gradient slice is
+    identically zero this step are skipped as torch.optim.Adam skips ``grad is None`` (nsff_adam_step_segments)."""
+    if seg_start is None:
+        _check(load().nsff_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(state), _ptr(lr),
+                                     float(beta1), float(beta2), float(eps), float(weight_decay), _stream()), "nsff_adam_step")
+        return
+    _check(load().nsff_adam_step_segments(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(state),
+                                          _ptr(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                          C.c_void_p(seg_start.data_ptr()), int(seg_used.numel()),
+                                          C.c_void_p(seg_used.data_ptr()), _stream()),
+           "nsff_adam_step_segments")
 
 
 def composite_backward(n_rays, n_samples, has_transient, flow_mode, noise_std, **tensors):

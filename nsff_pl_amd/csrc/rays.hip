@@ -244,6 +244,7 @@ __device__ __forceinline__ float frustum_count(const NsffFrustumArgs& v, float x
     const float ry = -rz * y * cy / fy;
     const long long frame = v.ts[0];
     float count = 0.f;
+    if (frame < 0 || frame >= v.n_frames) return count;          // a frame the table does not hold is seen by no camera
     for (int c = 0; c < v.n_cams; ++c) {
         const float* m = v.w2c + ((long long)c * v.n_frames + frame) * 12;
         const float cam0 = fmaf(m[2], rz, fmaf(m[1], ry, m[0] * rx)) + m[3];

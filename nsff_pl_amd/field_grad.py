@@ -437,12 +437,14 @@ def _flush_weight_grads():
     (one fused add per node instead of one per parameter).  Gradients therefore reach the parameters through
     ``loss.backward()``; ``torch.autograd.grad(..., parameters)`` needs NSFF_WGRAD_OVERLAP=0."""
     tid = _graph_task_id()
-    items = [e[1:] for e in _PENDING if e[0] == tid]          # entries of other passes died with those passes: dropped
-    del _PENDING[:]
+    items = [e[1:] for e in _PENDING if e[0] == tid]
+    # only THIS pass's entries leave the list: an enclosing backward that is still running (re-entrant backward, checkpoint
+    # recompute, a hook that renders and differentiates) keeps its own; entries of passes that died are drop_stale_pending's
+    _PENDING[:] = [e for e in _PENDING if e[0] != tid]
+    for dev, side in _SIDE.items():           # always: the optimizer step must not race the side-stream accumulation
+        torch.cuda.current_stream(dev).wait_stream(side)
     if not items:
         return
-    for dev, side in _SIDE.items():
-        torch.cuda.current_stream(dev).wait_stream(side)
     with torch.no_grad():
         for plist, grads, _keep in items:
             if grads is None:                # already accumulated in place by nsff_weight_grad_accumulate

@@ -9,11 +9,13 @@ their shapes, ``state_dict`` keys and identity (``nn.Parameter`` objects are unt
 
 Where this differs from ``torch.optim.Adam`` -- read before swapping it in elsewhere:
 
-* **Every element is updated every step.**  torch skips parameters whose ``.grad`` is None; here ``.grad`` always exists
-  (a slice of the flat buffer, zero after ``zero_grad``).  With ``weight_decay == 0`` (the reference's default, opt.py) a
-  zero gradient only decays the moments, as torch would for a zero-valued gradient; with ``weight_decay > 0`` a parameter
-  that never receives a gradient (an unused head) WOULD BE DECAYED where torch leaves it alone -- so a non-zero
-  ``weight_decay`` must be acknowledged with ``decay_unused=True``.
+* **Parameters without a gradient.**  torch skips parameters whose ``.grad`` is None; here ``.grad`` always exists (a
+  slice of the flat buffer, zero after ``zero_grad``).  With ``weight_decay == 0`` (the reference's default, opt.py:84)
+  every element is updated every step: a zero gradient only decays the moments, as torch would for a zero-valued gradient.
+  With ``weight_decay > 0`` a parameter that never receives a gradient (an unused head) must NOT be decayed, so the step
+  runs in its segment form (``nsff_adam_step_segments``): a parameter tensor whose gradient slice is identically zero this
+  step keeps its value and its moments, which is what torch does for ``grad is None``.  ``decay_unused=True`` selects the
+  plain every-element step instead (one launch fewer).
 * **HIP device only.**  There is no CPU implementation (tests drive CPU runs with a torch-op twin, tests/common.py).
 * **Shared storage.**  ``module.state_dict()`` tensors are views of the one flat buffer: ``torch.save`` of such a dict
   writes the whole buffer once per file.  Use :func:`detached_state` (or ``NSFFTrainer.checkpoint``) to get clones.
@@ -31,10 +33,7 @@ class FlatAdam:
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("FlatAdam: no parameters")
-        if weight_decay != 0 and not decay_unused:
-            raise ValueError("FlatAdam updates every element every step: with weight_decay != 0 parameters that never "
-                             "receive a gradient are decayed too (torch.optim.Adam skips them).  Pass decay_unused=True to "
-                             "accept that, or use weight_decay=0 (the reference's default).")
+        self.decay_unused = bool(decay_unused)
         dev = self.params[0].device
         self._check_device(dev)
         if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
@@ -48,6 +47,12 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros(padded, device=dev)
         self.state = torch.zeros(4, device=dev)                # [0] = steps taken
         self.lr = torch.tensor(float(lr), device=dev)
+        # parameter tensor k = flat elements [seg_start[k], seg_start[k + 1]) -- the segment form of the step (see above)
+        offs = [0]
+        for p in self.params:
+            offs.append(offs[-1] + p.numel())
+        self.seg_start = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.seg_used = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self.param_groups = [{"lr": self.lr, "params": self.params}]   # (what loggers / schedulers look at)
         with torch.no_grad():
             off = 0
@@ -100,8 +105,10 @@ class FlatAdam:
         self.flat_grad.zero_()
 
     def step(self):
+        skip_unused = self.weight_decay != 0 and not self.decay_unused
         _lib.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.state, self.lr,
-                       self.betas[0], self.betas[1], self.eps, self.weight_decay)
+                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                       self.seg_start if skip_unused else None, self.seg_used if skip_unused else None)
 
     def set_lr(self, lr):
         self.lr.fill_(float(lr))

@@ -51,12 +51,14 @@ class NSFFTrainer:
     """models = {'fine', 'coarse'?}, embeddings = {'xyz','dir','t'?,'a'?} exactly as train.py:40-84 builds them.
 
     hparams (attribute or dict access): N_samples, N_importance, perturb, noise_std, chunk, lambda_geo_init,
-    thickness, topk, lr, weight_decay, decay_step, decay_gamma -- reference names and defaults (opt.py).
+    thickness, topk, lr, weight_decay, decay_step, decay_gamma -- reference names and defaults (opt.py) -- and
+    decay_unused (False: with weight_decay > 0 a parameter that receives no gradient is left alone, as torch.optim.Adam
+    leaves ``grad is None`` parameters alone; True: the plain every-element step, see optim.FlatAdam).
     """
 
     DEFAULTS = dict(N_samples=128, N_importance=0, perturb=1.0, noise_std=1.0, chunk=32 * 1024,
                     lambda_geo_init=0.04, thickness=1, topk=1.0, lr=5e-4, weight_decay=0.0,
-                    decay_step=[20], decay_gamma=0.1)
+                    decay_step=[20], decay_gamma=0.1, decay_unused=False)
 
     def __init__(self, models, embeddings, n_frames, hparams=None, Ks=None, Ps=None,
                  output_transient=True, output_transient_flow=("fw", "bw", "disocc"), graph=False, optimizer_cls=FlatAdam):
@@ -111,7 +113,8 @@ class NSFFTrainer:
 
     def _make_optimizer(self):
         hp = self.hp
-        self.optimizer = self.optimizer_cls(self.params, lr=hp["lr"], eps=1e-8, weight_decay=hp["weight_decay"])
+        self.optimizer = self.optimizer_cls(self.params, lr=hp["lr"], eps=1e-8, weight_decay=hp["weight_decay"],
+                                            decay_unused=hp["decay_unused"])
         self._flat_grad = self.optimizer.flat_grad
         self._lr_epoch = -1
 
@@ -251,32 +254,57 @@ class NSFFTrainer:
         for k in ("t", "a"):
             if k in self.embeddings:
                 sd.update({f"embedding_{k}.{kk}": v for kk, v in detached_state(self.embeddings[k]).items()})
-        opt = self.optimizer.torch_state_dict() if hasattr(self.optimizer, "torch_state_dict") else self.optimizer.state_dict()
+        opt = None                                  # (before the first step / to(): no optimizer state exists yet)
+        if self.optimizer is not None:
+            opt = self.optimizer.torch_state_dict() if hasattr(self.optimizer, "torch_state_dict") else self.optimizer.state_dict()
         return {"state_dict": sd, "optimizer": opt, "epoch": self.current_epoch}
 
-    def load_checkpoint(self, ckpt):
-        """Inverse of :meth:`checkpoint`; also takes a reference checkpoint's ``state_dict`` (same prefixes) with a
-        ``torch.optim.Adam`` optimizer state over the same parameter order."""
+    def load_checkpoint(self, ckpt, strict=False, prefixes_to_ignore=()):
+        """Inverse of :meth:`checkpoint`; also takes a reference (Lightning) checkpoint: ``state_dict`` with the same
+        prefixes and the ``torch.optim.Adam`` state under ``optimizer_states[0]`` (train.py:279-290).  Like the reference's
+        ``load_ckpt`` (utils/__init__.py:82-104: ``load_state_dict(..., strict=False)``) tensors the checkpoint does not hold
+        keep their current values and ``prefixes_to_ignore`` drops checkpoint entries by (un-prefixed) key prefix;
+        ``strict=True`` raises KeyError on a missing tensor instead.  Returns the list of keys that were not loaded."""
         sd = ckpt["state_dict"]
+        missing = []
+
+        def load_into(module, prefix):
+            sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+            sub = {k: v for k, v in sub.items() if not any(k.startswith(ig) for ig in prefixes_to_ignore)}
+            for k, p in module.state_dict().items():
+                if k in sub:
+                    p.copy_(sub[k])                 # in place: parameters stay views of the flat buffer
+                elif strict:
+                    raise KeyError(f"checkpoint has no tensor {prefix}{k}")
+                else:
+                    missing.append(prefix + k)
         with torch.no_grad():
             for typ, m in self.models.items():
-                sub = {k[len(f"nerf_{typ}."):]: v for k, v in sd.items() if k.startswith(f"nerf_{typ}.")}
-                for k, p in m.state_dict().items():
-                    p.copy_(sub[k])                 # in place: parameters stay views of the flat buffer
+                load_into(m, f"nerf_{typ}.")
             for name in ("t", "a"):
                 if name in self.embeddings:
-                    sub = {k[len(f"embedding_{name}."):]: v for k, v in sd.items() if k.startswith(f"embedding_{name}.")}
-                    for k, p in self.embeddings[name].state_dict().items():
-                        p.copy_(sub[k])
-        if self.optimizer is None:
+                    load_into(self.embeddings[name], f"embedding_{name}.")
+        if self.optimizer is None and self.params[0].is_cuda:
             self._make_optimizer()
-        if "optimizer" in ckpt and ckpt["optimizer"] is not None:
-            if "param_groups" in ckpt["optimizer"]:
-                self.optimizer.load_torch_state_dict(ckpt["optimizer"])
+        opt = ckpt.get("optimizer")
+        if opt is None and ckpt.get("optimizer_states"):         # Lightning's layout: one entry per optimizer
+            opt = ckpt["optimizer_states"][0]
+        if opt is not None and self.optimizer is not None:
+            if "param_groups" in opt:
+                try:
+                    self.optimizer.load_torch_state_dict(opt)
+                except ValueError as e:                          # another parameter list (e.g. a partial warm start)
+                    import warnings
+                    warnings.warn(f"load_checkpoint: optimizer state not taken over ({e}); Adam moments start from zero")
             else:
-                self.optimizer.load_state_dict(ckpt["optimizer"])
+                self.optimizer.load_state_dict(opt)
+        elif opt is not None:
+            import warnings
+            warnings.warn("load_checkpoint: the checkpoint holds optimizer state but no optimizer exists yet (call .to(device) "
+                          "first); Adam moments will start from zero")
         self.current_epoch = int(ckpt.get("epoch", self.current_epoch))
         self._invalidate_packs()
+        return missing
 
     def on_train_epoch_end(self):
         """MultiStepLR(milestones=decay_step, gamma=decay_gamma) of train.py:143-146, stepped once per epoch."""

@@ -111,6 +111,13 @@ def cpu_flat_adam():
             p, g, m, v = self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq
             self.state[0] += 1
             t = float(self.state[0])
+            live = None
+            if self.weight_decay and not self.decay_unused:     # the segment form: tensors with an all-zero gradient are skipped
+                live = torch.zeros_like(p, dtype=torch.bool)
+                offs = self.seg_start.tolist()
+                for a, b in zip(offs[:-1], offs[1:]):
+                    live[a:b] = bool((g[a:b] != 0).any())
+                keep = (p.clone(), m.clone(), v.clone())
             if self.weight_decay:
                 g = g + self.weight_decay * p
             m.lerp_(g, 1 - b1)
@@ -118,4 +125,7 @@ def cpu_flat_adam():
             step_size = float(self.lr) / (1 - b1 ** t)
             denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(self.eps)
             p.addcdiv_(m, denom, value=-step_size)
+            if live is not None:
+                for buf, old in zip((p, m, v), keep):
+                    buf.copy_(torch.where(live, buf, old))
     return TorchFlatAdam
