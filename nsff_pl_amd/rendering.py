@@ -23,9 +23,11 @@ from . import ray_geometry
 
 Z_FAR = 0.95  # flows are zeroed beyond this depth (reference rendering.py:316)
 
-# Not part of the interface: tests/common.py::fine_depths patches this to evaluate the fine pass at given
-# (N_rays, S_fine) depths, because the inverse-CDF draw is ill-conditioned in near-empty bins (tests/parity.py).
-_FINE_DEPTHS_OVERRIDE = None
+# Test seam, per call and explicit: ``render_rays(..., **{FINE_DEPTHS_KW: zs})`` evaluates the fine pass at the given
+# (N_rays, S_fine) depths instead of the ones it sampled -- the inverse-CDF draw is ill-conditioned in near-empty bins
+# (tests/parity.py), so per-sample fine keys of two correct fp32 implementations are only comparable at identical depths.
+# Only tests/common.py::fine_depths_kw builds this keyword; there is no module state a product call could inherit.
+FINE_DEPTHS_KW = "_parity_test_fine_depths"
 
 
 def _new(ref, *shape):
@@ -313,8 +315,10 @@ def render_rays(models,
                 results['static_zs_fine'] = zs_static
                 if output_transient:
                     results['transient_zs_fine'] = zs_transient
-            if _FINE_DEPTHS_OVERRIDE is not None:
-                zs_fine = _FINE_DEPTHS_OVERRIDE.to(rays.device).contiguous().float()
+            if kwargs.get(FINE_DEPTHS_KW) is not None:
+                zs_fine = torch.as_tensor(kwargs[FINE_DEPTHS_KW]).to(rays.device).contiguous().float()
+                if tuple(zs_fine.shape) != (n_rays, S_fine):
+                    raise ValueError(f"{FINE_DEPTHS_KW}: expected shape {(n_rays, S_fine)}, got {tuple(zs_fine.shape)}")
                 xyz_fine = (rays[:, None, 0:3] + rays[:, None, 3:6] * zs_fine[..., None]).contiguous()
             zs, xyz = zs_fine, xyz_fine
         else:

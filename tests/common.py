@@ -19,18 +19,13 @@ CHAINED_KEYS = ("xyzs_fw_bw", "xyzs_bw_fw", "rgb_fw", "rgb_bw", "disocc_fw", "di
 SAMPLE_KEYS = ("static_zs_fine", "transient_zs_fine", "zs_fine", "xyzs_fine")
 
 
-@contextlib.contextmanager
-def fine_depths(zs_fine):
-    """Evaluate the fine pass of nsff_pl_amd.render_rays at the given (N_rays, S_fine) depths (numpy / tensor /
-    None = free-running).  sample_pdf is ill-conditioned in near-empty bins (tests/parity.py), so per-sample fine
-    keys of two correct fp32 implementations are only comparable at identical depths."""
+def fine_depths_kw(zs_fine):
+    """Keyword arguments that make ONE nsff_pl_amd.render_rays call evaluate its fine pass at the given (N_rays, S_fine)
+    depths (numpy / tensor; None = {} = free-running).  sample_pdf is ill-conditioned in near-empty bins
+    (tests/parity.py), so per-sample fine keys of two correct fp32 implementations are only comparable at identical
+    depths.  The seam is this explicit per-call keyword: nothing is patched, no state outlives the call."""
     import nsff_pl_amd.rendering as R
-    old = R._FINE_DEPTHS_OVERRIDE
-    R._FINE_DEPTHS_OVERRIDE = None if zs_fine is None else torch.as_tensor(zs_fine)
-    try:
-        yield
-    finally:
-        R._FINE_DEPTHS_OVERRIDE = old
+    return {} if zs_fine is None else {R.FINE_DEPTHS_KW: torch.as_tensor(zs_fine)}
 
 
 def load_golden(name):

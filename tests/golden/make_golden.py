@@ -6,7 +6,8 @@ absent on the GPU box) on CPU torch and records inputs + every output key of
 scenes of ``tests/scenes.py``.  Only data is written (inputs, expected outputs, a weight
 checksum); no reference source travels.
 
-    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py                      # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py --only g19_c2_subset # (re)writes the named render cases only
 
 Import recipe: models/rendering.py pulls kornia, cupy (via
 models/softsplat) and the datasets package (cv2, torchvision) at import time although the
@@ -68,8 +69,13 @@ def main():
     torch.set_grad_enabled(False)
     DRAW_SEED = 4242
 
+    only = None
+    if "--only" in sys.argv:
+        only = sys.argv[sys.argv.index("--only") + 1].split(",")
     worst = 0.0
     for name in scenes.CASES:
+        if only is not None and name not in only:
+            continue
         cfg, rays, ts = scenes.case_inputs(name)
         models, embeddings = scenes.build_scene(NeRF, PosEmbedding, cfg)
         dataset = scenes.DatasetStub(cfg["seed"]) if cfg.get("dataset") else None
@@ -112,6 +118,8 @@ def main():
         size = os.path.getsize(os.path.join(HERE, name + ".npz")) / 1024
         print(f"{name:28s} keys={len(res):2d} oracle-vs-reference max-norm rel err {case_worst:.2e}  ({size:.0f} KiB)")
 
+    if only is not None:
+        return
     # ---- gradient goldens: d<outputs, fixed cotangents>/d(parameters) from the reference ----
     torch.set_grad_enabled(True)
     for name in scenes.GRAD_CASES:

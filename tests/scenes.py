@@ -59,6 +59,11 @@ CASES = {
     "g18_wide_inputs_train": dict(n_rays=12, N_samples=32, N_importance=24, transient=True, viewdir=True, appearance=True,
                                   test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=18,
                                   n_tau=96, xyz_emb=(11, 12), dir_emb=(15, 16)),
+    # 24 rays OF THE C2 BENCH / FULL-SIZE TEST BATCH (synthetic_rays(1024, 42), the g3 scene's weights): the full-size GPU test
+    # compares exactly these rows of its 1024-ray render with the reference's outputs, chained re-query keys included
+    "g19_c2_subset": dict(n_rays=24, N_samples=64, N_importance=64, transient=True, viewdir=False,
+                          appearance=False, test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=2,
+                          batch=(1024, 42, 0)),
     "g7b_static_noise_odd": dict(n_rays=9, N_samples=48, N_importance=40, transient=False, viewdir=True,
                                  appearance=False, test_time=False, flow=[], gain=2.5, seed=8,
                                  perturb=0.5, noise_std=0.7),
@@ -145,9 +150,20 @@ def wide_rays(n_rays, seed):
     return torch.cat([o, d], 1).float(), ts
 
 
+def subset_rows(cfg):
+    """Row indices (into the larger synthetic batch) of a case with cfg['batch'] = (batch rays, ray seed, subset seed)."""
+    n_batch, _, sub_seed = cfg["batch"]
+    return np.random.RandomState(sub_seed).choice(n_batch, cfg["n_rays"], replace=False).astype(np.int64)
+
+
 def case_inputs(name):
     cfg = CASES[name]
-    if cfg.get("dataset"):
+    if cfg.get("batch"):
+        n_batch, ray_seed, sub_seed = cfg["batch"]
+        rays, ts = synthetic_rays(n_batch, ray_seed)
+        idx = torch.from_numpy(subset_rows(cfg))
+        rays, ts = rays[idx], ts[idx]
+    elif cfg.get("dataset"):
         rays, ts = wide_rays(cfg["n_rays"], cfg["seed"])
     else:
         rays, ts = synthetic_rays(cfg["n_rays"], cfg["seed"])

@@ -17,14 +17,13 @@ for native in ("0", "1"):
     _to_dev(models, emb)
     draws = scenes.replay_draws(cfg, meta["draw_seed"])
     kw = scenes.render_kwargs(cfg)
-    R._FINE_DEPTHS_OVERRIDE = torch.from_numpy(want["zs_fine"])
     orig = (R.torch.rand, R.torch.randn)
     if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
         rp = _Replay(cfg, draws)
         R.torch.rand, R.torch.randn = rp.rand, rp.randn
     res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
                         cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
-                        test_time=False, **kw)
+                        test_time=False, **kw, **common.fine_depths_kw(want["zs_fine"]))
     R.torch.rand, R.torch.randn = orig
     scenes.cotangent_loss(res).backward()
     out[native] = {n: p.grad.detach().double().cpu() for n, p in scenes.named_grad_params(models, emb) if p.grad is not None}
