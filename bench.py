@@ -218,6 +218,17 @@ class Bench:
         return interp_step if interp else eval_step
 
 
+LAST_STEP_EVENTS = []        # sorted per-step HIP-event milliseconds of the most recent timed() on this rank
+
+
+def median_step_ms():
+    ev = LAST_STEP_EVENTS
+    if not ev:
+        return None
+    n = len(ev)
+    return ev[n // 2] if n % 2 else 0.5 * (ev[n // 2 - 1] + ev[n // 2])
+
+
 def timed(step, steps, warmup, world, device, prof=False, bench=None):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; returns (seconds [max over ranks],
     field-kernel (launches, ms, flops) from HIP events on the launch stream when prof, per-rank report).  The report
@@ -242,15 +253,24 @@ def timed(step, steps, warmup, world, device, prof=False, bench=None):
         bench.gather_ms()                       # (drop the warm-up's record)
     if prof:
         _lib.prof_enable(True)
+    # hipEvent pairs around every step on torch's current stream, median -- reported beside the
+    # wall-clock figure the driver's contract asks for (K steps between two barrier + synchronize brackets)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if gpu else None
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        if gpu:
+            marks[i].record()
         step()
     if gpu:
+        marks[steps].record()
         torch.cuda.synchronize()
     own = time.perf_counter() - t0              # this rank's own K steps, before waiting for the others
     fence()
     elapsed = time.perf_counter() - t0
-    kern = (0, 0.0, 0.0, 0.0)
+    LAST_STEP_EVENTS.clear()
+    if gpu and steps > 0:
+        LAST_STEP_EVENTS.extend(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps)))
+    kern = (0, 0.0, 0.0, 0.0, None)
     if prof:
         kern = _lib.prof_collect()
         _lib.prof_enable(False)
@@ -268,8 +288,11 @@ def timed(step, steps, warmup, world, device, prof=False, bench=None):
     return elapsed, kern, per_rank
 
 
+NOMINAL_GHZ = 2.4            # the clock the dense peaks of MI355X_MICROARCH.md are quoted at
+
+
 def roofline_block(precision, kern):
-    launches, kernel_ms, kernel_flops, executed_flops = kern
+    launches, kernel_ms, kernel_flops, executed_flops, clock_ghz = kern
     achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     executed = executed_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     try:    # measured separately with rocprofv3 --pmc (profiles/collect_pmc.sh): bytes cannot be counted from here
@@ -277,7 +300,12 @@ def roofline_block(precision, kern):
     except Exception:
         traffic = None
     return {"bound": "mfma", "kernel": KERNEL_NAME[precision], "achieved": achieved, "peak": PEAK_TFLOPS[precision],
-            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision], "traffic": traffic,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision],
+            "clock_ghz": clock_ghz,
+            "frac_at_clock": None if not clock_ghz else achieved / (PEAK_TFLOPS[precision] * clock_ghz / NOMINAL_GHZ),
+            "clock_note": "shader clock measured inside the timed field launches (s_memtime ticks per XCD / HIP-event time); "
+                          f"`peak` and `frac` use the nominal {NOMINAL_GHZ} GHz peak, frac_at_clock scales the peak to the clock the part held",
+            "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/field_traffic.json)",
             "executed": executed,
             "mfma_issue_frac": executed * MFMA_PER_PRODUCT[precision] / PEAK_TFLOPS[precision],
@@ -287,6 +315,37 @@ def roofline_block(precision, kern):
                     "2 of the 18 256x256 layers; the f16x3 mode issues 3 f16 MFMAs per executed product (mfma_issue_frac)",
             "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
             "flop_per_launch": kernel_flops / max(launches, 1)}
+
+
+def readme_eval(bench, steps=2):
+    import scenes
+    import nsff_pl_amd as A
+    from nsff_pl_amd import evaluate
+    dev = bench.device
+    cfg = dict(scenes.CASES["g6_readme_viewdir"], appearance=False)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    for m in list(models.values()) + [emb["t"]]:
+        m.to(dev)
+    H, W = 288, 512
+    K = torch.tensor([[400.0, 0, W / 2], [0, 400.0, H / 2], [0, 0, 1]])
+    c2w = torch.tensor([[1.0, 0, 0, 0.02], [0, 1.0, 0, -0.01], [0, 0, 1.0, 0.0]])
+    rays = evaluate.frame_rays(K, c2w, H, W, device=dev)
+    ts = torch.full((H * W,), 8, device=dev, dtype=torch.long)
+    kw = dict(output_transient=True, output_transient_flow=['fw', 'bw'])
+    out = {"reference_published": {"seconds_per_frame": 8.04, "ray_samples_per_s": 2.35e6, "hardware": "RTX 2080 Ti (implied)",
+                                   "source": "test.ipynb:122"},
+           "config": "512x288, N_samples=128, N_importance=0, use_viewdir=True, flows fw+bw, chunk=16384, test_time, every key "
+                     "(24 tensors, 1.75 GB per frame) delivered to the host; random-init weights, synthetic pose"}
+    pool = evaluate.PinnedPool(depth=2)
+    forms = (("resident", dict()), ("blocking_cpu_every_chunk", dict(to_cpu=True)), ("pinned_async", dict(to_host=pool)))
+    for name, egress in forms:
+        def step():
+            return evaluate.render_frame(models, emb, rays, ts, scenes.N_FRAMES - 1, 128, 0, 1024 * 16, **egress, **kw)
+        t, _, _ = timed(step, steps, 1, 1, dev)
+        out[name] = {"seconds_per_frame": t / steps, "ray_samples_per_s": H * W * 128 * steps / t,
+                     "vs_published": (H * W * 128 * steps / t) / 2.35e6}
+    out["blocking_cpu_every_chunk"]["note"] = "the reference's own egress (eval.py:106-107 / test.ipynb cell 1): .cpu() of every key per chunk"
+    return out
 
 
 def aux_block(bench, args):
@@ -301,8 +360,8 @@ def aux_block(bench, args):
     rf = roofline_block("f16", kern)
     aux["fast_mode_f16"] = {"label": "FAST MODE, not parity-grade (one f16 MFMA per product; ~5e-3 max-norm error, see DESIGN.md 8)",
                             "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 10 / t, "ms_per_step": t / 10 * 1e3,
-                            "steps": 10, "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "unit", "frac",
-                                                                         "avg_launch_ms", "launches")}}
+                            "steps": 10, "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "clock_ghz",
+                                                                         "frac_at_clock", "avg_launch_ms", "launches")}}
     config.set_precision(args.precision)
     config.set_tile_points(args.tile_points if args.precision == "f16x3" else 0)
     # (1b) the TRAINING forward of the same C2 call (what a training step launches: every layer executed, activations and
@@ -311,7 +370,8 @@ def aux_block(bench, args):
     rf = roofline_block(args.precision, kern)
     aux["train_forward"] = {"label": "C2 forward as a training step runs it (autograd on): activation-saving kernels, no folded layers",
                             "ms_per_step": t / 10 * 1e3, "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 10 / t,
-                            "roofline": dict({k: rf[k] for k in ("achieved", "executed", "peak", "unit", "frac", "avg_launch_ms", "launches")},
+                            "roofline": dict({k: rf[k] for k in ("achieved", "executed", "peak", "unit", "frac", "clock_ghz", "frac_at_clock",
+                                                                 "avg_launch_ms", "launches")},
                                              kernel=TRAIN_KERNEL_NAME.get(args.precision, KERNEL_NAME[args.precision]))}
     # (2) C3 as SURVEY 8d defines it: one 512x288 test-time frame WITH the frustum-visibility test of every sample point
     # (eval.py:134 always passes `dataset`), and without it for comparison
@@ -324,6 +384,11 @@ def aux_block(bench, args):
     # ... and with the pixels (rgb_fine, depth_fine) delivered to pinned host memory chunk by chunk on a copy stream (row N4)
     t, _, _ = timed(bench.frame_steps(False, to_host=True), 3, 1, 1, dev)
     aux["eval_ms_per_frame_pixels_to_pinned_host"] = t / 3 * 1e3
+    # (2b) the reference's ONE published timing, like for like (test.ipynb:122, config :34,78-85 -- SURVEY section 6): one
+    # 512x288 frame, N_samples=128, N_importance=0, NeRF('fine', encode_transient, output_flow) with the constructor's
+    # default use_viewdir=True, output_transient_flow=['fw','bw'], chunk=16384, EVERY result key brought to the host after
+    # every chunk: 8.04 s on an RTX 2080 Ti = 2.35 M ray-samples/s
+    aux["readme_eval"] = readme_eval(bench)
     # (3) C5 inner loop: 2 rendered + 9 interpolated frames.  Random-init flow heads saturate at +-flow_scale: at the default
     # 0.2 NDC every sample moves ~+-50 px and the splat runs on its FAR path; a trained field moves a few pixels -- the NEAR
     # figure uses flow_scale 0.02 (+-5 px) on the same weights.  Both are reported, each labelled.
@@ -392,6 +457,7 @@ def main():
             "eval": lambda: bench.frame_steps(False), "eval_interp": lambda: bench.frame_steps(True)}[args.workload]()
 
     elapsed, kern, per_rank = timed(step, args.steps, args.warmup, world, device, prof=not args.standin, bench=bench)
+    median_ms = median_step_ms()               # (of the headline's steps: the aux block below times other things)
 
     aux = None
     if rank == 0 and world == 1 and args.workload == "render" and not args.no_aux and not args.standin:
@@ -403,11 +469,15 @@ def main():
             "metric": "ray-samples/sec (coarse+fine, static+dynamic)" + (" -- TRAINING step" if args.workload == "train" else ""),
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median_events": median_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
             "config": {"workload": "C2 (BASELINE.json configs[1]): static+dynamic NSFF, 1024 rays/GPU x (64 coarse + "
                                    "64 importance -> 192 fine pts), train-mode fwd, fw/bw flow warp t+-1, "
-                                   "perturb=1 noise_std=1, 8x256 MLPs, N_tau=48, all 47 outputs on device",
+                                   "perturb=1 noise_std=1, 8x256 MLPs, N_tau=48, all 47 outputs on device.  `value` is "
+                                   "render_rays' throughput with autograd DISABLED (the train-mode FLAGS, inference launches: "
+                                   "nothing kept for a backward pass); what a trainer's forward costs is aux.train_forward, "
+                                   "the whole training step aux.train_ms_per_step_*",
                        "rays_per_gpu": N_RAYS, "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE,
                        "parallelism": f"ray-shard x{world}, pixel all-gather" if bench.live else "single GPU",
                        "rays_per_s": world * N_RAYS * args.steps / elapsed,

@@ -173,6 +173,7 @@ _SIGNATURES = {
     "nsff_mpi_composite": (C.c_int, [C.POINTER(MpiArgs), _fp]),
     "nsff_prof_enable": (C.c_int, [C.c_int]),
     "nsff_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nsff_prof_collect_clock": (C.c_int, [C.POINTER(C.c_int64)] + [C.POINTER(C.c_double)] * 5),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -580,6 +581,11 @@ def prof_enable(on):
 
 
 def prof_collect():
-    n, ms, fl, ex = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
-    _check(load().nsff_prof_collect(C.byref(n), C.byref(ms), C.byref(fl), C.byref(ex)), "nsff_prof_collect")
-    return n.value, ms.value, fl.value, ex.value
+    """(launches, ms, algorithmic flops, executed flops, shader clock in GHz or None) of the field launches since prof_enable."""
+    n, ms, fl, ex, tk, tms = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    _check(load().nsff_prof_collect_clock(C.byref(n), C.byref(ms), C.byref(fl), C.byref(ex), C.byref(tk), C.byref(tms)),
+           "nsff_prof_collect_clock")
+    ghz = tk.value / tms.value * 1e-6 if tms.value > 0 else None
+    if ghz is not None and not (0.5 < ghz < 3.0):       # counters of different XCDs disagreeing, a wrapped stamp: no claim
+        ghz = None
+    return n.value, ms.value, fl.value, ex.value, ghz

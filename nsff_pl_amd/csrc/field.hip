@@ -373,10 +373,28 @@ __global__ void nsff_posenc_kernel(const PosencArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t e0, e1; double flops, executed; };
+struct ProfRec { hipEvent_t e0, e1; double flops, executed; int span_slot; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+// Shader clock under load: profiled f16 launches stamp s_memtime (first / last tick seen on each XCD: the counters of
+// different XCDs need not share an origin) into a slot of this pool; nsff_prof_collect turns ticks / event time into GHz.
+// One slot = NSFF_SPAN_WORDS uint64: [2 x] = min, [2 x + 1] = max of XCD x.  Allocated at the first nsff_prof_enable(1),
+// never on a product path (no profiling -> kernels get a null pointer and stamp nothing).
+constexpr int SPAN_SLOTS = 4096;
+unsigned long long* g_span_pool = nullptr;
+int g_span_next = 0;
+int span_pool_reset() {
+    std::vector<unsigned long long> init((size_t)SPAN_SLOTS * NSFF_SPAN_WORDS);
+    for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+    if (!g_span_pool) {
+        hipError_t e = hipMalloc(&g_span_pool, init.size() * 8);
+        if (e != hipSuccess) { g_span_pool = nullptr; return nsff_hip_fail(e); }
+    }
+    hipError_t e = hipMemcpy(g_span_pool, init.data(), init.size() * 8, hipMemcpyHostToDevice);
+    g_span_next = 0;
+    return e == hipSuccess ? NSFF_OK : nsff_hip_fail(e);
+}
 
 double field_flops_per_point(const NsffModelDesc& d, int static_mode, int transient_mode, int flow_heads) {
     const double W = d.W;
@@ -588,10 +606,16 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     if (tiles > 0x7fffffffLL) return NSFF_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     ProfRec pr{};
+    pr.span_slot = -1;
     bool prof = false;
+    unsigned long long* span = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         prof = g_prof_on;
+        if (prof && g_span_pool && g_span_next < SPAN_SLOTS && g.precision != NSFF_PREC_F32) {
+            pr.span_slot = g_span_next++;
+            span = g_span_pool + (size_t)pr.span_slot * NSFF_SPAN_WORDS;
+        }
     }
     if (prof) {
         hipError_t e = hipEventCreate(&pr.e0); if (e != hipSuccess) return nsff_hip_fail(e);
@@ -604,10 +628,10 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
         // 128 points, no spilled registers: 41 MB instead of 79 MB of HBM traffic per C2 launch and -0.8 % time); launches
         // too small to give every CU such a tile keep the 64-point tiling (two workgroups per CU)
         const int tile_default = g.n_points >= 128LL * 256 ? 130 : 64;
-        const int rc3 = nsff_h3_field_query(desc, packed_v, args, g.tile_points ? g.tile_points : tile_default, st);
+        const int rc3 = nsff_h3_field_query(desc, packed_v, args, g.tile_points ? g.tile_points : tile_default, st, span);
         if (rc3 != NSFF_OK) return rc3;
     } else if (g.precision == NSFF_PREC_F16) {
-        const int rc3 = nsff_h3_field_query(desc, packed_v, args, NSFF_H3_FAST, st);
+        const int rc3 = nsff_h3_field_query(desc, packed_v, args, NSFF_H3_FAST, st, span);
         if (rc3 != NSFF_OK) return rc3;
     } else {
         hipLaunchKernelGGL(nsff_field_kernel, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
@@ -630,17 +654,27 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
 
 int nsff_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (on && !g_prof_on) {
+        const int rc = span_pool_reset();          // (synchronous: profiling is switched on outside timed regions)
+        if (rc != NSFF_OK) return rc;
+    }
     g_prof_on = on != 0;
     return NSFF_OK;
 }
 
 int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops) {
+    return nsff_prof_collect_clock(launches, total_ms, total_flops, executed_flops, nullptr, nullptr);
+}
+
+int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops,
+                            double* shader_ticks, double* ticks_ms) {
     std::vector<ProfRec> recs;
+    std::vector<unsigned long long> spans;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         recs.swap(g_prof);
     }
-    double ms = 0, fl = 0, ex = 0;
+    double ms = 0, fl = 0, ex = 0, ticks = 0, tms = 0;
     for (auto& r : recs) {
         hipError_t e = hipEventSynchronize(r.e1);
         if (e != hipSuccess) return nsff_hip_fail(e);
@@ -649,7 +683,26 @@ int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops, 
         if (e != hipSuccess) return nsff_hip_fail(e);
         ms += t; fl += r.flops; ex += r.executed;
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        if (r.span_slot >= 0 && g_span_pool) {
+            if (spans.empty()) {                   // (every event above is complete: the stamps of those launches are too)
+                spans.resize((size_t)SPAN_SLOTS * NSFF_SPAN_WORDS);
+                if (hipMemcpy(spans.data(), g_span_pool, spans.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) spans.clear();
+            }
+            if (!spans.empty()) {
+                const unsigned long long* sp = spans.data() + (size_t)r.span_slot * NSFF_SPAN_WORDS;
+                double sum = 0; int n = 0;
+                for (int x = 0; x < NSFF_SPAN_WORDS / 2; ++x)
+                    if (sp[2 * x + 1] > sp[2 * x]) { sum += (double)(sp[2 * x + 1] - sp[2 * x]); ++n; }
+                if (n > 0) { ticks += sum / n; tms += t; }
+            }
+        }
     }
+    if (!spans.empty()) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        span_pool_reset();
+    }
+    if (shader_ticks) *shader_ticks = ticks;
+    if (ticks_ms) *ticks_ms = tms;
     if (launches) *launches = (int64_t)recs.size();
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;

@@ -114,7 +114,17 @@ struct H3KArgs {
     int octave_freqs;                // freqs[f+1] == 2 freqs[f], n_freqs <= 10, one 64-column segment: the doubling encoder applies
     float freqs[NSFF_MAX_FREQS];
     int ld_emb, off_xyz, off_dir, off_a, off_t;
+    unsigned long long* span;        // profiling only (else null): per-XCD first / last s_memtime tick of the launch
 };
+
+// Every 16th workgroup stamps the shader-clock counter into the launch's span slot (nsff_prof_collect_clock): min on entry,
+// max on exit, in the pair of its XCD (HW_REG_XCC_ID, id 20, bits 3:0) -- two fire-and-forget atomics, profiling only.
+__device__ __forceinline__ void span_stamp(unsigned long long* span, bool last) {
+    if (span == nullptr || (blockIdx.x & 15) != 0 || threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (last) atomicMax(span + 2 * xcc + 1, t); else atomicMin(span + 2 * xcc, t);
+}
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H3_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -890,6 +900,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         return h;
     };
     H3_SPAN(0);
+    span_stamp(a.span, false);
     const H3Step s0 = step_at(s_begin);
     const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
     load_bias<MTW>(br, fbias(s0.bias_off), nb0, lane);
@@ -1006,6 +1017,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
     }
     H3_SPAN(1);
+    span_stamp(a.span, true);
     { [[maybe_unused]] const int i = 31; H3_STAMP(0); }   // (timing build) end of the workgroup's work: slot 31, stamp 0
 }
 
@@ -1273,7 +1285,7 @@ int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, vo
 }
 
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
-                        int points_per_block, hipStream_t st) {
+                        int points_per_block, hipStream_t st, unsigned long long* span) {
     const NsffModelDesc& d = *desc;
     const NsffFieldArgs& g = *args;
     H3KArgs k{};
@@ -1281,6 +1293,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     if (rc) return rc;
     if (g.xyz && 3 + 6 * g.n_freqs != d.in_xyz) return NSFF_ERR_INVALID;
     k.packed = reinterpret_cast<const uint32_t*>(packed);
+    k.span = span;
     k.xyz = g.xyz; k.x_emb = g.x_emb; k.dir_emb = g.dir_emb; k.a_emb = g.a_emb; k.t_emb = g.t_emb;
     k.raw = g.raw; k.n_points = g.n_points; k.pts_per_ray = g.pts_per_ray;
     k.save_acts = reinterpret_cast<_Float16*>(g.save_acts);

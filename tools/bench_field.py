@@ -55,7 +55,7 @@ def main():
         for _ in range(args.iters):
             call()
         torch.cuda.synchronize()
-        k, ms, fl, _ex = _lib.prof_collect()
+        k, ms, fl, _ex, _ghz = _lib.prof_collect()
         _lib.prof_enable(False)
         res[name] = (ms / k, fl / k)
         print(f"{name:14s} P={P:7d}  {ms / k:8.3f} ms  {fl / (ms * 1e-3) / 1e12:7.2f} TFLOP/s")
