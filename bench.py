@@ -110,19 +110,26 @@ class Bench:
         self.gather_spans = []                  # (start, end) of every pixel all-gather: HIP events on the GPU, seconds on the CPU
 
     def gather(self, out, keys, counts=None):
-        """The step's one collective, bracketed so that rank 0 can report it separately from the render time."""
+        """The step's one collective, OVERLAPPED: issued on the gather side stream behind this step's render and
+        joined one step later, so it runs beside the next step's kernels; bracketed by events on that stream so that rank 0
+        can report the collective's own time.  `finish()` joins what is still in flight (timed() calls it inside the timed
+        region, before the closing synchronize)."""
         from nsff_pl_amd import dist as ndist
         if self.device.type == "cuda":
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            merged = ndist.all_gather_pixels(out, keys, counts=counts)
-            e1.record()
-            self.gather_spans.append((e0, e1))
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            handle = ndist.all_gather_pixels_async(out, keys, counts=counts, events=ev)
+            self.gather_spans.append(ev)
         else:
             t0 = time.perf_counter()
-            merged = ndist.all_gather_pixels(out, keys, counts=counts)
+            handle = ndist.all_gather_pixels_async(out, keys, counts=counts)
+            handle.wait()                                   # (CPU stand-in: nothing to overlap with; time the collective)
             self.gather_spans.append((t0, time.perf_counter()))
-        return merged
+        prev, self.pending = getattr(self, "pending", None), handle
+        return prev.wait() if prev is not None else None
+
+    def finish(self):
+        prev, self.pending = getattr(self, "pending", None), None
+        return prev.wait() if prev is not None else None
 
     def gather_ms(self):
         """Total milliseconds of the recorded gathers (call after a synchronize); clears the record."""
@@ -204,7 +211,10 @@ class Bench:
                                          keys=keys, to_host=pool, **ekw)
 
         def eval_step():
-            out = render_t(7, ("rgb_fine", "depth_fine"))
+            if self.standin:                               # CPU plumbing check (tests): constant pixels of this rank's block
+                out = {"rgb_fine": torch.full((hi - lo, 3), float(rank)), "depth_fine": torch.zeros(hi - lo)}
+            else:
+                out = render_t(7, ("rgb_fine", "depth_fine"))
             if self.live and not to_host:
                 counts = [b - a_ for a_, b in (ndist.shard_bounds(H * W, world, r) for r in range(world))]
                 self.gather(out, ("rgb_fine", "depth_fine"), counts=counts)
@@ -248,6 +258,8 @@ def timed(step, steps, warmup, world, device, prof=False, bench=None):
             torch.cuda.synchronize()
     for _ in range(warmup):
         step()
+    if bench is not None:
+        bench.finish()
     fence()
     if bench is not None:
         bench.gather_ms()                       # (drop the warm-up's record)
@@ -261,6 +273,8 @@ def timed(step, steps, warmup, world, device, prof=False, bench=None):
         if gpu:
             marks[i].record()
         step()
+    if bench is not None:
+        bench.finish()                          # the last step's overlapped pixel gather joins inside the timed region
     if gpu:
         marks[steps].record()
         torch.cuda.synchronize()

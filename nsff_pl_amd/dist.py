@@ -127,12 +127,26 @@ def _pack(results, keys, pad_to):
     return buf, widths
 
 
+def _unpack(out, results, keys, widths, counts, pad_to, world):
+    if all(c == pad_to for c in counts):
+        rows = out                                            # even shards: the gathered buffer already is the row list
+    else:
+        gathered = out.view(world, pad_to, out.shape[1])
+        rows = torch.cat([gathered[r, :counts[r]] for r in range(world)], 0)
+    merged, c0 = {}, 0
+    for k, wdt in zip(keys, widths):
+        merged[k] = rows[:, c0:c0 + wdt].reshape((rows.shape[0],) + tuple(results[k].shape[1:]))
+        c0 += wdt
+    return merged
+
+
 def all_gather_pixels(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group=None):
     """All-gather the per-ray tensors `keys` of every rank with ONE collective.
 
     results: this rank's render_rays dict.  counts: rays per rank (list, len world) when
     shards are uneven; None = every rank holds the same number.  Returns {key: (sum N, ...)}.
     The collective runs whenever a process group exists (world size 1 included: same call path on one GPU as on eight).
+    Synchronous on the caller's stream; :func:`all_gather_pixels_async` is the overlapped form.
     """
     live = dist.is_initialized()
     world = dist.get_world_size(group) if live else 1
@@ -146,16 +160,72 @@ def all_gather_pixels(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group=None)
     else:
         out = buf.new_empty(world * pad_to, buf.shape[1])
         dist.all_gather_into_tensor(out, buf, group=group)
-    if all(c == pad_to for c in counts):
-        rows = out                                            # even shards: the gathered buffer already is the row list
-    else:
-        gathered = out.view(world, pad_to, buf.shape[1])
-        rows = torch.cat([gathered[r, :counts[r]] for r in range(world)], 0)
-    merged, c0 = {}, 0
-    for k, wdt in zip(keys, widths):
-        merged[k] = rows[:, c0:c0 + wdt].reshape((rows.shape[0],) + tuple(results[k].shape[1:]))
-        c0 += wdt
-    return merged
+    return _unpack(out, results, keys, widths, counts, pad_to, world)
+
+
+_GATHER_STREAM = {}
+
+
+class PendingPixels:
+    """Handle of an overlapped pixel all-gather (:func:`all_gather_pixels_async`); ``wait()`` returns the merged dict and
+    makes the caller's current stream (GPU) / thread (CPU) wait for the collective -- not before."""
+
+    def __init__(self, finish):
+        self._finish, self._merged = finish, None
+
+    def wait(self):
+        if self._finish is not None:
+            self._merged, self._finish = self._finish(), None
+        return self._merged
+
+
+def all_gather_pixels_async(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group=None, events=None):
+    """:func:`all_gather_pixels` off the render stream ("on a side stream overlapped with the next
+    frame's render"): pack, collective and unpack are enqueued on a per-device side stream behind an event dependency on
+    the caller's stream, so the caller can go on enqueueing the next frame's kernels at once; the returned
+    :class:`PendingPixels` joins the side stream into the then-current stream when ``wait()`` is called.  Values are
+    bit-identical to the synchronous form.  CPU tensors (gloo tests): the collective is issued with ``async_op=True`` and
+    completed in ``wait()``.  events: optional (start, end) ``torch.cuda.Event`` pair recorded on the side stream around the
+    gather (bench.py reports the collective's own time from them)."""
+    ref = results[keys[0]]
+    if not ref.is_cuda:
+        live = dist.is_initialized()
+        world = dist.get_world_size(group) if live else 1
+        if counts is None:
+            counts = [ref.shape[0]] * world
+        pad_to = max(counts)
+        buf, widths = _pack(results, keys, pad_to)
+        out, work = buf, None
+        if live:
+            out = buf.new_empty(world * pad_to, buf.shape[1])
+            work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
+
+        def finish_cpu():
+            if work is not None:
+                work.wait()
+            return _unpack(out, results, keys, widths, counts, pad_to, world)
+        return PendingPixels(finish_cpu)
+    dev = ref.device
+    if dev not in _GATHER_STREAM:
+        _GATHER_STREAM[dev] = torch.cuda.Stream(device=dev)
+    side, cur = _GATHER_STREAM[dev], torch.cuda.current_stream(dev)
+    side.wait_stream(cur)                                   # the pixels are complete where the caller's stream stands now
+    with torch.cuda.stream(side):
+        if events is not None:
+            events[0].record(side)
+        merged = all_gather_pixels(results, keys, counts, group)      # RCCL orders itself behind the CURRENT (= side) stream
+        done = events[1] if events is not None else torch.cuda.Event()
+        done.record(side)
+    for k in keys:
+        results[k].record_stream(side)                      # (read by the side stream: not to be recycled under it)
+
+    def finish_gpu():
+        now = torch.cuda.current_stream(dev)
+        now.wait_event(done)
+        for v in merged.values():
+            v.record_stream(now)
+        return merged
+    return PendingPixels(finish_gpu)
 
 
 def render_rays_sharded(render_fn, models, embeddings, rays, ts, *args,

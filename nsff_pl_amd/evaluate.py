@@ -160,6 +160,40 @@ def render_frame_sharded(models, embeddings, rays, ts, max_t, N_samples, N_impor
     return merged
 
 
+def render_sequence_sharded(models, embeddings, samples, max_t, N_samples, N_importance, img_wh, chunk=1024 * 32,
+                            gather_keys=ndist.DEFAULT_PIXEL_KEYS, **kwargs):
+    """The plain frame loop (``interp == 0``) of :func:`render_sequence` with the rays of every frame sharded over the ranks:
+    rank r renders block r of each frame, and the ONE pixel all-gather of frame k runs on a side stream while frame k + 1
+    renders (:func:`nsff_pl_amd.dist.all_gather_pixels_async`).  Yields ``(name, rgb (h,w,3), depth (h,w))``
+    with the complete image on every rank, values clipped like eval.py:218-222 -- one frame behind the renders."""
+    import torch.distributed as dist
+    w, h = img_wh
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    pending = None
+
+    def emit(item):
+        name, handle = item
+        px = handle.wait()
+        return name, torch.clip(px['rgb_fine'].view(h, w, 3), 0, 1), px['depth_fine'].view(h, w)
+    for i, sample in enumerate(samples):
+        rays, ts = sample['rays'], sample.get('ts')
+        bounds = [ndist.shard_bounds(rays.shape[0], world, r) for r in range(world)]
+        lo, hi = bounds[rank]
+        kw = dict(kwargs)
+        for per_ray in ("view_dir", "t_embedded", "a_embedded"):
+            if per_ray in kw and kw[per_ray] is not None:
+                kw[per_ray] = kw[per_ray][lo:hi]
+        local = render_frame(models, embeddings, rays[lo:hi], None if ts is None else ts[lo:hi], max_t, N_samples,
+                             N_importance, chunk, keys=gather_keys, **kw)
+        handle = ndist.all_gather_pixels_async(local, gather_keys, counts=[b - a for a, b in bounds])
+        if pending is not None:
+            yield emit(pending)                     # frame i - 1: its gather ran beside this frame's render
+        pending = (f"{i:03d}", handle)
+    if pending is not None:
+        yield emit(pending)
+
+
 def render_sequence(models, embeddings, samples, max_t, N_samples, N_importance, img_wh, chunk=1024 * 32, interp=0,
                     K=None, **kwargs):
     """The frame loop of the reference's ``eval.py`` (:171-222) as a generator of ``(name, rgb (h,w,3), depth (h,w))``

@@ -34,6 +34,19 @@ def test_bench_self_launches_two_ranks():
     assert 0 < pr["gather_ms_per_step_min"] <= pr["gather_ms_per_step_max"] <= pr["ms_per_step_max"]
 
 
+def test_bench_strong_scaling_form_launches_two_ranks():
+    """`--workload eval --gpus N`: ONE 147 456-ray frame sharded by shard_bounds over the ranks + the (overlapped) pixel
+    all-gather with uneven-shard counts -- the strong-scaling line of BASELINE.md section 4."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "eval", "--standin"], capture_output=True, text=True, timeout=600, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["rays_per_frame"] == 512 * 288
+    assert line["value"] > 0 and "STAND-IN" in line["data"] and line["per_rank"]["gather_ms_per_step_max"] > 0
+
+
 def test_bench_single_process_and_torchrun_forms():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--standin"],
                          capture_output=True, text=True, timeout=600, env=_env())

@@ -58,6 +58,27 @@ def _worker(rank, world, port, n_rays, ret):
     both = ndist.all_gather_pixels({k: full[k][:4] + rank for k in keys}, keys)
     ok = ok and both["rgb_fine"].shape == (4 * world, 3) and \
         torch.equal(both["depth_fine"][4:], full["depth_fine"][:4] + 1)
+    # the overlapped form (the gather of frame k beside the render of frame k + 1): same values bit for bit,
+    # even and uneven shards, several gathers in flight completed out of issue order
+    counts = [b - a for a, b in (ndist.shard_bounds(n_rays, world, r) for r in range(world))]
+    sync = ndist.all_gather_pixels(local, keys, counts=counts)
+    h1 = ndist.all_gather_pixels_async(local, keys, counts=counts)
+    h2 = ndist.all_gather_pixels_async({k: full[k][:4] + rank for k in keys}, keys)
+    later, first = h2.wait(), h1.wait()
+    ok = ok and all(torch.equal(first[k], sync[k]) and torch.equal(first[k], full[k]) for k in keys)
+    ok = ok and all(torch.equal(later[k], both[k]) for k in keys) and h1.wait() is first
+    # the sharded frame loop: every rank ends up with every complete frame, one frame behind its renders
+    from nsff_pl_amd import evaluate
+    real = evaluate.render_frame
+    evaluate.render_frame = lambda m, e, r_, t_, *a, keys=None, **kw: {k: v for k, v in fn(m, e, r_, t_).items() if k in keys}
+    try:
+        samples = [dict(rays=rays, ts=ts), dict(rays=rays.flip(0), ts=ts.flip(0))]
+        frames = list(evaluate.render_sequence_sharded(models, emb, samples, 29, 64, 64, (n_rays, 1)))
+    finally:
+        evaluate.render_frame = real
+    ok = ok and [f[0] for f in frames] == ["000", "001"]
+    ok = ok and torch.equal(frames[0][1].reshape(-1, 3), full["rgb_fine"].clip(0, 1))
+    ok = ok and torch.equal(frames[1][2].reshape(-1), full["depth_fine"].flip(0))
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

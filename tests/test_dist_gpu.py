@@ -65,6 +65,29 @@ def test_pixel_all_gather_runs_through_rccl(hip_lib, nccl_world1, monkeypatch):
     assert calls == [(rays.shape[0], 5)] * 2            # ONE collective per gather: rgb(3) + depth(1) + alpha(1) packed
 
 
+def test_overlapped_pixel_all_gather_on_a_side_stream(hip_lib, nccl_world1, monkeypatch):
+    """all_gather_pixels_async: the RCCL collective is issued from a side stream (not the render stream), the merged pixels
+    equal the synchronous gather bit for bit, and wait() orders the caller's stream behind it."""
+    streams = []
+    real = dist.all_gather_into_tensor
+    monkeypatch.setattr(dist, "all_gather_into_tensor",
+                        lambda out, inp, **kw: (streams.append(torch.cuda.current_stream().cuda_stream), real(out, inp, **kw))[1])
+    cfg, rays, ts, models, emb = _scene()
+    keys = ("rgb_fine", "depth_fine")
+    render = torch.cuda.current_stream().cuda_stream
+    outs, handles = [], []
+    for shift in (0, 1):                                   # two frames: the second renders while the first one's gather runs
+        out = A.render_rays(models, emb, rays, (ts + shift).clamp(max=scenes.N_FRAMES - 1), scenes.N_FRAMES - 1, cfg["N_samples"],
+                            0, 0, cfg["N_importance"], test_time=True, **scenes.render_kwargs(cfg))
+        outs.append(out)
+        handles.append(ndist.all_gather_pixels_async(out, keys))
+    for out, h in zip(outs, handles):
+        merged = h.wait()
+        assert all(torch.equal(merged[k], out[k]) for k in keys)
+        (merged["rgb_fine"] * 2).sum().item()              # consumed on the render stream right after wait()
+    assert len(streams) == 2 and all(st != render for st in streams)
+
+
 def test_sharded_frame_equals_the_unsharded_one(hip_lib, nccl_world1):
     cfg, _, _, models, emb = _scene()
     H, W = 36, 64
