@@ -492,10 +492,10 @@ int nsff_prof_enable(int on);
  * kernels executed for them: inference launches evaluate the heads that read the activation-free
  * *_xyz_encoding_final layers (nerf.py:170,195) with pre-multiplied rows and skip those 256x256 layers. */
 int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops);
-/* The same, plus the shader clock the f16 / f16x3 field kernels ran at: while profiling is on those launches stamp
- * s_memtime (first and last tick seen on each XCD) and this call returns the summed ticks of the stamped launches and the
- * summed event milliseconds of the same launches: clock [GHz] = shader_ticks / ticks_ms * 1e-6 (0 / 0 when nothing was
- * stamped, e.g. exact-fp32 launches).                                                                                   */
+/* The same, plus the shader clock the f16 / f16x3 field kernels ran at: while profiling is on a sample of every launch's
+ * workgroups measure their own lifetime with s_memtime (shader-clock ticks) and s_memrealtime (the constant-rate wall clock,
+ * hipDeviceAttributeWallClockRate); this call returns the summed shader ticks and the summed wall time of those lifetimes in
+ * milliseconds: clock [GHz] = shader_ticks / ticks_ms * 1e-6 (0 / 0 when nothing was measured, e.g. exact-fp32 launches). */
 int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops,
                             double* shader_ticks, double* ticks_ms);
 

@@ -377,21 +377,20 @@ struct ProfRec { hipEvent_t e0, e1; double flops, executed; int span_slot; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
-// Shader clock under load: profiled f16 launches stamp s_memtime (first / last tick seen on each XCD: the counters of
-// different XCDs need not share an origin) into a slot of this pool; nsff_prof_collect turns ticks / event time into GHz.
-// One slot = NSFF_SPAN_WORDS uint64: [2 x] = min, [2 x + 1] = max of XCD x.  Allocated at the first nsff_prof_enable(1),
-// never on a product path (no profiling -> kernels get a null pointer and stamp nothing).
+// Shader clock under load: a sample of the workgroups of a profiled f16 launch add their lifetimes in shader-clock ticks and
+// in wall-clock ticks to a slot of this pool (field_h3.hip: span_begin / span_end); nsff_prof_collect_clock turns the ratio
+// into GHz with the device's wall-clock rate.  Allocated at the first nsff_prof_enable(1), never on a product path (no
+// profiling -> kernels get a null pointer and measure nothing).
 constexpr int SPAN_SLOTS = 4096;
 unsigned long long* g_span_pool = nullptr;
 int g_span_next = 0;
 int span_pool_reset() {
-    std::vector<unsigned long long> init((size_t)SPAN_SLOTS * NSFF_SPAN_WORDS);
-    for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+    const size_t bytes = (size_t)SPAN_SLOTS * NSFF_SPAN_WORDS * 8;
     if (!g_span_pool) {
-        hipError_t e = hipMalloc(&g_span_pool, init.size() * 8);
+        hipError_t e = hipMalloc(&g_span_pool, bytes);
         if (e != hipSuccess) { g_span_pool = nullptr; return nsff_hip_fail(e); }
     }
-    hipError_t e = hipMemcpy(g_span_pool, init.data(), init.size() * 8, hipMemcpyHostToDevice);
+    hipError_t e = hipMemset(g_span_pool, 0, bytes);
     g_span_next = 0;
     return e == hipSuccess ? NSFF_OK : nsff_hip_fail(e);
 }
@@ -690,16 +689,20 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
             }
             if (!spans.empty()) {
                 const unsigned long long* sp = spans.data() + (size_t)r.span_slot * NSFF_SPAN_WORDS;
-                double sum = 0; int n = 0;
-                for (int x = 0; x < NSFF_SPAN_WORDS / 2; ++x)
-                    if (sp[2 * x + 1] > sp[2 * x]) { sum += (double)(sp[2 * x + 1] - sp[2 * x]); ++n; }
-                if (n > 0) { ticks += sum / n; tms += t; }
+                if (sp[1] > 0) { ticks += (double)sp[0]; tms += (double)sp[1]; }
             }
         }
     }
     if (!spans.empty()) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         span_pool_reset();
+    }
+    if (tms > 0) {                                  // wall-clock ticks -> milliseconds (the rate is reported in kHz)
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+            tms = tms / (double)khz;
+        else
+            ticks = tms = 0;
     }
     if (shader_ticks) *shader_ticks = ticks;
     if (ticks_ms) *ticks_ms = tms;

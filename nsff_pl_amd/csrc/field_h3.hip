@@ -117,13 +117,21 @@ struct H3KArgs {
     unsigned long long* span;        // profiling only (else null): per-XCD first / last s_memtime tick of the launch
 };
 
-// Every 16th workgroup stamps the shader-clock counter into the launch's span slot (nsff_prof_collect_clock): min on entry,
-// max on exit, in the pair of its XCD (HW_REG_XCC_ID, id 20, bits 3:0) -- two fire-and-forget atomics, profiling only.
-__device__ __forceinline__ void span_stamp(unsigned long long* span, bool last) {
+// Shader clock under load (profiling only, span != null): every 16th workgroup measures its own lifetime in shader-clock ticks
+// (s_memtime) and in ticks of the constant-rate wall clock (s_memrealtime: hipDeviceAttributeWallClockRate) and adds both to
+// the launch's slot -- a per-workgroup ratio, so counters of different CUs / XCDs need not share an origin (they do not:
+// first-to-last s_memtime across the chip is garbage).  clock = sum(shader ticks) / sum(wall ticks) * wall rate.
+struct SpanT { unsigned long long t, r; };
+__device__ __forceinline__ SpanT span_begin(const unsigned long long* span) {
+    SpanT s{0ull, 0ull};
+    if (span != nullptr && (blockIdx.x & 15) == 0) { s.t = __builtin_amdgcn_s_memtime(); s.r = __builtin_amdgcn_s_memrealtime(); }
+    return s;
+}
+__device__ __forceinline__ void span_end(unsigned long long* span, const SpanT& s0) {
     if (span == nullptr || (blockIdx.x & 15) != 0 || threadIdx.x != 0) return;
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-    const unsigned long long t = __builtin_amdgcn_s_memtime();
-    if (last) atomicMax(span + 2 * xcc + 1, t); else atomicMin(span + 2 * xcc, t);
+    const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(span, t - s0.t);
+    atomicAdd(span + 1, r - s0.r);
 }
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         return h;
     };
     H3_SPAN(0);
-    span_stamp(a.span, false);
+    const SpanT span0 = span_begin(a.span);
     const H3Step s0 = step_at(s_begin);
     const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
     load_bias<MTW>(br, fbias(s0.bias_off), nb0, lane);
@@ -1017,7 +1025,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
     }
     H3_SPAN(1);
-    span_stamp(a.span, true);
+    span_end(a.span, span0);
     { [[maybe_unused]] const int i = 31; H3_STAMP(0); }   // (timing build) end of the workgroup's work: slot 31, stamp 0
 }
 

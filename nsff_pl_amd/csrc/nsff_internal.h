@@ -12,8 +12,9 @@ int nsff_fold_rows_f32(const NsffModelDesc* desc, const float* const* params, fl
 // args already validated by nsff_field_query; points_per_block is 64 / 128 / 129 / 130 (f16x3 tilings) or
 // NSFF_H3_FAST (the single-product "f16" fast mode on the same packed weights)
 #define NSFF_H3_FAST 1
-// span (or null): NSFF_SPAN_WORDS uint64 that receive, per XCD, the first / last s_memtime tick of the launch (profiling)
-#define NSFF_SPAN_WORDS 32
+// span (or null, profiling): NSFF_SPAN_WORDS zeroed uint64 that receive the summed lifetimes of a sample of the launch's
+// workgroups in shader-clock ticks [0] and in wall-clock ticks [1]
+#define NSFF_SPAN_WORDS 2
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
                         int points_per_block, hipStream_t st, unsigned long long* span = nullptr);
 

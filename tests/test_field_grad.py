@@ -144,6 +144,10 @@ def test_failed_backward_does_not_lose_later_weight_gradients(hip_lib):
         torch.cuda.synchronize()
         assert trunk.grad is not None
         assert torch.allclose(trunk.grad, got, rtol=1e-5, atol=1e-6 * float(got.abs().max()))
+        # what the failed pass queued is never delivered (the assert above) and stays in the list only until the next
+        # drop_stale_pending() (NSFFTrainer.step calls it): the end-of-pass flush removes ITS pass's entries and nothing
+        # else, so that a re-entrant backward cannot throw away what the enclosing pass has queued
+        field_grad.drop_stale_pending()
         assert not field_grad._PENDING
 
 
@@ -176,6 +180,42 @@ def test_a_forward_inside_a_backward_pass_keeps_the_queued_weight_gradients(hip_
     torch.cuda.synchronize()
     assert ran == [1] and not field_grad._PENDING
     assert trunk.grad is not None and torch.allclose(trunk.grad, want, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
+
+
+def test_a_backward_inside_a_backward_pass_keeps_the_enclosing_pass_entries(hip_lib):
+    """Deferred mode, re-entrant: a hook of the outer pass renders AND differentiates (its own backward pass, its own
+    end-of-pass flush).  That inner flush must deliver the inner gradients and leave what the outer pass has queued alone:
+    afterwards .grad holds outer + inner (round-3 advisor finding: the inner flush emptied the whole list)."""
+    dev = torch.device("cuda:0")
+    cfg = scenes.CASES["g3_nsff_train"]
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    model = models["fine"].to(dev)
+    freqs = [float(f) for f in emb["xyz"].freqs]
+    g = torch.Generator().manual_seed(17)
+    xyz = (torch.rand(256, 3, generator=g) * 2 - 1).to(dev)
+    xyz2 = (torch.rand(128, 3, generator=g) * 2 - 1).to(dev)
+    t_rows = torch.randn(4, scenes.N_TAU, generator=g).to(dev)
+    trunk = model.transient_xyz_encoding_3[0].weight
+    outer = torch.autograd.grad(field_grad.field(model, xyz, freqs, t_rows, 64, True, True).sum(), [trunk])[0]
+    inner = torch.autograd.grad(field_grad.field(model, xyz2, freqs, t_rows[:2], 64, True, True).square().sum(), [trunk])[0]
+    t_leaf = t_rows.clone().requires_grad_(True)
+    seen = []
+
+    def hook(grad):                                # runs after the outer field node's backward queued its entry
+        before = len(field_grad._PENDING)
+        with torch.enable_grad():
+            field_grad.field(model, xyz2, freqs, t_rows[:2], 64, True, True).square().sum().backward()
+        seen.append((before, len(field_grad._PENDING)))
+        return grad
+    t_leaf.register_hook(hook)
+    for p in model.parameters():
+        p.grad = None
+    with field_grad.deferred_weight_grads():
+        field_grad.field(model, xyz, freqs, t_leaf, 64, True, True).sum().backward()
+    torch.cuda.synchronize()
+    assert seen == [(1, 1)] and not field_grad._PENDING          # the inner pass took its own entry, the outer one survived it
+    want = outer + inner
+    assert torch.allclose(trunk.grad, want, rtol=1e-5, atol=2e-6 * float(want.abs().max()))
 
 
 @pytest.mark.gpu
