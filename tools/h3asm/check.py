@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Run the generated trunk body (gen.py) in the functional simulator (isa.py) on one 128-point tile and compare the activation
+tile it leaves in LDS with a numpy evaluation of the same layers in the same f16x3 arithmetic.
+
+    python tools/h3asm/check.py [static|dynamic|noskip|twoskips] ...
+
+What this proves before any GPU time is spent: register allocation, every s_waitcnt count (a register written by an
+outstanding load may not be touched), barrier placement (cross-wave LDS race detector), the weight-slot refill order, the
+bias-table initialisation, the rebuild of the skip layer's input tile, the phase program.  What it cannot prove: the
+hardware's own semantics (MFMA operand layouts, v_permlane32_swap, exec-masked loads) -- those are taken from the kernels
+that are already parity-green on the MI355X (csrc/field_h3.hip) -- and timing.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen
+from isa import Sim, SimError, halfs_of, f16_rtz_pack
+
+PK_BASE = 0x1_0000_0000
+PH_BASE = 0x2_0000_0000
+T_BASE = 0x3_0000_0000
+LDS_X = 0
+LDS_BIAS = 2 * gen.PLANE_B + 8192          # behind the two planes and the raw-record image
+
+
+def split_rtz(x):
+    """fp32 array -> (hi, lo) fp16 arrays, both rounded toward zero (v_cvt_pkrtz), lo = rtz(x - hi)"""
+    z = np.zeros_like(x, np.float32)
+    hi = halfs_of(f16_rtz_pack(x.astype(np.float32), z))[0]
+    lo = halfs_of(f16_rtz_pack((x.astype(np.float32) - hi).astype(np.float32), z))[0]
+    return hi.astype(np.float16), lo.astype(np.float16)
+
+
+def pack_segment(W):
+    """W (256, K) fp32, K = 16 nks -> u32 stream [wave][ks][mt][part][lane][8 halfs], hi = fp16(x) to nearest, lo = fp16(x - hi)"""
+    K = W.shape[1]
+    nks = K // 16
+    hi = W.astype(np.float16)
+    lo = (W - hi.astype(np.float32)).astype(np.float16)
+    out = np.zeros((4, nks, 2, 2, 64, 8), np.float16)
+    lane = np.arange(64)
+    for wv in range(4):
+        for ks in range(nks):
+            for mt in range(2):
+                n = 64 * wv + 32 * mt + (lane & 31)
+                for t in range(8):
+                    c = 16 * ks + 8 * (lane >> 5) + t
+                    out[wv, ks, mt, 0, :, t] = hi[n, c]
+                    out[wv, ks, mt, 1, :, t] = lo[n, c]
+    return out.reshape(-1).view(np.uint32), hi, lo
+
+
+def build_program(segs, in_t):
+    """Phase descriptors for a trunk (the host-side builder in csrc/field_h3a.hip does the same).
+    segs: list of dict(nks, off, bias (index or None), post ('relu' | 'none'), rebuild (bool))."""
+    B = gen.BODY
+    ph = []
+
+    def desc(body, flags=0, bias=0, n1=16, r1=None, r2=None):
+        r1 = r1 if r1 is not None else segs[0]
+        r2 = r2 if r2 is not None else r1
+        return [body, flags, 1024 * bias, n1, r1["off"], r1["nks"] * 4096, r2["off"], r2["nks"] * 4096]
+
+    def refill_fields(t):
+        nxt = segs[t + 1] if t + 1 < len(segs) else None
+        nx2 = segs[t + 2] if t + 2 < len(segs) else None
+        if nxt is None:
+            return dict(n1=16, r1=segs[t], r2=segs[t])
+        return dict(n1=nxt["nks"], r1=nxt, r2=nx2 if (nxt["nks"] < 16 and nx2 is not None) else nxt)
+    rb = (1 << gen.F_REBUILD) | ((1 << gen.F_REBUILD_T) if in_t > 0 else 0)
+    s0 = segs[0]
+    assert s0["nks"] in (4, 8) and s0["post"] == "relu" and s0["bias"] is not None
+    ph.append(desc(0, 1 << gen.F_INIT, s0["bias"], s0["nks"], s0, segs[1] if len(segs) > 1 else s0))
+    pending_b = False
+    for t, sg in enumerate(segs):
+        nxt = segs[t + 1] if t + 1 < len(segs) else None
+        init_next = (1 << gen.F_INIT) if (nxt is not None and nxt["bias"] is not None) else 0
+        nbias = nxt["bias"] if (nxt is not None and nxt["bias"] is not None) else 0
+        if sg["nks"] == 16:
+            assert t > 0 and pending_b, "a 16-wide segment rides the epilogue of the one before it"
+            ph.append(desc(B["A16R"], (1 << gen.F_INIT) if sg["bias"] is not None else 0, sg["bias"] or 0))
+            if sg["post"] == "relu":
+                ph.append(desc(B["B16R"], init_next, nbias, **refill_fields(t)))
+                pending_b = True
+            else:
+                assert nxt is not None and nxt["rebuild"] and nxt["bias"] is None
+                ph.append(desc(B["B16X"], rb, 0, **refill_fields(t)))
+                pending_b = False
+        else:
+            assert not pending_b and sg["post"] == "relu"
+            ph.append(desc(B["A4"] if sg["nks"] == 4 else B["A8"], rb if sg["rebuild"] else 0))
+            ph.append(desc(B["B4"] if sg["nks"] == 4 else B["B8"], 0, 0, **refill_fields(t)))
+            ph.append(desc(B["EPI_A"], init_next, nbias))
+            pending_b = True
+    assert pending_b
+    ph.append(desc(B["EPI_B"]))
+    ph.append(desc(B["END"]))
+    ph.append(desc(B["END"]))
+    return np.array(ph, np.uint32)
+
+
+def make_case(kind, seed=0):
+    rng = np.random.RandomState(seed)
+    in_t = 48 if kind in ("dynamic",) else 0
+    k0 = 128 if in_t else 64
+    D = 8
+    skips = {"static": [4], "dynamic": [4], "noskip": [], "twoskips": [2, 5]}[kind]
+    layers = []
+    segs = []
+    off = 4096                                  # (packed buffer: keep offset 0 unused)
+    bufs = []
+
+    def add_seg(W, bias, post, rebuild):
+        nonlocal off
+        stream, hi, lo = pack_segment(W)
+        bidx = None
+        if bias is not None:
+            bidx = len([s_ for s_ in segs if s_["bias"] is not None])
+        segs.append(dict(nks=W.shape[1] // 16, off=off, bias=bidx, post=post, rebuild=rebuild, hi=hi, lo=lo, b=bias))
+        bufs.append((off, stream))
+        off += stream.size * 4
+    scale = 2.5 / np.sqrt(256.0)
+    for l in range(D):
+        b = (rng.randn(256) * 0.1).astype(np.float32)
+        if l == 0:
+            add_seg((rng.randn(256, k0) * 2.5 / np.sqrt(k0)).astype(np.float32), b, "relu", False)
+        elif l in skips:
+            add_seg((rng.randn(256, 256) * scale).astype(np.float32), b, "none", False)
+            add_seg((rng.randn(256, k0) * 2.5 / np.sqrt(k0)).astype(np.float32), None, "relu", True)
+        else:
+            add_seg((rng.randn(256, 256) * scale).astype(np.float32), b, "relu", False)
+    pk = np.zeros(off // 4 + 16, np.uint32)
+    for o, st in bufs:
+        pk[o // 4:o // 4 + st.size] = st
+    # input tile: xyz part (64 columns) random, time part = per-ray rows of a small table
+    x_xyz = (rng.randn(128, 64) * 0.7).astype(np.float32)
+    x_xyz[:, 63] = 0
+    n_rays = 5
+    t_table = (rng.randn(n_rays, max(in_t, 4)) * 0.5).astype(np.float32)
+    ray_of = (np.arange(128) * n_rays) // 128
+    x_in = np.zeros((128, k0), np.float32)
+    x_in[:, :64] = x_xyz
+    if in_t:
+        x_in[:, 64:64 + in_t] = t_table[ray_of, :in_t]
+    return dict(kind=kind, in_t=in_t, k0=k0, segs=segs, pk=pk, x_in=x_in, t_table=t_table, ray_of=ray_of)
+
+
+def reference(case):
+    """the same layers in numpy: products Wh.xh + Wh.xl + Wl.xh accumulated in float64, fp32 after every layer"""
+    xin_h, xin_l = split_rtz(case["x_in"])
+    xh_, xl_ = xin_h.astype(np.float64), xin_l.astype(np.float64)
+    acc = None
+    for sg in case["segs"]:
+        Wh, Wl = sg["hi"].astype(np.float64), sg["lo"].astype(np.float64)
+        if sg["rebuild"]:
+            xh_, xl_ = xin_h.astype(np.float64), xin_l.astype(np.float64)
+        K = Wh.shape[1]
+        prod = xh_[:, :K] @ Wh.T + xl_[:, :K] @ Wh.T + xh_[:, :K] @ Wl.T          # (128, 256)
+        acc = (prod + (sg["b"][None, :] if sg["b"] is not None else acc)).astype(np.float32).astype(np.float64) \
+            if sg["b"] is not None else (acc + prod).astype(np.float32).astype(np.float64)
+        if sg["post"] == "relu":
+            v = np.maximum(acc, 0).astype(np.float32)
+            h, l = split_rtz(v)
+            xh_, xl_ = h.astype(np.float64), l.astype(np.float64)
+    return (xh_ + xl_).astype(np.float32)
+
+
+def run_case(kind, seed=0, verbose=True):
+    case = make_case(kind, seed)
+    prog, _ = gen.build()
+    sim = Sim(prog)
+    sim.add_buffer(PK_BASE, case["pk"])
+    phases = build_program(case["segs"], case["in_t"])
+    sim.add_buffer(PH_BASE, phases.reshape(-1))
+    sim.add_buffer(T_BASE, case["t_table"].reshape(-1).view(np.uint32))
+    # LDS: input tile as the encoder leaves it (hi / lo planes), bias table
+    lds_h = sim.lds.view(np.float16)
+    xh_, xl_ = split_rtz(case["x_in"])
+    for r in range(128):
+        base = (LDS_X + r * gen.LDH_B) // 2
+        lds_h[base:base + case["k0"]] = xh_[r]
+        lds_h[base + gen.PLANE_B // 2:base + gen.PLANE_B // 2 + case["k0"]] = xl_[r]
+    lds_f = sim.lds.view(np.float32)
+    for sg in case["segs"]:
+        if sg["bias"] is not None:
+            o = (LDS_BIAS + 1024 * sg["bias"]) // 4
+            lds_f[o:o + 256] = sg["b"]
+    stride_t = case["t_table"].shape[1] * 4
+    for w in sim.waves:
+        tid = 64 * w.id + np.arange(64)
+        w.s[gen.S_PK.i], w.s[gen.S_PK.i + 1] = PK_BASE & 0xFFFFFFFF, PK_BASE >> 32
+        w.s[gen.S_PH.i], w.s[gen.S_PH.i + 1] = PH_BASE & 0xFFFFFFFF, PH_BASE >> 32
+        w.s[gen.S_LDS.i], w.s[gen.S_BIASLDS.i], w.s[gen.S_WAVE.i], w.s[gen.S_INT.i] = LDS_X, LDS_BIAS, w.id, case["in_t"]
+        w.v[gen.V_TMP.i] = tid
+        row, q = tid >> 2, tid & 3
+        for reg, rows in ((gen.V_TPA, row), (gen.V_TPB, row + 64)):
+            addr = T_BASE + case["ray_of"][rows].astype(np.int64) * stride_t + 64 * q
+            addr = np.where(16 * q < max(case["in_t"], 1), addr, T_BASE)        # (lanes that load nothing: any valid address)
+            w.v[reg.i] = (addr & 0xFFFFFFFF).astype(np.uint32)
+            w.v[reg.i + 1] = (addr >> 32).astype(np.uint32)
+    t0 = time.time()
+    sim.run()
+    dt = time.time() - t0
+    # result: the last activation in the two planes
+    got = np.zeros((128, 256), np.float32)
+    for r in range(128):
+        base = (LDS_X + r * gen.LDH_B) // 2
+        got[r] = lds_h[base:base + 256].astype(np.float32) + lds_h[base + gen.PLANE_B // 2:base + gen.PLANE_B // 2 + 256].astype(np.float32)
+    want = reference(case)
+    err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+    n_mf = sim.waves[0].n_mfma
+    want_mf = sum(sg["nks"] for sg in case["segs"]) * 24
+    if verbose:
+        print(f"{kind:9s} phases {len(phases) - 2:2d}  MFMAs/wave {n_mf} (expected {want_mf})  instructions/wave {sim.waves[0].n_inst}  "
+              f"max-norm rel err {err:.2e}  |want| max {np.abs(want).max():.3g}  ({dt:.1f} s)")
+    assert n_mf == want_mf
+    assert err < 2e-6, err
+    return err
+
+
+if __name__ == "__main__":
+    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips"]
+    for k in kinds:
+        try:
+            run_case(k)
+        except SimError as e:
+            sys.exit(f"{k}: SIMULATION ERROR: {e}")
+    print("simulation OK")
