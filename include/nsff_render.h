@@ -125,8 +125,11 @@ int nsff_time_rows_backward(const float* g_cur, const float* g_next, const float
 typedef struct NsffFieldArgs {
     int64_t n_points;        /* P                                                   */
     int32_t precision;       /* NSFF_PREC_*: must match the packed buffer           */
-    int32_t tile_points;     /* F16X3 only: 0 = library default (128 points as eight waves of 32 neurons; 64 points for
-                                inference launches below 32768 points), 64 = 64-point tiles, 130 = the 128-point tiling */
+    int32_t tile_points;     /* F16X3 only: 0 = library default (128-point tiles; 64 points for inference launches below
+                                32768 points), 64 = 64-point tiles, 130 = 128-point tiles: the hand-scheduled body
+                                (nsff_field_kernel_h3a: one wave per SIMD, resident weights, two 64-point halves) for
+                                inference launches it covers, else eight waves of 32 neurons; 131 = 128-point tiles,
+                                always the compiler-scheduled eight-wave kernel                                       */
     int32_t pts_per_ray;     /* ray index of point p is p / pts_per_ray             */
     int32_t static_mode;     /* 0 skip, 1 sigma only, 2 rgb+sigma                   */
     int32_t transient_mode;  /* 0 skip, 1 sigma only, 2 rgb+sigma(+flow heads)      */

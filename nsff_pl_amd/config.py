@@ -40,11 +40,14 @@ def get_precision():
 
 def set_tile_points(n):
     """f16x3 only: tiling of the field kernel.  0 = library default (130; inference launches below 32768 points: 64);
-    64 = 64 points, four waves of 64 neurons, two workgroups per CU; 130 = 128 points, eight waves of 32 neurons, one
-    workgroup per CU (also the training forward's default)."""
+    64 = 64 points, four waves of 64 neurons, two workgroups per CU; 130 = 128 points per workgroup: the hand-scheduled
+    body (four waves, one per SIMD, resident weights, two 64-point halves half a layer apart) for inference launches whose
+    trunks it executes, else eight waves of 32 neurons (also the training forward's default); 131 = 128 points, always the
+    compiler-scheduled eight-wave form (A/B comparisons, and a second implementation for the parity suite)."""
     global _tile_points
-    if n not in (0, 64, 130):
-        raise ValueError("tile_points must be 0 (library default), 64 or 130 (128 points, 8 waves x 32 neurons)")
+    if n not in (0, 64, 130, 131):
+        raise ValueError("tile_points must be 0 (library default), 64, 130 (128 points: hand-scheduled body where it applies) "
+                         "or 131 (128 points, 8 waves x 32 neurons, compiler-scheduled)")
     _tile_points = n
 
 

@@ -570,7 +570,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     if (g.static_mode == 0 && g.transient_mode == 0) return NSFF_ERR_INVALID;
     if (g.flow_heads < 0 || g.flow_heads > 2 || (g.flow_heads && !d.has_flow)) return NSFF_ERR_INVALID;
     if (g.precision != NSFF_PREC_F32 && g.precision != NSFF_PREC_F16X3 && g.precision != NSFF_PREC_F16) return NSFF_ERR_INVALID;
-    if (g.tile_points != 0 && g.tile_points != 64 && g.tile_points != 130) return NSFF_ERR_INVALID;
+    if (g.tile_points != 0 && g.tile_points != 64 && g.tile_points != 130 && g.tile_points != 131) return NSFF_ERR_INVALID;
     if (g.transient_mode && !d.has_transient) return NSFF_ERR_INVALID;
     if (g.n_points == 0) return NSFF_OK;
     if (!g.raw) return NSFF_ERR_NULL;

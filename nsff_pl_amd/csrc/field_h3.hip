@@ -39,7 +39,8 @@ typedef _Float16 h2f __attribute__((ext_vector_type(2)));
 
 #ifdef H3_TIMING
 // debug build only (make timing): s_memtime stamps of the first 256 workgroups, 6 per step and wave
-__device__ unsigned g_h3_timing[256 * 8 * 32 * 6];
+__device__ unsigned g_h3_timing[256 * 8 * 32 * 6 + 256 * 4 * 256];    // (+ the records of nsff_field_kernel_h3a: H3A_TBASE)
+#define H3A_TBASE (256 * 8 * 32 * 6)
 __device__ unsigned long long g_h3_span[2] = {~0ull, 0ull};     // first / last s_memtime of the launch (tick calibration)
 #define H3_SPAN(k) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
     if (k) atomicMax(&g_h3_span[1], t_); else atomicMin(&g_h3_span[0], t_); } } while (0)
@@ -124,6 +125,9 @@ struct H3KArgs {
 struct SpanT { unsigned long long t, r; };
 __device__ __forceinline__ SpanT span_begin(const unsigned long long* span) {
     SpanT s{0ull, 0ull};
+#ifdef H3_TIMING
+    s.t = __builtin_amdgcn_s_memtime();
+#endif
     if (span != nullptr && (blockIdx.x & 15) == 0) { s.t = __builtin_amdgcn_s_memtime(); s.r = __builtin_amdgcn_s_memrealtime(); }
     return s;
 }
@@ -548,7 +552,10 @@ __device__ __forceinline__ void split_store2(_Float16* xh, _Float16* xl, int idx
 // OCTAVE: allow the angle-doubling encoder (inference).  The training forward keeps one exact sincos per column: its
 // gradients are compared with autograd of the reference network, whose ReLU pattern -- a function of sin(512 x) eight
 // layers deep -- answers a 4-ulp change of the encoding with per-cent changes of single weight gradients.
-template <int M, int THREADS, bool SPLIT, bool OCTAVE = true>
+// ILP: let the compiler interleave the three axes' range reductions (the hand-scheduled kernel runs the encoder with one wave per
+// SIMD and the whole register file to itself: dependent VALU chains are what it waits for; the eight-wave kernels keep one
+// reduction at a time for their register budget)
+template <int M, int THREADS, bool SPLIT, bool OCTAVE = true, bool ILP = false>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
                                             const float (&x)[3], int tid) {
     constexpr int G = THREADS / M;               // threads per point row
@@ -585,7 +592,7 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
         for (int c = 0; c < 3; ++c) {
             sn[c] = 0.f; cs[c] = 0.f;
             if (f0 < a.n_freqs) sincosf(a.freqs[f0] * x[c], &sn[c], &cs[c]);
-            __builtin_amdgcn_sched_barrier(0);                      // one range reduction at a time (register pressure)
+            if constexpr (!ILP) __builtin_amdgcn_sched_barrier(0);  // one range reduction at a time (register pressure)
         }
         const int c0 = 3 + 6 * OPP * q;                             // odd: first value alone, then even-aligned pairs
         float carry = 0.f;                                          // cos of the last axis waits for the next octave's first sin
@@ -1029,6 +1036,235 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     { [[maybe_unused]] const int i = 31; H3_STAMP(0); }   // (timing build) end of the workgroup's work: slot 31, stamp 0
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nsff_field_kernel_h3a: the f16x3 inference trunk with a HAND-SCHEDULED body (tools/h3asm/gen.py -> field_h3a_body.inc).
+// One wave per SIMD (four waves x 512 registers), 128 points per workgroup as two 64-point halves; a wave owns 64 neurons,
+// the current layer's weights of those neurons are resident in its 256 accumulation registers and are multiplied with both
+// halves half a layer apart, so that one half's epilogue (ReLU, hi / lo split, LDS stores) and the next layer's weight stream
+// run in the MFMA shadow of the other half: 192 MFMAs (6 144 matrix-pipe cycles) between two barriers, every weight byte
+// crosses the CU's vector-memory path once per 128 points, every activation fragment is read from LDS once per wave.
+// C++ keeps what is not the trunk: the input encoder (build_input), the bias table, the heads and the raw records.
+// The body executes a PHASE PROGRAM built on the host (h3a_build_program): one 8-dword descriptor per phase, fetched from
+// the kernel-argument segment with scalar loads one phase ahead.
+#ifdef H3_TIMING
+#include "field_h3a_body_timing.inc"     // (python3 tools/h3asm/gen.py --timing: a stamp per phase, `make timing`)
+#elif defined(H3A_BODY_INC)
+#include H3A_BODY_INC                    // (timing experiments: make variant NAME=x DEFS='-DH3A_BODY_INC=\"field_h3a_body_x.inc\"')
+#else
+#include "field_h3a_body.inc"
+#endif
+constexpr int H3A_MAX_PHASES = 36, H3A_MAX_BIAS = 12;
+struct H3APhase { uint32_t d[8]; };     // body, flags, bias table offset, n1, r1 offset / wave stride, r2 offset / wave stride (bytes)
+struct H3AArgs {
+    H3KArgs k;
+    H3APhase ph[2][H3A_MAX_PHASES];     // [static trunk, dynamic trunk]
+    uint32_t bias_off[2][H3A_MAX_BIAS]; // packed word offset of bias table row i
+    int n_bias[2];
+    int head[2];                        // HEAD_* evaluated on the trunk's last activation
+};
+static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
+
+__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa) {
+    const H3KArgs& a = aa.k;
+    constexpr int M = 128, THREADS = 256;
+    __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
+    __shared__ __attribute__((aligned(16))) float sRaw[M * NSFF_RAW_STRIDE];
+    __shared__ __attribute__((aligned(16))) float sBias[H3A_MAX_BIAS * NSFF_W];
+    __shared__ float sRed[1];
+    for (int i = threadIdx.x; i < M * NSFF_RAW_STRIDE; i += THREADS) sRaw[i] = 0.f;
+    _Float16* sXh = sX;
+    _Float16* sXl = sX + M * LDH;
+    const int lane = threadIdx.x & 63;
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    long long tile = blockIdx.x;
+    int tr = a.n_static_steps > 0 ? 0 : 1, piece = 0;
+    if (a.split_trunks) {
+        if (tile < a.grid_tiles) { tr = 0; piece = 1; }
+        else { tile -= a.grid_tiles; tr = 1; piece = 2; }
+    }
+    const long long p0 = tile * M;
+    const uint32_t* __restrict__ pk = a.packed;
+    const SpanT span0 = span_begin(a.span);
+#ifdef H3_TIMING
+#define H3A_TSTAMP(k) do { if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define H3A_TSTAMP(k) do {} while (0)
+#endif
+    float px[3] = {0.f, 0.f, 0.f};
+    {
+        const long long bp = p0 + build_row<M, THREADS>(threadIdx.x);
+        if (bp < a.n_points) { px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2]; }
+    }
+    // bias table of this trunk (fp32 rows of 256): the body initialises its accumulators from it with ds_read_b128
+    for (int i = threadIdx.x; i < aa.n_bias[tr] * NSFF_W; i += THREADS)
+        sBias[i] = reinterpret_cast<const float*>(pk)[aa.bias_off[tr][i >> 8] + (i & 255)];
+    H3A_TSTAMP(52);
+    asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));      // (the point has landed: no compiler wait behind the statement below)
+    H3A_TSTAMP(53);
+    {
+        // weight slots 0..7 (the first segment, and the start of the second one) are requested NOW: 128 KiB per workgroup cross
+        // the CU's vector-memory path while the encoder below computes.  Only the loads in flight survive the statement.
+        const H3APhase& d0 = aa.ph[tr][0];
+        asm volatile(H3A_PRE
+                     :
+                     : [pk] "s"((unsigned long long)(uintptr_t)pk), [wave] "s"(wave_id), [tid] "v"((unsigned)threadIdx.x),
+                       [n1] "s"(d0.d[3]), [r1] "s"(d0.d[4]), [r1w] "s"(d0.d[5]), [r2] "s"(d0.d[6]), [r2w] "s"(d0.d[7])
+                     : H3A_PRE_CLOBBERS);
+    }
+    build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1, px, threadIdx.x);
+    // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
+    const float* tpa = reinterpret_cast<const float*>(pk);
+    const float* tpb = tpa;
+    if (tr == 1) {
+        const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const long long last = a.n_points - 1;
+        const long long pa = p0 + row < last ? p0 + row : last, pb = p0 + 64 + row < last ? p0 + 64 + row : last;
+        if (16 * q < a.in_t) {
+            tpa = a.t_emb + (pa / a.pts_per_ray) * a.in_t + 16 * q;
+            tpb = a.t_emb + (pb / a.pts_per_ray) * a.in_t + 16 * q;
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned long long phases = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() +
+                                          offsetof(H3AArgs, ph) + (size_t)tr * sizeof(aa.ph[0]);
+        const unsigned long long pkb = (unsigned long long)(uintptr_t)pk;
+        const unsigned lds = (unsigned)(uintptr_t)sX, biaslds = (unsigned)(uintptr_t)sBias;
+        const unsigned in_t = tr == 1 ? (unsigned)a.in_t : 0u;
+        const unsigned tpa0 = (unsigned)((uintptr_t)tpa), tpa1 = (unsigned)((uintptr_t)tpa >> 32);
+        const unsigned tpb0 = (unsigned)((uintptr_t)tpb), tpb1 = (unsigned)((uintptr_t)tpb >> 32);
+        const unsigned tid = threadIdx.x;
+#ifdef H3_TIMING
+        // 256 dwords per (workgroup & 255, wave): [0] kernel entry, [1] input built, [52..] C++ stamps, [62] body left, [63] records
+        // stored, [64 + 6 i ..] the body's records: dispatcher visit i and the five stamps of the phase before it
+        unsigned* tdbg = g_h3_timing + H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256;
+        if (lane == 0) { tdbg[0] = (unsigned)span0.t; tdbg[1] = (unsigned)__builtin_amdgcn_s_memtime(); }
+        const unsigned long long dbg = (unsigned long long)(uintptr_t)(tdbg + 64);
+#endif
+        asm volatile(H3A_BODY
+                     :
+                     : [pk] "s"(pkb),
+#ifdef H3_TIMING
+                       [dbg] "s"(dbg),
+#endif
+                       [phases] "s"(phases), [lds] "s"(lds), [biaslds] "s"(biaslds), [wave] "s"(wave_id),
+                       [in_t] "s"(in_t), [tid] "v"(tid), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1)
+                     : H3A_CLOBBERS);
+    }
+#ifdef H3_TIMING
+    if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();
+    {
+        struct HeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
+        const int head = aa.head[tr];
+        HeadSel hs{a.L.s_sigma_w, a.L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
+        if (head == HEAD_S_FOLD) hs = HeadSel{a.L.s_fold_w, a.L.s_fold_b, 4, 0, 0x15u};
+        if (head == HEAD_T_FOLD) hs = HeadSel{a.L.t_fold_w, a.L.t_fold_b, (int)a.L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
+        WRing<1, true> none;
+        H3A_TSTAMP(54);
+        heads<4, 4, true, 1>(sXh, sXl, sRed, pk, hs.w_off, hs.b_off, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0,
+                             wave_id, lane, none, false, nullptr);
+        H3A_TSTAMP(55);
+    }
+    __syncthreads();
+    H3A_TSTAMP(56);
+    for (int i = threadIdx.x; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
+        const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
+        const int q4 = i % (NSFF_RAW_STRIDE / 4);
+        if (p < a.n_points && (piece == 0 || (piece == 1) == (q4 == 0)))
+            reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
+    }
+    span_end(a.span, span0);
+#ifdef H3_TIMING
+    if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + 63] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+}
+
+// Phase program of one trunk = steps [s0, s1) of the step program (see tools/h3asm/check.py::build_program, the reference
+// implementation of this function, which the simulator runs).  Returns false when the trunk's structure is not one the body
+// executes -- the caller then launches the compiler-scheduled kernel instead.
+static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, H3APhase* ph, uint32_t* bias_off, int& n_bias,
+                              int& head) {
+    struct Seg { uint32_t off; int nks, bias; bool relu, rebuild; };
+    Seg segs[MAX_STEPS];
+    int n = 0;
+    n_bias = 0;
+    head = HEAD_NONE;
+    for (int i = s0; i < s1; ++i) {
+        const H3Step& st = k.steps[i];
+        if (st.nks != 4 && st.nks != 8 && st.nks != 16) return false;
+        if (st.post != POST_RELU && st.post != POST_NONE) return false;
+        if (st.pre == PRE_SIDE) return false;         // (st.save only names an activation slot: this path is never a saving launch)
+        if (st.head != HEAD_NONE) {
+            if (i != s1 - 1 || (st.head != HEAD_S_FOLD && st.head != HEAD_T_FOLD && st.head != HEAD_S_SIGMA)) return false;
+            head = st.head;
+        }
+        Seg& g = segs[n++];
+        g.off = st.w_off * 4u; g.nks = st.nks; g.relu = st.post == POST_RELU;
+        g.rebuild = i > s0 && st.pre != PRE_NONE;
+        g.bias = -1;
+        if (st.bias_off != NSFF_NONE) {
+            if (n_bias >= H3A_MAX_BIAS) return false;
+            g.bias = n_bias;
+            bias_off[n_bias++] = st.bias_off;
+        }
+        if (i == s0 && st.pre == PRE_NONE) return false;
+    }
+    if (n == 0 || head == HEAD_NONE) return false;
+    if (segs[0].nks == 16 || !segs[0].relu || segs[0].bias < 0) return false;
+    int np = 0;
+    auto put = [&](uint32_t body, uint32_t flags, int bias, int n1, const Seg& r1, const Seg& r2) {
+        if (np >= H3A_MAX_PHASES) return false;
+        H3APhase& p = ph[np++];
+        p.d[0] = body; p.d[1] = flags; p.d[2] = 1024u * (uint32_t)(bias < 0 ? 0 : bias); p.d[3] = (uint32_t)n1;
+        p.d[4] = r1.off; p.d[5] = (uint32_t)r1.nks * 4096u; p.d[6] = r2.off; p.d[7] = (uint32_t)r2.nks * 4096u;
+        return true;
+    };
+    const uint32_t rb = H3A_F_REBUILD | (dynamic ? H3A_F_REBUILD_T : 0u);
+    if (!put(H3A_BODY_END, H3A_F_INIT, segs[0].bias, segs[0].nks, segs[0], n > 1 ? segs[1] : segs[0])) return false;
+    bool pending_b = false;
+    for (int t = 0; t < n; ++t) {
+        const Seg& g = segs[t];
+        const Seg* nxt = t + 1 < n ? &segs[t + 1] : nullptr;
+        const Seg* nx2 = t + 2 < n ? &segs[t + 2] : nullptr;
+        const uint32_t init_next = (nxt && nxt->bias >= 0) ? H3A_F_INIT : 0u;
+        const int nbias = (nxt && nxt->bias >= 0) ? nxt->bias : 0;
+        // weight-slot refills of this segment's B phase: slot j < n1 <- the next segment, j >= n1 <- the one after it
+        const Seg& r1 = nxt ? *nxt : g;
+        const Seg& r2 = (nxt && nxt->nks < 16 && nx2) ? *nx2 : r1;
+        const int n1 = nxt ? nxt->nks : 16;
+        bool ok = true;
+        if (g.nks == 16) {
+            if (t == 0 || !pending_b) return false;
+            ok = ok && put(H3A_BODY_A16R, g.bias >= 0 ? H3A_F_INIT : 0u, g.bias, 16, g, g);
+            if (g.relu) {
+                ok = ok && put(H3A_BODY_B16R, init_next, nbias, n1, r1, r2);
+                pending_b = true;
+            } else {
+                if (!nxt || !nxt->rebuild || nxt->bias >= 0 || nxt->nks == 16) return false;
+                ok = ok && put(H3A_BODY_B16X, rb, 0, n1, r1, r2);
+                pending_b = false;
+            }
+        } else {
+            if (pending_b || !g.relu) return false;
+            if (t > 0 && (!g.rebuild || g.bias >= 0)) return false;
+            if (t == 0)     // slots 0..7 were requested in front of the encoder (H3A_PRE, descriptor 0), 8..15 ride in this A phase
+                ok = ok && put(g.nks == 4 ? H3A_BODY_A4F : H3A_BODY_A8F, 0u, 0, g.nks, g, n > 1 ? segs[1] : g);
+            else
+                ok = ok && put(g.nks == 4 ? H3A_BODY_A4 : H3A_BODY_A8, rb, 0, 16, g, g);
+            // the B phase carries the epilogue of half A and ends with the bias rows of the next segment in acc_A
+            ok = ok && put(g.nks == 4 ? H3A_BODY_B4 : H3A_BODY_B8, init_next, nbias, n1, r1, r2);
+            pending_b = true;
+        }
+        if (!ok) return false;
+    }
+    if (!pending_b) return false;
+    return put(H3A_BODY_EPI_B, 0u, 0, 16, segs[0], segs[0]) && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]) &&
+           put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]);
+}
+
 // ---------------------------------------------------------------------------------
 struct PackSegH3 {
     const float* src;
@@ -1396,8 +1632,33 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         lrc = launch(nsff_field_kernel_h3<4, 1, true, 1>, 128, 512);
     } else if (points_per_block == 64) {
         lrc = launch(nsff_field_kernel_h3<2, 1>, 64, 256);
-    } else {                                      // 128 points, eight waves of 32 neurons (half the weight stream)
-        lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
+    } else {
+        // 128 points per workgroup.  Default: the hand-scheduled body (nsff_field_kernel_h3a) whenever the launch's trunks have a
+        // structure it executes (raw positions, a 64-column position embedding, a time code of at most 64 columns in float4
+        // rows, no view-direction branch in this launch); otherwise -- and with points_per_block == 131 -- the
+        // compiler-scheduled eight-wave form.
+        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 && !(g.static_mode == 2 && d.use_viewdir);
+        if (asm_body && g.transient_mode)
+            asm_body = k.L.kt == 64 && (d.in_t & 3) == 0 && ((uintptr_t)g.t_emb & 15) == 0;
+        H3AArgs ka{};
+        if (asm_body) {
+            ka.k = k;
+            ka.n_bias[0] = ka.n_bias[1] = 0; ka.head[0] = ka.head[1] = HEAD_NONE;
+            if (k.n_static_steps > 0)
+                asm_body = h3a_build_program(k, 0, k.n_static_steps, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0]);
+            if (asm_body && n > k.n_static_steps)
+                asm_body = h3a_build_program(k, k.n_static_steps, n, true, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
+        }
+        if (asm_body) {
+            const long long tiles = (g.n_points + 127) / 128;
+            if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
+            ka.k.grid_tiles = tiles;
+            ka.k.split_trunks = both ? 1 : 0;
+            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)(both ? 2 * tiles : tiles)), dim3(256), 0, st, ka);
+            lrc = NSFF_OK;
+        } else {                                  // eight waves of 32 neurons (half the weight stream of the 64-point tiling)
+            lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
+        }
     }
     if (lrc != NSFF_OK) return lrc;
     return nsff_launch_status();

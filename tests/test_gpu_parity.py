@@ -22,12 +22,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-130"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-130", "f16x3-131"])
 def precision(request):
-    """Every test runs on the two parity-grade arithmetics: exact fp32 MFMA and the fp16-split kernel -- the latter in
-    both tilings the library picks by launch size (64-point tiles for the small golden scenes = "f16x3", the 128-point
-    eight-wave tiling of large launches forced with "f16x3-130").  The single-product "f16" fast mode has its own
-    error-reporting test (tests/test_fast_mode.py)."""
+    """Every test runs on the two parity-grade arithmetics: exact fp32 MFMA and the fp16-split kernels -- the latter in
+    every form the library has: what it picks by launch size ("f16x3": 64-point tiles for the small golden scenes, 128-point
+    tiles for the full-size tests), 128-point tiles forced ("f16x3-130": the HAND-SCHEDULED body nsff_field_kernel_h3a
+    wherever a launch's trunks qualify -- every scene without a view-direction branch -- else the compiler-scheduled
+    eight-wave kernel) and the compiler-scheduled eight-wave kernel forced ("f16x3-131").  The single-product "f16" fast
+    mode has its own error-reporting test (tests/test_fast_mode.py)."""
     from nsff_pl_amd import config
     name, _, tile = request.param.partition("-")
     config.set_precision(name)
@@ -403,7 +405,7 @@ def test_frame_rays_match_reference(stages, hip_lib):
 def test_full_frame_eval_512x288(hip_lib, precision):
     """One 512x288 frame, test-time flags, 32768-ray chunks like eval.f; PSNR against the oracle on a subset."""
     if precision not in ("f32", "f16x3"):
-        pytest.skip("full-frame run only on the two shipped modes")
+        pytest.skip("full-frame run only on the two shipped modes (f16x3 = the hand-scheduled 128-point kernel at this size)")
     from nsff_pl_amd import evaluate
     cfg = dict(scenes.CASES["g4_nsff_test"])
     models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)

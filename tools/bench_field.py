@@ -55,10 +55,10 @@ def main():
         for _ in range(args.iters):
             call()
         torch.cuda.synchronize()
-        k, ms, fl, _ex, _ghz = _lib.prof_collect()
+        k, ms, fl, _ex, ghz = _lib.prof_collect()
         _lib.prof_enable(False)
         res[name] = (ms / k, fl / k)
-        print(f"{name:14s} P={P:7d}  {ms / k:8.3f} ms  {fl / (ms * 1e-3) / 1e12:7.2f} TFLOP/s")
+        print(f"{name:14s} P={P:7d}  {ms / k:8.3f} ms  {fl / (ms * 1e-3) / 1e12:7.2f} TFLOP/s  clock {ghz if ghz is None else round(ghz, 3)} GHz")
     ms = res["coarse_s+t"][0] + res["fine_s+t+flow"][0] + 2 * res["warp_t"][0]
     fl = res["coarse_s+t"][1] + res["fine_s+t+flow"][1] + 2 * res["warp_t"][1]
     print(f"C2 mix [{args.precision}] {ms:8.3f} ms  {fl / (ms * 1e-3) / 1e12:7.2f} TFLOP/s  ({fl / (ms * 1e-3) / peak:.3f} of the dense MFMA peak "

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Audit of the compiled nsff_field_kernel_h3a (run by `make -C nsff_pl_amd/csrc audit`): the body between #ASMSTART / #ASMEND owns
+v24..v255, a0..a255 and s40..s99 only WHILE IT RUNS -- hipcc may use them before and after (the clobber list tells it that nothing
+of its own survives the statement).  What must hold: no spilled VGPRs, no scratch, 512 registers allocated, one asm statement,
+and between the kernel's entry and the asm no compiler code may leave a value in the asm-owned range that it reads back after
+the asm (the clobber list guarantees it; the audit reports the count of compiler instructions and the descriptor fields)."""
+import re
+import subprocess
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "nsff_pl_amd/csrc/field_h3.hip"
+out = "/tmp/field_h3_audit.s"
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                      stderr=subprocess.DEVNULL)
+txt = open(out).read()
+m = re.search(r'^(_ZN\S*nsff_field_kernel_h3aE\S*):', txt, re.M)
+name = m.group(1)
+body = txt[m.end():]
+body = body[:body.index(".Lfunc_end")]
+lines = body.split("\n")
+# the body is the one asm statement that holds MFMAs (the encoder / heads have one-instruction statements of their own); the
+# pre-issue statement is the one with global loads into accumulation registers -- between the two the compiler's code (the
+# input encoder) must not touch an accumulation register: the loads are in flight
+n_asm, n_pre, inasm, before, after, seen, cur, curl = 0, 0, False, 0, 0, False, 0, 0
+between, agpr_between = False, []
+for ln in lines:
+    if "#ASMSTART" in ln:
+        inasm, cur, curl = True, 0, 0
+        continue
+    if "#ASMEND" in ln:
+        inasm = False
+        if cur > 100:
+            n_asm, seen, between = n_asm + 1, True, False
+        elif curl >= 32:
+            n_pre, between = n_pre + 1, True
+        continue
+    t = ln.strip()
+    if inasm:
+        cur += "v_mfma" in t
+        curl += t.startswith("global_load_dwordx4 a[")
+        continue
+    if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+        continue
+    if between and (re.search(r"\ba\[?\d", t.split(";")[0]) or "accvgpr" in t):
+        agpr_between.append(t)
+    if seen:
+        after += 1
+    else:
+        before += 1
+k = txt.index(".amdhsa_kernel " + name)
+meta = txt[k:k + 4000]
+get = lambda key: re.search(r"\.amdhsa_" + key + r"\s+(\S+)", meta).group(1)
+md = txt[txt.index("amdhsa.kernels"):]
+md = md[md.index(name):]
+spill_v = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", md).group(1))
+spill_s = int(re.search(r"\.sgpr_spill_count:\s*(\d+)", md).group(1))
+print(f"{name}: asm statements {n_asm}, compiler instructions before / after the body {before} / {after}")
+print(f"  next_free_vgpr {get('next_free_vgpr')}  accum_offset {get('accum_offset')}  next_free_sgpr {get('next_free_sgpr')}  "
+      f"scratch {get('private_segment_fixed_size')} B  LDS {get('group_segment_fixed_size')} B  spills: {spill_v} VGPR, {spill_s} SGPR")
+print(f"  pre-issue statements {n_pre}; compiler instructions touching accumulation registers between it and the body: {len(agpr_between)}")
+for t in agpr_between[:8]:
+    print("     ", t)
+ok = n_pre == 1 and not agpr_between and n_asm == 1 and spill_v == 0 and int(get("private_segment_fixed_size")) == 0 and int(get("next_free_vgpr")) == 512
+sys.exit(0 if ok else "AUDIT FAILED")

@@ -74,7 +74,8 @@ def build_program(segs, in_t):
     rb = (1 << gen.F_REBUILD) | ((1 << gen.F_REBUILD_T) if in_t > 0 else 0)
     s0 = segs[0]
     assert s0["nks"] in (4, 8) and s0["post"] == "relu" and s0["bias"] is not None
-    ph.append(desc(0, 1 << gen.F_INIT, s0["bias"], s0["nks"], s0, segs[1] if len(segs) > 1 else s0))
+    first = dict(n1=s0["nks"], r1=s0, r2=segs[1] if len(segs) > 1 else s0)
+    ph.append(desc(0, 1 << gen.F_INIT, s0["bias"], **first))
     pending_b = False
     for t, sg in enumerate(segs):
         nxt = segs[t + 1] if t + 1 < len(segs) else None
@@ -92,9 +93,11 @@ def build_program(segs, in_t):
                 pending_b = False
         else:
             assert not pending_b and sg["post"] == "relu"
-            ph.append(desc(B["A4"] if sg["nks"] == 4 else B["A8"], rb if sg["rebuild"] else 0))
-            ph.append(desc(B["B4"] if sg["nks"] == 4 else B["B8"], 0, 0, **refill_fields(t)))
-            ph.append(desc(B["EPI_A"], init_next, nbias))
+            if t == 0:          # the first segment: slots 0..7 were requested by the pre-issue statement, 8..15 ride in its A phase
+                ph.append(desc(B["A4F"] if sg["nks"] == 4 else B["A8F"], 0, 0, **first))
+            else:
+                ph.append(desc(B["A4"] if sg["nks"] == 4 else B["A8"], rb if sg["rebuild"] else 0))
+            ph.append(desc(B["B4"] if sg["nks"] == 4 else B["B8"], init_next, nbias, **refill_fields(t)))
             pending_b = True
     assert pending_b
     ph.append(desc(B["EPI_B"]))
@@ -171,8 +174,8 @@ def reference(case):
 
 def run_case(kind, seed=0, verbose=True):
     case = make_case(kind, seed)
-    prog, _ = gen.build()
-    sim = Sim(prog)
+    pre, prog, _ = gen.build()
+    sim = Sim(pre + prog)                      # the two asm statements back to back (the encoder between them is C++)
     sim.add_buffer(PK_BASE, case["pk"])
     phases = build_program(case["segs"], case["in_t"])
     sim.add_buffer(PH_BASE, phases.reshape(-1))
@@ -190,18 +193,21 @@ def run_case(kind, seed=0, verbose=True):
             o = (LDS_BIAS + 1024 * sg["bias"]) // 4
             lds_f[o:o + 256] = sg["b"]
     stride_t = case["t_table"].shape[1] * 4
+    I_S, I_V = gen.IN_S, gen.IN_V
     for w in sim.waves:
         tid = 64 * w.id + np.arange(64)
-        w.s[gen.S_PK.i], w.s[gen.S_PK.i + 1] = PK_BASE & 0xFFFFFFFF, PK_BASE >> 32
-        w.s[gen.S_PH.i], w.s[gen.S_PH.i + 1] = PH_BASE & 0xFFFFFFFF, PH_BASE >> 32
-        w.s[gen.S_LDS.i], w.s[gen.S_BIASLDS.i], w.s[gen.S_WAVE.i], w.s[gen.S_INT.i] = LDS_X, LDS_BIAS, w.id, case["in_t"]
-        w.v[gen.V_TMP.i] = tid
+        for name, val in (("pk", PK_BASE), ("phases", PH_BASE)):
+            w.s[I_S[name].i], w.s[I_S[name].i + 1] = val & 0xFFFFFFFF, val >> 32
+        for name, val in (("lds", LDS_X), ("biaslds", LDS_BIAS), ("wave", w.id), ("in_t", case["in_t"]), ("n1", phases[0][3]),
+                          ("r1", phases[0][4]), ("r1w", phases[0][5]), ("r2", phases[0][6]), ("r2w", phases[0][7])):
+            w.s[I_S[name].i] = int(val)
+        w.v[I_V["tid"].i] = tid
         row, q = tid >> 2, tid & 3
-        for reg, rows in ((gen.V_TPA, row), (gen.V_TPB, row + 64)):
+        for names, rows in ((("tpa0", "tpa1"), row), (("tpb0", "tpb1"), row + 64)):
             addr = T_BASE + case["ray_of"][rows].astype(np.int64) * stride_t + 64 * q
             addr = np.where(16 * q < max(case["in_t"], 1), addr, T_BASE)        # (lanes that load nothing: any valid address)
-            w.v[reg.i] = (addr & 0xFFFFFFFF).astype(np.uint32)
-            w.v[reg.i + 1] = (addr >> 32).astype(np.uint32)
+            w.v[I_V[names[0]].i] = (addr & 0xFFFFFFFF).astype(np.uint32)
+            w.v[I_V[names[1]].i] = (addr >> 32).astype(np.uint32)
     t0 = time.time()
     sim.run()
     dt = time.time() - t0

@@ -42,7 +42,7 @@ T0 = 40                     # temporaries v40..v63
 STASH = 64                  # v64..v95: [half][plane][8 dwords]
 XH0 = 96                    # XH[b][nt] = v[96 + 8 b + 4 nt : +4]
 XL0 = 112                   # XL[nt] = v[112 + 4 nt : +4]
-SPARE = 120
+XL2 = 120                   # v120..v127: lo fragments of a phase's LAST k-step (so that the phase barrier can sit a k-step early)
 ACC = {"A": 128, "B": 192}
 
 # ---- SGPRs (asm-owned: s40..s99)
@@ -59,7 +59,7 @@ D_BODY, D_FLAGS, D_BIAS, D_N1, D_R1, D_R1W, D_R2, D_R2W = range(8)
 # an input tile at all (A4 / A8 also run the first layer, where the tile is still the encoder's)
 F_INIT, F_REBUILD_T, F_REBUILD = 0, 1, 2
 
-BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_A=8, EPI_B=9)
+BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11)
 
 
 def xh(b, nt):
@@ -149,6 +149,9 @@ class Stream:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+EXP = os.environ.get("H3A_EXP", "")          # timing experiments (results are garbage): nomix, noswap, nowrite, noride, andsub
+
+
 def epilogue_unit(half, u, tset):
     """ReLU -> hi / lo split -> lanes i, i+32 trade halves -> two 16-byte LDS stores of (tile u>>1, quad pair p = u&1) of
     `half`'s accumulators.  In place on the accumulator registers; 8 temporaries from set `tset`."""
@@ -167,6 +170,18 @@ def epilogue_unit(half, u, tset):
             I_v_permlane32_swap(L[0], L[2]), I_v_permlane32_swap(L[1], L[3])]
     off = half_off(half) + NT_B * nt + 64 * mt + 16 * p
     out += [I_ds_write_b128(V_WR_H, V(H[0].i, 4), off), I_ds_write_b128(V_WR_L, V(L[0].i, 4), off)]
+    if "nomix" in EXP:
+        out = [I_valu("v_mov_b32", i.args["d"], i.args["s"][1]) if i.op.startswith("v_fma_mix") else i for i in out]
+    if "noswap" in EXP:
+        out = [i for i in out if i.op != "v_permlane32_swap"]
+    if "nowrite" in EXP:
+        out = [i for i in out if i.kind != "lds_w"]
+    if "nocvt" in EXP:
+        out = [I_valu("v_mov_b32", i.args["d"], i.args["s"][0]) if i.op == "v_cvt_pkrtz_f16_f32" else i for i in out]
+    if "nomax" in EXP:
+        out = [i for i in out if i.op != "v_max_f32"]
+    if "noride" in EXP:
+        out = []
     return out
 
 
@@ -191,18 +206,23 @@ def frag_reads_h(half, ks, b):
     return [I_ds_read_b128(xh(b, nt), V_RD_H, half_off(half) + NT_B * nt + 32 * ks) for nt in range(2)]
 
 
-def frag_reads_l(half, ks):
-    return [I_ds_read_b128(xl(nt), V_RD_L, half_off(half) + NT_B * nt + 32 * ks) for nt in range(2)]
+def xl2(nt):
+    return V(XL2 + 4 * nt, 4)
 
 
-def mfmas(half, ks):
+def frag_reads_l(half, ks, second=False):
+    return [I_ds_read_b128(xl2(nt) if second else xl(nt), V_RD_L, half_off(half) + NT_B * nt + 32 * ks) for nt in range(2)]
+
+
+def mfmas(half, ks, second_xl=False):
     b = ks & 1
     out = []
     for part, xsel in ((1, "h"), (0, "h"), (0, "l")):      # Wl.xh, Wh.xh, Wh.xl: the lo fragments are needed last
         for mt in range(2):
             for nt in range(2):
                 d = acc(half, mt, nt)
-                out.append(I_mfma(d, wslot(ks, mt, part), xh(b, nt) if xsel == "h" else xl(nt), d))
+                bop = xh(b, nt) if xsel == "h" else (xl2(nt) if second_xl else xl(nt))
+                out.append(I_mfma(d, wslot(ks, mt, part), bop, d))
     return out
 
 
@@ -240,17 +260,20 @@ def rebuild_parts(half, name):
         p1 += [I_v_cmp_lt_u32_vcc(j, V_N4), I_s_and_saveexec(S_SAVE), ("TLOAD", I_gload_x4_v(F[j], ptr, 16 * j)), I_s_mov_exec(S_SAVE)]
     p1.append(I_label(f"L_{name}_nr1"))
     H = [V(T0 + 16 + k) for k in range(8)]                  # v56..v63: packed hi halfs of the 16 columns
-    Lr = [V(SPARE + k) for k in range(8)]                   # v120..v127: packed lo halfs
     p2 = [I_s_cmp("s_bitcmp1_b32", S(S_CUR + D_FLAGS), F_REBUILD_T), I_branch("s_cbranch_scc0", f"L_{name}_nr2"),
           ("NEED_VM", "tload")]
+    # lo halfs are packed back into the float4 registers they came from: columns 0..7 -> F[0], columns 8..15 -> F[2]
     for j in range(4):
+        dst = F[j & 2]
         for pr in range(2):
             a_, b_ = F[j].sub(2 * pr), F[j].sub(2 * pr + 1)
             h = H[2 * j + pr]
-            p2 += [I_v_cvt_pkrtz(h, a_, b_), I_v_sub_lo_half(a_, h, a_), I_v_sub_hi_half(b_, h, b_),
-                   I_v_cvt_pkrtz(Lr[2 * j + pr], a_, b_)]
+            p2 += [I_v_cvt_pkrtz(h, a_, b_), I_v_sub_lo_half(a_, h, a_), I_v_sub_hi_half(b_, h, b_)]
+        # (both pairs converted before either lo pack: the packs of float4 j = 1, 3 land in the upper half of F[j - 1])
+        p2 += [I_v_cvt_pkrtz(dst.sub(2 * (j & 1)), F[j].sub(0), F[j].sub(1)),
+               I_v_cvt_pkrtz(dst.sub(2 * (j & 1) + 1), F[j].sub(2), F[j].sub(3))]
     p2 += [I_ds_write_b128(V_ST_H, V(H[0].i, 4), ho + 128), I_ds_write_b128(V_ST_H, V(H[4].i, 4), ho + 144),
-           I_ds_write_b128(V_ST_L, V(Lr[0].i, 4), ho + 128), I_ds_write_b128(V_ST_L, V(Lr[4].i, 4), ho + 144)]
+           I_ds_write_b128(V_ST_L, F[0], ho + 128), I_ds_write_b128(V_ST_L, F[2], ho + 144)]
     p2.append(I_label(f"L_{name}_nr2"))
     return p1, p2
 
@@ -260,119 +283,202 @@ def spread(n_items, n_gaps):
     return [(g + 1) * n_items // n_gaps - g * n_items // n_gaps for g in range(n_gaps)]
 
 
-BARRIER_AT = 8              # the phase barrier sits in front of MFMA `BARRIER_AT` of the last k-step
+TIMING = False              # --timing: every dispatcher visit stores stamps of the phase before it (debug builds only)
+RIDE_CAP = 3                # riding instructions per MFMA gap where the ride does not fit the gaps (short B phases)
 
 
-def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, prefetch=True, rebuild=None, vm_waits=False):
-    """One phase: `nks` k-steps of MFMAs on acc_<half> from X_<half>.
-    ride: None | 'epi' (epilogue of the other half rides in k-steps 1 .. nks-1)
+def guarded_init(s, name, half):
+    """acc_<half> := bias table row of the descriptor (flag F_INIT)"""
+    skip = f"L_{name}_noinit"
+    s.emit(I_s_cmp("s_bitcmp1_b32", S(S_CUR + D_FLAGS), F_INIT))
+    s.emit(I_branch("s_cbranch_scc0", skip))
+    s.emit(I_valu("v_add_u32", V_BADDR, S(S_CUR + D_BIAS), V_BIAS, text=f"v_add_u32_e32 {V_BADDR}, {S(S_CUR + D_BIAS)}, {V_BIAS}"))
+    for r in init_reads(half):
+        s.emit(r, "init", group="init")
+    s.emit(I_label(skip))
+
+
+def emit_rebuild(s, part, first):
+    for r in part:
+        if isinstance(r, tuple) and r[0] == "NEED_VM":
+            s.need_vm(r[1])
+        elif isinstance(r, tuple):
+            s.emit(r[1], "tload", group="rebuild_t")
+        else:
+            # the stash stores are issued under F_REBUILD, everything of the time-code part under F_REBUILD_T
+            s.emit(r, "rebuild", group="rebuild_x" if (first and r.kind == "lds_w") else "rebuild_t")
+
+
+def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebuild=None, vm_mode=None, stream_slots=None):
+    """One phase: `nks` k-steps of MFMAs on acc_<half> from X_<half>.  The phase's barrier sits in front of MFMA 8 of the
+    LAST BUT ONE k-step: by then every fragment of this half has been read (the last k-step's lo fragments go to the second
+    XL buffer) and the ride's stores are done, and 16 MFMAs remain to cover what follows the barrier -- the bias-table
+    reads into the other half's accumulators (flag F_INIT) and the first fragments of the next phase.
+    ride: None | 'epi' (epilogue of the other half in the gaps of k-steps 1 .. barrier)
     refills: weight slot refills behind every k-step (B phases)
-    rebuild: None | half whose input tile is restored by a guarded cluster in k-step 1
-    tail_init: bias-table reads into the other half's accumulators behind the barrier (guarded by F_INIT)
-    prefetch: read the first fragments of the other half behind the barrier
-    vm_waits: A phases -- wait for slot ks's weights in front of k-step ks (counted against the 16-slot refill order)"""
+    rebuild: None | half whose input tile is restored by two guarded clusters
+    vm_mode: None | 'formula' (A phase behind a B phase that issued its 16 refills in slot order: vmcnt(4 (15 - ks)) in front
+             of k-step ks) | 'model' (first segment: slots 0..7 were requested before the encoder ran, slots 8..15 ride here)
+    stream_slots: weight slots whose loads ride in this phase, one piece per gap from the first gap on"""
     s = Stream()
     s.emit(I_label(f"L_{name}"))
     oh = other(half)
-    # fragments of k-step 0 were requested by the previous phase: model them as outstanding
+    last = nks - 1
+    bar = (last - 1, 8)
     for nt in range(2):
         s.lds_q.append((("xh", 0), None))
     for nt in range(2):
         s.lds_q.append((("xl", 0), None))
-    if ride == "epi":
-        # (the previous tail's bias reads into the ACCUMULATORS OF THIS PHASE precede the fragment prefetch in the queue)
-        pass
+    if vm_mode == "model":
+        for ks in range(8):
+            for c in range(4):
+                s.vm_q.append((("w", ks), None))
+
+    def stamp(k):           # timing build: s[78 + 2 k : 79 + 2 k] = s_memtime (k = 0 entry, 1 first MFMA, 2 / 3 around the barrier, 4 end)
+        if TIMING:
+            s.emit(raw(f"s_memtime s[{78 + 2 * k}:{79 + 2 * k}]"))
+    stamp(0)
     ride_ins = epilogue_stream(oh) if ride == "epi" else []
     rb_parts = rebuild_parts(rebuild, name) if rebuild is not None else None
-    # the ride occupies the gaps of k-steps 1 .. last (up to the barrier)
-    last = nks - 1
-    ride_gaps = [(ks, m) for ks in range(1, nks) for m in range(12) if not (ks == last and m >= BARRIER_AT - 1)]
+    ride_gaps = [(ks, m) for ks in range(1, nks) for m in range(12) if (ks, m) < (bar[0], bar[1] - 1)]
     per_gap = dict(zip(ride_gaps, spread(len(ride_ins), len(ride_gaps)))) if ride_ins else {}
-    ri = 0
+    pieces = []
+    if stream_slots is not None:
+        s.emit(I_salu("s_add_u32", S_R1, S_R1, 4096 * stream_slots[0], scc=True))
+        s.emit(I_salu("s_add_u32", S_R2, S_R2, 4096 * stream_slots[0], scc=True))
+        for slot in stream_slots:
+            pieces += [(slot, pc) for pc in refill(slot)]
+        every = max(1, (12 * nks - 2) // len(pieces))
+    ri = pi = gi = 0
     for ks in range(nks):
-        ms = mfmas(half, ks)
-        for m, mf in enumerate(ms):
+        for m, mf in enumerate(mfmas(half, ks, second_xl=(ks == last))):
             # ---- in front of the MFMA
             if m == 0:
-                if vm_waits:
+                if vm_mode == "formula":
                     s.wait(vm=min(4 * (15 - ks), 63))
+                elif vm_mode == "model":
+                    s.need_vm(("w", ks))
                 s.need_lds(("xh", ks))
             if m == 8:
                 s.need_lds(("xl", ks))
-            if ks == last and m == BARRIER_AT:
+            if (ks, m) == bar:
+                stamp(2)
                 s.wait(lgkm=0)
                 s.emit(I_barrier())
+                stamp(3)
+            if ks == 0 and m == 0:
+                stamp(1)
             s.emit(mf)
             # ---- behind it
             if m == 0 and ks < last:
                 for r in frag_reads_h(half, ks + 1, (ks + 1) & 1):
                     s.emit(r, ("xh", ks + 1))
-            if m == 11 and ks < last:
+                if ks + 1 == last:                      # the last k-step's lo fragments: second buffer, requested a k-step early
+                    for r in frag_reads_l(half, last, second=True):
+                        s.emit(r, ("xl", last))
+            if m == 11 and ks + 1 < last:
                 for r in frag_reads_l(half, ks + 1):
                     s.emit(r, ("xl", ks + 1))
-            if rebuild is not None and m == 2 and ks in (0, nks // 2):
-                for r in rb_parts[0 if ks == 0 else 1]:
-                    if isinstance(r, tuple) and r[0] == "NEED_VM":
-                        s.need_vm(r[1])
-                    elif isinstance(r, tuple):
-                        s.emit(r[1], "tload", group="rebuild_t")
-                    else:
-                        # the stash stores are issued under F_REBUILD, everything of the time-code part under F_REBUILD_T
-                        s.emit(r, "rebuild", group="rebuild_x" if (ks == 0 and r.kind == "lds_w") else "rebuild_t")
+            if rebuild is not None and m == 2 and ks in (0, max(1, (nks - 1) // 2)):
+                emit_rebuild(s, rb_parts[0 if ks == 0 else 1], ks == 0)
             if refills and ks >= 1 and 3 <= m <= 7:
                 for r in refill(ks - 1)[m - 3]:
                     s.emit(r, ("w", ks - 1))
-            n = per_gap.get((ks, m), 0)
-            for _ in range(n):
+            if pieces and gi % every == 0 and pi < len(pieces):
+                for r in pieces[pi][1]:
+                    s.emit(r, ("w", pieces[pi][0]))
+                pi += 1
+            gi += 1
+            for _ in range(per_gap.get((ks, m), 0)):
                 s.emit(ride_ins[ri], "ride")
                 ri += 1
-            if ks == last and m == BARRIER_AT:
+            if (ks, m) == bar:
                 if tail_init:
-                    skip = f"L_{name}_noinit"
-                    s.emit(I_s_cmp("s_bitcmp1_b32", S(S_CUR + D_FLAGS), F_INIT))
-                    s.emit(I_branch("s_cbranch_scc0", skip))
-                    s.emit(I_valu("v_add_u32", V_BADDR, S(S_CUR + D_BIAS), V_BIAS,
-                                  text=f"v_add_u32_e32 {V_BADDR}, {S(S_CUR + D_BIAS)}, {V_BIAS}"))
-                    for r in init_reads(oh):
-                        s.emit(r, "init", group="init")
-                    s.emit(I_label(skip))
-                if prefetch:
-                    for r in frag_reads_h(oh, 0, 0):
-                        s.emit(r, ("xh'", 0))
-            if ks == last and m == 11:
-                if refills:
-                    for r in refill_flat(last):
-                        s.emit(r, ("w", last))
-                if prefetch:
-                    for r in frag_reads_l(oh, 0):
-                        s.emit(r, ("xl'", 0))
-    assert ri == len(ride_ins)
-    if not prefetch:
-        s.wait(lgkm=0)
+                    guarded_init(s, name, oh)
+                for r in frag_reads_h(oh, 0, 0):
+                    s.emit(r, ("xh'", 0))
+            if ks == last and m == 0:
+                for r in frag_reads_l(oh, 0):
+                    s.emit(r, ("xl'", 0))
+            if ks == last and m == 11 and refills:
+                for r in refill_flat(last):
+                    s.emit(r, ("w", last))
+    assert ri == len(ride_ins) and pi == len(pieces)
+    stamp(4)
     s.emit(I_branch("s_branch", "L_dispatch"))
     return s.ins
 
 
-def bare_epilogue(name, half, end):
-    """Epilogue of `half` with no MFMAs beside it.  EPI_A: then barrier, bias init of acc_A (flag) and the first fragments of A.
-    EPI_B (end of the trunk): everything this wave started has landed when the body is left."""
+def short_b_body(name, nks):
+    """B phase of a short segment (the first layer, a skip layer's input part): MFMAs on acc_B, the weight-slot refills, and the
+    epilogue of half A -- RIDE_CAP instructions per gap from k-step 1 on, the rest behind the last MFMA.  The phase barrier
+    comes last (every read of X_B and every store into X_A of this wave is done), then the bias-table reads into acc_A (flag)
+    and the first fragments of the next A phase."""
+    s = Stream()
+    s.emit(I_label(f"L_{name}"))
+    last = nks - 1
+    for nt in range(2):
+        s.lds_q.append((("xh", 0), None))
+    for nt in range(2):
+        s.lds_q.append((("xl", 0), None))
+
+    def stamp(k):
+        if TIMING:
+            s.emit(raw(f"s_memtime s[{78 + 2 * k}:{79 + 2 * k}]"))
+    stamp(0)
+    ride_ins = epilogue_stream("A")
+    ri = 0
+    for ks in range(nks):
+        for m, mf in enumerate(mfmas("B", ks)):
+            if m == 0:
+                s.need_lds(("xh", ks))
+            if m == 8:
+                s.need_lds(("xl", ks))
+            if ks == 0 and m == 0:
+                stamp(1)
+            s.emit(mf)
+            if m == 0 and ks < last:
+                for r in frag_reads_h("B", ks + 1, (ks + 1) & 1):
+                    s.emit(r, ("xh", ks + 1))
+            if m == 11 and ks < last:
+                for r in frag_reads_l("B", ks + 1):
+                    s.emit(r, ("xl", ks + 1))
+            if ks >= 1 and 3 <= m <= 7:
+                for r in refill(ks - 1)[m - 3]:
+                    s.emit(r, ("w", ks - 1))
+            if ks >= 1:
+                for _ in range(RIDE_CAP if not (3 <= m <= 7) else RIDE_CAP - 1):
+                    if ri < len(ride_ins):
+                        s.emit(ride_ins[ri], "ride")
+                        ri += 1
+    for r in refill_flat(last):
+        s.emit(r, ("w", last))
+    stamp(2)
+    while ri < len(ride_ins):
+        s.emit(ride_ins[ri], "ride")
+        ri += 1
+    s.wait(vm=0, lgkm=0)
+    s.emit(I_barrier())
+    stamp(3)
+    guarded_init(s, name, "A")
+    for r in frag_reads_h("A", 0, 0) + frag_reads_l("A", 0):
+        s.emit(r)
+    stamp(4)
+    s.emit(I_branch("s_branch", "L_dispatch"))
+    return s.ins
+
+
+def bare_epilogue(name, half):
+    """Epilogue of `half` with no MFMAs beside it (end of the trunk): everything this wave started has landed when it is left."""
     s = Stream()
     s.emit(I_label(f"L_{name}"))
     s.emit(I_nop(7)); s.emit(I_nop(7))          # the last MFMAs on these accumulators were issued a few states ago
-    for r in epilogue_stream(half):
-        s.emit(r, "ride")
+    # two units at a time, instruction by instruction: independent chains for the in-order VALU
+    units = [epilogue_unit(half, u, u & 1) for u in range(8)]
+    for u in range(0, 8, 2):
+        for x, y in zip(units[u], units[u + 1]):
+            s.emit(x, "ride"); s.emit(y, "ride")
     s.wait(vm=0, lgkm=0)
-    if not end:
-        s.emit(I_barrier())
-        skip = f"L_{name}_noinit"
-        s.emit(I_s_cmp("s_bitcmp1_b32", S(S_CUR + D_FLAGS), F_INIT))
-        s.emit(I_branch("s_cbranch_scc0", skip))
-        s.emit(I_valu("v_add_u32", V_BADDR, S(S_CUR + D_BIAS), V_BIAS, text=f"v_add_u32_e32 {V_BADDR}, {S(S_CUR + D_BIAS)}, {V_BIAS}"))
-        for r in init_reads(half):
-            s.emit(r, "init", group="init")
-        s.emit(I_label(skip))
-        for r in frag_reads_h(half, 0, 0) + frag_reads_l(half, 0):
-            s.emit(r)
     s.emit(I_branch("s_branch", "L_dispatch"))
     return s.ins
 
@@ -381,22 +487,49 @@ def raw(text, wr=(), rd=()):
     return Inst("raw", text, rd, wr, "other")
 
 
+# Inline-asm operands and the registers the simulator's harness presets in their place
+IN_S = dict(pk=S(0, 2), phases=S(2, 2), lds=S(4), biaslds=S(5), wave=S(6), in_t=S(7), r1=S(8), r1w=S(9), r2=S(10), r2w=S(11), n1=S(12))
+IN_V = dict(tid=V(0), tpa0=V(1), tpa1=V(2), tpb0=V(3), tpb1=V(4))
+
+
+def in_s(dst, name):
+    src = IN_S[name]
+    op = "s_mov_b64" if dst.n == 2 else "s_mov_b32"
+    return Inst(op, f"{op} {dst}, %[{name}]", [src], [dst], "salu", dict(d=dst, s=[src]))
+
+
+def in_v(dst, name):
+    return Inst("v_mov_b32", f"v_mov_b32 {dst}, %[{name}]", [IN_V[name]], [dst], "valu", dict(d=dst, s=[IN_V[name]]))
+
+
+def pre_issue():
+    """The FIRST asm statement of the kernel, in front of the input encoder: request weight slots 0..7 (the first segment, and
+    the start of the second where the first is four k-steps long) so that the 128 KiB cross the CU's vector-memory path while
+    the encoder computes.  Nothing but the loads in flight survives this statement; the compiler-generated code between the
+    two statements does not touch accumulation registers (tools/h3asm/audit.py checks that).
+    Operands: %[pk] s64, %[wave] s32, %[tid] v32, %[r1] / %[r1w] / %[r2] / %[r2w] / %[n1] s32 (fields of phase descriptor 0)."""
+    o = [in_s(S_PK, "pk"), in_s(S_WAVE, "wave"), in_v(V_TMP, "tid"), in_s(S(S_CUR + D_N1), "n1"),
+         in_s(S_R1, "r1"), in_s(S_R2, "r2"), in_s(S_T0, "r1w"), in_s(S_T1, "r2w")]
+    o += [I_salu("s_mul_i32", S_T0, S_WAVE, S_T0), I_salu("s_add_u32", S_R1, S_R1, S_T0, scc=True),
+          I_salu("s_mul_i32", S_T1, S_WAVE, S_T1), I_salu("s_add_u32", S_R2, S_R2, S_T1, scc=True),
+          I_valu("v_and_b32", V_LANE16, 63, V_TMP), I_valu("v_lshlrev_b32", V_LANE16, 4, V_LANE16)]
+    for ks in range(8):
+        o += refill_flat(ks)
+    return o
+
+
 def prologue():
-    """Inputs (inline-asm operands): %[pk] s64, %[phases] s64 (phase descriptors), %[lds] s32 (byte address of the activation
-    tile), %[biaslds] s32, %[wave] s32, %[in_t] s32, %[tid] v32, %[tpa] v64, %[tpb] v64, %[first] (descriptor 0 is the prologue's:
-    weight streams of the first two segments, bias offset of segment 0)."""
+    """The second asm statement (behind the encoder and a workgroup barrier).  Operands: %[pk] s64, %[phases] s64 (phase
+    descriptors), %[lds] s32 (byte address of the activation tile), %[biaslds] s32, %[wave] s32, %[in_t] s32, %[tid] v32,
+    %[tpa0/1] %[tpb0/1] v32 (time-code row pointers)."""
     o = []
     e = o.append
-    e(raw("s_mov_b64 s[40:41], %[pk]", [S_PK]))
-    e(raw("s_mov_b64 s[46:47], %[phases]", [S_PH]))
-    e(raw("s_mov_b32 s42, %[lds]", [S_LDS]))
-    e(raw("s_mov_b32 s43, %[biaslds]", [S_BIASLDS]))
-    e(raw("s_mov_b32 s44, %[wave]", [S_WAVE]))
-    e(raw("s_mov_b32 s45, %[in_t]", [S_INT]))
-    e(raw("v_mov_b32 v39, %[tid]", [V_TMP]))
-    e(raw("v_mov_b32 v34, %[tpa0]", [V(34)])); e(raw("v_mov_b32 v35, %[tpa1]", [V(35)]))
-    e(raw("v_mov_b32 v36, %[tpb0]", [V(36)])); e(raw("v_mov_b32 v37, %[tpb1]", [V(37)]))
-    # descriptor 0 -> cur, descriptor 1 -> nxt (fetched now, valid after the first lgkmcnt(0) below)
+    if TIMING:
+        e(raw("s_mov_b64 s[76:77], %[dbg]")); e(raw("s_memtime s[74:75]"))
+    e(in_s(S_PK, "pk")); e(in_s(S_PH, "phases")); e(in_s(S_LDS, "lds")); e(in_s(S_BIASLDS, "biaslds"))
+    e(in_s(S_WAVE, "wave")); e(in_s(S_INT, "in_t")); e(in_v(V_TMP, "tid"))
+    e(in_v(V(34), "tpa0")); e(in_v(V(35), "tpa1")); e(in_v(V(36), "tpb0")); e(in_v(V(37), "tpb1"))
+    # descriptor 0 -> cur (bias row of segment 0), descriptor 1 -> nxt (fetched now, valid after the lgkmcnt(0) below)
     e(I_s_load(S(S_CUR, 8), S_PH, 0))
     e(I_s_load(S(S_NXT, 8), S_PH, 32))
     e(I_salu("s_add_u32", S(46), S(46), 64, scc=True)); e(I_salu("s_addc_u32", S(47), S(47), 0, scc=True))
@@ -426,23 +559,18 @@ def prologue():
     e(I_valu("v_lshlrev_b32", V(T0 + 5), 5, V(T0 + 4))); e(I_valu("v_add_u32", V_ST_H, V_ST_H, V(T0 + 5)))
     e(I_valu("v_add_u32", V_ST_H, S_LDS, V_ST_H, text=f"v_add_u32_e32 {V_ST_H}, {S_LDS}, {V_ST_H}"))
     e(I_valu("v_add_u32", V_ST_L, PLANE_B, V_ST_H, text=f"v_add_u32_e32 {V_ST_L}, {PLANE_B}, {V_ST_H}"))
-    # n4 = float4s of time code this thread restores: clamp((in_t - 16 q) / 4, 0, 4)   (v_n4 = min(4, max(0, ...)) via u32 tricks)
+    # n4 = float4s of time code this thread restores: clamp((in_t - 16 q) / 4, 0, 4)
     e(I_valu("v_lshlrev_b32", V(T0 + 5), 4, V(T0 + 4)))                       # 16 q
     e(I_valu("v_mov_b32", V_N4, S_INT, text=f"v_mov_b32_e32 {V_N4}, {S_INT}"))
     e(I_valu("v_min_u32", V(T0 + 5), V(T0 + 5), V_N4))                        # min(16 q, in_t)
     e(I_valu("v_sub_u32", V_N4, V_N4, V(T0 + 5)))                             # in_t - min(16 q, in_t) >= 0
     e(I_valu("v_lshrrev_b32", V_N4, 2, V_N4)); e(I_valu("v_min_u32", V_N4, 4, V_N4))
-    # stash of the input tile (the C++ encoder built it and synchronised the workgroup before the asm)
+    # stash of the input tile (the C++ encoder built it and synchronised the workgroup before this statement)
     for hb in range(2):
         st, ho = STASH + 16 * hb, hb * HALF_B
         e(I_ds_read_b128(V(st, 4), V_ST_H, ho)); e(I_ds_read_b128(V(st + 4, 4), V_ST_H, ho + 16))
         e(I_ds_read_b128(V(st + 8, 4), V_ST_L, ho)); e(I_ds_read_b128(V(st + 12, 4), V_ST_L, ho + 16))
     e(I_wait(lgkm=0))                                                         # descriptors + stash
-    # weights: descriptor 0 names the streams -- r1 = segment 0 (slots < n1), r2 = segment 1 (slots >= n1)
-    e(I_salu("s_mul_i32", S_T0, S_WAVE, S(S_CUR + D_R1W))); e(I_salu("s_add_u32", S_R1, S(S_CUR + D_R1), S_T0, scc=True))
-    e(I_salu("s_mul_i32", S_T0, S_WAVE, S(S_CUR + D_R2W))); e(I_salu("s_add_u32", S_R2, S(S_CUR + D_R2), S_T0, scc=True))
-    for ks in range(16):
-        o.extend(refill_flat(ks))
     # acc_A, acc_B := bias of segment 0 (flag), first fragments of half A
     e(I_s_cmp("s_bitcmp1_b32", S(S_CUR + D_FLAGS), F_INIT)); e(I_branch("s_cbranch_scc0", "L_pro_noinit"))
     e(I_valu("v_add_u32", V_BADDR, S(S_CUR + D_BIAS), V_BIAS, text=f"v_add_u32_e32 {V_BADDR}, {S(S_CUR + D_BIAS)}, {V_BIAS}"))
@@ -452,17 +580,33 @@ def prologue():
     return o
 
 
+def timing_store():
+    """lane 0 stores six dwords at *s[76:77] (+= 24): the stamp of the previous dispatcher visit (s74, issued one phase ago) and
+    the five stamps the phase in between left in s78..s87; then a new visit stamp is requested.  The stores are entries of the
+    in-order VMEM queue: counted waits for older loads only get stricter."""
+    o = [raw("v_mov_b32 v32, 0"), raw("s_mov_b64 exec, 1")]
+    for k, sr in enumerate((74, 78, 80, 82, 84, 86)):
+        o += [raw(f"v_mov_b32 v39, s{sr}"), raw(f"global_store_dword v32, v39, s[76:77] offset:{4 * k}")]
+    o += [raw("s_mov_b64 exec, -1"), raw("s_add_u32 s76, s76, 24"), raw("s_addc_u32 s77, s77, 0"), raw("s_memtime s[74:75]")]
+    return o
+
+
+DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "EPI_B")
+
+
 def dispatcher():
     o = [I_label("L_dispatch")]
     e = o.append
-    # cur <- nxt (valid: every body ends its LDS / SMEM traffic with lgkmcnt(0) before it comes here or before its barrier)
+    if TIMING:
+        o.extend(timing_store())
+    # cur <- nxt (valid: every body ends its LDS / SMEM traffic with lgkmcnt(0) at its barrier)
     for k in range(8):
         e(I_salu("s_mov_b32", S(S_CUR + k), S(S_NXT + k)))
     e(I_s_load(S(S_NXT, 8), S_PH, 0))
     e(I_salu("s_add_u32", S(46), S(46), 32, scc=True)); e(I_salu("s_addc_u32", S(47), S(47), 0, scc=True))
     e(I_salu("s_mul_i32", S_T0, S_WAVE, S(S_CUR + D_R1W))); e(I_salu("s_add_u32", S_R1, S(S_CUR + D_R1), S_T0, scc=True))
     e(I_salu("s_mul_i32", S_T0, S_WAVE, S(S_CUR + D_R2W))); e(I_salu("s_add_u32", S_R2, S(S_CUR + D_R2), S_T0, scc=True))
-    for name in ("A16R", "B16R", "EPI_A", "A4", "B4", "A8", "B8", "B16X", "EPI_B"):
+    for name in DISPATCH_ORDER:
         e(I_s_cmp("s_cmp_eq_u32", S(S_CUR + D_BODY), BODY[name]))
         e(I_branch("s_cbranch_scc1", f"L_{name}"))
     e(I_branch("s_branch", "L_end"))
@@ -470,26 +614,29 @@ def dispatcher():
 
 
 def build():
-    prog = []
-    prog += prologue()
-    prog.append(I_branch("s_branch", "L_dispatch"))
+    """-> (pre-issue statement, main statement, bodies)"""
     bodies = {
-        "A16R": phase_body("A16R", "A", 16, ride="epi", tail_init=True, vm_waits=True),
+        "A16R": phase_body("A16R", "A", 16, ride="epi", tail_init=True, vm_mode="formula"),
         "B16R": phase_body("B16R", "B", 16, ride="epi", refills=True, tail_init=True),
         "B16X": phase_body("B16X", "B", 16, refills=True, rebuild="A"),
-        "A4": phase_body("A4", "A", 4, rebuild="B", vm_waits=True),
-        "A8": phase_body("A8", "A", 8, rebuild="B", vm_waits=True),
-        "B4": phase_body("B4", "B", 4, refills=True, prefetch=False),
-        "B8": phase_body("B8", "B", 8, refills=True, prefetch=False),
-        "EPI_A": bare_epilogue("EPI_A", "A", end=False),
-        "EPI_B": bare_epilogue("EPI_B", "B", end=True),
+        "A4": phase_body("A4", "A", 4, rebuild="B", vm_mode="formula"),
+        "A8": phase_body("A8", "A", 8, rebuild="B", vm_mode="formula"),
+        "A4F": phase_body("A4F", "A", 4, vm_mode="model", stream_slots=list(range(8, 16))),
+        "A8F": phase_body("A8F", "A", 8, vm_mode="model", stream_slots=list(range(8, 16))),
+        "B4": short_b_body("B4", 4),
+        "B8": short_b_body("B8", 8),
+        "EPI_B": bare_epilogue("EPI_B", "B"),
     }
-    for name in ("A16R", "B16R", "B16X", "A4", "A8", "B4", "B8", "EPI_A", "EPI_B"):
+    prog = prologue()
+    prog.append(I_branch("s_branch", "L_dispatch"))
+    for name in bodies:
         prog += bodies[name]
     prog += dispatcher()
     prog.append(I_label("L_end"))
     prog.append(I_wait(vm=0, lgkm=0))
-    return prog, bodies
+    if TIMING:
+        prog += timing_store() + [I_wait(vm=0, lgkm=0)]
+    return pre_issue(), prog, bodies
 
 
 def render(prog):
@@ -524,15 +671,28 @@ def lint(bodies, prog):
 
 
 def main():
-    prog, bodies = build()
+    global TIMING
+    TIMING = "--timing" in sys.argv
+    pre, prog, bodies = build()
     errs = lint(bodies, prog)
     for e_ in errs[:40]:
         print("LINT:", e_)
     if errs:
         sys.exit(f"{len(errs)} hazard(s)")
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "nsff_pl_amd", "csrc", "field_h3a_body.inc")
-    text = ("// GENERATED by tools/h3asm/gen.py -- do not edit.  The hand-scheduled trunk body of nsff_field_kernel_h3a\n"
-            "// (one asm statement; registers v24..v255, a0..a255, s40..s99 are its own).\n" + render(prog))
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "nsff_pl_amd", "csrc",
+                       "field_h3a_body_timing.inc" if TIMING else (f"field_h3a_body_{EXP}.inc" if EXP else "field_h3a_body.inc"))
+    clob = ", ".join([f'"v{i}"' for i in range(24, 256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(40, 100)] +
+                     ['"vcc"', '"scc"', '"memory"'])
+    pre_wr = sorted({r for i in pre for r in i.wr if r[0] in ("v", "a") or (r[0] == "s" and r[1] < 100)})
+    pre_clob = ", ".join([f'"{f}{i}"' for f, i in pre_wr] + ['"scc"', '"memory"'])
+    consts = "".join(f"#define H3A_BODY_{k} {v}\n" for k, v in BODY.items())
+    consts += f"#define H3A_F_INIT {1 << F_INIT}\n#define H3A_F_REBUILD_T {1 << F_REBUILD_T}\n#define H3A_F_REBUILD {1 << F_REBUILD}\n"
+    macro = lambda name, insts: f"#define {name} \\\n" + render(insts).replace("\n", " \\\n").rstrip(" \\\n") + "\n"
+    text = ("// GENERATED by tools/h3asm/gen.py -- do not edit.  The hand-scheduled trunk body of nsff_field_kernel_h3a:\n"
+            "// H3A_PRE (weight slots 0..7 requested in front of the encoder) and H3A_BODY (the trunk; registers v24..v255,\n"
+            "// a0..a255, s40..s99 are its own while it runs).\n" + consts +
+            "#define H3A_PRE_CLOBBERS " + pre_clob + "\n" + macro("H3A_PRE", pre) +
+            "#define H3A_CLOBBERS " + clob + "\n" + macro("H3A_BODY", prog))
     with open(out, "w") as f:
         f.write(text)
     n_m = sum(1 for i in prog if i.kind == "mfma")
