@@ -42,7 +42,7 @@ N_RAYS, N_SAMPLES, N_IMPORTANCE = 1024, 64, 64
 # MI355X_MICROARCH.md dense peaks: fp32 MFMA (v_mfma_f32_32x32x2_f32) and f16 MFMA (32x32x16)
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
 MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "f16": 1}
-KERNEL_NAME = {"f32": "nsff_field_kernel", "f16x3": "nsff_field_kernel_h3<4,1,false,1,true>", "f16": "nsff_field_kernel_h3<4,1,false,2,false>"}
+KERNEL_NAME = {"f32": "nsff_field_kernel", "f16x3": "nsff_field_kernel_h3a", "f16": "nsff_field_kernel_h3<4,1,false,2,false>"}
 TRAIN_KERNEL_NAME = {"f16x3": "nsff_field_kernel_h3<4,1,true,1,true>"}
 DTYPE_TEXT = {"f32": "f32",
               "f16x3": "f16x3 (fp32 operands split into 2 halfs, 3 f16 MFMAs per product, fp32 accumulate; same 1e-4 parity as f32)",

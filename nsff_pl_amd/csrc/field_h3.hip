@@ -552,9 +552,29 @@ __device__ __forceinline__ void split_store2(_Float16* xh, _Float16* xl, int idx
 // OCTAVE: allow the angle-doubling encoder (inference).  The training forward keeps one exact sincos per column: its
 // gradients are compared with autograd of the reference network, whose ReLU pattern -- a function of sin(512 x) eight
 // layers deep -- answers a 4-ulp change of the encoding with per-cent changes of single weight gradients.
-// ILP: let the compiler interleave the three axes' range reductions (the hand-scheduled kernel runs the encoder with one wave per
-// SIMD and the whole register file to itself: dependent VALU chains are what it waits for; the eight-wave kernels keep one
-// reduction at a time for their register budget)
+// sin / cos of an embedding angle (|a| < 2^15; here up to ~800 rad) without the library's argument classification: three-step
+// Cody-Waite reduction by pi/2 (the first two constants have so few bits that k C1, k C2 are exact; the fmas make the rest
+// exact to the last step) and the cephes single-precision kernels on [-pi/4, pi/4] -- ~25 VALU instead of the library's two code
+// paths under a per-lane branch; absolute error ~1e-7 (the encoder is compared with the reference's at 2e-6).
+__device__ __forceinline__ void sincos_cw(float a, float* s, float* c) {
+    const float k = __builtin_rintf(a * 0.63661977236758134f);
+    float r = fmaf(k, -1.5703125f, a);
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.54978995489188216e-8f, r);
+    const float r2 = r * r;
+    float sp = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// ILP: the hand-scheduled kernel's encoder -- one wave per SIMD with the whole register file to itself, dependent VALU chains are
+// what it waits for: the three axes' range reductions may interleave and use sincos_cw; the eight-wave kernels keep the library
+// call, one reduction at a time, for their register budget
 template <int M, int THREADS, bool SPLIT, bool OCTAVE = true, bool ILP = false>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
                                             const float (&x)[3], int tid) {
@@ -591,7 +611,10 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             sn[c] = 0.f; cs[c] = 0.f;
-            if (f0 < a.n_freqs) sincosf(a.freqs[f0] * x[c], &sn[c], &cs[c]);
+            if (f0 < a.n_freqs) {
+                if constexpr (ILP) sincos_cw(a.freqs[f0] * x[c], &sn[c], &cs[c]);
+                else sincosf(a.freqs[f0] * x[c], &sn[c], &cs[c]);
+            }
             if constexpr (!ILP) __builtin_amdgcn_sched_barrier(0);  // one range reduction at a time (register pressure)
         }
         const int c0 = 3 + 6 * OPP * q;                             // odd: first value alone, then even-aligned pairs
@@ -608,7 +631,10 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
             if (k + 1 < OPP) {
                 if (SPLIT && k == 2 && f0 + 3 < a.n_freqs) {        // (five octaves per part only)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) sincosf(a.freqs[f0 + 3] * x[c], &sn[c], &cs[c]);
+                    for (int c = 0; c < 3; ++c) {
+                        if constexpr (ILP) sincos_cw(a.freqs[f0 + 3] * x[c], &sn[c], &cs[c]);
+                        else sincosf(a.freqs[f0 + 3] * x[c], &sn[c], &cs[c]);
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -1037,6 +1063,64 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
 }
 
 
+
+// Heads of nsff_field_kernel_h3a: wave w evaluates the (folded) head tile on point tile w = 32 points, all 16 k-steps.  The
+// whole head tile of the wave (hi + lo halfs of 16 k-steps = 32 KiB) is REQUESTED by h3a_head_request() before the workgroup
+// barrier behind the trunk -- one L2 round trip instead of two, hidden behind the barrier -- and the three product terms run as
+// three accumulator chains.  Activations with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-6 relative; the outputs are
+// compared at 1e-4 of their maximum): sigmoid(v) = 1 / (1 + 2^(-v log2 e)), tanh(v) = 1 - 2 / (2^(2 v log2 e) + 1).
+struct H3AHeadW { h8 wh[16], wl[16]; float bv[8]; };
+__device__ __forceinline__ void h3a_head_request(H3AHeadW& hw, const uint32_t* __restrict__ pk, uint32_t w_off, uint32_t b_off,
+                                                 int n_rows, int lane) {
+    const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        hw.wh[j] = __builtin_bit_cast(h8, w[(j * 2 + 0) * 64]);
+        hw.wl[j] = __builtin_bit_cast(h8, w[(j * 2 + 1) * 64]);
+    }
+    const float* bias = reinterpret_cast<const float*>(pk + b_off);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        hw.bv[r] = row < n_rows ? bias[row] : 0.f;
+    }
+}
+__device__ __forceinline__ float fast_sigmoid(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+__device__ __forceinline__ float fast_tanh(float v) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * v) + 1.0f);
+}
+__device__ __forceinline__ void h3a_heads(const H3AHeadW& hw, const _Float16* sXh, const _Float16* sXl, int n_rows, unsigned kinds,
+                                          float flow_scale, float* sRaw, int slot0, int wave, int lane) {
+    f32x16 acc0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[c][r] = 0.f;
+    const _Float16* bh = sXh + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
+    const _Float16* bl = sXl + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const h8 xh = lds_h8(bh + ks * 16), xl = lds_h8(bl + ks * 16);
+        acc0[0] = MFMA_H(hw.wl[ks], xh, acc0[0]);
+        acc0[1] = MFMA_H(hw.wh[ks], xl, acc0[1]);
+        acc0[2] = MFMA_H(hw.wh[ks], xh, acc0[2]);
+    }
+    float* rec = sRaw + (32 * wave + (lane & 31)) * NSFF_RAW_STRIDE + slot0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < n_rows) {
+            float v = ((acc0[0][r] + acc0[1][r]) + acc0[2][r]) + hw.bv[r];
+            const unsigned kind = (kinds >> (2 * row)) & 3u;
+            if (kind == ACT_SIGMOID) v = fast_sigmoid(v);
+            else if (kind == ACT_FLOW) v = flow_scale * fast_tanh(v);
+            rec[row] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // nsff_field_kernel_h3a: the f16x3 inference trunk with a HAND-SCHEDULED body (tools/h3asm/gen.py -> field_h3a_body.inc).
 // One wave per SIMD (four waves x 512 registers), 128 points per workgroup as two 64-point halves; a wave owns 64 neurons,
@@ -1071,7 +1155,6 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
     __shared__ __attribute__((aligned(16))) float sRaw[M * NSFF_RAW_STRIDE];
     __shared__ __attribute__((aligned(16))) float sBias[H3A_MAX_BIAS * NSFF_W];
-    __shared__ float sRed[1];
     for (int i = threadIdx.x; i < M * NSFF_RAW_STRIDE; i += THREADS) sRaw[i] = 0.f;
     _Float16* sXh = sX;
     _Float16* sXl = sX + M * LDH;
@@ -1112,6 +1195,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
                        [n1] "s"(d0.d[3]), [r1] "s"(d0.d[4]), [r1w] "s"(d0.d[5]), [r2] "s"(d0.d[6]), [r2w] "s"(d0.d[7])
                      : H3A_PRE_CLOBBERS);
     }
+    H3A_TSTAMP(57);
     build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1, px, threadIdx.x);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
     const float* tpa = reinterpret_cast<const float*>(pk);
@@ -1155,17 +1239,17 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 #ifdef H3_TIMING
     if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-    __syncthreads();
     {
         struct HeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
         const int head = aa.head[tr];
         HeadSel hs{a.L.s_sigma_w, a.L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
         if (head == HEAD_S_FOLD) hs = HeadSel{a.L.s_fold_w, a.L.s_fold_b, 4, 0, 0x15u};
         if (head == HEAD_T_FOLD) hs = HeadSel{a.L.t_fold_w, a.L.t_fold_b, (int)a.L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
-        WRing<1, true> none;
+        H3AHeadW hw;
+        h3a_head_request(hw, pk, hs.w_off, hs.b_off, hs.n_rows, lane);     // (in flight across the barrier)
+        __syncthreads();
         H3A_TSTAMP(54);
-        heads<4, 4, true, 1>(sXh, sXl, sRed, pk, hs.w_off, hs.b_off, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0,
-                             wave_id, lane, none, false, nullptr);
+        h3a_heads(hw, sXh, sXl, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0, wave_id, lane);
         H3A_TSTAMP(55);
     }
     __syncthreads();

@@ -44,7 +44,7 @@ else:
     seq = [11, 7] + [1, 2] * 3 + [1, 3, 5, 7] + [1, 2] * 3 + [9]
 print(f"{which} trunk, mean cycles over 256 workgroups x 4 waves")
 print(f"  kernel entry -> input built   {d(0, 1).mean():8.0f}   = point + bias requests {d(0, 52).mean():.0f}, point landed {d(52, 53).mean():.0f}, "
-      f"encoder {d(53, 1).mean():.0f}")
+      f"weight pre-issue {d(53, 57).mean():.0f}, encoder {d(57, 1).mean():.0f}")
 print(f"  body prologue                 {dd(rec[:, :, 0, 0], rec[:, :, 1, 0]).mean():8.0f}   (asm start -> first dispatch)")
 tot = 0.0
 for i, b in enumerate(seq):
