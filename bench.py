@@ -362,6 +362,55 @@ def readme_eval(bench, steps=2):
     return out
 
 
+def backward_rooflines(bench, args, steps=4):
+    from nsff_pl_amd import _lib
+    spans = {"nsff_field_backward": [], "nsff_weight_grad": []}
+    fwd_flops = []
+    orig = {n: getattr(_lib, n) for n in ("field_backward", "weight_grad", "weight_grad_accumulate", "field_query")}
+
+    def timed_call(name, key):
+        def f(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig[name](*a, **k)
+            e1.record()
+            spans[key].append((e0, e1))
+            return r
+        return f
+    keep_models = bench.models
+    bench.graph = False
+    step = bench.train_step()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    _lib.field_backward = timed_call("field_backward", "nsff_field_backward")
+    _lib.weight_grad = timed_call("weight_grad", "nsff_weight_grad")
+    _lib.weight_grad_accumulate = timed_call("weight_grad_accumulate", "nsff_weight_grad")
+    try:
+        _lib.prof_enable(True)
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        launches, ms, flops, _ex, ghz = _lib.prof_collect()
+        _lib.prof_enable(False)
+    finally:
+        for n, f in orig.items():
+            setattr(_lib, n, f)
+    bench.models = keep_models
+    out = {"note": "per field node of a training step (four per step); FLOPs = 2 x MACs of the differentiated layers = those of the "
+                   "node's training forward; nsff_weight_grad = the GEMM launches + the split-K reduction that accumulates into .grad",
+           "forward_launches": launches, "forward_ms_per_launch": ms / max(launches, 1)}
+    per_node = flops / max(launches, 1)
+    for key, sp in spans.items():
+        t = sum(a.elapsed_time(b) for a, b in sp)
+        n = len(sp)
+        tf = per_node * n / (t * 1e-3) / 1e12 if t > 0 else 0.0
+        out[key] = {"calls": n, "avg_ms": t / max(n, 1), "achieved": tf, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
+                    "frac": tf / PEAK_TFLOPS["f16x3"], "bound": "mfma (f16, one product per MAC)" if key == "nsff_field_backward"
+                    else "hbm / mfma balanced (128 FLOP per byte of saved activations)"}
+    return out
+
+
 def aux_block(bench, args):
     """The other configurations, a few steps each, after the headline (single GPU only)."""
     from nsff_pl_amd import config
@@ -387,6 +436,11 @@ def aux_block(bench, args):
                             "roofline": dict({k: rf[k] for k in ("achieved", "executed", "peak", "unit", "frac", "clock_ghz", "frac_at_clock",
                                                                  "avg_launch_ms", "launches")},
                                              kernel=TRAIN_KERNEL_NAME.get(args.precision, KERNEL_NAME[args.precision]))}
+    # (1c) the two other MFMA kernels of a training step, each against the same f16 peak: nsff_field_backward (data gradients,
+    # one f16 product per MAC) and the weight-gradient GEMMs (nsff_weight_grad*: dW = dY^T X over the saved activations).
+    # Algorithmic FLOPs of either = 2 x MACs of the layers it differentiates = the FLOPs of the training forward launch of the
+    # same field node; time = HIP events around the C-ABI calls (on the stream they are issued on) during eager training steps.
+    aux["train_backward_kernels"] = backward_rooflines(bench, args)
     # (2) C3 as SURVEY 8d defines it: one 512x288 test-time frame WITH the frustum-visibility test of every sample point
     # (eval.py:134 always passes `dataset`), and without it for comparison
     t, _, _ = timed(bench.frame_steps(False), 3, 1, 1, dev)

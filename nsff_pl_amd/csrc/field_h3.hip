@@ -1324,7 +1324,7 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, H3
             if (t == 0 || !pending_b) return false;
             ok = ok && put(H3A_BODY_A16R, g.bias >= 0 ? H3A_F_INIT : 0u, g.bias, 16, g, g);
             if (g.relu) {
-                ok = ok && put(H3A_BODY_B16R, init_next, nbias, n1, r1, r2);
+                ok = ok && put(nxt ? H3A_BODY_B16R : H3A_BODY_B16L, init_next, nbias, n1, r1, r2);   // (the last segment requests nothing)
                 pending_b = true;
             } else {
                 if (!nxt || !nxt->rebuild || nxt->bias >= 0 || nxt->nks == 16) return false;

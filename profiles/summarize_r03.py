@@ -14,7 +14,7 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNELS = ("nsff_field_kernel_h3", "nsff_field_kernel(", "mpi_composite_kernel", "composite_bwd_kernel", "composite_kernel",
+KERNELS = ("nsff_field_kernel_h3a", "nsff_field_kernel_h3", "nsff_field_kernel(", "mpi_composite_kernel", "composite_bwd_kernel", "composite_kernel",
            "fine_samples_kernel", "coarse_samples_kernel", "warp_points_kernel", "splat_tiles_kernel", "splat_far_kernel",
            "splat_scan_kernel", "splat_bin_kernel", "splat_gather_kernel", "frustum_visibility_kernel",
            "nsff_field_bwd_kernel", "nsff_wgrad_kernel", "nsff_wgrad_reduce_kernel", "field_input_bwd_kernel", "loss_rays_kernel",
@@ -25,7 +25,7 @@ def short(name):
     for k in KERNELS:
         if k in name:
             extra = ""
-            if k == "nsff_field_kernel_h3":
+            if k == "nsff_field_kernel_h3" and "<" in name:
                 extra = name[name.index("<"):name.index(">") + 1]
             if k == "nsff_wgrad_kernel":
                 extra = name[name.index("<"):name.index(">") + 1]

@@ -85,7 +85,7 @@ def build_program(segs, in_t):
             assert t > 0 and pending_b, "a 16-wide segment rides the epilogue of the one before it"
             ph.append(desc(B["A16R"], (1 << gen.F_INIT) if sg["bias"] is not None else 0, sg["bias"] or 0))
             if sg["post"] == "relu":
-                ph.append(desc(B["B16R"], init_next, nbias, **refill_fields(t)))
+                ph.append(desc(B["B16R"] if nxt is not None else B["B16L"], init_next, nbias, **refill_fields(t)))
                 pending_b = True
             else:
                 assert nxt is not None and nxt["rebuild"] and nxt["bias"] is None

@@ -59,7 +59,7 @@ D_BODY, D_FLAGS, D_BIAS, D_N1, D_R1, D_R1W, D_R2, D_R2W = range(8)
 # an input tile at all (A4 / A8 also run the first layer, where the tile is still the encoder's)
 F_INIT, F_REBUILD_T, F_REBUILD = 0, 1, 2
 
-BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11)
+BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12)
 
 
 def xh(b, nt):
@@ -591,7 +591,7 @@ def timing_store():
     return o
 
 
-DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "EPI_B")
+DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B")
 
 
 def dispatcher():
@@ -618,6 +618,7 @@ def build():
     bodies = {
         "A16R": phase_body("A16R", "A", 16, ride="epi", tail_init=True, vm_mode="formula"),
         "B16R": phase_body("B16R", "B", 16, ride="epi", refills=True, tail_init=True),
+        "B16L": phase_body("B16L", "B", 16, ride="epi"),        # the trunk's last segment: nothing left to request
         "B16X": phase_body("B16X", "B", 16, refills=True, rebuild="A"),
         "A4": phase_body("A4", "A", 4, rebuild="B", vm_mode="formula"),
         "A8": phase_body("A8", "A", 8, rebuild="B", vm_mode="formula"),
