@@ -482,6 +482,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle-ms", type=float, default=600.0,
+                    help="untimed steps run for this long BEFORE the W warm-up steps: the part comes out of its idle state (95 MHz "
+                         "while the CPU baseline runs) and its power management settles; 0 = none.  Reported in config.settle_ms")
     ap.add_argument("--no-aux", action="store_true", help="skip the aux block (other configurations after the headline)")
     ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16"],
                     help="arithmetic of the dense layers; f32 and f16x3 pass the same 1e-4 parity tests, f16 is the "
@@ -524,6 +527,21 @@ def main():
     step = {"render": bench.render_step, "train": bench.train_step,
             "eval": lambda: bench.frame_steps(False), "eval_interp": lambda: bench.frame_steps(True)}[args.workload]()
 
+    if args.settle_ms > 0 and not args.standin:
+        # the same number of settle steps on every rank (a step may end in a collective): sized from ten steps on this rank
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        n_settle = int(args.settle_ms * 1e-3 / max((time.perf_counter() - t0) / 10, 1e-6)) + 1
+        if dist.is_initialized():
+            nt = torch.tensor([n_settle], device=device)
+            dist.all_reduce(nt, op=dist.ReduceOp.MAX)
+            n_settle = int(nt.item())
+        for _ in range(n_settle):
+            step()
+        bench.finish()
+        torch.cuda.synchronize()
     elapsed, kern, per_rank = timed(step, args.steps, args.warmup, world, device, prof=not args.standin, bench=bench)
     median_ms = median_step_ms()               # (of the headline's steps: the aux block below times other things)
 
@@ -546,6 +564,7 @@ def main():
                                    "render_rays' throughput with autograd DISABLED (the train-mode FLAGS, inference launches: "
                                    "nothing kept for a backward pass); what a trainer's forward costs is aux.train_forward, "
                                    "the whole training step aux.train_ms_per_step_*",
+                       "settle_ms": args.settle_ms,
                        "rays_per_gpu": N_RAYS, "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE,
                        "parallelism": f"ray-shard x{world}, pixel all-gather" if bench.live else "single GPU",
                        "rays_per_s": world * N_RAYS * args.steps / elapsed,
