@@ -57,47 +57,7 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
 class _Pass:
     """Inputs shared by the coarse and the fine pass of one render_rays call."""
     __slots__ = ("embeddings", "rays", "ts", "max_t", "noise_std", "test_time", "kwargs",
-                 "freqs_xyz", "dir_embedded", "n_rays", "rec", "draws")
-
-
-_RNG_STREAM = {}
-
-
-class _Draws:
-    """The call's torch RNG draws, made in the reference's order on a SIDE stream: they depend on nothing, so the nine small
-    generator kernels of a call run beside the field kernels instead of between them (same generator, same host order of the
-    calls -> the same values as on the render stream).  ``join()`` makes the render stream wait for what was drawn so far;
-    it is called in front of every launch that consumes a draw."""
-
-    def __init__(self, device):
-        self.device = device
-        self.main = torch.cuda.current_stream(device)
-        if device not in _RNG_STREAM:
-            _RNG_STREAM[device] = torch.cuda.Stream(device=device)
-        self.side = _RNG_STREAM[device]
-        self.forked = False
-        self.dirty = False
-
-    def _draw(self, fn, shape):
-        if not self.forked:                     # (also what makes the side stream part of a hipGraph capture of the call)
-            self.side.wait_stream(self.main)
-            self.forked = True
-        with torch.cuda.stream(self.side):
-            t = fn(*shape, device=self.device)
-        t.record_stream(self.main)
-        self.dirty = True
-        return t
-
-    def rand(self, *shape):
-        return self._draw(torch.rand, shape)
-
-    def randn(self, *shape):
-        return self._draw(torch.randn, shape)
-
-    def join(self):
-        if self.dirty:
-            self.main.wait_stream(self.side)
-            self.dirty = False
+                 "freqs_xyz", "dir_embedded", "n_rays", "rec")
 
 
 def _embed_rows(embeddings, key, idx):
@@ -172,8 +132,8 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
 
     # RNG draws, in the reference's order (rendering.py:207, 213, then 128 for fw and bw)
     nstd = float(ctx.noise_std)
-    noise_s = ctx.draws.randn(n_rays, S)
-    noise_t = ctx.draws.randn(n_rays, S) if output_transient else None
+    noise_s = torch.randn(n_rays, S, device=zs.device)
+    noise_t = torch.randn(n_rays, S, device=zs.device) if output_transient else None
     if ctx.rec is not None and nstd != 0:        # the draws are needed again when gradients are taken
         ctx.rec[f"{typ}_static"], ctx.rec[f"{typ}_transient"] = noise_s, noise_t
 
@@ -210,12 +170,12 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         if P:
             _lib.warp_points(raw, xyz, zs, Z_FAR, xyz_fw, xyz_bw)
             query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1)
-        noise_fw = ctx.draws.randn(n_rays, S)
+        noise_fw = torch.randn(n_rays, S, device=zs.device)
         out('rgb_fw', n_rays, 3)
         results['xyzs_bw'] = xyz_bw
         if P:
             query(f"{typ}_warp_bw", raw_bw, xyz_bw, 0, 2, 1, tm1)
-        noise_bw = ctx.draws.randn(n_rays, S)
+        noise_bw = torch.randn(n_rays, S, device=zs.device)
         if ctx.rec is not None and nstd != 0:
             ctx.rec[f"{typ}_warp_fw"], ctx.rec[f"{typ}_warp_bw"] = noise_fw, noise_bw
         out('rgb_bw', n_rays, 3)
@@ -257,7 +217,6 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
                     args['disocc_bw'] = out('disocc_bw', n_rays, 1)
                     args['disoccs_bw'] = out('disoccs_bw', n_rays, S, 1)
     if n_rays:
-        ctx.draws.join()
         _lib.composite(**args)
 
 
@@ -312,7 +271,6 @@ def render_rays(models,
         ctx.noise_std, ctx.test_time, ctx.kwargs, ctx.n_rays = noise_std, test_time, kwargs, n_rays
         ctx.freqs_xyz = [float(f) for f in embedding_xyz.freqs]
         ctx.rec = rec
-        ctx.draws = _Draws(rays.device)
         ctx.dir_embedded = None
         if any(m.use_viewdir for m in models.values()):
             view_dir = kwargs.get('view_dir', rays[:, 3:6])
@@ -320,10 +278,9 @@ def render_rays(models,
 
         # coarse depths: one linspace shared by all rays, optional stratified jitter
         z_lin = _unit_linspace(N_samples, rays.device)
-        perturb_rand = ctx.draws.rand(n_rays, N_samples) if perturb > 0 else None
+        perturb_rand = torch.rand(n_rays, N_samples, device=rays.device) if perturb > 0 else None
         zs = _new(rays, n_rays, N_samples)
         xyz_coarse = _new(rays, n_rays, N_samples, 3)
-        ctx.draws.join()
         if n_rays:
             _lib.coarse_samples(rays, z_lin, perturb, perturb_rand, zs, xyz_coarse)
 
@@ -341,9 +298,8 @@ def render_rays(models,
                 u_s = _unit_linspace(N_importance, rays.device)
                 u_t = u_s
             else:
-                u_s = ctx.draws.rand(n_rays, N_importance)
-                u_t = ctx.draws.rand(n_rays, N_importance) if output_transient else None
-                ctx.draws.join()
+                u_s = torch.rand(n_rays, N_importance, device=rays.device)
+                u_t = torch.rand(n_rays, N_importance, device=rays.device) if output_transient else None
             S_fine = N_samples + (2 if output_transient else 1) * N_importance
             zs_static = _new(rays, n_rays, N_importance) if test_time else None
             zs_transient = _new(rays, n_rays, N_importance) if (test_time and output_transient) else None
