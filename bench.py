@@ -427,6 +427,13 @@ def aux_block(bench, args):
                                                                          "frac_at_clock", "avg_launch_ms", "launches")}}
     config.set_precision(args.precision)
     config.set_tile_points(args.tile_points if args.precision == "f16x3" else 0)
+    # (1a) the headline call as ONE replayed hipGraph (nsff_pl_amd.graphs.GraphedRender): same kernels, no per-launch host work
+    from nsff_pl_amd.graphs import GraphedRender
+    gr = GraphedRender(bench.models, bench.emb, bench.scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0, N_IMPORTANCE, test_time=False, **bench.kw)
+    gr(bench.rays, bench.ts)
+    t, _, _ = timed(lambda: gr(bench.rays, bench.ts), 20, 3, 1, dev)
+    aux["render_as_hip_graph"] = {"ms_per_step": t / 20 * 1e3, "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 20 / t,
+                                  "note": "the C2 call captured once and replayed (23 kernel nodes incl. the generator kernels)"}
     # (1b) the TRAINING forward of the same C2 call (what a training step launches: every layer executed, activations and
     # ReLU sign bits kept for the backward pass) next to the headline's inference launches
     t, kern, _ = timed(bench.render_step(train_forward=True), 10, 2, 1, dev, prof=True)

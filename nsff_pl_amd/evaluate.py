@@ -88,7 +88,7 @@ class HostFrame(dict):
 
 @torch.no_grad()
 def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, chunk=1024 * 32,
-                 keys=None, to_cpu=False, to_host=None, sync=True, **kwargs):
+                 keys=None, to_cpu=False, to_host=None, sync=True, graph=None, **kwargs):
     """Batched inference on the rays of one frame (reference eval.py:81-110).
 
     keys: iterable of result keys to keep (default: all, like the reference).
@@ -98,6 +98,9 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
     host tensors (``sync=False`` leaves the last copies in flight: call ``.wait()``).  ``True`` allocates FRESH buffers
     for this call (no two frames ever share memory); a :class:`PinnedPool` reuses ``depth`` rotating buffer sets (a frame
     is valid until ``depth`` later frames went through the pool); a dict supplies caller-owned buffers per key.
+    graph: a :class:`nsff_pl_amd.graphs.GraphedRender` built with this call's flags (test_time=True, perturb = noise_std = 0):
+    every chunk is one replayed hipGraph (one capture per distinct chunk size); kept tensors are copied out of the graph's
+    buffers, so the returned frame is the caller's.
     """
     B = rays.shape[0]
     results = {}
@@ -116,8 +119,12 @@ def render_frame(models, embeddings, rays, ts, max_t, N_samples, N_importance, c
         for per_ray in ("view_dir", "t_embedded", "a_embedded"):
             if per_ray in kw and kw[per_ray] is not None:
                 kw[per_ray] = kw[per_ray][i:i + chunk]
-        out = render_rays(models, embeddings, rays[i:i + chunk], None if ts is None else ts[i:i + chunk],
-                          max_t, N_samples, 0, 0, N_importance, chunk, test_time=True, **kw)
+        if graph is not None:
+            out = graph(rays[i:i + chunk], None if ts is None else ts[i:i + chunk])
+            out = {k: v.clone() for k, v in out.items() if keys is None or k in keys}    # (the graph owns its outputs)
+        else:
+            out = render_rays(models, embeddings, rays[i:i + chunk], None if ts is None else ts[i:i + chunk],
+                              max_t, N_samples, 0, 0, N_importance, chunk, test_time=True, **kw)
         kept = {k: v for k, v in out.items() if keys is None or k in keys}
         if host is not None:
             done = torch.cuda.Event()
