@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      20
+#define NSFF_ABI_VERSION      21
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -501,6 +501,16 @@ int nsff_prof_collect(int64_t* launches, double* total_ms, double* total_flops, 
  * milliseconds: clock [GHz] = shader_ticks / ticks_ms * 1e-6 (0 / 0 when nothing was measured, e.g. exact-fp32 launches). */
 int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_flops, double* executed_flops,
                             double* shader_ticks, double* ticks_ms);
+
+/* Which kernel the LAST nsff_field_query of this process launched (diagnostics; tests assert that large inference launches run
+ * the hand-scheduled body and not a fallback): */
+#define NSFF_KERNEL_F32       1   /* nsff_field_kernel: exact fp32 MFMA                                               */
+#define NSFF_KERNEL_H3_64     2   /* f16x3, 64-point tiles (launches below 32768 points, tile_points = 64)           */
+#define NSFF_KERNEL_H3_8WAVE  3   /* f16x3, 128-point tiles, eight waves of 32 neurons, compiler-scheduled           */
+#define NSFF_KERNEL_H3A       4   /* f16x3, 128-point tiles, hand-scheduled body (nsff_field_kernel_h3a)             */
+#define NSFF_KERNEL_H3_SAVE   5   /* f16x3 training forward (keeps activations)                                      */
+#define NSFF_KERNEL_F16_FAST  6   /* single-product fast mode                                                        */
+int         nsff_last_field_kernel(void);
 
 int         nsff_abi_version(void);
 const char* nsff_last_hip_error(void);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 20
+ABI_VERSION = 21
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -131,6 +131,7 @@ class FlowGradArgs(C.Structure):
 # name -> (restype, argtypes); also the list of symbols the header declares
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
+    "nsff_last_field_kernel": (C.c_int, []),
     "nsff_last_hip_error": (C.c_char_p, []),
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
     "nsff_param_count": (C.c_int, [C.POINTER(ModelDesc)]),
@@ -574,6 +575,14 @@ def mpi_composite(H, W, S, dt, accum_fw, accum_bw, static_rgb, static_alpha, zs,
                 static_rgb=_ptr(static_rgb), static_alpha=_ptr(static_alpha), zs=_ptr(zs), rgb=_ptr(rgb),
                 depth=_ptr(depth))
     _check(load().nsff_mpi_composite(C.byref(a), _stream()), "nsff_mpi_composite")
+
+
+KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast"}
+
+
+def last_field_kernel():
+    """name of the kernel the last field_query of this process launched (include/nsff_render.h: NSFF_KERNEL_*)"""
+    return KERNEL_NAMES[load().nsff_last_field_kernel()]
 
 
 def prof_enable(on):

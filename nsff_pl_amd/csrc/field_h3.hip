@@ -1612,6 +1612,10 @@ int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, vo
     return nsff_launch_status();
 }
 
+// which kernel the last f16 / f16x3 launch of this process took (nsff_last_field_kernel: tests assert that large inference
+// launches really run the hand-scheduled body instead of silently falling back)
+int g_nsff_last_h3_kernel = 0;
+
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
                         int points_per_block, hipStream_t st, unsigned long long* span) {
     const NsffModelDesc& d = *desc;
@@ -1710,12 +1714,16 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     if (points_per_block == NSFF_H3_FAST) {       // "f16": one product per MAC, 128-point tiles, two workgroups per CU
         if (saves) return NSFF_ERR_INVALID;
         lrc = launch(nsff_field_kernel_h3<4, 1, false, 2, false>, 128, 256);
+        g_nsff_last_h3_kernel = NSFF_KERNEL_F16_FAST;
     } else if (saves && points_per_block == 64) { // training forward, 64-point tiling (A/B against the default below)
         lrc = launch(nsff_field_kernel_h3<2, 1, true>, 64, 256);
+        g_nsff_last_h3_kernel = NSFF_KERNEL_H3_SAVE;
     } else if (saves) {                           // training forward: 128 points, eight waves of 32 neurons
         lrc = launch(nsff_field_kernel_h3<4, 1, true, 1>, 128, 512);
+        g_nsff_last_h3_kernel = NSFF_KERNEL_H3_SAVE;
     } else if (points_per_block == 64) {
         lrc = launch(nsff_field_kernel_h3<2, 1>, 64, 256);
+        g_nsff_last_h3_kernel = NSFF_KERNEL_H3_64;
     } else {
         // 128 points per workgroup.  Default: the hand-scheduled body (nsff_field_kernel_h3a) whenever the launch's trunks have a
         // structure it executes (raw positions, a 64-column position embedding, a time code of at most 64 columns in float4
@@ -1740,8 +1748,10 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             ka.k.split_trunks = both ? 1 : 0;
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)(both ? 2 * tiles : tiles)), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
+            g_nsff_last_h3_kernel = NSFF_KERNEL_H3A;
         } else {                                  // eight waves of 32 neurons (half the weight stream of the 64-point tiling)
             lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
+            g_nsff_last_h3_kernel = NSFF_KERNEL_H3_8WAVE;
         }
     }
     if (lrc != NSFF_OK) return lrc;

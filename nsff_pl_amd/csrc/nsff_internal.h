@@ -18,3 +18,4 @@ int nsff_fold_rows_f32(const NsffModelDesc* desc, const float* const* params, fl
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
                         int points_per_block, hipStream_t st, unsigned long long* span = nullptr);
 
+extern int g_nsff_last_h3_kernel;

@@ -362,6 +362,28 @@ def test_c2_full_size_properties(hip_lib):
     print("C2 subset vs reference, worst keys:", sorted(worst.items(), key=lambda kv: -kv[1])[:6])
 
 
+def test_large_inference_launches_run_the_hand_scheduled_kernel(hip_lib, precision):
+    """No silent fallback: a C2-sized f16x3 call (every launch >= 32768 points, no view-direction branch) must take
+    nsff_field_kernel_h3a by default and with tile_points = 130, the eight-wave kernel with 131, the 64-point tiling below the
+    size threshold, and the activation-saving kernel when gradients are wanted."""
+    if not precision.startswith("f16x3"):
+        pytest.skip("f16x3 kernels only")
+    cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024)
+    rays, ts = scenes.synthetic_rays(1024, 42)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    kw = scenes.render_kwargs(cfg)
+    want = {"f16x3": "h3a", "f16x3-130": "h3a", "f16x3-131": "h3_8wave"}[precision]
+    with torch.no_grad():
+        A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)
+    assert _lib.last_field_kernel() == want
+    with torch.no_grad():
+        A.render_rays(models, emb, rays[:16].to(DEV), ts[:16].to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)
+    assert _lib.last_field_kernel() == ("h3_64" if precision == "f16x3" else want)
+    A.render_rays(models, emb, rays[:256].to(DEV), ts[:256].to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)   # autograd on
+    assert _lib.last_field_kernel() == "h3_save"
+
+
 def test_ragged_and_empty_batches(hip_lib):
     cfg = dict(scenes.CASES["g4_nsff_test"])
     models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
