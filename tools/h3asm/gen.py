@@ -524,6 +524,10 @@ def prologue():
     %[tpa0/1] %[tpb0/1] v32 (time-code row pointers)."""
     o = []
     e = o.append
+    if "align64" in EXP:
+        e(raw(".p2align 6"))
+    if "shift4" in EXP:
+        e(raw(".p2align 6")); e(raw("s_nop 0"))
     if TIMING:
         e(raw("s_mov_b64 s[76:77], %[dbg]")); e(raw("s_memtime s[74:75]"))
     e(in_s(S_PK, "pk")); e(in_s(S_PH, "phases")); e(in_s(S_LDS, "lds")); e(in_s(S_BIASLDS, "biaslds"))
