@@ -10,3 +10,6 @@ cat gpurun_out/r04_$TAG/rocm_smi_load.txt | grep -iE "power|sclk|mclk" | head
 bash profiles/collect_r04.sh $TAG stats pmc > gpurun_out/r04_$TAG/collect.log 2>&1
 python profiles/summarize_r03.py gpurun_out/r04_$TAG > gpurun_out/r04_$TAG/pmc_summary.txt 2>&1
 head -60 gpurun_out/r04_$TAG/pmc_summary.txt
+# what travels back must stay small (64 MiB limit): keep the summaries and the stats tables, drop the raw traces / counter dumps
+cp gpurun_out/r04_$TAG/bench_stats/bench_kernel_stats.csv gpurun_out/r04_$TAG/bench_kernel_stats.csv
+rm -rf gpurun_out/r04_$TAG/bench_pmc gpurun_out/r04_$TAG/fast_pmc gpurun_out/r04_$TAG/fast_stats gpurun_out/r04_$TAG/bench_stats
