@@ -511,6 +511,13 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
 #define NSFF_KERNEL_H3_SAVE   5   /* f16x3 training forward (keeps activations)                                      */
 #define NSFF_KERNEL_F16_FAST  6   /* single-product fast mode                                                        */
 int         nsff_last_field_kernel(void);
+/* Host-only (no GPU work): the f16x3 step program of an inference launch with these modes -- steps[n][4] = {weight segment
+ * offset (words), bias offset (words; 0xFFFFFFFF = accumulate), nks | pre << 8 | post << 16 | head << 24, 0} -- and the phase
+ * programs (8-dword descriptors, 36 at most per trunk) the hand-scheduled kernel would execute for its static / dynamic trunk;
+ * n_phases[t] = 0 when trunk t is absent or not covered by that kernel.  Used by the tests that pin the host-side program
+ * builder to the one the simulator runs (tools/h3asm/check.py).  steps: room for 28 x 4, phases_*: room for 36 x 8.       */
+int         nsff_h3a_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
+                             int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases);
 
 int         nsff_abi_version(void);
 const char* nsff_last_hip_error(void);

@@ -132,6 +132,8 @@ class FlowGradArgs(C.Structure):
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
     "nsff_last_field_kernel": (C.c_int, []),
+    "nsff_h3a_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "nsff_last_hip_error": (C.c_char_p, []),
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
     "nsff_param_count": (C.c_int, [C.POINTER(ModelDesc)]),
@@ -583,6 +585,23 @@ KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_s
 def last_field_kernel():
     """name of the kernel the last field_query of this process launched (include/nsff_render.h: NSFF_KERNEL_*)"""
     return KERNEL_NAMES[load().nsff_last_field_kernel()]
+
+
+def h3a_program(model, static_mode, transient_mode):
+    """(steps, n_static_steps, phases_static, phases_dynamic) of an f16x3 inference launch, from the host-side builders alone
+    (no GPU): steps = [(w_off_words, bias_off_words or None, nks, pre, post, head)], phases_* = [[8 dwords]] or []."""
+    desc = model_desc(model)
+    steps = (C.c_uint32 * (28 * 4))()
+    ps, pd = (C.c_uint32 * (36 * 8))(), (C.c_uint32 * (36 * 8))()
+    n, ns, nph = C.c_int(0), C.c_int(0), (C.c_int * 2)()
+    _check(load().nsff_h3a_program(C.byref(desc), int(static_mode), int(transient_mode), steps, C.byref(n), C.byref(ns), ps, pd, nph),
+           "nsff_h3a_program")
+    out = []
+    for i in range(n.value):
+        w, b, packed = steps[4 * i], steps[4 * i + 1], steps[4 * i + 2]
+        out.append((w, None if b == 0xFFFFFFFF else b, packed & 0xFF, (packed >> 8) & 0xFF, (packed >> 16) & 0xFF, packed >> 24))
+    rows = lambda arr, k: [[int(arr[8 * i + j]) for j in range(8)] for i in range(k)]
+    return out, ns.value, rows(ps, nph[0]), rows(pd, nph[1])
 
 
 def prof_enable(on):

@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 // implementation of this function, which the simulator runs).  Returns false when the trunk's structure is not one the body
 // executes -- the caller then launches the compiler-scheduled kernel instead.
 static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, H3APhase* ph, uint32_t* bias_off, int& n_bias,
-                              int& head) {
+                              int& head, int* n_phases = nullptr) {
     struct Seg { uint32_t off; int nks, bias; bool relu, rebuild; };
     Seg segs[MAX_STEPS];
     int n = 0;
@@ -1345,8 +1345,10 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, H3
         if (!ok) return false;
     }
     if (!pending_b) return false;
-    return put(H3A_BODY_EPI_B, 0u, 0, 16, segs[0], segs[0]) && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]) &&
-           put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]);
+    const bool done = put(H3A_BODY_EPI_B, 0u, 0, 16, segs[0], segs[0]) && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]) &&
+                      put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]);
+    if (n_phases) *n_phases = np;
+    return done;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1612,6 +1614,103 @@ int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, vo
     return nsff_launch_status();
 }
 
+// Step program of a launch (reference nerf.py:162-208): fills k.steps / k.n_steps / k.n_static_steps from the layout k.L.
+// fold: an inference launch (nothing saved for a backward pass).
+static int h3_step_program(const NsffModelDesc& d, int static_mode, int transient_mode, bool fold, H3KArgs& k) {
+    int n = 0;
+    auto push = [&](uint32_t w, uint32_t b, uint32_t kcols, int pre, int post, int head, int slot = -1) {
+        H3Step& s = k.steps[n++];
+        s.w_off = w; s.bias_off = b; s.nks = (uint16_t)(kcols / 16);
+        s.pre = (uint8_t)pre; s.post = (uint8_t)post; s.head = (uint8_t)head;
+        s.save = (uint8_t)(slot + 1);
+    };
+    // activation slots of the training forward: trunk layer l -> slot0 + l, *_final -> slot0 + D
+    auto trunk = [&](const NsffTrunkLayoutH3& T, int pre_kind, int last_head, int slot0) {
+        for (int l = 0; l < d.D; ++l) {
+            const int head = (l == d.D - 1) ? last_head : HEAD_NONE;
+            if (l == 0) {
+                push(T.seg_x[0], T.bias[0], T.k0, pre_kind, POST_RELU, HEAD_NONE, slot0);
+            } else if ((nsff_skip_layers(&d) >> l) & 1u) {
+                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
+                push(T.seg_x[l], NSFF_NONE, T.k0, pre_kind, POST_RELU, head, slot0 + l);
+            } else {
+                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_RELU, head, slot0 + l);
+            }
+        }
+    };
+    // Inference launches (nothing saved for a backward pass) never execute the activation-free *_xyz_encoding_final
+    // layers: the heads that read them are evaluated on the last trunk activation with pre-multiplied rows (NsffLayoutH3).
+    if (static_mode == 2 && fold && !d.use_viewdir) {
+        trunk(k.L.st, PRE_INPUT, HEAD_S_FOLD, 0);
+    } else if (static_mode == 2 && fold) {               // view directions: *_final folded into static_dir_encoding
+        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
+        push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
+        push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
+    } else if (static_mode) {
+        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
+        if (static_mode == 2) {
+            push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB, d.D);
+            if (d.use_viewdir) {
+                push(k.L.dir_h, k.L.dir_b, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
+                push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
+            }
+        }
+    }
+    k.n_static_steps = n;
+    if (transient_mode && fold) {
+        trunk(k.L.tr, PRE_INPUT_T, HEAD_T_FOLD, d.D + 1);
+    } else if (transient_mode) {
+        trunk(k.L.tr, PRE_INPUT_T, HEAD_NONE, d.D + 1);
+        push(k.L.tr.final_w, k.L.tr.final_b, NSFF_W, PRE_NONE, POST_LINEAR, HEAD_T, 2 * d.D + 1);
+    }
+    if (n > MAX_STEPS) return NSFF_ERR_INVALID;
+    k.n_steps = n;
+    return NSFF_OK;
+}
+
+// Host-only export of what a launch would execute (no GPU work): the step program and, when the hand-scheduled body covers the
+// launch's trunks, its phase programs -- tests pin h3a_build_program to the builder the simulator runs (tools/h3asm/check.py).
+// steps: [n][4] = {w_off (words), bias_off (words, NSFF_NONE = accumulate), nks | pre << 8 | post << 16 | head << 24, 0};
+// phases_static / phases_dynamic: [H3A_MAX_PHASES][8] descriptors; n_phases[2] = descriptors written (0 = trunk absent or
+// not covered).
+extern "C" int nsff_h3a_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
+                                int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases) {
+    if (!desc || !steps || !n_steps || !n_static_steps || !phases_static || !phases_dynamic || !n_phases) return NSFF_ERR_NULL;
+    H3KArgs k{};
+    int rc = nsff_make_layout_h3(*desc, k.L);
+    if (rc) return rc;
+    rc = h3_step_program(*desc, static_mode, transient_mode, true, k);
+    if (rc) return rc;
+    for (int i = 0; i < k.n_steps; ++i) {
+        const H3Step& st = k.steps[i];
+        steps[4 * i + 0] = st.w_off; steps[4 * i + 1] = st.bias_off;
+        steps[4 * i + 2] = (uint32_t)st.nks | ((uint32_t)st.pre << 8) | ((uint32_t)st.post << 16) | ((uint32_t)st.head << 24);
+        steps[4 * i + 3] = 0;
+    }
+    *n_steps = k.n_steps; *n_static_steps = k.n_static_steps;
+    n_phases[0] = n_phases[1] = 0;
+    H3APhase ph[H3A_MAX_PHASES];
+    uint32_t boff[H3A_MAX_BIAS];
+    int nb = 0, head = 0;
+    if (k.n_static_steps > 0 && !(static_mode == 2 && desc->use_viewdir)) {
+        for (auto& p : ph) for (auto& x : p.d) x = 0;
+        int np = 0;
+        if (h3a_build_program(k, 0, k.n_static_steps, false, ph, boff, nb, head, &np)) {
+            n_phases[0] = np;
+            for (int i = 0; i < n_phases[0]; ++i) for (int j = 0; j < 8; ++j) phases_static[8 * i + j] = ph[i].d[j];
+        }
+    }
+    if (k.n_steps > k.n_static_steps) {
+        for (auto& p : ph) for (auto& x : p.d) x = 0;
+        int np = 0;
+        if (h3a_build_program(k, k.n_static_steps, k.n_steps, true, ph, boff, nb, head, &np)) {
+            n_phases[1] = np;
+            for (int i = 0; i < n_phases[1]; ++i) for (int j = 0; j < 8; ++j) phases_dynamic[8 * i + j] = ph[i].d[j];
+        }
+    }
+    return NSFF_OK;
+}
+
 // which kernel the last f16 / f16x3 launch of this process took (nsff_last_field_kernel: tests assert that large inference
 // launches really run the hand-scheduled body instead of silently falling back)
 int g_nsff_last_h3_kernel = 0;
@@ -1648,56 +1747,12 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         if (g.freqs[i + 1] != 2.0f * g.freqs[i]) k.octave_freqs = 0;
     k.ld_emb = g.ld_emb; k.off_xyz = g.off_xyz; k.off_dir = g.off_dir; k.off_a = g.off_a; k.off_t = g.off_t;
 
-    // ---- step program (reference nerf.py:162-208) ----
-    int n = 0;
-    auto push = [&](uint32_t w, uint32_t b, uint32_t kcols, int pre, int post, int head, int slot = -1) {
-        H3Step& s = k.steps[n++];
-        s.w_off = w; s.bias_off = b; s.nks = (uint16_t)(kcols / 16);
-        s.pre = (uint8_t)pre; s.post = (uint8_t)post; s.head = (uint8_t)head;
-        s.save = (uint8_t)(slot + 1);
-    };
-    // activation slots of the training forward: trunk layer l -> slot0 + l, *_final -> slot0 + D
-    auto trunk = [&](const NsffTrunkLayoutH3& T, int pre_kind, int last_head, int slot0) {
-        for (int l = 0; l < d.D; ++l) {
-            const int head = (l == d.D - 1) ? last_head : HEAD_NONE;
-            if (l == 0) {
-                push(T.seg_x[0], T.bias[0], T.k0, pre_kind, POST_RELU, HEAD_NONE, slot0);
-            } else if ((nsff_skip_layers(&d) >> l) & 1u) {
-                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
-                push(T.seg_x[l], NSFF_NONE, T.k0, pre_kind, POST_RELU, head, slot0 + l);
-            } else {
-                push(T.seg_h[l], T.bias[l], NSFF_W, PRE_NONE, POST_RELU, head, slot0 + l);
-            }
-        }
-    };
-    // Inference launches (nothing saved for a backward pass) never execute the activation-free *_xyz_encoding_final
-    // layers: the heads that read them are evaluated on the last trunk activation with pre-multiplied rows (NsffLayoutH3).
     const bool fold = !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
-    if (g.static_mode == 2 && fold && !d.use_viewdir) {
-        trunk(k.L.st, PRE_INPUT, HEAD_S_FOLD, 0);
-    } else if (g.static_mode == 2 && fold) {               // view directions: *_final folded into static_dir_encoding
-        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
-        push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
-        push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
-    } else if (g.static_mode) {
-        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
-        if (g.static_mode == 2) {
-            push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB, d.D);
-            if (d.use_viewdir) {
-                push(k.L.dir_h, k.L.dir_b, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
-                push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
-            }
-        }
+    {
+        const int prc = h3_step_program(d, g.static_mode, g.transient_mode, fold, k);
+        if (prc != NSFF_OK) return prc;
     }
-    k.n_static_steps = n;
-    if (g.transient_mode && fold) {
-        trunk(k.L.tr, PRE_INPUT_T, HEAD_T_FOLD, d.D + 1);
-    } else if (g.transient_mode) {
-        trunk(k.L.tr, PRE_INPUT_T, HEAD_NONE, d.D + 1);
-        push(k.L.tr.final_w, k.L.tr.final_b, NSFF_W, PRE_NONE, POST_LINEAR, HEAD_T, 2 * d.D + 1);
-    }
-    if (n > MAX_STEPS) return NSFF_ERR_INVALID;
-    k.n_steps = n;
+    const int n = k.n_steps;
 
     // one trunk per workgroup when the launch evaluates both (see the kernel): grid = 2 x tiles
     const bool both = n > k.n_static_steps && k.n_static_steps > 0;

@@ -56,3 +56,50 @@ def test_simulator_notices_a_missing_wait(monkeypatch):
     monkeypatch.setattr(gen.Stream, "need_lds", lambda self, tag: None if tag[0] == "xl" else orig(self, tag))
     with pytest.raises(isa.SimError, match="outstanding"):
         check.run_case("static", verbose=False)
+
+
+# ---- the C++ host-side program builder (csrc/field_h3.hip: h3_step_program + h3a_build_program) against the Python builder the
+# simulator runs (check.build_program), through the host-only C-ABI nsff_h3a_program: no GPU involved
+ARCHS = [(8, [4], 10, 48), (8, [2, 5], 10, 48), (4, [], 10, 48), (2, [], 6, 16), (2, [1], 10, 64), (6, [1, 2, 3, 4, 5], 4, 32),
+         (8, [7], 10, 48), (8, [1, 3, 5, 7], 10, 36)]
+
+
+@pytest.mark.parametrize("arch", range(len(ARCHS)))
+def test_cxx_phase_program_equals_the_simulated_builder(arch):
+    import torch
+    import nsff_pl_amd as A
+    from nsff_pl_amd import _lib
+    D, skips, n_freqs, n_tau = ARCHS[arch]
+    torch.manual_seed(0)
+    m = A.NeRF("fine", D=D, skips=skips, in_channels_xyz=3 + 6 * n_freqs, use_viewdir=False, encode_transient=True,
+               in_channels_t=n_tau, output_flow=True)
+    for sm, tm in ((2, 2), (1, 1), (2, 0), (0, 2)):
+        steps, n_static, ph_s, ph_d = _lib.h3a_program(m, sm, tm)
+        assert (len(ph_s) > 0) == (sm > 0) and (len(ph_d) > 0) == (tm > 0)
+        for lo, hi, got, in_t in ((0, n_static, ph_s, 0), (n_static, len(steps), ph_d, n_tau)):
+            if hi == lo:
+                continue
+            segs, nb = [], 0
+            for i, (w, b, nks, pre, post, head) in enumerate(steps[lo:hi]):
+                segs.append(dict(nks=nks, off=4 * w, bias=None if b is None else nb, post="relu" if post == 1 else "none",
+                                 rebuild=i > 0 and pre != 0))
+                nb += b is not None
+            want = [list(map(int, r)) for r in check.build_program(segs, in_t)]
+            assert len(want) == len(got)
+            B = gen.BODY
+            uses_streams = {B["B16R"], B["B16X"], B["B4"], B["B8"], B["A4F"], B["A8F"]}        # (+ descriptor 0: the pre-issue)
+            for i, (w_, g_) in enumerate(zip(want, got)):
+                n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else 3       # body, flags, bias row; stream fields where they are read
+                assert w_[:n_cmp] == g_[:n_cmp], (ARCHS[arch], sm, tm, i, w_, g_)
+
+
+def test_compiled_kernel_audit():
+    """512 registers, no scratch, no spilled VGPRs, one body statement, and no compiler use of accumulation registers between the
+    pre-issue statement and the body (the weight loads are in flight there)"""
+    import shutil
+    import subprocess
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "h3asm", "audit.py"), os.path.join(ROOT, "nsff_pl_amd", "csrc", "field_h3.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
