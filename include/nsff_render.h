@@ -516,7 +516,7 @@ int         nsff_last_field_kernel(void);
  * programs (8-dword descriptors, 36 at most per trunk) the hand-scheduled kernel would execute for its static / dynamic trunk;
  * n_phases[t] = 0 when trunk t is absent or not covered by that kernel.  Used by the tests that pin the host-side program
  * builder to the one the simulator runs (tools/h3asm/check.py).  steps: room for 28 x 4, phases_*: room for 36 x 8.       */
-int         nsff_h3a_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
+int         nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
                              int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases);
 
 int         nsff_abi_version(void);

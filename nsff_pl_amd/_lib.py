@@ -132,7 +132,7 @@ class FlowGradArgs(C.Structure):
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
     "nsff_last_field_kernel": (C.c_int, []),
-    "nsff_h3a_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
+    "nsff_field_phase_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "nsff_last_hip_error": (C.c_char_p, []),
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
@@ -594,8 +594,8 @@ def h3a_program(model, static_mode, transient_mode):
     steps = (C.c_uint32 * (28 * 4))()
     ps, pd = (C.c_uint32 * (36 * 8))(), (C.c_uint32 * (36 * 8))()
     n, ns, nph = C.c_int(0), C.c_int(0), (C.c_int * 2)()
-    _check(load().nsff_h3a_program(C.byref(desc), int(static_mode), int(transient_mode), steps, C.byref(n), C.byref(ns), ps, pd, nph),
-           "nsff_h3a_program")
+    _check(load().nsff_field_phase_program(C.byref(desc), int(static_mode), int(transient_mode), steps, C.byref(n), C.byref(ns), ps, pd, nph),
+           "nsff_field_phase_program")
     out = []
     for i in range(n.value):
         w, b, packed = steps[4 * i], steps[4 * i + 1], steps[4 * i + 2]

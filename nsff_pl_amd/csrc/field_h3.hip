@@ -1673,7 +1673,7 @@ static int h3_step_program(const NsffModelDesc& d, int static_mode, int transien
 // steps: [n][4] = {w_off (words), bias_off (words, NSFF_NONE = accumulate), nks | pre << 8 | post << 16 | head << 24, 0};
 // phases_static / phases_dynamic: [H3A_MAX_PHASES][8] descriptors; n_phases[2] = descriptors written (0 = trunk absent or
 // not covered).
-extern "C" int nsff_h3a_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
+extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
                                 int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases) {
     if (!desc || !steps || !n_steps || !n_static_steps || !phases_static || !phases_dynamic || !n_phases) return NSFF_ERR_NULL;
     H3KArgs k{};

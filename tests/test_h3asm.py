@@ -59,7 +59,7 @@ def test_simulator_notices_a_missing_wait(monkeypatch):
 
 
 # ---- the C++ host-side program builder (csrc/field_h3.hip: h3_step_program + h3a_build_program) against the Python builder the
-# simulator runs (check.build_program), through the host-only C-ABI nsff_h3a_program: no GPU involved
+# simulator runs (check.build_program), through the host-only C-ABI nsff_field_phase_program: no GPU involved
 ARCHS = [(8, [4], 10, 48), (8, [2, 5], 10, 48), (4, [], 10, 48), (2, [], 6, 16), (2, [1], 10, 64), (6, [1, 2, 3, 4, 5], 4, 32),
          (8, [7], 10, 48), (8, [1, 3, 5, 7], 10, 36)]
 
