@@ -1784,21 +1784,36 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         // structure it executes (raw positions, a 64-column position embedding, a time code of at most 64 columns in float4
         // rows, no view-direction branch in this launch); otherwise -- and with points_per_block == 131 -- the
         // compiler-scheduled eight-wave form.
-        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 && !(g.static_mode == 2 && d.use_viewdir);
+        // A launch whose STATIC trunk has the view-direction branch (not covered) next to a dynamic trunk is issued as two
+        // launches: the static workgroups on the eight-wave kernel, the dynamic ones on the hand-scheduled kernel -- each
+        // writes its own part of the raw records (piece 1 / piece 2), as the workgroups of one split launch do.
+        const bool static_uncovered = g.static_mode == 2 && d.use_viewdir;
+        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 && !(static_uncovered && !g.transient_mode);
         if (asm_body && g.transient_mode)
             asm_body = k.L.kt == 64 && (d.in_t & 3) == 0 && ((uintptr_t)g.t_emb & 15) == 0;
         H3AArgs ka{};
         if (asm_body) {
             ka.k = k;
             ka.n_bias[0] = ka.n_bias[1] = 0; ka.head[0] = ka.head[1] = HEAD_NONE;
-            if (k.n_static_steps > 0)
+            if (k.n_static_steps > 0 && !static_uncovered)
                 asm_body = h3a_build_program(k, 0, k.n_static_steps, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0]);
             if (asm_body && n > k.n_static_steps)
                 asm_body = h3a_build_program(k, k.n_static_steps, n, true, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
         }
-        if (asm_body) {
-            const long long tiles = (g.n_points + 127) / 128;
-            if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        const long long tiles = (g.n_points + 127) / 128;
+        if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        if (asm_body && static_uncovered) {
+            // (1) static trunk: the first half of a split launch's grid = static workgroups only
+            k.grid_tiles = tiles;
+            k.split_trunks = 1;
+            hipLaunchKernelGGL((nsff_field_kernel_h3<4, 1, false, 1>), dim3((unsigned)tiles), dim3(512), 0, st, k);
+            // (2) dynamic trunk: a split launch whose static half is empty (grid_tiles = 0: every workgroup is a dynamic one)
+            ka.k.grid_tiles = 0;
+            ka.k.split_trunks = 1;
+            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)tiles), dim3(256), 0, st, ka);
+            lrc = NSFF_OK;
+            g_nsff_last_h3_kernel = NSFF_KERNEL_H3A;
+        } else if (asm_body) {
             ka.k.grid_tiles = tiles;
             ka.k.split_trunks = both ? 1 : 0;
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)(both ? 2 * tiles : tiles)), dim3(256), 0, st, ka);

@@ -89,3 +89,41 @@ def test_trunks_the_body_does_not_cover_take_the_eight_wave_kernel(hip_lib):
     t_rows = torch.randn(9, 48, generator=g).to(DEV)
     _, kern = _query(m, P, S, 2, 2, 2, xyz, [float(f) for f in emb.freqs], t_rows, 130)
     assert kern == "h3_8wave"
+
+
+def test_view_direction_model_runs_as_two_launches(hip_lib):
+    """A launch with a view-direction static trunk (not covered by the hand-scheduled body) next to a dynamic trunk: the static
+    workgroups take the eight-wave kernel, the dynamic ones the hand-scheduled kernel, each writing its part of the records --
+    the records equal those of the all-eight-wave launch (static part bit for bit, dynamic part to 2e-5)."""
+    torch.manual_seed(11)
+    emb, emb_d = A.PosEmbedding(9, 10), A.PosEmbedding(3, 4)
+    m = A.NeRF("fine", use_viewdir=True, encode_appearance=True, in_channels_a=48, encode_transient=True, output_flow=True)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(".weight"):
+                p.mul_(2.5)
+    m.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    S, n_rays = 128, 11
+    P = S * n_rays
+    xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
+    t_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
+    a_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
+    dirs = emb_d(torch.randn(n_rays, 3, generator=g)).to(DEV).contiguous()
+    freqs = [float(f) for f in emb.freqs]
+    out = {}
+    for tile in (130, 131):
+        config.set_precision("f16x3"); config.set_tile_points(tile)
+        raw = torch.empty(P, _lib.RAW_STRIDE, device=DEV)
+        try:
+            _lib.field_query(m, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows, dir_emb=dirs, a_emb=a_rows)
+            torch.cuda.synchronize()
+            out[tile] = (raw.cpu().numpy(), _lib.last_field_kernel())
+        finally:
+            config.set_tile_points(0)
+    (a, ka), (b, kb) = out[130], out[131]
+    assert ka == "h3a" and kb == "h3_8wave"
+    assert np.array_equal(a[:, 0:4], b[:, 0:4])                                   # static part: the same kernel in both
+    for lo, hi in ((4, 8), (8, 14)):
+        assert np.abs(a[:, lo:hi] - b[:, lo:hi]).max() <= 2e-5 * np.abs(b[:, lo:hi]).max()
+    assert np.abs(b[:, 4:14]).max() > 0
