@@ -109,7 +109,7 @@ def test_view_direction_model_runs_as_two_launches(hip_lib):
     xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
     t_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
     a_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
-    dirs = emb_d(torch.randn(n_rays, 3, generator=g)).to(DEV).contiguous()
+    dirs = emb_d(torch.randn(n_rays, 3, generator=g).to(DEV)).contiguous()
     freqs = [float(f) for f in emb.freqs]
     out = {}
     for tile in (130, 131):
