@@ -3,10 +3,10 @@
 TAG=${1:-p}
 mkdir -p gpurun_out/r04_$TAG
 rocm-smi --showpower --showmaxpower --showclocks --showperflevel > gpurun_out/r04_$TAG/rocm_smi_idle.txt 2>&1
-( python bench.py --steps 400 --warmup 3 --no-cpu-baseline --no-aux > gpurun_out/r04_$TAG/bench_long.json 2>/dev/null & 
-  sleep 45; rocm-smi --showpower --showclocks > gpurun_out/r04_$TAG/rocm_smi_load.txt 2>&1; wait )
-tail -c 600 gpurun_out/r04_$TAG/bench_long.json; echo
-cat gpurun_out/r04_$TAG/rocm_smi_load.txt | grep -iE "power|sclk|mclk" | head
+# the command the stats pass below profiles, un-profiled on the same box (the pair the roofline's avg_launch_ms is checked against)
+python bench.py --no-cpu-baseline --no-aux > gpurun_out/r04_$TAG/bench_same_command.json 2>/dev/null
+python bench.py --steps 400 --warmup 3 --no-cpu-baseline --no-aux > gpurun_out/r04_$TAG/bench_long.json 2>/dev/null
+tail -c 400 gpurun_out/r04_$TAG/bench_same_command.json; echo
 bash profiles/collect_r04.sh $TAG stats pmc > gpurun_out/r04_$TAG/collect.log 2>&1
 python profiles/summarize_r03.py gpurun_out/r04_$TAG > gpurun_out/r04_$TAG/pmc_summary.txt 2>&1
 head -60 gpurun_out/r04_$TAG/pmc_summary.txt
