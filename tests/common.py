@@ -62,16 +62,23 @@ def oracle_render(cfg, models, emb, rays, ts, draws=None, dataset=None, zs_fine_
         zs_fine_override=zs_fine_override)
 
 
+# The two keys that cannot hold 1e-4 on two scenes, with the error MEASURED on the MI355X (tools/debug/chained_key_errors.py:
+# worst over fp32 / f16x3, every kernel, saving and inference launches, at the reference's depths; gpurun_out/r04_chained.txt) and
+# the bound asserted = 2 x that.  They are the cycle points x + fw(x) + bw(x + fw(x)): a second MLP pass at a position that already
+# carries fp32 rounding, through sin(2^9 x) (2^11 on g18).  Every other chained key (rgb_fw / rgb_bw, disocc*, ...) holds 1e-4 on
+# every scene, and these two hold it on every other scene (6.3e-5 on g3, < 5e-5 on the C2 subset g19).
+MEASURED_ABOVE_1E4 = {
+    ("gain3", "xyzs_fw_bw"): 6.71e-4, ("gain3", "xyzs_bw_fw"): 6.66e-4,          # g3b: weights x 3, sigma up to 33
+    ("emb11", "xyzs_bw_fw"): 1.45e-4, ("emb11", "xyzs_fw_bw"): 1.05e-4,          # g18: 12-frequency embedding (2^11 x)
+}
+
+
 def key_rtol(key, cfg):
-    """1e-4 everywhere; chained re-query keys (a second MLP pass at x + flow: the highest embedding frequency amplifies the
-    fp32 rounding of the first pass) get 2e-3 on the gain-3 stress scene and 4e-4 where the position embedding reaches 2^11
-    instead of the default 2^9 (four times the amplification; measured 1.05e-4 on the 12-frequency scene g18)."""
+    """1e-4 for every key of every scene, except the per-key measured bounds above (2 x the measurement)."""
     import parity
-    if key in CHAINED_KEYS and cfg["gain"] > 2.5:
-        return 2e-3
-    if key in CHAINED_KEYS and cfg.get("xyz_emb", (9, 10))[0] > 9:
-        return 4e-4
-    return parity.RTOL
+    scene = "gain3" if cfg["gain"] > 2.5 else ("emb11" if cfg.get("xyz_emb", (9, 10))[0] > 9 else None)
+    m = MEASURED_ABOVE_1E4.get((scene, key))
+    return parity.RTOL if m is None else 2 * m
 
 
 def fine_sample_tolerances(cfg, coarse, u_s, u_t):
