@@ -229,6 +229,7 @@ class Bench:
 
 
 LAST_STEP_EVENTS = []        # sorted per-step HIP-event milliseconds of the most recent timed() on this rank
+LAST_HOST_ISSUE_MS = [None]  # host milliseconds per step spent ISSUING the most recent timed() loop (before any synchronize)
 
 
 def median_step_ms():
@@ -273,6 +274,7 @@ def timed(step, steps, warmup, world, device, prof=False, bench=None):
         if gpu:
             marks[i].record()
         step()
+    LAST_HOST_ISSUE_MS[0] = (time.perf_counter() - t0) / max(steps, 1) * 1e3
     if bench is not None:
         bench.finish()                          # the last step's overlapped pixel gather joins inside the timed region
     if gpu:
@@ -551,6 +553,7 @@ def main():
         torch.cuda.synchronize()
     elapsed, kern, per_rank = timed(step, args.steps, args.warmup, world, device, prof=not args.standin, bench=bench)
     median_ms = median_step_ms()               # (of the headline's steps: the aux block below times other things)
+    host_issue_ms = LAST_HOST_ISSUE_MS[0]
 
     aux = None
     if rank == 0 and world == 1 and args.workload == "render" and not args.no_aux and not args.standin:
@@ -563,6 +566,8 @@ def main():
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_median_events": median_ms,
+            # host time per step to ISSUE the launches (no synchronize inside): close to ms_per_step = the host is the limit
+            "host_issue_ms_per_step": host_issue_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
             "config": {"workload": "C2 (BASELINE.json configs[1]): static+dynamic NSFF, 1024 rays/GPU x (64 coarse + "

@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      21
+#define NSFF_ABI_VERSION      22
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -163,10 +163,36 @@ typedef struct NsffFieldArgs {
     void*   save_xin;
     void*   save_masks;
     void*   save_side;
+    /* inference (F16X3, input A), optional: the time code's part of the dynamic trunk's input layers, computed once per ray by
+     * nsff_time_bias from the same t_emb rows: (n_rays, t_bias_rows, 256) fp32.  With it -- and pts_per_ray a multiple of 64 --
+     * the hand-scheduled kernel multiplies no time-code column (8 of a dynamic trunk's 128 k-steps); results agree with the
+     * plain launch to fp32 rounding.  t_emb must be given either way (it is what every other kernel variant reads). */
+    const float* t_bias;
+    int32_t t_bias_rows;     /* nsff_time_bias_rows(desc), or 0                     */
+    int32_t reserved0;
 } NsffFieldArgs;
 
 int nsff_field_query(const NsffModelDesc* desc, const void* packed,
                      const NsffFieldArgs* args, void* stream);
+
+/* ---- a2/a3: what the time code contributes to the dynamic trunk, once per RAY instead of once per point.  Every sample of a
+ * ray shares its time code (reference rendering.py:153,168,221,227 repeat it), so for layer 0 and the skip layers -- the layers
+ * whose input holds [xyz | t] (nerf.py:163-167) -- the product of the time-code columns is a per-ray vector:
+ *     out[ray][i][n] = b_l[n] + sum_j W_l[n][in_xyz + j] * t_rows[ray][j],   l = 0, then the skip layers in ascending order
+ * (i = 0 .. nsff_time_bias_rows(desc) - 1), in fp32.  nsff_field_query takes the result as NsffFieldArgs::t_bias.
+ * Up to NSFF_MAX_TIME_BIAS_JOBS (model, time rows) pairs per launch: a render_rays call needs the coarse model at t and the fine
+ * model at t, t + 1, t - 1.  w[i] / b[i]: weight (256, in_xyz + in_t [+ 256 for a skip layer]) and bias (256) of
+ * transient_xyz_encoding_{l_i + 1}, the parameters themselves (PyTorch Linear layout, no pack needed). */
+#define NSFF_MAX_TIME_BIAS_JOBS 4
+typedef struct NsffTimeBiasJob {
+    const NsffModelDesc* desc;
+    const float* w[NSFF_MAX_LAYERS];
+    const float* b[NSFF_MAX_LAYERS];
+    const float* t_rows;     /* (n_rays, in_t)                                      */
+    float* out;              /* (n_rays, nsff_time_bias_rows(desc), 256)            */
+} NsffTimeBiasJob;
+int nsff_time_bias_rows(const NsffModelDesc* desc);      /* 0: the model has no dynamic trunk */
+int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64_t n_rays, void* stream);
 
 /* ---- N1: backward of the field query (training).  Mixed precision: fp16 MFMA operands, fp32 accumulation;
  * every point's gradient row is normalised by its own power of two (block floating point), weight-gradient
@@ -510,14 +536,17 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
 #define NSFF_KERNEL_H3A       4   /* f16x3, 128-point tiles, hand-scheduled body (nsff_field_kernel_h3a)             */
 #define NSFF_KERNEL_H3_SAVE   5   /* f16x3 training forward (keeps activations)                                      */
 #define NSFF_KERNEL_F16_FAST  6   /* single-product fast mode                                                        */
+#define NSFF_KERNEL_H3A_TBIAS 7   /* NSFF_KERNEL_H3A with the time code folded into per-ray bias rows (NsffFieldArgs::t_bias) */
 int         nsff_last_field_kernel(void);
 /* Host-only (no GPU work): the f16x3 step program of an inference launch with these modes -- steps[n][4] = {weight segment
  * offset (words), bias offset (words; 0xFFFFFFFF = accumulate), nks | pre << 8 | post << 16 | head << 24, 0} -- and the phase
  * programs (8-dword descriptors, 36 at most per trunk) the hand-scheduled kernel would execute for its static / dynamic trunk;
  * n_phases[t] = 0 when trunk t is absent or not covered by that kernel.  Used by the tests that pin the host-side program
- * builder to the one the simulator runs (tools/h3asm/check.py).  steps: room for 28 x 4, phases_*: room for 36 x 8.       */
-int         nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
-                             int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases);
+ * builder to the one the simulator runs (tools/h3asm/check.py).  steps: room for 28 x 4, phases_*: room for 36 x 8.
+ * fold_t != 0: the dynamic trunk's program of a launch that was given NsffFieldArgs::t_bias (bias fields of its descriptors
+ * then index a table whose per-ray rows follow the plain ones: half A's row replaces the layer's bias row, half B's is appended). */
+int         nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, int fold_t, uint32_t* steps,
+                             int* n_steps, int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases);
 
 int         nsff_abi_version(void);
 const char* nsff_last_hip_error(void);

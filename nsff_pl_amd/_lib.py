@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 21
+ABI_VERSION = 22
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -44,7 +44,14 @@ class FieldArgs(C.Structure):
                 ("x_emb", _fp), ("ld_emb", C.c_int32),
                 ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
                 ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp), ("save_masks", _fp),
-                ("save_side", _fp)]
+                ("save_side", _fp), ("t_bias", _fp), ("t_bias_rows", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class TimeBiasJob(C.Structure):
+    _fields_ = [("desc", C.POINTER(ModelDesc)), ("w", _fp * 8), ("b", _fp * 8), ("t_rows", _fp), ("out", _fp)]
+
+
+MAX_TIME_BIAS_JOBS = 4
 
 
 _COMPOSITE_PTRS_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "xyz_fw", "xyz_bw",
@@ -132,8 +139,10 @@ class FlowGradArgs(C.Structure):
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
     "nsff_last_field_kernel": (C.c_int, []),
-    "nsff_field_phase_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "nsff_field_phase_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "nsff_time_bias_rows": (C.c_int, [C.POINTER(ModelDesc)]),
+    "nsff_time_bias": (C.c_int, [C.POINTER(TimeBiasJob), C.c_int32, C.c_int64, C.c_void_p]),
     "nsff_last_hip_error": (C.c_char_p, []),
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
     "nsff_param_count": (C.c_int, [C.POINTER(ModelDesc)]),
@@ -333,7 +342,7 @@ def posenc(x, freqs, out):
 def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
                 xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
                 x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, save_masks=None, save_side=None,
-                precision=None):
+                precision=None, t_bias=None):
     from . import config
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
@@ -361,7 +370,43 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     a.save_xin = None if save_xin is None else save_xin.data_ptr()
     a.save_masks = None if save_masks is None else save_masks.data_ptr()
     a.save_side = None if save_side is None else save_side.data_ptr()
+    if t_bias is not None:                      # (n_rays, rows, 256) from time_bias(): the time code's part of the input layers
+        a.t_bias, a.t_bias_rows = _ptr(t_bias), int(t_bias.shape[1])
     _check(load().nsff_field_query(C.byref(desc), _ptr(packed), C.byref(a), _stream()), "nsff_field_query")
+
+
+def time_bias_rows(model):
+    """rows per ray of time_bias() for this model (0: no dynamic trunk)"""
+    return load().nsff_time_bias_rows(C.byref(model_desc(model)))
+
+
+def time_bias(jobs):
+    """jobs: [(model, t_rows (n_rays, in_t))] (at most MAX_TIME_BIAS_JOBS, one n_rays) -> [(n_rays, rows, 256) fp32]: per ray,
+    bias + time-code columns' product of the dynamic trunk's layer 0 and skip layers (nsff_time_bias: ONE launch for all
+    jobs); field_query(..., t_bias=) then multiplies no time-code column."""
+    assert 1 <= len(jobs) <= MAX_TIME_BIAS_JOBS
+    arr = (TimeBiasJob * len(jobs))()
+    keep, outs, per_model = [], [], {}
+    n_rays = int(jobs[0][1].shape[0])
+    for j, (model, t_rows) in enumerate(jobs):
+        if id(model) not in per_model:
+            desc = model_desc(model)
+            lins = [getattr(model, f"transient_xyz_encoding_{l + 1}")[0] for l in [0] + sorted(set(int(v) for v in model.skips))]
+            wb = [(m.weight.detach(), m.bias.detach()) for m in lins]
+            for w, b in wb:
+                _ptr(w), _ptr(b)                # (contiguous fp32 GPU tensors, or an assertion)
+            per_model[id(model)] = (desc, C.pointer(desc), wb)
+        desc, pdesc, wb = per_model[id(model)]
+        assert t_rows.shape == (n_rays, desc.in_t)
+        out = torch.empty(n_rays, len(wb), 256, device=t_rows.device, dtype=torch.float32)
+        arr[j].desc = pdesc
+        for i, (w, b) in enumerate(wb):
+            arr[j].w[i], arr[j].b[i] = w.data_ptr(), b.data_ptr()
+        arr[j].t_rows, arr[j].out = _ptr(t_rows), _ptr(out)
+        outs.append(out)
+    keep.append(per_model)
+    _check(load().nsff_time_bias(arr, len(jobs), n_rays, _stream()), "nsff_time_bias")
+    return outs
 
 
 def coarse_samples(rays, z_lin, perturb, perturb_rand, zs, xyz):
@@ -579,7 +624,7 @@ def mpi_composite(H, W, S, dt, accum_fw, accum_bw, static_rgb, static_alpha, zs,
     _check(load().nsff_mpi_composite(C.byref(a), _stream()), "nsff_mpi_composite")
 
 
-KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast"}
+KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast", 7: "h3a_tb"}
 
 
 def last_field_kernel():
@@ -587,14 +632,15 @@ def last_field_kernel():
     return KERNEL_NAMES[load().nsff_last_field_kernel()]
 
 
-def h3a_program(model, static_mode, transient_mode):
+def h3a_program(model, static_mode, transient_mode, fold_t=False):
     """(steps, n_static_steps, phases_static, phases_dynamic) of an f16x3 inference launch, from the host-side builders alone
-    (no GPU): steps = [(w_off_words, bias_off_words or None, nks, pre, post, head)], phases_* = [[8 dwords]] or []."""
+    (no GPU): steps = [(w_off_words, bias_off_words or None, nks, pre, post, head)], phases_* = [[8 dwords]] or [].
+    fold_t: the dynamic trunk's program of a launch that is given t_bias (time code folded into per-ray bias rows)."""
     desc = model_desc(model)
     steps = (C.c_uint32 * (28 * 4))()
     ps, pd = (C.c_uint32 * (36 * 8))(), (C.c_uint32 * (36 * 8))()
     n, ns, nph = C.c_int(0), C.c_int(0), (C.c_int * 2)()
-    _check(load().nsff_field_phase_program(C.byref(desc), int(static_mode), int(transient_mode), steps, C.byref(n), C.byref(ns), ps, pd, nph),
+    _check(load().nsff_field_phase_program(C.byref(desc), int(static_mode), int(transient_mode), int(fold_t), steps, C.byref(n), C.byref(ns), ps, pd, nph),
            "nsff_field_phase_program")
     out = []
     for i in range(n.value):

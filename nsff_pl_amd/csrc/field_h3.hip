@@ -95,6 +95,8 @@ struct H3KArgs {
     const float* dir_emb;
     const float* a_emb;
     const float* t_emb;
+    const float* t_bias;       // (rays, tb_rows, 256) fp32: bias + time-code part of the dynamic trunk's input layers (nsff_time_bias), or null
+    int tb_rows;
     float* raw;
     // training forward (SAVE variant), all fragment-major so that the weight-gradient GEMM streams them:
     _Float16* save_acts;       // (slots, tiles, 4 ks, 256 rows, 16 pts) fp16 post-activation values, or null
@@ -1138,12 +1140,13 @@ __device__ __forceinline__ void h3a_heads(const H3AHeadW& hw, const _Float16* sX
 #else
 #include "field_h3a_body.inc"
 #endif
-constexpr int H3A_MAX_PHASES = 36, H3A_MAX_BIAS = 12;
+constexpr int H3A_MAX_PHASES = 36, H3A_MAX_BIAS = 16;
+constexpr uint32_t H3A_TB_ROW = 0x80000000u, H3A_TB_HALF_B = 0x100u;    // bias_off entry: row (entry & 0xff) of the per-ray table, of the ray of half A / B
 struct H3APhase { uint32_t d[8]; };     // body, flags, bias table offset, n1, r1 offset / wave stride, r2 offset / wave stride (bytes)
 struct H3AArgs {
     H3KArgs k;
     H3APhase ph[2][H3A_MAX_PHASES];     // [static trunk, dynamic trunk]
-    uint32_t bias_off[2][H3A_MAX_BIAS]; // packed word offset of bias table row i
+    uint32_t bias_off[2][H3A_MAX_BIAS]; // packed word offset of bias table row i, or H3A_TB_ROW | [H3A_TB_HALF_B] | row of H3KArgs::t_bias
     int n_bias[2];
     int head[2];                        // HEAD_* evaluated on the trunk's last activation
 };
@@ -1180,8 +1183,21 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
         if (bp < a.n_points) { px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2]; }
     }
     // bias table of this trunk (fp32 rows of 256): the body initialises its accumulators from it with ds_read_b128
-    for (int i = threadIdx.x; i < aa.n_bias[tr] * NSFF_W; i += THREADS)
-        sBias[i] = reinterpret_cast<const float*>(pk)[aa.bias_off[tr][i >> 8] + (i & 255)];
+    // (dynamic trunk with the time code folded in: the rows of its input layers are per ray -- every 64-point half of the tile
+    // lies inside one ray, the host checked pts_per_ray % 64 == 0 -- and the body never sees a time-code column)
+    const bool tb = tr == 1 && a.t_bias != nullptr;
+    long long tb_ray[2] = {0, 0};
+    if (tb) {
+        const long long last = a.n_points - 1;
+        tb_ray[0] = (p0 < last ? p0 : last) / a.pts_per_ray;
+        tb_ray[1] = (p0 + 64 < last ? p0 + 64 : last) / a.pts_per_ray;
+    }
+    for (int i = threadIdx.x; i < aa.n_bias[tr] * NSFF_W; i += THREADS) {
+        const uint32_t off = aa.bias_off[tr][i >> 8];
+        const float* src = reinterpret_cast<const float*>(pk) + off;
+        if (off & H3A_TB_ROW) src = a.t_bias + (tb_ray[(off & H3A_TB_HALF_B) ? 1 : 0] * a.tb_rows + (off & 0xffu)) * NSFF_W;
+        sBias[i] = src[i & 255];
+    }
     H3A_TSTAMP(52);
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));      // (the point has landed: no compiler wait behind the statement below)
     H3A_TSTAMP(53);
@@ -1196,11 +1212,11 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
                      : H3A_PRE_CLOBBERS);
     }
     H3A_TSTAMP(57);
-    build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1, px, threadIdx.x);
+    build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
     const float* tpa = reinterpret_cast<const float*>(pk);
     const float* tpb = tpa;
-    if (tr == 1) {
+    if (tr == 1 && !tb) {
         const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
         const long long last = a.n_points - 1;
         const long long pa = p0 + row < last ? p0 + row : last, pb = p0 + 64 + row < last ? p0 + 64 + row : last;
@@ -1215,7 +1231,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
                                           offsetof(H3AArgs, ph) + (size_t)tr * sizeof(aa.ph[0]);
         const unsigned long long pkb = (unsigned long long)(uintptr_t)pk;
         const unsigned lds = (unsigned)(uintptr_t)sX, biaslds = (unsigned)(uintptr_t)sBias;
-        const unsigned in_t = tr == 1 ? (unsigned)a.in_t : 0u;
+        const unsigned in_t = (tr == 1 && !tb) ? (unsigned)a.in_t : 0u;
         const unsigned tpa0 = (unsigned)((uintptr_t)tpa), tpa1 = (unsigned)((uintptr_t)tpa >> 32);
         const unsigned tpb0 = (unsigned)((uintptr_t)tpb), tpb1 = (unsigned)((uintptr_t)tpb >> 32);
         const unsigned tid = threadIdx.x;
@@ -1269,9 +1285,12 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 // Phase program of one trunk = steps [s0, s1) of the step program (see tools/h3asm/check.py::build_program, the reference
 // implementation of this function, which the simulator runs).  Returns false when the trunk's structure is not one the body
 // executes -- the caller then launches the compiler-scheduled kernel instead.
-static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, H3APhase* ph, uint32_t* bias_off, int& n_bias,
-                              int& head, int* n_phases = nullptr) {
-    struct Seg { uint32_t off; int nks, bias; bool relu, rebuild; };
+// fold_t (dynamic trunk, H3KArgs::t_bias given): the time-code part of every input segment is not executed -- its product is in
+// the per-ray rows of the bias table (H3A_TB_ROW entries: one row per half for the layer's first segment) -- so an input
+// segment runs its position part only (k0s / 16 of its k-steps; the waves' blocks of the packed segment keep their stride).
+static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bool fold_t, H3APhase* ph, uint32_t* bias_off,
+                              int& n_bias, int& head, int* n_phases = nullptr) {
+    struct Seg { uint32_t off, stride; int nks, bias, bias_b; bool relu, rebuild; };
     Seg segs[MAX_STEPS];
     int n = 0;
     n_bias = 0;
@@ -1287,27 +1306,46 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, H3
         }
         Seg& g = segs[n++];
         g.off = st.w_off * 4u; g.nks = st.nks; g.relu = st.post == POST_RELU;
+        g.stride = (uint32_t)st.nks * 4096u;
         g.rebuild = i > s0 && st.pre != PRE_NONE;
-        g.bias = -1;
+        g.bias = g.bias_b = -1;
         if (st.bias_off != NSFF_NONE) {
             if (n_bias >= H3A_MAX_BIAS) return false;
-            g.bias = n_bias;
+            g.bias = g.bias_b = n_bias;
             bias_off[n_bias++] = st.bias_off;
         }
         if (i == s0 && st.pre == PRE_NONE) return false;
     }
     if (n == 0 || head == HEAD_NONE) return false;
     if (segs[0].nks == 16 || !segs[0].relu || segs[0].bias < 0) return false;
+    if (fold_t) {
+        if (!dynamic) return false;
+        int row = 0;
+        for (int t = 0; t < n; ++t) {
+            if (segs[t].nks == 16) continue;
+            if (segs[t].nks * 16 != (int)(k.L.k0s + k.L.kt)) return false;
+            segs[t].nks = (int)k.L.k0s / 16;
+            Seg& first = segs[t == 0 ? 0 : t - 1];          // (a skip layer's 256-wide segment precedes its input segment and carries the bias)
+            if (first.bias < 0 || first.bias != first.bias_b || n_bias >= H3A_MAX_BIAS) return false;
+            bias_off[first.bias] = H3A_TB_ROW | (uint32_t)row;
+            first.bias_b = n_bias;
+            bias_off[n_bias++] = H3A_TB_ROW | H3A_TB_HALF_B | (uint32_t)row;
+            ++row;
+        }
+        if (row != k.tb_rows) return false;
+    }
     int np = 0;
     auto put = [&](uint32_t body, uint32_t flags, int bias, int n1, const Seg& r1, const Seg& r2) {
         if (np >= H3A_MAX_PHASES) return false;
         H3APhase& p = ph[np++];
         p.d[0] = body; p.d[1] = flags; p.d[2] = 1024u * (uint32_t)(bias < 0 ? 0 : bias); p.d[3] = (uint32_t)n1;
-        p.d[4] = r1.off; p.d[5] = (uint32_t)r1.nks * 4096u; p.d[6] = r2.off; p.d[7] = (uint32_t)r2.nks * 4096u;
+        p.d[4] = r1.off; p.d[5] = r1.stride; p.d[6] = r2.off; p.d[7] = r2.stride;
         return true;
     };
-    const uint32_t rb = H3A_F_REBUILD | (dynamic ? H3A_F_REBUILD_T : 0u);
-    if (!put(H3A_BODY_END, H3A_F_INIT, segs[0].bias, segs[0].nks, segs[0], n > 1 ? segs[1] : segs[0])) return false;
+    const uint32_t rb = H3A_F_REBUILD | ((dynamic && !fold_t) ? H3A_F_REBUILD_T : 0u);
+    // descriptor 0 (the body's prologue): acc_A := row `bias`, acc_B := the row (flags >> 16) bytes behind it
+    if (!put(H3A_BODY_END, H3A_F_INIT | ((1024u * (uint32_t)(segs[0].bias_b - segs[0].bias)) << 16), segs[0].bias, segs[0].nks, segs[0],
+             n > 1 ? segs[1] : segs[0])) return false;
     bool pending_b = false;
     for (int t = 0; t < n; ++t) {
         const Seg& g = segs[t];
@@ -1322,7 +1360,7 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, H3
         bool ok = true;
         if (g.nks == 16) {
             if (t == 0 || !pending_b) return false;
-            ok = ok && put(H3A_BODY_A16R, g.bias >= 0 ? H3A_F_INIT : 0u, g.bias, 16, g, g);
+            ok = ok && put(H3A_BODY_A16R, g.bias >= 0 ? H3A_F_INIT : 0u, g.bias_b, 16, g, g);   // (an A phase's tail initialises acc_B)
             if (g.relu) {
                 ok = ok && put(nxt ? H3A_BODY_B16R : H3A_BODY_B16L, init_next, nbias, n1, r1, r2);   // (the last segment requests nothing)
                 pending_b = true;
@@ -1673,8 +1711,8 @@ static int h3_step_program(const NsffModelDesc& d, int static_mode, int transien
 // steps: [n][4] = {w_off (words), bias_off (words, NSFF_NONE = accumulate), nks | pre << 8 | post << 16 | head << 24, 0};
 // phases_static / phases_dynamic: [H3A_MAX_PHASES][8] descriptors; n_phases[2] = descriptors written (0 = trunk absent or
 // not covered).
-extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, uint32_t* steps, int* n_steps,
-                                int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases) {
+extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, int fold_t, uint32_t* steps,
+                                int* n_steps, int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases) {
     if (!desc || !steps || !n_steps || !n_static_steps || !phases_static || !phases_dynamic || !n_phases) return NSFF_ERR_NULL;
     H3KArgs k{};
     int rc = nsff_make_layout_h3(*desc, k.L);
@@ -1695,7 +1733,7 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
     if (k.n_static_steps > 0 && !(static_mode == 2 && desc->use_viewdir)) {
         for (auto& p : ph) for (auto& x : p.d) x = 0;
         int np = 0;
-        if (h3a_build_program(k, 0, k.n_static_steps, false, ph, boff, nb, head, &np)) {
+        if (h3a_build_program(k, 0, k.n_static_steps, false, false, ph, boff, nb, head, &np)) {
             n_phases[0] = np;
             for (int i = 0; i < n_phases[0]; ++i) for (int j = 0; j < 8; ++j) phases_static[8 * i + j] = ph[i].d[j];
         }
@@ -1703,12 +1741,118 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
     if (k.n_steps > k.n_static_steps) {
         for (auto& p : ph) for (auto& x : p.d) x = 0;
         int np = 0;
-        if (h3a_build_program(k, k.n_static_steps, k.n_steps, true, ph, boff, nb, head, &np)) {
+        k.tb_rows = fold_t ? nsff_time_bias_rows(desc) : 0;
+        if (h3a_build_program(k, k.n_static_steps, k.n_steps, true, fold_t != 0, ph, boff, nb, head, &np)) {
             n_phases[1] = np;
             for (int i = 0; i < n_phases[1]; ++i) for (int j = 0; j < 8; ++j) phases_dynamic[8 * i + j] = ph[i].d[j];
         }
     }
     return NSFF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nsff_time_bias: per-ray rows  b_l + W_l[:, in_xyz : in_xyz + in_t] t  of the dynamic trunk's input layers (see the header).
+// One thread per neuron, sixteen rays per workgroup; weights and time codes are staged in LDS.  ~75 MFLOP per C2 call -- its cost is the launch.
+namespace {
+struct TimeBiasJobK { const float* w[NSFF_MAX_LAYERS]; const float* b[NSFF_MAX_LAYERS]; int ld[NSFF_MAX_LAYERS];
+                      const float* t_rows; float* out; int rows, in_xyz, in_t; };
+struct TimeBiasArgs { TimeBiasJobK job[NSFF_MAX_TIME_BIAS_JOBS]; long long n_rays; };
+constexpr int TB_RAYS = 16;
+__global__ __launch_bounds__(256) void nsff_time_bias_kernel(const TimeBiasArgs a) {
+    const TimeBiasJobK& j = a.job[blockIdx.z];
+    const int i = blockIdx.y, n = threadIdx.x;
+    if (i >= j.rows) return;
+    const long long r0 = (long long)blockIdx.x * TB_RAYS;
+    __shared__ __attribute__((aligned(16))) float st[TB_RAYS][64];     // the workgroup's time codes, zero-padded (in_t <= 64: the layout check)
+    // the layer's time-code columns go through LDS sixteen at a time: consecutive lanes read consecutive floats of a row (a row's
+    // slice starts at an odd offset of a (256, ld) matrix: one lane per row would touch 64 cache lines per load), the tile is
+    // stored column-major with a one-float pad (conflict-free both ways).  Every global load of the workgroup is requested up
+    // front -- the kernel is one memory latency long, not one per stage.
+    __shared__ float sw[16][NSFF_W + 1];
+    const float* __restrict__ wl = j.w[i] + j.in_xyz;
+    const int ld = j.ld[i], in_t = j.in_t;
+    float tv[TB_RAYS / 4], wv[4][16];
+#pragma unroll
+    for (int k = 0; k < TB_RAYS / 4; ++k) {
+        const int e = threadIdx.x + 256 * k, r = e >> 6, c = e & 63;
+        const long long ray = r0 + r < a.n_rays ? r0 + r : a.n_rays - 1;
+        tv[k] = c < in_t ? j.t_rows[ray * in_t + c] : 0.f;
+    }
+    const float b = j.b[i][n];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = threadIdx.x + 256 * k, row = e >> 4, c = 16 * q + (e & 15);
+            wv[q][k] = c < in_t ? wl[row * ld + c] : 0.f;
+        }
+#pragma unroll
+    for (int k = 0; k < TB_RAYS / 4; ++k) { const int e = threadIdx.x + 256 * k; st[e >> 6][e & 63] = tv[k]; }
+    float acc[TB_RAYS];
+#pragma unroll
+    for (int r = 0; r < TB_RAYS; ++r) acc[r] = b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (16 * q >= in_t) break;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int e = threadIdx.x + 256 * k; sw[e & 15][e >> 4] = wv[q][k]; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {               // (columns in ascending order: one fixed summation order per output)
+            const float w0 = sw[u][n], w1 = sw[u + 1][n], w2 = sw[u + 2][n], w3 = sw[u + 3][n];
+#pragma unroll
+            for (int r = 0; r < TB_RAYS; ++r) {         // (the time codes are wave-uniform: one 16-byte broadcast read per four columns)
+                const float4 t4 = *reinterpret_cast<const float4*>(&st[r][16 * q + u]);
+                acc[r] = fmaf(w3, t4.w, fmaf(w2, t4.z, fmaf(w1, t4.y, fmaf(w0, t4.x, acc[r]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TB_RAYS; ++r)
+        if (r0 + r < a.n_rays) j.out[((r0 + r) * j.rows + i) * NSFF_W + n] = acc[r];
+}
+}  // namespace
+
+extern "C" int nsff_time_bias_rows(const NsffModelDesc* desc) {
+    if (!desc || !desc->has_transient || desc->in_t < 1) return 0;
+    return 1 + __builtin_popcount(nsff_skip_layers(desc));
+}
+
+extern "C" int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64_t n_rays, void* stream) {
+    if (!jobs) return NSFF_ERR_NULL;
+    if (n_jobs < 1 || n_jobs > NSFF_MAX_TIME_BIAS_JOBS || n_rays < 0) return NSFF_ERR_INVALID;
+    if (n_rays == 0) return NSFF_OK;
+    TimeBiasArgs a{};
+    a.n_rays = n_rays;
+    int max_rows = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const NsffTimeBiasJob& jb = jobs[q];
+        if (!jb.desc || !jb.t_rows || !jb.out) return NSFF_ERR_NULL;
+        const NsffModelDesc& d = *jb.desc;
+        NsffLayoutH3 L;
+        const int rc = nsff_make_layout_h3(d, L);
+        if (rc) return rc;
+        TimeBiasJobK& k = a.job[q];
+        k.rows = nsff_time_bias_rows(&d);
+        if (k.rows < 1) return NSFF_ERR_INVALID;
+        k.in_xyz = d.in_xyz; k.in_t = d.in_t; k.t_rows = jb.t_rows; k.out = jb.out;
+        const uint32_t skips = nsff_skip_layers(&d);
+        int i = 0;
+        for (int l = 0; l < d.D; ++l) {
+            if (l != 0 && !((skips >> l) & 1u)) continue;
+            k.w[i] = jb.w[i]; k.b[i] = jb.b[i];
+            if (!k.w[i] || !k.b[i]) return NSFF_ERR_NULL;
+            k.ld[i] = d.in_xyz + d.in_t + (l ? NSFF_W : 0);
+            ++i;
+        }
+        max_rows = std::max(max_rows, k.rows);
+    }
+    const long long gx = (n_rays + TB_RAYS - 1) / TB_RAYS;
+    if (gx > 0x7fffffffLL) return NSFF_ERR_INVALID;
+    hipLaunchKernelGGL(nsff_time_bias_kernel, dim3((unsigned)gx, (unsigned)max_rows, (unsigned)n_jobs), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    return nsff_launch_status();
 }
 
 // which kernel the last f16 / f16x3 launch of this process took (nsff_last_field_kernel: tests assert that large inference
@@ -1796,9 +1940,21 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             ka.k = k;
             ka.n_bias[0] = ka.n_bias[1] = 0; ka.head[0] = ka.head[1] = HEAD_NONE;
             if (k.n_static_steps > 0 && !static_uncovered)
-                asm_body = h3a_build_program(k, 0, k.n_static_steps, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0]);
-            if (asm_body && n > k.n_static_steps)
-                asm_body = h3a_build_program(k, k.n_static_steps, n, true, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
+                asm_body = h3a_build_program(k, 0, k.n_static_steps, false, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0]);
+            if (asm_body && n > k.n_static_steps) {
+                // the time code as per-ray bias rows (nsff_time_bias): whenever the caller supplied them and a 64-point half
+                // never straddles two rays; otherwise the body multiplies the time-code columns like any other input
+                bool fold_t = g.t_bias != nullptr && g.pts_per_ray > 0 && g.pts_per_ray % 64 == 0 &&
+                              g.t_bias_rows == nsff_time_bias_rows(desc);
+                if (fold_t) {
+                    ka.k.t_bias = g.t_bias; ka.k.tb_rows = g.t_bias_rows;
+                    fold_t = h3a_build_program(ka.k, k.n_static_steps, n, true, true, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
+                }
+                if (!fold_t) {
+                    ka.k.t_bias = nullptr; ka.k.tb_rows = 0;
+                    asm_body = h3a_build_program(k, k.n_static_steps, n, true, false, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
+                }
+            }
         }
         const long long tiles = (g.n_points + 127) / 128;
         if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
@@ -1812,13 +1968,13 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             ka.k.split_trunks = 1;
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)tiles), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
-            g_nsff_last_h3_kernel = NSFF_KERNEL_H3A;
+            g_nsff_last_h3_kernel = ka.k.t_bias ? NSFF_KERNEL_H3A_TBIAS : NSFF_KERNEL_H3A;
         } else if (asm_body) {
             ka.k.grid_tiles = tiles;
             ka.k.split_trunks = both ? 1 : 0;
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)(both ? 2 * tiles : tiles)), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
-            g_nsff_last_h3_kernel = NSFF_KERNEL_H3A;
+            g_nsff_last_h3_kernel = ka.k.t_bias ? NSFF_KERNEL_H3A_TBIAS : NSFF_KERNEL_H3A;
         } else {                                  // eight waves of 32 neurons (half the weight stream of the 64-point tiling)
             lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
             g_nsff_last_h3_kernel = NSFF_KERNEL_H3_8WAVE;

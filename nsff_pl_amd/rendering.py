@@ -57,7 +57,7 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
 class _Pass:
     """Inputs shared by the coarse and the fine pass of one render_rays call."""
     __slots__ = ("embeddings", "rays", "ts", "max_t", "noise_std", "test_time", "kwargs",
-                 "freqs_xyz", "dir_embedded", "n_rays", "rec")
+                 "freqs_xyz", "dir_embedded", "n_rays", "rec", "tbias", "neighbour_rows")
 
 
 def _embed_rows(embeddings, key, idx):
@@ -88,6 +88,41 @@ def _neighbour_time_rows(embeddings, ts, max_t):
             _embed_rows(embeddings, 't', torch.clamp(ts - 1, min=0)))
 
 
+def _plan_time_bias(ctx, models, t_embedded, N_samples, N_importance, output_transient, flows):
+    """The time code enters the dynamic trunk at layer 0 and at the skip layers, and every sample of a ray shares it
+    (rendering.py:153,168,221,227 repeat the row): its product with those layers' time-code columns is computed here once per
+    RAY -- one launch for every (model, time rows) pair of this call -- and handed to the field launches as bias rows
+    (`_lib.time_bias`); the hand-scheduled f16x3 kernel then multiplies no time-code column.  Fills ctx.tbias[(typ, which)],
+    which in 't' | 'fw' | 'bw', for the launches that can use it (inference in f16x3, 128-point tiles, samples per ray a
+    multiple of 64); the others run as before."""
+    ctx.tbias, ctx.neighbour_rows = {}, None
+    n_rays = ctx.n_rays
+    if (not output_transient or t_embedded is None or ctx.rec is not None or n_rays == 0
+            or config.get_precision() != "f16x3" or config.get_tile_points() not in (0, 130)):
+        return
+    passes = []
+    if N_importance > 0:
+        passes.append(('coarse', N_samples))
+        passes.append(('fine', N_samples + 2 * N_importance))
+    else:
+        passes.append(('fine', N_samples))
+    jobs, tags = [], []
+    for typ, S in passes:
+        model = models[typ]
+        if not model.encode_transient or S % 64 or (n_rays * S < 32768 and config.get_tile_points() == 0):
+            continue
+        if t_embedded.shape != (n_rays, model.in_channels_t):
+            continue
+        jobs.append((model, t_embedded)); tags.append((typ, 't'))
+        if typ == 'fine' and flows and not ctx.test_time and hasattr(model, "transient_flow_fw"):
+            ctx.neighbour_rows = _neighbour_time_rows(ctx.embeddings, ctx.ts, ctx.max_t)
+            jobs.append((model, ctx.neighbour_rows[0])); tags.append((typ, 'fw'))
+            jobs.append((model, ctx.neighbour_rows[1])); tags.append((typ, 'bw'))
+    if jobs:
+        for tag, out in zip(tags, _lib.time_bias(jobs)):
+            ctx.tbias[tag] = out
+
+
 def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
                t_embedded, a_embedded):
     """One model pass: field query, optional flow-warp re-queries, compositing.
@@ -112,7 +147,7 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
     side = dict(dir_emb=ctx.dir_embedded if model.use_viewdir and not sigma_only else None,
                 a_emb=a_embedded if (model.use_viewdir and model.in_channels_a > 0 and not sigma_only) else None)
 
-    def query(tag, raw_out, pts, static_mode, transient_mode, flow_heads, t_rows, **extra):
+    def query(tag, raw_out, pts, static_mode, transient_mode, flow_heads, t_rows, which='t', **extra):
         """One field launch.  When gradients will be taken (ctx.rec) and the configuration allows it, this launch
         already is the training forward: it keeps the activations the backward kernels need."""
         saves = {}
@@ -120,8 +155,9 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
             acts, xin, masks, side_rows = field_grad.alloc_saves(model, P, zs.device, bool(transient_mode), bool(static_mode))
             saves = dict(save_acts=acts, save_xin=xin, save_masks=masks, save_side=side_rows)
             ctx.rec.setdefault("saved", {})[tag] = (raw_out, acts, xin, masks, pts.view(-1, 3), side_rows)
+        t_bias = ctx.tbias.get((typ, which)) if (transient_mode and not saves) else None
         _lib.field_query(model, raw_out, P, S, static_mode=static_mode, transient_mode=transient_mode,
-                         flow_heads=flow_heads, xyz=pts, freqs=ctx.freqs_xyz, t_emb=t_rows, **saves, **extra)
+                         flow_heads=flow_heads, xyz=pts, freqs=ctx.freqs_xyz, t_emb=t_rows, t_bias=t_bias, **saves, **extra)
     if P:
         query(typ, raw, xyz, 1 if sigma_only else 2, 0 if not output_transient else (1 if sigma_only else 2),
               2 if want_flow else 0, t_embedded if output_transient else None, **side)
@@ -166,15 +202,15 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         xyz_bw = _new(zs, n_rays, S, 3)
         raw_fw = _new(zs, P, _lib.RAW_STRIDE)
         raw_bw = _new(zs, P, _lib.RAW_STRIDE)
-        tp1, tm1 = _neighbour_time_rows(ctx.embeddings, ts, ctx.max_t)
+        tp1, tm1 = ctx.neighbour_rows if ctx.neighbour_rows is not None else _neighbour_time_rows(ctx.embeddings, ts, ctx.max_t)
         if P:
             _lib.warp_points(raw, xyz, zs, Z_FAR, xyz_fw, xyz_bw)
-            query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1)
+            query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1, which='fw')
         noise_fw = torch.randn(n_rays, S, device=zs.device)
         out('rgb_fw', n_rays, 3)
         results['xyzs_bw'] = xyz_bw
         if P:
-            query(f"{typ}_warp_bw", raw_bw, xyz_bw, 0, 2, 1, tm1)
+            query(f"{typ}_warp_bw", raw_bw, xyz_bw, 0, 2, 1, tm1, which='bw')
         noise_bw = torch.randn(n_rays, S, device=zs.device)
         if ctx.rec is not None and nstd != 0:
             ctx.rec[f"{typ}_warp_fw"], ctx.rec[f"{typ}_warp_bw"] = noise_fw, noise_bw
@@ -271,6 +307,7 @@ def render_rays(models,
         ctx.noise_std, ctx.test_time, ctx.kwargs, ctx.n_rays = noise_std, test_time, kwargs, n_rays
         ctx.freqs_xyz = [float(f) for f in embedding_xyz.freqs]
         ctx.rec = rec
+        ctx.tbias, ctx.neighbour_rows = {}, None
         ctx.dir_embedded = None
         if any(m.use_viewdir for m in models.values()):
             view_dir = kwargs.get('view_dir', rays[:, 3:6])
@@ -291,6 +328,8 @@ def render_rays(models,
             if output_transient:
                 t_embedded = kwargs['t_embedded'] if 't_embedded' in kwargs else embeddings['t'](ts)
                 t_embedded = t_embedded.detach().contiguous().float()
+            _plan_time_bias(ctx, models, t_embedded, N_samples, N_importance, output_transient,
+                            kwargs.get('output_transient_flow', []))
             _inference(results, ctx, model, xyz_coarse, zs, output_transient, [], t_embedded, None)
 
             det = perturb == 0
@@ -334,6 +373,7 @@ def render_rays(models,
             if output_transient:
                 t_embedded = kwargs['t_embedded'] if 't_embedded' in kwargs else embeddings['t'](ts)
                 t_embedded = t_embedded.detach().contiguous().float()
+            _plan_time_bias(ctx, models, t_embedded, N_samples, 0, output_transient, kwargs.get('output_transient_flow', []))
         output_transient_flow = [] if not output_transient else kwargs.get('output_transient_flow', [])
         _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
                    t_embedded, a_embedded)

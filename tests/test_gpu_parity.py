@@ -365,7 +365,7 @@ def test_c2_full_size_properties(hip_lib, precision):
     with torch.no_grad():
         inf = _np(A.render_rays(models, emb, rd, td, 29, 64, 0, 0, 64, 32768, test_time=False, **kw, **common.fine_depths_kw(zs)))
     if precision.startswith("f16x3"):
-        assert _lib.last_field_kernel() == ("h3_8wave" if precision.endswith("131") else "h3a")
+        assert _lib.last_field_kernel() == ("h3_8wave" if precision.endswith("131") else "h3a_tb")
     for k in gold:
         parity.assert_close(k + " (inference launches)", inf[k][idx], gold[k], common.key_rtol(k, cfg))
 
@@ -381,7 +381,8 @@ def test_large_inference_launches_run_the_hand_scheduled_kernel(hip_lib, precisi
     models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
     _to_dev(models, emb)
     kw = scenes.render_kwargs(cfg)
-    want = {"f16x3": "h3a", "f16x3-130": "h3a", "f16x3-131": "h3_8wave"}[precision]
+    # (h3a_tb: the hand-scheduled kernel with the time code folded into per-ray bias rows -- 64 / 192 samples per ray)
+    want = {"f16x3": "h3a_tb", "f16x3-130": "h3a_tb", "f16x3-131": "h3_8wave"}[precision]
     with torch.no_grad():
         A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)
     assert _lib.last_field_kernel() == want

@@ -24,12 +24,12 @@ ARCHS = [  # D, skips, n_freqs, n_tau
 MODES = [(2, 2, 2), (2, 2, 0), (0, 2, 1), (1, 1, 0), (2, 0, 0), (1, 0, 0)]      # (static_mode, transient_mode, flow heads)
 
 
-def _query(m, P, S, sm, tm, fh, xyz, freqs, t_rows, tile):
+def _query(m, P, S, sm, tm, fh, xyz, freqs, t_rows, tile, t_bias=None):
     config.set_precision("f16x3")
     config.set_tile_points(tile)
     raw = torch.empty(P, _lib.RAW_STRIDE, device=DEV)
     try:
-        _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None)
+        _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, t_bias=t_bias)
         torch.cuda.synchronize()
         return raw, _lib.last_field_kernel()
     finally:
@@ -67,6 +67,23 @@ def test_hand_scheduled_kernel_equals_eight_wave_kernel(arch, hip_lib):
             scale = max(np.abs(b[:, lo:hi]).max(), 1e-30)
             err = np.abs(a[:, lo:hi] - b[:, lo:hi]).max() / scale
             assert err <= 2e-5, f"arch {ARCHS[arch]} mode {(sm, tm, fh)} P={P}: {what} columns differ by {err:.2e}"
+        if tm:
+            # the same launch with the time code folded into per-ray bias rows: taken when no 64-point half straddles two rays,
+            # silently the plain launch otherwise; the folded product is exact fp32 instead of f16x3 -- same 2e-5 contract
+            (tb,) = _lib.time_bias([(m, t_rows)])
+            w0 = getattr(m, "transient_xyz_encoding_1")[0]
+            want_tb0 = (t_rows.double() @ w0.weight.double()[:, 3 + 6 * n_freqs:].T + w0.bias.double()).float()
+            assert tb.shape == (n_rays, 1 + len(skips), 256)
+            assert (tb[:, 0] - want_tb0).abs().max().item() <= 2e-6 * want_tb0.abs().max().item()
+            got_tb, kern_tb = _query(m, P, S, sm, tm, fh, xyz, freqs, t_rows, 130, t_bias=tb)
+            assert kern_tb == ("h3a_tb" if S % 64 == 0 else "h3a"), (kern_tb, S)
+            c = got_tb.cpu().numpy()
+            for lo, hi, what in ((0, 4, "static"), (4, 8, "dynamic"), (8, 14, "flows")):
+                scale = max(np.abs(b[:, lo:hi]).max(), 1e-30)
+                err = np.abs(c[:, lo:hi] - b[:, lo:hi]).max() / scale
+                assert err <= 2e-5, f"arch {ARCHS[arch]} mode {(sm, tm, fh)} P={P} S={S}: {what} columns with t_bias differ by {err:.2e}"
+            if S % 64:
+                assert np.array_equal(c, a)
         if sm == 2 and tm == 2 and fh == 2 and not checked_oracle:
             f = orc.field_from_module(m)
             x_emb = np.concatenate([orc.pos_embedding(xyz.cpu().numpy(), np.asarray(freqs, np.float32)),

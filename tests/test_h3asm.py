@@ -45,7 +45,7 @@ def test_stream_passes_the_hazard_lint():
     assert all(i.kind != "mfma" for i in pre)
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic"])
+@pytest.mark.parametrize("kind", ["static", "dynamic", "dynamic_tb", "twoskips_tb"])
 def test_simulated_trunk_matches_numpy(kind):
     assert check.run_case(kind, verbose=False) < 2e-6
 
@@ -91,6 +91,28 @@ def test_cxx_phase_program_equals_the_simulated_builder(arch):
             for i, (w_, g_) in enumerate(zip(want, got)):
                 n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else 3       # body, flags, bias row; stream fields where they are read
                 assert w_[:n_cmp] == g_[:n_cmp], (ARCHS[arch], sm, tm, i, w_, g_)
+        if tm == 0:
+            continue
+        # the same launch with the time code folded into per-ray bias rows (NsffFieldArgs::t_bias): input segments run their
+        # position part only, the layer's first segment gets a second table row for half B
+        steps, n_static, _, ph_f = _lib.h3a_program(m, sm, tm, fold_t=True)
+        segs, nb = [], 0
+        for i, (w, b, nks, pre, post, head) in enumerate(steps[n_static:]):
+            segs.append(dict(nks=nks, off=4 * w, bias=None if b is None else nb, post="relu" if post == 1 else "none",
+                             rebuild=i > 0 and pre != 0))
+            nb += b is not None
+        for t, sg in enumerate(segs):
+            if sg["nks"] == 16:
+                continue
+            sg.update(wstride=sg["nks"] * 4096, nks=4)
+            first = segs[0 if t == 0 else t - 1]
+            first["bias_b"] = nb
+            nb += 1
+        want = [list(map(int, r)) for r in check.build_program(segs, 0)]
+        assert len(want) == len(ph_f) and nb <= 16
+        for i, (w_, g_) in enumerate(zip(want, ph_f)):
+            n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else 3
+            assert w_[:n_cmp] == g_[:n_cmp], (ARCHS[arch], sm, tm, "fold_t", i, w_, g_)
 
 
 def test_compiled_kernel_audit():

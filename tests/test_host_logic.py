@@ -56,13 +56,14 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 21
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 22
 
 
 def test_struct_layouts_match_the_header_sizes():
     # natural-alignment layout of the C structs (pointer = 8 bytes)
     assert C.sizeof(_lib.ModelDesc) == 48
-    assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 4 * _lib.MAX_FREQS + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8 and _lib.MAX_FREQS == 24
+    assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 4 * _lib.MAX_FREQS + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8 + 8 + 8 and _lib.MAX_FREQS == 24
+    assert C.sizeof(_lib.TimeBiasJob) == 8 + 64 + 64 + 16
     assert C.sizeof(_lib.FieldBwdArgs) == 16 + 8 * 8 and C.sizeof(_lib.WgradJob) == 32
     assert C.sizeof(_lib.SplatArgs) == 12 + 16 + 48 + 4 + 5 * 8 + 16 and C.sizeof(_lib.MpiArgs) == 16 + 7 * 8
     assert C.sizeof(_lib.LossArgs) == 24 + 8 + 8 + 8 * (len(_lib._LOSS_IN) + 3 + len(_lib.LOSS_GRADS))
@@ -94,6 +95,15 @@ def test_layout_and_argument_validation_without_gpu():
     a = _lib.FieldArgs()
     a.n_points, a.pts_per_ray, a.static_mode = 64, 1, 2
     assert lib.nsff_field_query(C.byref(d), None, C.byref(a), None) == -2
+    assert lib.nsff_time_bias_rows(C.byref(d)) == 2                            # layer 0 + the skip layer
+    two = _lib.model_desc(m); two.skip = 0; two.skip_mask = 0b100100
+    assert lib.nsff_time_bias_rows(C.byref(two)) == 3
+    st = _lib.model_desc(A.NeRF('coarse', use_viewdir=False, encode_transient=False))
+    assert lib.nsff_time_bias_rows(C.byref(st)) == 0
+    assert lib.nsff_time_bias(None, 1, 4, None) == -2
+    jobs = (_lib.TimeBiasJob * 1)()
+    assert lib.nsff_time_bias(jobs, 0, 4, None) == -1 and lib.nsff_time_bias(jobs, 5, 4, None) == -1
+    assert lib.nsff_time_bias(jobs, 1, 4, None) == -2                          # (null members)
     c = _lib.CompositeArgs()
     c.n_rays, c.n_samples = 4, 0
     assert lib.nsff_composite(C.byref(c), None) == -1

@@ -56,14 +56,15 @@ def pack_segment(W):
 
 def build_program(segs, in_t):
     """Phase descriptors for a trunk (the host-side builder in csrc/field_h3a.hip does the same).
-    segs: list of dict(nks, off, bias (index or None), post ('relu' | 'none'), rebuild (bool))."""
+    segs: list of dict(nks, off, bias (index or None), post ('relu' | 'none'), rebuild (bool)[, wstride (bytes between the
+    waves' blocks of the packed segment, default nks * 4096), bias_b (table row of half B, default = bias)])."""
     B = gen.BODY
     ph = []
 
     def desc(body, flags=0, bias=0, n1=16, r1=None, r2=None):
         r1 = r1 if r1 is not None else segs[0]
         r2 = r2 if r2 is not None else r1
-        return [body, flags, 1024 * bias, n1, r1["off"], r1["nks"] * 4096, r2["off"], r2["nks"] * 4096]
+        return [body, flags, 1024 * bias, n1, r1["off"], r1.get("wstride", r1["nks"] * 4096), r2["off"], r2.get("wstride", r2["nks"] * 4096)]
 
     def refill_fields(t):
         nxt = segs[t + 1] if t + 1 < len(segs) else None
@@ -75,7 +76,8 @@ def build_program(segs, in_t):
     s0 = segs[0]
     assert s0["nks"] in (4, 8) and s0["post"] == "relu" and s0["bias"] is not None
     first = dict(n1=s0["nks"], r1=s0, r2=segs[1] if len(segs) > 1 else s0)
-    ph.append(desc(0, 1 << gen.F_INIT, s0["bias"], **first))
+    # descriptor 0 initialises both halves: acc_A from row `bias`, acc_B from the row (flags >> 16) bytes behind it
+    ph.append(desc(0, (1 << gen.F_INIT) | ((1024 * (s0.get("bias_b", s0["bias"]) - s0["bias"])) << 16), s0["bias"], **first))
     pending_b = False
     for t, sg in enumerate(segs):
         nxt = segs[t + 1] if t + 1 < len(segs) else None
@@ -83,7 +85,8 @@ def build_program(segs, in_t):
         nbias = nxt["bias"] if (nxt is not None and nxt["bias"] is not None) else 0
         if sg["nks"] == 16:
             assert t > 0 and pending_b, "a 16-wide segment rides the epilogue of the one before it"
-            ph.append(desc(B["A16R"], (1 << gen.F_INIT) if sg["bias"] is not None else 0, sg["bias"] or 0))
+            # (an A phase's tail initialises acc_B: the segment's row of half B -- they differ when the time code is folded in)
+            ph.append(desc(B["A16R"], (1 << gen.F_INIT) if sg["bias"] is not None else 0, sg.get("bias_b", sg["bias"]) or 0))
             if sg["post"] == "relu":
                 ph.append(desc(B["B16R"] if nxt is not None else B["B16L"], init_next, nbias, **refill_fields(t)))
                 pending_b = True
@@ -108,10 +111,13 @@ def build_program(segs, in_t):
 
 def make_case(kind, seed=0):
     rng = np.random.RandomState(seed)
-    in_t = 48 if kind in ("dynamic",) else 0
+    # *_tb: the dynamic trunk with the time code folded into per-ray bias rows (every 64-point half inside one ray): the body runs
+    # the position part of the input segments only (4 of their 8 k-steps), the table holds b + W_t t(ray of the half)
+    tb = kind.endswith("_tb")
+    in_t = 48 if kind in ("dynamic", "dynamic_tb", "twoskips_tb") else 0
     k0 = 128 if in_t else 64
     D = 8
-    skips = {"static": [4], "dynamic": [4], "noskip": [], "twoskips": [2, 5]}[kind]
+    skips = {"static": [4], "dynamic": [4], "noskip": [], "twoskips": [2, 5], "dynamic_tb": [4], "twoskips_tb": [2, 5]}[kind]
     layers = []
     segs = []
     off = 4096                                  # (packed buffer: keep offset 0 unused)
@@ -124,6 +130,8 @@ def make_case(kind, seed=0):
         if bias is not None:
             bidx = len([s_ for s_ in segs if s_["bias"] is not None])
         segs.append(dict(nks=W.shape[1] // 16, off=off, bias=bidx, post=post, rebuild=rebuild, hi=hi, lo=lo, b=bias))
+        if tb and W.shape[1] == k0:
+            segs[-1].update(nks=4, wstride=(k0 // 16) * 4096)
         bufs.append((off, stream))
         off += stream.size * 4
     scale = 2.5 / np.sqrt(256.0)
@@ -144,12 +152,29 @@ def make_case(kind, seed=0):
     x_xyz[:, 63] = 0
     n_rays = 5
     t_table = (rng.randn(n_rays, max(in_t, 4)) * 0.5).astype(np.float32)
-    ray_of = (np.arange(128) * n_rays) // 128
+    ray_of = (np.arange(128) * n_rays) // 128 if not tb else np.arange(128) // 64 * 3
     x_in = np.zeros((128, k0), np.float32)
     x_in[:, :64] = x_xyz
     if in_t:
         x_in[:, 64:64 + in_t] = t_table[ray_of, :in_t]
-    return dict(kind=kind, in_t=in_t, k0=k0, segs=segs, pk=pk, x_in=x_in, t_table=t_table, ray_of=ray_of)
+    rows = {sg["bias"]: sg["b"] for sg in segs if sg["bias"] is not None}
+    if tb:
+        # rows of the segments that carry the bias of a layer with an input part: the layer's first segment (layer 0: the input
+        # segment itself, a skip layer: the 256-wide segment in front of its input segment)
+        th, tl = split_rtz(x_in[:, 64:])
+        nrow = len(rows)
+        for i, sg in enumerate(segs):
+            if sg["hi"].shape[1] != k0:
+                continue
+            tgt = segs[i] if i == 0 else segs[i - 1]
+            assert tgt["bias"] is not None
+            Wh, Wl = sg["hi"][:, 64:].astype(np.float64), sg["lo"][:, 64:].astype(np.float64)
+            part = th.astype(np.float64) @ Wh.T + tl.astype(np.float64) @ Wh.T + th.astype(np.float64) @ Wl.T   # (128, 256)
+            rows[tgt["bias"]] = (tgt["b"] + part[0]).astype(np.float32)
+            tgt["bias_b"] = nrow
+            rows[nrow] = (tgt["b"] + part[64]).astype(np.float32)
+            nrow += 1
+    return dict(kind=kind, in_t=in_t, k0=k0, segs=segs, pk=pk, x_in=x_in, t_table=t_table, ray_of=ray_of, rows=rows, tb=tb)
 
 
 def reference(case):
@@ -177,7 +202,8 @@ def run_case(kind, seed=0, verbose=True):
     pre, prog, _ = gen.build()
     sim = Sim(pre + prog)                      # the two asm statements back to back (the encoder between them is C++)
     sim.add_buffer(PK_BASE, case["pk"])
-    phases = build_program(case["segs"], case["in_t"])
+    body_in_t = 0 if case["tb"] else case["in_t"]       # (the body sees no time-code columns when they are folded into the table)
+    phases = build_program(case["segs"], body_in_t)
     sim.add_buffer(PH_BASE, phases.reshape(-1))
     sim.add_buffer(T_BASE, case["t_table"].reshape(-1).view(np.uint32))
     # LDS: input tile as the encoder leaves it (hi / lo planes), bias table
@@ -188,24 +214,23 @@ def run_case(kind, seed=0, verbose=True):
         lds_h[base:base + case["k0"]] = xh_[r]
         lds_h[base + gen.PLANE_B // 2:base + gen.PLANE_B // 2 + case["k0"]] = xl_[r]
     lds_f = sim.lds.view(np.float32)
-    for sg in case["segs"]:
-        if sg["bias"] is not None:
-            o = (LDS_BIAS + 1024 * sg["bias"]) // 4
-            lds_f[o:o + 256] = sg["b"]
+    for row, vec in case["rows"].items():
+        o = (LDS_BIAS + 1024 * row) // 4
+        lds_f[o:o + 256] = vec
     stride_t = case["t_table"].shape[1] * 4
     I_S, I_V = gen.IN_S, gen.IN_V
     for w in sim.waves:
         tid = 64 * w.id + np.arange(64)
         for name, val in (("pk", PK_BASE), ("phases", PH_BASE)):
             w.s[I_S[name].i], w.s[I_S[name].i + 1] = val & 0xFFFFFFFF, val >> 32
-        for name, val in (("lds", LDS_X), ("biaslds", LDS_BIAS), ("wave", w.id), ("in_t", case["in_t"]), ("n1", phases[0][3]),
+        for name, val in (("lds", LDS_X), ("biaslds", LDS_BIAS), ("wave", w.id), ("in_t", body_in_t), ("n1", phases[0][3]),
                           ("r1", phases[0][4]), ("r1w", phases[0][5]), ("r2", phases[0][6]), ("r2w", phases[0][7])):
             w.s[I_S[name].i] = int(val)
         w.v[I_V["tid"].i] = tid
         row, q = tid >> 2, tid & 3
         for names, rows in ((("tpa0", "tpa1"), row), (("tpb0", "tpb1"), row + 64)):
             addr = T_BASE + case["ray_of"][rows].astype(np.int64) * stride_t + 64 * q
-            addr = np.where(16 * q < max(case["in_t"], 1), addr, T_BASE)        # (lanes that load nothing: any valid address)
+            addr = np.where(16 * q < max(body_in_t, 1), addr, T_BASE)        # (lanes that load nothing: any valid address)
             w.v[I_V[names[0]].i] = (addr & 0xFFFFFFFF).astype(np.uint32)
             w.v[I_V[names[1]].i] = (addr >> 32).astype(np.uint32)
     t0 = time.time()
@@ -229,7 +254,7 @@ def run_case(kind, seed=0, verbose=True):
 
 
 if __name__ == "__main__":
-    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips"]
+    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips", "dynamic_tb", "twoskips_tb"]
     for k in kinds:
         try:
             run_case(k)

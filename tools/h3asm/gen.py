@@ -578,7 +578,12 @@ def prologue():
     # acc_A, acc_B := bias of segment 0 (flag), first fragments of half A
     e(I_s_cmp("s_bitcmp1_b32", S(S_CUR + D_FLAGS), F_INIT)); e(I_branch("s_cbranch_scc0", "L_pro_noinit"))
     e(I_valu("v_add_u32", V_BADDR, S(S_CUR + D_BIAS), V_BIAS, text=f"v_add_u32_e32 {V_BADDR}, {S(S_CUR + D_BIAS)}, {V_BIAS}"))
-    o.extend(init_reads("A")); o.extend(init_reads("B"))
+    o.extend(init_reads("A"))
+    # (half B's row of segment 0 sits (flags >> 16) bytes behind half A's: the same row, or the next ray's where the time code is
+    # folded into per-ray rows)
+    e(I_salu("s_lshr_b32", S_T0, S(S_CUR + D_FLAGS), 16, scc=True))
+    e(I_valu("v_add_u32", V_BADDR, S_T0, V_BADDR, text=f"v_add_u32_e32 {V_BADDR}, {S_T0}, {V_BADDR}"))
+    o.extend(init_reads("B"))
     e(I_label("L_pro_noinit"))
     o.extend(frag_reads_h("A", 0, 0)); o.extend(frag_reads_l("A", 0))
     return o
