@@ -689,6 +689,79 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
     }
 }
 
+// The hand-scheduled kernel's position encoder for the reference's embedding (ten octaves, 63 columns padded to 64): nothing
+// is decided at run time.  Two threads per point row; thread part q (wave-uniform: waves 0, 1 / 2, 3) encodes octaves 5 q .. 5 q + 4
+// of the three axes -- a sincos at its first and fourth octave, the others by angle doubling (as build_input's OCTAVE path) --
+// and stores its 33 / 31 columns as 16-byte LDS stores per plane: q = 0 columns 0..31 and column 32, q = 1 column 33, 34..35,
+// 36..39, 40..63 (column 63 = 0).  Rows of points past the end are encoded like any other (their records are never stored).
+__device__ __forceinline__ void h3a_split2(float v0, float v1, unsigned& h, unsigned& l) {
+    const h2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    const h2 ll = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(hh, v0), minus_hi_half(hh, v1));
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ void h3a_store8(_Float16* rh, _Float16* rl, int col, const float* w) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h3a_split2(w[2 * i], w[2 * i + 1], h[i], l[i]);
+    *reinterpret_cast<u4v*>(rh + col) = u4v{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u4v*>(rl + col) = u4v{l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const H3KArgs& a, const float (&x)[3], int tid) {
+    const int r = tid & 127;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const float fa = a.freqs[5 * q], fb = a.freqs[5 * q + 3];
+    float v[30], sn[3], cs[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sincos_cw(fa * x[c], &sn[c], &cs[c]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { v[6 * k + c] = sn[c]; v[6 * k + 3 + c] = cs[c]; }
+        if (k == 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sincos_cw(fb * x[c], &sn[c], &cs[c]);
+        } else if (k < 4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float s2 = 2.f * sn[c] * cs[c], c2 = fmaf(-2.f * sn[c], sn[c], 1.f);
+                sn[c] = s2; cs[c] = c2;
+            }
+        }
+    }
+    _Float16* rh = sXh + r * LDH;
+    _Float16* rl = sXl + r * LDH;
+    unsigned h, l;
+    if (q == 0) {
+        float w[32];
+        w[0] = x[0]; w[1] = x[1]; w[2] = x[2];
+#pragma unroll
+        for (int i = 0; i < 29; ++i) w[3 + i] = v[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h3a_store8(rh, rl, 8 * j, w + 8 * j);
+        h3a_split2(v[29], 0.f, h, l);
+        *reinterpret_cast<unsigned short*>(rh + 32) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(rl + 32) = (unsigned short)l;
+    } else {
+        h3a_split2(v[0], 0.f, h, l);
+        *reinterpret_cast<unsigned short*>(rh + 33) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(rl + 33) = (unsigned short)l;
+        h3a_split2(v[1], v[2], h, l);
+        *reinterpret_cast<unsigned*>(rh + 34) = h;
+        *reinterpret_cast<unsigned*>(rl + 34) = l;
+        unsigned hb, lb;
+        h3a_split2(v[3], v[4], h, l); h3a_split2(v[5], v[6], hb, lb);
+        *reinterpret_cast<u2v*>(rh + 36) = u2v{h, hb};
+        *reinterpret_cast<u2v*>(rl + 36) = u2v{l, lb};
+        float w[24];
+#pragma unroll
+        for (int i = 0; i < 23; ++i) w[i] = v[7 + i];
+        w[23] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) h3a_store8(rh, rl, 40 + 8 * j, w + 8 * j);
+    }
+}
+
 template <int M, int THREADS, bool SPLIT>
 __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, int tid) {
     constexpr int G = THREADS / M;
@@ -1146,7 +1219,7 @@ struct H3APhase { uint32_t d[8]; };     // body, flags, bias table offset, n1, r
 struct H3AArgs {
     H3KArgs k;
     H3APhase ph[2][H3A_MAX_PHASES];     // [static trunk, dynamic trunk]
-    uint32_t bias_off[2][H3A_MAX_BIAS]; // packed word offset of bias table row i, or H3A_TB_ROW | [H3A_TB_HALF_B] | row of H3KArgs::t_bias
+    __attribute__((aligned(16))) uint32_t bias_off[2][H3A_MAX_BIAS]; // packed word offset of bias table row i, or H3A_TB_ROW | [H3A_TB_HALF_B] | row of H3KArgs::t_bias
     int n_bias[2];
     int head[2];                        // HEAD_* evaluated on the trunk's last activation
 };
@@ -1177,33 +1250,50 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 #else
 #define H3A_TSTAMP(k) do {} while (0)
 #endif
-    float px[3] = {0.f, 0.f, 0.f};
+    // Everything this workgroup reads before its trunk starts is REQUESTED first and waited for once: the point, the bias-table
+    // rows (sixteen loads in flight), then -- the pre-issue statement -- weight slots 0..7: 128 KiB that cross the CU's vector-memory
+    // path while the encoder below computes.  The compiler's wait for the point sits behind the statement (its first use).
+    float px[3];
     {
-        const long long bp = p0 + build_row<M, THREADS>(threadIdx.x);
-        if (bp < a.n_points) { px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2]; }
-    }
-    // bias table of this trunk (fp32 rows of 256): the body initialises its accumulators from it with ds_read_b128
-    // (dynamic trunk with the time code folded in: the rows of its input layers are per ray -- every 64-point half of the tile
-    // lies inside one ray, the host checked pts_per_ray % 64 == 0 -- and the body never sees a time-code column)
-    const bool tb = tr == 1 && a.t_bias != nullptr;
-    long long tb_ray[2] = {0, 0};
-    if (tb) {
         const long long last = a.n_points - 1;
-        tb_ray[0] = (p0 < last ? p0 : last) / a.pts_per_ray;
-        tb_ray[1] = (p0 + 64 < last ? p0 + 64 : last) / a.pts_per_ray;
+        const long long bp = p0 + build_row<M, THREADS>(threadIdx.x) < last ? p0 + build_row<M, THREADS>(threadIdx.x) : last;
+        px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2];      // (rows past the end: the last point)
     }
-    for (int i = threadIdx.x; i < aa.n_bias[tr] * NSFF_W; i += THREADS) {
-        const uint32_t off = aa.bias_off[tr][i >> 8];
-        const float* src = reinterpret_cast<const float*>(pk) + off;
-        if (off & H3A_TB_ROW) src = a.t_bias + (tb_ray[(off & H3A_TB_HALF_B) ? 1 : 0] * a.tb_rows + (off & 0xffu)) * NSFF_W;
-        sBias[i] = src[i & 255];
+    // bias table of this trunk (fp32 rows of 256): the body initialises its accumulators from it with ds_read_b128.
+    // (dynamic trunk with the time code folded in: the rows of its input layers are per ray -- every 64-point half of the tile
+    // lies inside one ray, the host checked pts_per_ray % 64 == 0 and n_points < 2^31 -- and the body never sees a time-code column)
+    const bool tb = tr == 1 && a.t_bias != nullptr;
+    float bv[H3A_MAX_BIAS];
+    const int nb = aa.n_bias[tr];
+    {
+        // row r's bytes from the packed buffer's start (wave-uniform, branch-free; the table's 16 entries arrive as four 16-byte
+        // scalar loads): a plain row is a word offset, a per-ray row lies tb_delta = t_bias - packed further on, at the ray of
+        // its half.  Rows past the table's end read the buffer's first words (never stored).
+        long long tb_at[2] = {0, 0};
+        if (tb) {
+            const unsigned last = (unsigned)(a.n_points - 1), q0 = (unsigned)p0, ppr = (unsigned)a.pts_per_ray;
+            const long long delta = reinterpret_cast<const char*>(a.t_bias) - reinterpret_cast<const char*>(pk);
+            tb_at[0] = delta + (long long)((q0 < last ? q0 : last) / ppr) * (a.tb_rows * NSFF_W * 4);
+            tb_at[1] = delta + (long long)((q0 + 64u < last ? q0 + 64u : last) / ppr) * (a.tb_rows * NSFF_W * 4);
+        }
+        uint32_t boff[H3A_MAX_BIAS];
+#pragma unroll
+        for (int r4 = 0; r4 < H3A_MAX_BIAS / 4; ++r4) {
+            const u4v q = reinterpret_cast<const u4v*>(&aa.bias_off[tr][0])[r4];
+            boff[4 * r4] = q[0]; boff[4 * r4 + 1] = q[1]; boff[4 * r4 + 2] = q[2]; boff[4 * r4 + 3] = q[3];
+        }
+#pragma unroll
+        for (int r = 0; r < H3A_MAX_BIAS; ++r) {
+            const uint32_t off = r < nb ? boff[r] : 0u;
+            const long long at = (off & H3A_TB_ROW) ? tb_at[(off & H3A_TB_HALF_B) ? 1 : 0] + (long long)((off & 0xffu) * (NSFF_W * 4))
+                                                    : (long long)off * 4;
+            bv[r] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + at)[threadIdx.x];
+        }
     }
     H3A_TSTAMP(52);
-    asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));      // (the point has landed: no compiler wait behind the statement below)
     H3A_TSTAMP(53);
     {
-        // weight slots 0..7 (the first segment, and the start of the second one) are requested NOW: 128 KiB per workgroup cross
-        // the CU's vector-memory path while the encoder below computes.  Only the loads in flight survive the statement.
+        // Only the loads in flight survive the statement.
         const H3APhase& d0 = aa.ph[tr][0];
         asm volatile(H3A_PRE
                      :
@@ -1212,7 +1302,13 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
                      : H3A_PRE_CLOBBERS);
     }
     H3A_TSTAMP(57);
-    build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
+#pragma unroll
+    for (int r = 0; r < H3A_MAX_BIAS; ++r)
+        if (r < nb) sBias[r * NSFF_W + threadIdx.x] = bv[r];
+    if (a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb))
+        h3a_encode10(sXh, sXl, a, px, threadIdx.x);
+    else
+        build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
     const float* tpa = reinterpret_cast<const float*>(pk);
     const float* tpb = tpa;
@@ -1944,7 +2040,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             if (asm_body && n > k.n_static_steps) {
                 // the time code as per-ray bias rows (nsff_time_bias): whenever the caller supplied them and a 64-point half
                 // never straddles two rays; otherwise the body multiplies the time-code columns like any other input
-                bool fold_t = g.t_bias != nullptr && g.pts_per_ray > 0 && g.pts_per_ray % 64 == 0 &&
+                bool fold_t = g.t_bias != nullptr && g.pts_per_ray > 0 && g.pts_per_ray % 64 == 0 && g.n_points <= 0x7fffffffLL &&
                               g.t_bias_rows == nsff_time_bias_rows(desc);
                 if (fold_t) {
                     ka.k.t_bias = g.t_bias; ka.k.tb_rows = g.t_bias_rows;

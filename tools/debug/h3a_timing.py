@@ -24,8 +24,9 @@ t_rows = torch.randn(1024, scenes.N_TAU, device=dev)
 raw = torch.zeros(P, 16, device=dev)
 freqs = [float(f) for f in emb["xyz"].freqs]
 sm = 2 if which == "static" else 0                            # dynamic: the warp launch shape (dynamic trunk only)
+tb = _lib.time_bias([(model, t_rows)])[0] if which == "dynamic_tb" else None     # dynamic_tb: time code folded into bias rows
 for _ in range(3):
-    _lib.field_query(model, raw, P, S, sm, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows)
+    _lib.field_query(model, raw, P, S, sm, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows, t_bias=tb)
 torch.cuda.synchronize()
 lib = _lib.load()
 TBASE = 256 * 8 * 32 * 6
@@ -38,7 +39,7 @@ rec = t[:, :, 64:64 + 6 * 30].reshape(256, 4, 30, 6)           # record r >= 1: 
 dd = lambda a, b: ((b - a) & 0xffffffff).astype(np.float64)
 d = lambda a, b: dd(t[:, :, a], t[:, :, b])
 names = {1: "A16R", 2: "B16R", 3: "B16X", 4: "A4", 5: "A8", 6: "B4", 7: "B8", 9: "EPI_B", 10: "A4F", 11: "A8F", 12: "B16L"}
-if which == "static":
+if which in ("static", "dynamic_tb"):
     seq = [10, 6] + [1, 2] * 3 + [1, 3, 4, 6] + [1, 2] * 2 + [1, 12, 9]
 else:
     seq = [11, 7] + [1, 2] * 3 + [1, 3, 5, 7] + [1, 2] * 2 + [1, 12, 9]

@@ -4,7 +4,8 @@ mkdir -p gpurun_out/r04_ab; rm -f gpurun_out/r04_ab/*
 for i in 1 2 3; do
   python bench.py --steps 200 --warmup 20 --no-aux --no-cpu-baseline > gpurun_out/r04_ab/base_$i.json 2>gpurun_out/r04_ab/base_$i.err
   for kv in "$@"; do
-    env $kv python bench.py --steps 200 --warmup 20 --no-aux --no-cpu-baseline > gpurun_out/r04_ab/${kv}_$i.json 2>gpurun_out/r04_ab/${kv}_$i.err
+    name=$(echo "$kv" | tr '/' '-')
+    env $kv python bench.py --steps 200 --warmup 20 --no-aux --no-cpu-baseline > gpurun_out/r04_ab/${name}_$i.json 2>gpurun_out/r04_ab/${name}_$i.err
   done
 done
 python - <<'P'
