@@ -689,79 +689,6 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
     }
 }
 
-// The hand-scheduled kernel's position encoder for the reference's embedding (ten octaves, 63 columns padded to 64): nothing
-// is decided at run time.  Two threads per point row; thread part q (wave-uniform: waves 0, 1 / 2, 3) encodes octaves 5 q .. 5 q + 4
-// of the three axes -- a sincos at its first and fourth octave, the others by angle doubling (as build_input's OCTAVE path) --
-// and stores its 33 / 31 columns as 16-byte LDS stores per plane: q = 0 columns 0..31 and column 32, q = 1 column 33, 34..35,
-// 36..39, 40..63 (column 63 = 0).  Rows of points past the end are encoded like any other (their records are never stored).
-__device__ __forceinline__ void h3a_split2(float v0, float v1, unsigned& h, unsigned& l) {
-    const h2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-    const h2 ll = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(hh, v0), minus_hi_half(hh, v1));
-    h = __builtin_bit_cast(unsigned, hh);
-    l = __builtin_bit_cast(unsigned, ll);
-}
-__device__ __forceinline__ void h3a_store8(_Float16* rh, _Float16* rl, int col, const float* w) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) h3a_split2(w[2 * i], w[2 * i + 1], h[i], l[i]);
-    *reinterpret_cast<u4v*>(rh + col) = u4v{h[0], h[1], h[2], h[3]};
-    *reinterpret_cast<u4v*>(rl + col) = u4v{l[0], l[1], l[2], l[3]};
-}
-__device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const H3KArgs& a, const float (&x)[3], int tid) {
-    const int r = tid & 127;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const float fa = a.freqs[5 * q], fb = a.freqs[5 * q + 3];
-    float v[30], sn[3], cs[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) sincos_cw(fa * x[c], &sn[c], &cs[c]);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { v[6 * k + c] = sn[c]; v[6 * k + 3 + c] = cs[c]; }
-        if (k == 2) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) sincos_cw(fb * x[c], &sn[c], &cs[c]);
-        } else if (k < 4) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float s2 = 2.f * sn[c] * cs[c], c2 = fmaf(-2.f * sn[c], sn[c], 1.f);
-                sn[c] = s2; cs[c] = c2;
-            }
-        }
-    }
-    _Float16* rh = sXh + r * LDH;
-    _Float16* rl = sXl + r * LDH;
-    unsigned h, l;
-    if (q == 0) {
-        float w[32];
-        w[0] = x[0]; w[1] = x[1]; w[2] = x[2];
-#pragma unroll
-        for (int i = 0; i < 29; ++i) w[3 + i] = v[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h3a_store8(rh, rl, 8 * j, w + 8 * j);
-        h3a_split2(v[29], 0.f, h, l);
-        *reinterpret_cast<unsigned short*>(rh + 32) = (unsigned short)h;
-        *reinterpret_cast<unsigned short*>(rl + 32) = (unsigned short)l;
-    } else {
-        h3a_split2(v[0], 0.f, h, l);
-        *reinterpret_cast<unsigned short*>(rh + 33) = (unsigned short)h;
-        *reinterpret_cast<unsigned short*>(rl + 33) = (unsigned short)l;
-        h3a_split2(v[1], v[2], h, l);
-        *reinterpret_cast<unsigned*>(rh + 34) = h;
-        *reinterpret_cast<unsigned*>(rl + 34) = l;
-        unsigned hb, lb;
-        h3a_split2(v[3], v[4], h, l); h3a_split2(v[5], v[6], hb, lb);
-        *reinterpret_cast<u2v*>(rh + 36) = u2v{h, hb};
-        *reinterpret_cast<u2v*>(rl + 36) = u2v{l, lb};
-        float w[24];
-#pragma unroll
-        for (int i = 0; i < 23; ++i) w[i] = v[7 + i];
-        w[23] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) h3a_store8(rh, rl, 40 + 8 * j, w + 8 * j);
-    }
-}
-
 template <int M, int THREADS, bool SPLIT>
 __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, int tid) {
     constexpr int G = THREADS / M;
@@ -1225,6 +1152,109 @@ struct H3AArgs {
 };
 static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
 
+// Weight slots 0..7 (the first segment and the start of the second), requested in front of / inside the encoder: statement K
+// loads slot K's 4 KiB of this wave from (K < n1 ? r1 : r2) + 4096 K -- the fields of phase descriptor 0, as the body's refills.
+struct H3APre {
+    unsigned long long pk;
+    unsigned r1, r2, n1, lane16;
+    template <int K> __device__ __forceinline__ void slot() const {
+        const unsigned off = (K < (int)n1 ? r1 : r2) + 4096u * K;
+#define H3A_SLOT_CASE(k) if constexpr (K == k) asm volatile(H3A_PRE_SLOT##k : : [pk] "s"(pk), [off] "s"(off), [lane16] "v"(lane16) : H3A_PRE_SLOT##k##_CLOBBERS)
+        H3A_SLOT_CASE(0); H3A_SLOT_CASE(1); H3A_SLOT_CASE(2); H3A_SLOT_CASE(3);
+        H3A_SLOT_CASE(4); H3A_SLOT_CASE(5); H3A_SLOT_CASE(6); H3A_SLOT_CASE(7);
+#undef H3A_SLOT_CASE
+    }
+};
+
+// The hand-scheduled kernel's position encoder for the reference's embedding (ten octaves, 63 columns padded to 64): nothing
+// is decided at run time.  Two threads per point row; thread part q (wave-uniform: waves 0, 1 / 2, 3) encodes octaves 5 q .. 5 q + 4
+// of the three axes -- a sincos at its first and fourth octave, the others by angle doubling (as build_input's OCTAVE path) --
+// and stores its 33 / 31 columns as 16-byte LDS stores per plane: q = 0 columns 0..31 and column 32, q = 1 column 33, 34..35,
+// 36..39, 40..63 (column 63 = 0).  Rows of points past the end are encoded like any other (their records are never stored).
+__device__ __forceinline__ void h3a_split2(float v0, float v1, unsigned& h, unsigned& l) {
+    const h2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    const h2 ll = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(hh, v0), minus_hi_half(hh, v1));
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ void h3a_store8(_Float16* rh, _Float16* rl, int col, const float* w) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h3a_split2(w[2 * i], w[2 * i + 1], h[i], l[i]);
+    *reinterpret_cast<u4v*>(rh + col) = u4v{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u4v*>(rl + col) = u4v{l[0], l[1], l[2], l[3]};
+}
+// `pre`: the weight pre-issue (H3APre below), one slot = four 16-byte loads per lane at a time: the eight statements are spread over
+// the encoder so that the 128 KiB cross the CU's vector-memory path (2 k cycles at 64 B / clock) WHILE it computes -- issued
+// back to back they hold every wave at the issue stage for that long.  Slots 0..2 are the caller's: requested behind its own
+// loads (the point, the bias rows) and landed with them -- the compiler's wait for the point cannot see the statements' loads
+// and waits for everything in flight, so what is requested in front of it shares the point's memory latency.
+template <class Pre>
+__device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const H3KArgs& a, const float (&x)[3], int tid, const Pre& pre) {
+    const int r = tid & 127;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const float fa = a.freqs[5 * q], fb = a.freqs[5 * q + 3];
+    float v[30], sn[3], cs[3];
+    pre.template slot<3>();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sincos_cw(fa * x[c], &sn[c], &cs[c]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { v[6 * k + c] = sn[c]; v[6 * k + 3 + c] = cs[c]; }
+        if (k == 0) pre.template slot<4>();
+        if (k == 3) pre.template slot<5>();
+        if (k == 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sincos_cw(fb * x[c], &sn[c], &cs[c]);
+        } else if (k < 4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float s2 = 2.f * sn[c] * cs[c], c2 = fmaf(-2.f * sn[c], sn[c], 1.f);
+                sn[c] = s2; cs[c] = c2;
+            }
+        }
+    }
+    _Float16* rh = sXh + r * LDH;
+    _Float16* rl = sXl + r * LDH;
+    unsigned h, l;
+    if (q == 0) {
+        float w[32];
+        w[0] = x[0]; w[1] = x[1]; w[2] = x[2];
+#pragma unroll
+        for (int i = 0; i < 29; ++i) w[3 + i] = v[i];
+        h3a_store8(rh, rl, 0, w);
+        pre.template slot<6>();
+        h3a_store8(rh, rl, 8, w + 8);
+        h3a_store8(rh, rl, 16, w + 16);
+        pre.template slot<7>();
+        h3a_store8(rh, rl, 24, w + 24);
+        h3a_split2(v[29], 0.f, h, l);
+        *reinterpret_cast<unsigned short*>(rh + 32) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(rl + 32) = (unsigned short)l;
+    } else {
+        h3a_split2(v[0], 0.f, h, l);
+        *reinterpret_cast<unsigned short*>(rh + 33) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(rl + 33) = (unsigned short)l;
+        h3a_split2(v[1], v[2], h, l);
+        *reinterpret_cast<unsigned*>(rh + 34) = h;
+        *reinterpret_cast<unsigned*>(rl + 34) = l;
+        unsigned hb, lb;
+        h3a_split2(v[3], v[4], h, l); h3a_split2(v[5], v[6], hb, lb);
+        *reinterpret_cast<u2v*>(rh + 36) = u2v{h, hb};
+        *reinterpret_cast<u2v*>(rl + 36) = u2v{l, lb};
+        pre.template slot<6>();
+        float w[24];
+#pragma unroll
+        for (int i = 0; i < 23; ++i) w[i] = v[7 + i];
+        w[23] = 0.f;
+        h3a_store8(rh, rl, 40, w);
+        pre.template slot<7>();
+        h3a_store8(rh, rl, 48, w + 8);
+        h3a_store8(rh, rl, 56, w + 16);
+    }
+}
+
 __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa) {
     const H3KArgs& a = aa.k;
     constexpr int M = 128, THREADS = 256;
@@ -1291,24 +1321,30 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
         }
     }
     H3A_TSTAMP(52);
-    H3A_TSTAMP(53);
+    H3APre pre;
     {
-        // Only the loads in flight survive the statement.
         const H3APhase& d0 = aa.ph[tr][0];
-        asm volatile(H3A_PRE
-                     :
-                     : [pk] "s"((unsigned long long)(uintptr_t)pk), [wave] "s"(wave_id), [tid] "v"((unsigned)threadIdx.x),
-                       [n1] "s"(d0.d[3]), [r1] "s"(d0.d[4]), [r1w] "s"(d0.d[5]), [r2] "s"(d0.d[6]), [r2w] "s"(d0.d[7])
-                     : H3A_PRE_CLOBBERS);
+        pre.pk = (unsigned long long)(uintptr_t)pk;
+        pre.n1 = d0.d[3];
+        pre.r1 = d0.d[4] + (unsigned)wave_id * d0.d[5];
+        pre.r2 = d0.d[6] + (unsigned)wave_id * d0.d[7];
+        pre.lane16 = (unsigned)lane << 4;
     }
-    H3A_TSTAMP(57);
+    pre.slot<0>(); pre.slot<1>(); pre.slot<2>();
+    // the one wait for this workgroup's own loads (and the three slots behind them): the bias rows go to LDS, the point is pinned as landed
 #pragma unroll
     for (int r = 0; r < H3A_MAX_BIAS; ++r)
         if (r < nb) sBias[r * NSFF_W + threadIdx.x] = bv[r];
-    if (a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb))
-        h3a_encode10(sXh, sXl, a, px, threadIdx.x);
-    else
+    asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
+    H3A_TSTAMP(53);
+    const bool lean = a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb);
+    if (lean) {
+        h3a_encode10(sXh, sXl, a, px, threadIdx.x, pre);
+    } else {
+        pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
         build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
+    }
+    H3A_TSTAMP(57);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
     const float* tpa = reinterpret_cast<const float*>(pk);
     const float* tpb = tpa;
@@ -1366,7 +1402,9 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     }
     __syncthreads();
     H3A_TSTAMP(56);
-    for (int i = threadIdx.x; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
+    unsigned tix = threadIdx.x;
+    asm volatile("" : "+v"(tix));       // (no 64-bit multiple of the thread index kept alive across the body: it has 24 registers)
+    for (int i = (int)tix; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
         const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
         const int q4 = i % (NSFF_RAW_STRIDE / 4);
         if (p < a.n_points && (piece == 0 || (piece == 1) == (q4 == 0)))

@@ -698,10 +698,19 @@ def main():
     consts = "".join(f"#define H3A_BODY_{k} {v}\n" for k, v in BODY.items())
     consts += f"#define H3A_F_INIT {1 << F_INIT}\n#define H3A_F_REBUILD_T {1 << F_REBUILD_T}\n#define H3A_F_REBUILD {1 << F_REBUILD}\n"
     macro = lambda name, insts: f"#define {name} \\\n" + render(insts).replace("\n", " \\\n").rstrip(" \\\n") + "\n"
+    # the same 32 loads as eight statements, one weight slot each, for the kernel to spread over its encoder: statement k takes
+    # %[pk] s64, %[off] s32 = (k < n1 ? r1 + wave r1w : r2 + wave r2w) + 4096 k, %[lane16] v32 = 16 (tid & 63)
+    slots = ""
+    for k in range(8):
+        body = f'    "v_add_u32 v32, %[off], %[lane16]\\n\\t" \\\n'
+        body += " \\\n".join(f'    "global_load_dwordx4 a[{16 * k + 4 * c}:{16 * k + 4 * c + 3}], v32, %[pk]' + (f" offset:{1024 * c}" if c else "") + '\\n\\t"'
+                               for c in range(4))
+        slots += f"#define H3A_PRE_SLOT{k} \\\n{body}\n"
+        slots += f"#define H3A_PRE_SLOT{k}_CLOBBERS " + ", ".join(['"v32"'] + [f'"a{16 * k + j}"' for j in range(16)] + ['"memory"']) + "\n"
     text = ("// GENERATED by tools/h3asm/gen.py -- do not edit.  The hand-scheduled trunk body of nsff_field_kernel_h3a:\n"
-            "// H3A_PRE (weight slots 0..7 requested in front of the encoder) and H3A_BODY (the trunk; registers v24..v255,\n"
-            "// a0..a255, s40..s99 are its own while it runs).\n" + consts +
-            "#define H3A_PRE_CLOBBERS " + pre_clob + "\n" + macro("H3A_PRE", pre) +
+            "// H3A_PRE (weight slots 0..7 requested in front of the encoder; H3A_PRE_SLOT0..7: the same loads one slot per statement)\n"
+            "// and H3A_BODY (the trunk; registers v24..v255, a0..a255, s40..s99 are its own while it runs).\n" + consts +
+            "#define H3A_PRE_CLOBBERS " + pre_clob + "\n" + macro("H3A_PRE", pre) + slots +
             "#define H3A_CLOBBERS " + clob + "\n" + macro("H3A_BODY", prog))
     with open(out, "w") as f:
         f.write(text)
