@@ -284,7 +284,7 @@ def spread(n_items, n_gaps):
 
 
 TIMING = False              # --timing: every dispatcher visit stores stamps of the phase before it (debug builds only)
-RIDE_CAP = 3                # riding instructions per MFMA gap where the ride does not fit the gaps (short B phases)
+RIDE_CAP = int(os.environ.get("H3A_RIDE_CAP", "7"))    # riding instructions per MFMA gap where the ride does not fit the gaps (short B phases)
 
 
 def guarded_init(s, name, half):
@@ -690,7 +690,8 @@ def main():
     if errs:
         sys.exit(f"{len(errs)} hazard(s)")
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "nsff_pl_amd", "csrc",
-                       "field_h3a_body_timing.inc" if TIMING else (f"field_h3a_body_{EXP}.inc" if EXP else "field_h3a_body.inc"))
+                       "field_h3a_body_timing.inc" if TIMING else (f"field_h3a_body_{EXP}.inc" if EXP else
+                       (f"field_h3a_body_cap{RIDE_CAP}.inc" if "H3A_RIDE_CAP" in os.environ else "field_h3a_body.inc")))
     clob = ", ".join([f'"v{i}"' for i in range(24, 256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(40, 100)] +
                      ['"vcc"', '"scc"', '"memory"'])
     pre_wr = sorted({r for i in pre for r in i.wr if r[0] in ("v", "a") or (r[0] == "s" and r[1] < 100)})
