@@ -1066,63 +1066,17 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
 
 
 
-// Heads of nsff_field_kernel_h3a: wave w evaluates the (folded) head tile on point tile w = 32 points, all 16 k-steps.  The
-// whole head tile of the wave (hi + lo halfs of 16 k-steps = 32 KiB) is REQUESTED by h3a_head_request() before the workgroup
-// barrier behind the trunk -- one L2 round trip instead of two, hidden behind the barrier -- and the three product terms run as
-// three accumulator chains.  Activations with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-6 relative; the outputs are
+// Heads of nsff_field_kernel_h3a: the body's HEAD phase (tools/h3asm/gen.py::head_body) multiplies the (folded) head tile with
+// the trunk's last activation -- wave w on points 32 w .. 32 w + 31, three accumulator chains, the tile requested in front of
+// the trunk's last epilogue -- and leaves the pre-activation sums in the raw-record image; the kernel's records loop adds the
+// bias and applies the activation with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-6 relative; the outputs are
 // compared at 1e-4 of their maximum): sigmoid(v) = 1 / (1 + 2^(-v log2 e)), tanh(v) = 1 - 2 / (2^(2 v log2 e) + 1).
-struct H3AHeadW { h8 wh[16], wl[16]; float bv[8]; };
-__device__ __forceinline__ void h3a_head_request(H3AHeadW& hw, const uint32_t* __restrict__ pk, uint32_t w_off, uint32_t b_off,
-                                                 int n_rows, int lane) {
-    const uint4* w = reinterpret_cast<const uint4*>(pk + w_off) + lane;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        hw.wh[j] = __builtin_bit_cast(h8, w[(j * 2 + 0) * 64]);
-        hw.wl[j] = __builtin_bit_cast(h8, w[(j * 2 + 1) * 64]);
-    }
-    const float* bias = reinterpret_cast<const float*>(pk + b_off);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        hw.bv[r] = row < n_rows ? bias[row] : 0.f;
-    }
-}
 __device__ __forceinline__ float fast_sigmoid(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 __device__ __forceinline__ float fast_tanh(float v) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * v) + 1.0f);
 }
-__device__ __forceinline__ void h3a_heads(const H3AHeadW& hw, const _Float16* sXh, const _Float16* sXl, int n_rows, unsigned kinds,
-                                          float flow_scale, float* sRaw, int slot0, int wave, int lane) {
-    f32x16 acc0[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[c][r] = 0.f;
-    const _Float16* bh = sXh + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
-    const _Float16* bl = sXl + (32 * wave + (lane & 31)) * LDH + 8 * (lane >> 5);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        const h8 xh = lds_h8(bh + ks * 16), xl = lds_h8(bl + ks * 16);
-        acc0[0] = MFMA_H(hw.wl[ks], xh, acc0[0]);
-        acc0[1] = MFMA_H(hw.wh[ks], xl, acc0[1]);
-        acc0[2] = MFMA_H(hw.wh[ks], xh, acc0[2]);
-    }
-    float* rec = sRaw + (32 * wave + (lane & 31)) * NSFF_RAW_STRIDE + slot0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < n_rows) {
-            float v = ((acc0[0][r] + acc0[1][r]) + acc0[2][r]) + hw.bv[r];
-            const unsigned kind = (kinds >> (2 * row)) & 3u;
-            if (kind == ACT_SIGMOID) v = fast_sigmoid(v);
-            else if (kind == ACT_FLOW) v = flow_scale * fast_tanh(v);
-            rec[row] = v;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // nsff_field_kernel_h3a: the f16x3 inference trunk with a HAND-SCHEDULED body (tools/h3asm/gen.py -> field_h3a_body.inc).
 // One wave per SIMD (four waves x 512 registers), 128 points per workgroup as two 64-point halves; a wave owns 64 neurons,
@@ -1151,6 +1105,15 @@ struct H3AArgs {
     int head[2];                        // HEAD_* evaluated on the trunk's last activation
 };
 static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
+
+// The heads evaluated on a trunk's last activation (HEAD_* of its last step): tile / bias offsets in the packed buffer (words),
+// rows, first float of the raw record, activation kinds (two bits per row).
+struct H3AHeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
+__host__ __device__ __forceinline__ H3AHeadSel h3a_head_sel(const NsffLayoutH3& L, int head) {
+    if (head == HEAD_S_FOLD) return H3AHeadSel{L.s_fold_w, L.s_fold_b, 4, 0, 0x15u};
+    if (head == HEAD_T_FOLD) return H3AHeadSel{L.t_fold_w, L.t_fold_b, (int)L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
+    return H3AHeadSel{L.s_sigma_w, L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
+}
 
 // Weight slots 0..7 (the first segment and the start of the second), requested in front of / inside the encoder: statement K
 // loads slot K's 4 KiB of this wave from (K < n1 ? r1 : r2) + 4096 K -- the fields of phase descriptor 0, as the body's refills.
@@ -1260,7 +1223,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     constexpr int M = 128, THREADS = 256;
     __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
     __shared__ __attribute__((aligned(16))) float sRaw[M * NSFF_RAW_STRIDE];
-    __shared__ __attribute__((aligned(16))) float sBias[H3A_MAX_BIAS * NSFF_W];
+    __shared__ __attribute__((aligned(16))) float sBias[(H3A_MAX_BIAS + 1) * NSFF_W];      // (+ one row: the heads' biases)
     for (int i = threadIdx.x; i < M * NSFF_RAW_STRIDE; i += THREADS) sRaw[i] = 0.f;
     _Float16* sXh = sX;
     _Float16* sXl = sX + M * LDH;
@@ -1320,6 +1283,9 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
             bv[r] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + at)[threadIdx.x];
         }
     }
+    // (the heads' biases -- 32 floats -- travel with the table: the records loop below reads them from LDS)
+    const H3AHeadSel hs = h3a_head_sel(a.L, aa.head[tr]);
+    const float hbias = reinterpret_cast<const float*>(pk)[hs.b_off + (threadIdx.x & 31)];
     H3A_TSTAMP(52);
     H3APre pre;
     {
@@ -1335,6 +1301,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 #pragma unroll
     for (int r = 0; r < H3A_MAX_BIAS; ++r)
         if (r < nb) sBias[r * NSFF_W + threadIdx.x] = bv[r];
+    if (threadIdx.x < 32) sBias[H3A_MAX_BIAS * NSFF_W + threadIdx.x] = hbias;
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
     H3A_TSTAMP(53);
     const bool lean = a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb);
@@ -1380,35 +1347,52 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 #ifdef H3_TIMING
                        [dbg] "s"(dbg),
 #endif
-                       [phases] "s"(phases), [lds] "s"(lds), [biaslds] "s"(biaslds), [wave] "s"(wave_id),
-                       [in_t] "s"(in_t), [tid] "v"(tid), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1)
+                       [phases] "s"(phases), [lds] "s"(lds), [biaslds] "s"(biaslds), [rawlds] "s"((unsigned)(uintptr_t)sRaw),
+                       [wave] "s"(wave_id), [in_t] "s"(in_t), [tid] "v"(tid), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1)
                      : H3A_CLOBBERS);
     }
 #ifdef H3_TIMING
     if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-    {
-        struct HeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
-        const int head = aa.head[tr];
-        HeadSel hs{a.L.s_sigma_w, a.L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
-        if (head == HEAD_S_FOLD) hs = HeadSel{a.L.s_fold_w, a.L.s_fold_b, 4, 0, 0x15u};
-        if (head == HEAD_T_FOLD) hs = HeadSel{a.L.t_fold_w, a.L.t_fold_b, (int)a.L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
-        H3AHeadW hw;
-        h3a_head_request(hw, pk, hs.w_off, hs.b_off, hs.n_rows, lane);     // (in flight across the barrier)
-        __syncthreads();
-        H3A_TSTAMP(54);
-        h3a_heads(hw, sXh, sXl, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0, wave_id, lane);
-        H3A_TSTAMP(55);
-    }
+    // The body's HEAD phase left the heads' pre-activation sums in the raw-record image; bias and activation are applied where
+    // the records leave: a thread always handles the same 16-byte quarter of a record (256 threads, 4 quarters per point).
     __syncthreads();
+    H3A_TSTAMP(54);
+    H3A_TSTAMP(55);
     H3A_TSTAMP(56);
     unsigned tix = threadIdx.x;
     asm volatile("" : "+v"(tix));       // (no 64-bit multiple of the thread index kept alive across the body: it has 24 registers)
-    for (int i = (int)tix; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
-        const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
-        const int q4 = i % (NSFF_RAW_STRIDE / 4);
-        if (p < a.n_points && (piece == 0 || (piece == 1) == (q4 == 0)))
-            reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = reinterpret_cast<const float4*>(sRaw)[i];
+    {
+        // per thread, for its four record floats: bias, and the activation as  y = fma(1 / (1 + 2^(c x)), ya, yb)  -- sigmoid:
+        // c = -log2 e, (ya, yb) = (1, 0); flow: c = 2 log2 e, (-2 s, s) = s tanh(x); none: x itself -- branch-free
+        const int q4 = (int)tix & 3;
+        float hb[4], hc[4], ya[4], yb[4];
+        bool plain[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 4 * q4 + e - hs.slot0;
+            const bool on = row >= 0 && row < hs.n_rows;
+            const unsigned kind = on ? (hs.kinds >> (2 * (row & 15))) & 3u : (unsigned)ACT_NONE;
+            hb[e] = on ? sBias[H3A_MAX_BIAS * NSFF_W + (row & 31)] : 0.f;
+            plain[e] = kind != ACT_SIGMOID && kind != ACT_FLOW;
+            hc[e] = kind == ACT_SIGMOID ? -1.4426950408889634f : (kind == ACT_FLOW ? 2.8853900817779268f : 0.f);
+            ya[e] = kind == ACT_FLOW ? -2.0f * a.flow_scale : 1.0f;
+            yb[e] = kind == ACT_FLOW ? a.flow_scale : 0.f;
+        }
+        for (int i = (int)tix; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
+            const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
+            if (p < a.n_points && (piece == 0 || (piece == 1) == (q4 == 0))) {
+                float4 v = reinterpret_cast<const float4*>(sRaw)[i];
+                float* ve = reinterpret_cast<float*>(&v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = ve[e] + hb[e];
+                    const float y = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hc[e] * x)), ya[e], yb[e]);
+                    ve[e] = plain[e] ? x : y;
+                }
+                reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = v;
+            }
+        }
     }
     span_end(a.span, span0);
 #ifdef H3_TIMING
@@ -1517,8 +1501,14 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
         if (!ok) return false;
     }
     if (!pending_b) return false;
-    const bool done = put(H3A_BODY_EPI_B, 0u, 0, 16, segs[0], segs[0]) && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]) &&
-                      put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]);
+    // the last epilogue requests the head tile (stream r1, no wave stride; n1 = its rows), the HEAD phase leaves the rows'
+    // pre-activation sums at float slot0 of the raw records (bias field = 4 slot0)
+    const H3AHeadSel hd = h3a_head_sel(k.L, head);
+    Seg tile = segs[0];
+    tile.off = hd.w_off * 4u; tile.stride = 0u;
+    bool done = put(H3A_BODY_EPI_B, 0u, 0, hd.n_rows, tile, tile) && put(H3A_BODY_HEAD, 0u, 0, hd.n_rows, tile, tile);
+    if (done) ph[np - 1].d[2] = 4u * (uint32_t)hd.slot0;
+    done = done && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]) && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]);
     if (n_phases) *n_phases = np;
     return done;
 }

@@ -84,12 +84,15 @@ def test_cxx_phase_program_equals_the_simulated_builder(arch):
                 segs.append(dict(nks=nks, off=4 * w, bias=None if b is None else nb, post="relu" if post == 1 else "none",
                                  rebuild=i > 0 and pre != 0))
                 nb += b is not None
-            want = [list(map(int, r)) for r in check.build_program(segs, in_t)]
+            # the heads of this trunk: rows and first record float (field_h3.hip::h3a_head_sel); the tile's offset is not compared
+            head = dict(off=0, n_rows=(4 if sm == 2 else 1) if in_t == 0 else 10, slot0=(0 if sm == 2 else 3) if in_t == 0 else 4)   # (10: a model with flow heads)
+            want = [list(map(int, r)) for r in check.build_program(segs, in_t, head)]
             assert len(want) == len(got)
             B = gen.BODY
             uses_streams = {B["B16R"], B["B16X"], B["B4"], B["B8"], B["A4F"], B["A8F"]}        # (+ descriptor 0: the pre-issue)
             for i, (w_, g_) in enumerate(zip(want, got)):
-                n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else 3       # body, flags, bias row; stream fields where they are read
+                # body, flags, bias row (HEAD: 4 x first record float)[, rows of the heads]; stream fields where they are read
+                n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else (4 if w_[0] in (B["EPI_B"], B["HEAD"]) else 3)
                 assert w_[:n_cmp] == g_[:n_cmp], (ARCHS[arch], sm, tm, i, w_, g_)
         if tm == 0:
             continue
@@ -108,10 +111,10 @@ def test_cxx_phase_program_equals_the_simulated_builder(arch):
             first = segs[0 if t == 0 else t - 1]
             first["bias_b"] = nb
             nb += 1
-        want = [list(map(int, r)) for r in check.build_program(segs, 0)]
+        want = [list(map(int, r)) for r in check.build_program(segs, 0, dict(off=0, n_rows=10, slot0=4))]
         assert len(want) == len(ph_f) and nb <= 16
         for i, (w_, g_) in enumerate(zip(want, ph_f)):
-            n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else 3
+            n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else (4 if w_[0] in (B["EPI_B"], B["HEAD"]) else 3)
             assert w_[:n_cmp] == g_[:n_cmp], (ARCHS[arch], sm, tm, "fold_t", i, w_, g_)
 
 

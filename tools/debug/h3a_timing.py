@@ -38,11 +38,11 @@ t = allt[TBASE:].reshape(256, 4, 256).astype(np.int64)
 rec = t[:, :, 64:64 + 6 * 30].reshape(256, 4, 30, 6)           # record r >= 1: [0] start of phase r - 1, [1..5] its five stamps
 dd = lambda a, b: ((b - a) & 0xffffffff).astype(np.float64)
 d = lambda a, b: dd(t[:, :, a], t[:, :, b])
-names = {1: "A16R", 2: "B16R", 3: "B16X", 4: "A4", 5: "A8", 6: "B4", 7: "B8", 9: "EPI_B", 10: "A4F", 11: "A8F", 12: "B16L"}
+names = {1: "A16R", 2: "B16R", 3: "B16X", 4: "A4", 5: "A8", 6: "B4", 7: "B8", 9: "EPI_B", 10: "A4F", 11: "A8F", 12: "B16L", 13: "HEAD"}
 if which in ("static", "dynamic_tb"):
-    seq = [10, 6] + [1, 2] * 3 + [1, 3, 4, 6] + [1, 2] * 2 + [1, 12, 9]
+    seq = [10, 6] + [1, 2] * 3 + [1, 3, 4, 6] + [1, 2] * 2 + [1, 12, 9, 13]
 else:
-    seq = [11, 7] + [1, 2] * 3 + [1, 3, 5, 7] + [1, 2] * 2 + [1, 12, 9]
+    seq = [11, 7] + [1, 2] * 3 + [1, 3, 5, 7] + [1, 2] * 2 + [1, 12, 9, 13]
 print(f"{which} trunk, mean cycles over 256 workgroups x 4 waves")
 print(f"  kernel entry -> input built   {d(0, 1).mean():8.0f}   = point + bias requests {d(0, 52).mean():.0f}, point landed {d(52, 53).mean():.0f}, "
       f"weight pre-issue {d(53, 57).mean():.0f}, encoder {d(57, 1).mean():.0f}")
@@ -53,7 +53,7 @@ for i, b in enumerate(seq):
     whole = dd(r[..., 0], rec[:, :, i + 2, 0])
     tot += whole.mean()
     line = f"  phase {i:2d} {names[b]:6s} {whole.mean():7.0f}"
-    if b != 9:
+    if b not in (9, 13):
         line += (f" | dispatch {dd(r[..., 0], r[..., 1]).mean():5.0f} | entry waits {dd(r[..., 1], r[..., 2]).mean():5.0f} | MFMAs to the barrier "
                  f"{dd(r[..., 2], r[..., 3]).mean():6.0f} | lgkmcnt(0) + barrier {dd(r[..., 3], r[..., 4]).mean():5.0f} | rest of the body "
                  f"{dd(r[..., 4], r[..., 5]).mean():5.0f} | end -> next dispatch {dd(r[..., 5], rec[:, :, i + 2, 0]).mean():5.0f}")

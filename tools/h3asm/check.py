@@ -24,7 +24,8 @@ PK_BASE = 0x1_0000_0000
 PH_BASE = 0x2_0000_0000
 T_BASE = 0x3_0000_0000
 LDS_X = 0
-LDS_BIAS = 2 * gen.PLANE_B + 8192          # behind the two planes and the raw-record image
+LDS_RAW = 2 * gen.PLANE_B                  # raw-record image: 128 points x 16 floats
+LDS_BIAS = LDS_RAW + 8192                  # behind the two planes and the raw-record image
 
 
 def split_rtz(x):
@@ -54,10 +55,26 @@ def pack_segment(W):
     return out.reshape(-1).view(np.uint32), hi, lo
 
 
-def build_program(segs, in_t):
+def pack_head(W):
+    """W (32, 256) fp32 -> u32 stream [ks][hi, lo][lane][8 halfs], row = lane & 31, column 16 ks + 8 (lane >> 5) + t"""
+    hi = W.astype(np.float16)
+    lo = (W - hi.astype(np.float32)).astype(np.float16)
+    out = np.zeros((16, 2, 64, 8), np.float16)
+    lane = np.arange(64)
+    for ks in range(16):
+        for t in range(8):
+            c = 16 * ks + 8 * (lane >> 5) + t
+            out[ks, 0, :, t] = hi[lane & 31, c]
+            out[ks, 1, :, t] = lo[lane & 31, c]
+    return out.reshape(-1).view(np.uint32), hi, lo
+
+
+def build_program(segs, in_t, head=None):
     """Phase descriptors for a trunk (the host-side builder in csrc/field_h3a.hip does the same).
     segs: list of dict(nks, off, bias (index or None), post ('relu' | 'none'), rebuild (bool)[, wstride (bytes between the
-    waves' blocks of the packed segment, default nks * 4096), bias_b (table row of half B, default = bias)])."""
+    waves' blocks of the packed segment, default nks * 4096), bias_b (table row of half B, default = bias)]).
+    head: dict(off (bytes of the head tile), n_rows, slot0) -- the last epilogue requests the tile, the HEAD phase leaves the
+    pre-activation sums of rows 0 .. n_rows - 1 at floats slot0 .. of every point's raw record."""
     B = gen.BODY
     ph = []
 
@@ -103,7 +120,9 @@ def build_program(segs, in_t):
             ph.append(desc(B["B4"] if sg["nks"] == 4 else B["B8"], init_next, nbias, **refill_fields(t)))
             pending_b = True
     assert pending_b
-    ph.append(desc(B["EPI_B"]))
+    hd = head or dict(off=segs[0]["off"], n_rows=0, slot0=0)
+    ph.append([B["EPI_B"], 0, 0, hd["n_rows"], hd["off"], 0, hd["off"], 0])
+    ph.append([B["HEAD"], 0, 4 * hd["slot0"], hd["n_rows"], hd["off"], 0, hd["off"], 0])
     ph.append(desc(B["END"]))
     ph.append(desc(B["END"]))
     return np.array(ph, np.uint32)
@@ -144,6 +163,14 @@ def make_case(kind, seed=0):
             add_seg((rng.randn(256, k0) * 2.5 / np.sqrt(k0)).astype(np.float32), None, "relu", True)
         else:
             add_seg((rng.randn(256, 256) * scale).astype(np.float32), b, "relu", False)
+    # the heads: 10 rows (dynamic) / 4 rows (static) of a 32-row tile, results at slot 4 / 0 of the raw records
+    n_rows, slot0 = (10, 4) if in_t else (4, 0)
+    Wh_ = np.zeros((32, 256), np.float32)
+    Wh_[:n_rows] = (rng.randn(n_rows, 256) * 0.3).astype(np.float32)
+    hstream, hhi, hlo = pack_head(Wh_)
+    head = dict(off=off, n_rows=n_rows, slot0=slot0, hi=hhi, lo=hlo)
+    bufs.append((off, hstream))
+    off += hstream.size * 4
     pk = np.zeros(off // 4 + 16, np.uint32)
     for o, st in bufs:
         pk[o // 4:o // 4 + st.size] = st
@@ -174,7 +201,7 @@ def make_case(kind, seed=0):
             tgt["bias_b"] = nrow
             rows[nrow] = (tgt["b"] + part[64]).astype(np.float32)
             nrow += 1
-    return dict(kind=kind, in_t=in_t, k0=k0, segs=segs, pk=pk, x_in=x_in, t_table=t_table, ray_of=ray_of, rows=rows, tb=tb)
+    return dict(kind=kind, in_t=in_t, k0=k0, segs=segs, pk=pk, x_in=x_in, t_table=t_table, ray_of=ray_of, rows=rows, tb=tb, head=head)
 
 
 def reference(case):
@@ -194,7 +221,20 @@ def reference(case):
             v = np.maximum(acc, 0).astype(np.float32)
             h, l = split_rtz(v)
             xh_, xl_ = h.astype(np.float64), l.astype(np.float64)
-    return (xh_ + xl_).astype(np.float32)
+    return (xh_ + xl_).astype(np.float32), xh_, xl_
+
+
+def head_reference(case, xh_, xl_):
+    """(chain Wl.xh + chain Wh.xl) + chain Wh.xh, each chain accumulated in fp32 order of the k-steps (float64 per MFMA)"""
+    hd = case["head"]
+    Wh, Wl = hd["hi"].astype(np.float64), hd["lo"].astype(np.float64)
+    c = [np.zeros((128, 32), np.float32) for _ in range(3)]
+    for ks in range(16):
+        k = slice(16 * ks, 16 * ks + 16)
+        c[0] = (c[0] + xh_[:, k] @ Wl[:, k].T).astype(np.float32)
+        c[1] = (c[1] + xl_[:, k] @ Wh[:, k].T).astype(np.float32)
+        c[2] = (c[2] + xh_[:, k] @ Wh[:, k].T).astype(np.float32)
+    return ((c[0] + c[1]).astype(np.float32) + c[2]).astype(np.float32)[:, :hd["n_rows"]]
 
 
 def run_case(kind, seed=0, verbose=True):
@@ -203,7 +243,7 @@ def run_case(kind, seed=0, verbose=True):
     sim = Sim(pre + prog)                      # the two asm statements back to back (the encoder between them is C++)
     sim.add_buffer(PK_BASE, case["pk"])
     body_in_t = 0 if case["tb"] else case["in_t"]       # (the body sees no time-code columns when they are folded into the table)
-    phases = build_program(case["segs"], body_in_t)
+    phases = build_program(case["segs"], body_in_t, case["head"])
     sim.add_buffer(PH_BASE, phases.reshape(-1))
     sim.add_buffer(T_BASE, case["t_table"].reshape(-1).view(np.uint32))
     # LDS: input tile as the encoder leaves it (hi / lo planes), bias table
@@ -223,7 +263,7 @@ def run_case(kind, seed=0, verbose=True):
         tid = 64 * w.id + np.arange(64)
         for name, val in (("pk", PK_BASE), ("phases", PH_BASE)):
             w.s[I_S[name].i], w.s[I_S[name].i + 1] = val & 0xFFFFFFFF, val >> 32
-        for name, val in (("lds", LDS_X), ("biaslds", LDS_BIAS), ("wave", w.id), ("in_t", body_in_t), ("n1", phases[0][3]),
+        for name, val in (("lds", LDS_X), ("biaslds", LDS_BIAS), ("wave", w.id), ("in_t", body_in_t), ("rawlds", LDS_RAW), ("n1", phases[0][3]),
                           ("r1", phases[0][4]), ("r1w", phases[0][5]), ("r2", phases[0][6]), ("r2w", phases[0][7])):
             w.s[I_S[name].i] = int(val)
         w.v[I_V["tid"].i] = tid
@@ -241,10 +281,19 @@ def run_case(kind, seed=0, verbose=True):
     for r in range(128):
         base = (LDS_X + r * gen.LDH_B) // 2
         got[r] = lds_h[base:base + 256].astype(np.float32) + lds_h[base + gen.PLANE_B // 2:base + gen.PLANE_B // 2 + 256].astype(np.float32)
-    want = reference(case)
+    want, fxh, fxl = reference(case)
     err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+    # the heads: pre-activation sums in the raw-record image, everything else untouched (zero)
+    hd = case["head"]
+    raw = sim.lds.view(np.float32)[LDS_RAW // 4:LDS_RAW // 4 + 128 * 16].reshape(128, 16).copy()
+    hwant = head_reference(case, fxh, fxl)
+    herr = float(np.abs(raw[:, hd["slot0"]:hd["slot0"] + hd["n_rows"]] - hwant).max() / max(np.abs(hwant).max(), 1e-30))
+    raw[:, hd["slot0"]:hd["slot0"] + hd["n_rows"]] = 0
+    assert not raw.any(), "the HEAD phase wrote outside its slots"
+    assert herr < 2e-6, herr
+    err = max(err, herr)
     n_mf = sim.waves[0].n_mfma
-    want_mf = sum(sg["nks"] for sg in case["segs"]) * 24
+    want_mf = sum(sg["nks"] for sg in case["segs"]) * 24 + 48
     if verbose:
         print(f"{kind:9s} phases {len(phases) - 2:2d}  MFMAs/wave {n_mf} (expected {want_mf})  instructions/wave {sim.waves[0].n_inst}  "
               f"max-norm rel err {err:.2e}  |want| max {np.abs(want).max():.3g}  ({dt:.1f} s)")

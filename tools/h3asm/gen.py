@@ -52,6 +52,7 @@ S_PH = S(46, 2)             # pointer to the NEXT phase descriptor to fetch
 S_SAVE = S(48, 2)
 S_R1, S_R2, S_SEL = S(50), S(51), S(52)
 S_T0, S_T1 = S(53), S(54)
+S_RAWLDS = S(55)            # byte address of the raw-record image in LDS (the heads' pre-activation sums go there)
 S_CUR = 56                  # s56..s63 current descriptor
 S_NXT = 64                  # s64..s71 next descriptor (being fetched)
 D_BODY, D_FLAGS, D_BIAS, D_N1, D_R1, D_R1W, D_R2, D_R2W = range(8)
@@ -59,7 +60,7 @@ D_BODY, D_FLAGS, D_BIAS, D_N1, D_R1, D_R1W, D_R2, D_R2W = range(8)
 # an input tile at all (A4 / A8 also run the first layer, where the tile is still the encoder's)
 F_INIT, F_REBUILD_T, F_REBUILD = 0, 1, 2
 
-BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12)
+BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12, HEAD=13)
 
 
 def xh(b, nt):
@@ -468,17 +469,115 @@ def short_b_body(name, nks):
     return s.ins
 
 
+HEAD_ACC = [V(128 + 16 * c, 16) for c in range(3)]     # three accumulator chains of the heads (acc_A's registers)
+
+
+def head_loads():
+    """The head tile [k-step][hi, lo][lane = tile row + 32 k-half][8 halfs] (32 KiB, stream r1 of the descriptor) -> a0..a127,
+    requested in front of the last epilogue: k-step ks' hi fragment in a[8 ks : 8 ks + 3], lo in a[8 ks + 4 : 8 ks + 7].  Only
+    the lanes whose row (lane & 31) is one of the n1 head rows load (the others keep stale, finite weights: their output rows
+    are never read); the last MFMAs of the trunk were issued long before the first load can return.
+    Returns [setup (VCC = the loading lanes; nothing of the epilogue touches VCC), group 0, ..., group 7]: a group is four loads
+    under the lane mask -- spread over the epilogue, so that the wave is not held at the issue stage for all 32 at once."""
+    row16 = V(T0 + 16)
+    setup = [I_valu("v_and_b32", row16, 0x1f0, V_LANE16), I_salu("s_lshl_b32", S_T0, S(S_CUR + D_N1), 4, scc=True),
+             I_v_cmp_gt_u32_vcc(S_T0, row16)]
+    groups = []
+    for g in range(8):
+        o = [I_s_and_saveexec(S_SAVE), I_valu("v_add_u32", V_OFF, S_R1, V_LANE16, text=f"v_add_u32_e32 {V_OFF}, {S_R1}, {V_LANE16}")]
+        o += [I_gload_x4_s(A(16 * g + 4 * c, 4), V_OFF, S_PK, 1024 * c) for c in range(4)]
+        o += [I_salu("s_add_u32", S_R1, S_R1, 4096, scc=True), I_s_mov_exec(S_SAVE)]
+        groups.append(o)
+    return [setup] + groups
+
+
+def head_body():
+    """HEAD: the narrow output layers on the trunk's last activation (both planes complete: EPI_B ended with a barrier).  Wave w
+    multiplies the 32-row head tile (a0..a127, see head_loads) with the fragments of points 32 w .. 32 w + 31 -- three
+    accumulator chains Wl.xh, Wh.xl, Wh.xh of sixteen MFMAs -- and leaves  (chain0 + chain1) + chain2  of head row
+    r < n1 at float D_BIAS / 4 + r of the point's raw record in LDS; bias and activation are applied where the records are stored."""
+    s = Stream()
+    e = s.emit
+    e(I_label("L_HEAD"))
+    vbh, vbl, vw, v4h, t0 = V(T0), V(T0 + 1), V(T0 + 2), V(T0 + 3), V(T0 + 4)
+    e(I_salu("s_mul_i32", S_T0, S_WAVE, NT_B))
+    e(I_valu("v_add_u32", vbh, S_T0, V_RD_H, text=f"v_add_u32_e32 {vbh}, {S_T0}, {V_RD_H}"))
+    e(I_valu("v_add_u32", vbl, S_T0, V_RD_L, text=f"v_add_u32_e32 {vbl}, {S_T0}, {V_RD_L}"))
+
+    # fragments of four k-steps in registers (three in flight ahead of the MFMAs: 96 matrix-pipe cycles per k-step do not cover
+    # an LDS round trip): hi in XH[b][nt], lo in XL / XL2
+    fh = lambda ks: xh((ks >> 1) & 1, ks & 1)
+    fl = lambda ks: (xl, xl2)[(ks >> 1) & 1](ks & 1)
+
+    def reads(ks):
+        return [I_ds_read_b128(fh(ks), vbh, 32 * ks), I_ds_read_b128(fl(ks), vbl, 32 * ks)]
+    for k0 in range(3):
+        for r in reads(k0):
+            e(r, ("x", k0))
+    s.wait(vm=0)
+    a0, a1, a2 = HEAD_ACC
+    for ks in range(16):
+        s.need_lds(("x", ks))
+        e(I_mfma(a0, A(8 * ks + 4, 4), fh(ks), a0 if ks else 0))
+        e(I_mfma(a1, A(8 * ks, 4), fl(ks), a1 if ks else 0))
+        e(I_mfma(a2, A(8 * ks, 4), fh(ks), a2 if ks else 0))
+        if ks + 3 < 16:                 # (into the registers of k-step ks - 1: its MFMAs were issued 96 cycles ago)
+            for r in reads(ks + 3):
+                e(r, ("x", ks + 3))
+    # record address of this lane's point: rawlds + (32 wave + (lane & 31)) * 64 + 16 (lane >> 5) + 4 slot0
+    e(I_valu("v_and_b32", t0, 0x1f0, V_LANE16)); e(I_valu("v_lshlrev_b32", t0, 2, t0))
+    e(I_valu("v_lshrrev_b32", v4h, 5, V_LANE16)); e(I_valu("v_and_b32", v4h, 0x10, v4h))
+    e(I_valu("v_add_u32", t0, t0, v4h))
+    e(I_salu("s_lshl_b32", S_T0, S_WAVE, 11, scc=True)); e(I_salu("s_add_u32", S_T0, S_T0, S_RAWLDS, scc=True))
+    e(I_salu("s_add_u32", S_T0, S_T0, S(S_CUR + D_BIAS), scc=True))
+    e(I_valu("v_add_u32", vw, S_T0, t0, text=f"v_add_u32_e32 {vw}, {S_T0}, {t0}"))
+    e(I_valu("v_lshrrev_b32", v4h, 2, v4h))                                     # 4 (lane >> 5)
+    e(I_nop(7)); e(I_nop(3))                                                    # (the last MFMAs' results)
+    for r in range(8):
+        e(I_valu("v_add_f32", a0.sub(r), a0.sub(r), a1.sub(r)))
+    for r in range(8):
+        e(I_valu("v_add_f32", a0.sub(r), a0.sub(r), a2.sub(r)))
+    for r in range(8):              # accumulator register r of a lane = head row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        c_r = (r & 3) + 8 * (r >> 2)
+        e(I_salu("s_sub_u32", S_T1, S(S_CUR + D_N1), c_r, scc=True))
+        e(I_salu("s_cselect_b32", S_T1, 0, S_T1))                               # (n1 <= c_r: no lane)
+        e(I_v_cmp_gt_u32_vcc(S_T1, v4h))
+        e(I_s_and_saveexec(S_SAVE))
+        e(I_ds_write_b32(vw, a0.sub(r), 4 * c_r), "hw")
+        e(I_s_mov_exec(S_SAVE))
+    s.wait(lgkm=0)
+    e(I_branch("s_branch", "L_dispatch"))
+    return s.ins
+
+
 def bare_epilogue(name, half):
-    """Epilogue of `half` with no MFMAs beside it (end of the trunk): everything this wave started has landed when it is left."""
+    """Epilogue of `half` with no MFMAs beside it (end of the trunk), behind the requests of the head tile; ends with the
+    workgroup barrier that publishes the last activation (everything this wave started has landed)."""
     s = Stream()
     s.emit(I_label(f"L_{name}"))
+    hl = head_loads()
+    for i in hl[0] + hl[1]:
+        s.emit(i, "head")
     s.emit(I_nop(7)); s.emit(I_nop(7))          # the last MFMAs on these accumulators were issued a few states ago
-    # two units at a time, instruction by instruction: independent chains for the in-order VALU
+    # two units at a time, instruction by instruction: independent chains for the in-order VALU; a group of head-tile loads
+    # in front of and in the middle of every pair
     units = [epilogue_unit(half, u, u & 1) for u in range(8)]
+    g = 2
     for u in range(0, 8, 2):
-        for x, y in zip(units[u], units[u + 1]):
+        n = len(units[u])
+        for k, (x, y) in enumerate(zip(units[u], units[u + 1])):
+            if k == n // 2 or (k == 0 and u > 0):
+                if g < len(hl):
+                    for i in hl[g]:
+                        s.emit(i, "head")
+                    g += 1
             s.emit(x, "ride"); s.emit(y, "ride")
+    while g < len(hl):
+        for i in hl[g]:
+            s.emit(i, "head")
+        g += 1
     s.wait(vm=0, lgkm=0)
+    s.emit(I_barrier())
     s.emit(I_branch("s_branch", "L_dispatch"))
     return s.ins
 
@@ -488,7 +587,8 @@ def raw(text, wr=(), rd=()):
 
 
 # Inline-asm operands and the registers the simulator's harness presets in their place
-IN_S = dict(pk=S(0, 2), phases=S(2, 2), lds=S(4), biaslds=S(5), wave=S(6), in_t=S(7), r1=S(8), r1w=S(9), r2=S(10), r2w=S(11), n1=S(12))
+IN_S = dict(pk=S(0, 2), phases=S(2, 2), lds=S(4), biaslds=S(5), wave=S(6), in_t=S(7), r1=S(8), r1w=S(9), r2=S(10), r2w=S(11), n1=S(12),
+            rawlds=S(13))
 IN_V = dict(tid=V(0), tpa0=V(1), tpa1=V(2), tpb0=V(3), tpb1=V(4))
 
 
@@ -531,7 +631,7 @@ def prologue():
     if TIMING:
         e(raw("s_mov_b64 s[76:77], %[dbg]")); e(raw("s_memtime s[74:75]"))
     e(in_s(S_PK, "pk")); e(in_s(S_PH, "phases")); e(in_s(S_LDS, "lds")); e(in_s(S_BIASLDS, "biaslds"))
-    e(in_s(S_WAVE, "wave")); e(in_s(S_INT, "in_t")); e(in_v(V_TMP, "tid"))
+    e(in_s(S_WAVE, "wave")); e(in_s(S_INT, "in_t")); e(in_s(S_RAWLDS, "rawlds")); e(in_v(V_TMP, "tid"))
     e(in_v(V(34), "tpa0")); e(in_v(V(35), "tpa1")); e(in_v(V(36), "tpb0")); e(in_v(V(37), "tpb1"))
     # descriptor 0 -> cur (bias row of segment 0), descriptor 1 -> nxt (fetched now, valid after the lgkmcnt(0) below)
     e(I_s_load(S(S_CUR, 8), S_PH, 0))
@@ -600,7 +700,7 @@ def timing_store():
     return o
 
 
-DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B")
+DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B", "HEAD")
 
 
 def dispatcher():
@@ -636,6 +736,7 @@ def build():
         "B4": short_b_body("B4", 4),
         "B8": short_b_body("B8", 8),
         "EPI_B": bare_epilogue("EPI_B", "B"),
+        "HEAD": head_body(),
     }
     prog = prologue()
     prog.append(I_branch("s_branch", "L_dispatch"))

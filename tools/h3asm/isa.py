@@ -96,6 +96,12 @@ def I_ds_write_b128(addr, data, off=0):
                 dict(addr=addr, data=data, off=off))
 
 
+def I_ds_write_b32(addr, data, off=0):
+    assert 0 <= off < 65536 and data.n == 1
+    return Inst("ds_write_b32", f"ds_write_b32 {addr}, {data} offset:{off}", [addr, data], [], "lds_w",
+                dict(addr=addr, data=data, off=off))
+
+
 def I_gload_x4_s(d, voff, sbase, off=0):
     """global_load_dwordx4 d, voff, s[base:base+1] offset  (address = sbase + zext(voff) + off)"""
     assert -4096 <= off <= 4095 and d.n == 4 and sbase.n == 2
@@ -137,6 +143,11 @@ def I_v_permlane32_swap(a, b):           # a.hi <-> b.lo
 
 def I_v_cmp_lt_u32_vcc(a, b):            # vcc = a < b   (a: constant or reg, b: VGPR)
     return Inst("v_cmp_lt_u32", f"v_cmp_lt_u32_e32 vcc, {_src(a)}, {b}", [x for x in (a, b) if _is_reg(x)], [VCC], "valu",
+                dict(a=a, b=b))
+
+
+def I_v_cmp_gt_u32_vcc(a, b):            # vcc = a > b   (a: constant or SGPR or reg, b: VGPR)
+    return Inst("v_cmp_gt_u32", f"v_cmp_gt_u32_e32 vcc, {_src(a)}, {b}", [x for x in (a, b) if _is_reg(x)], [VCC], "valu",
                 dict(a=a, b=b))
 
 
@@ -368,8 +379,8 @@ class Sim:
     # ---- LDS with race detection ----
     def _lds_access(self, w, byte_addr, n_dw, write, data=None, lanes=None):
         lanes = w.exec if lanes is None else lanes
-        if (byte_addr[lanes] % 16).any():
-            raise SimError(f"wave {w.id}: unaligned 16-byte LDS access")
+        if (byte_addr[lanes] % (4 * n_dw)).any():
+            raise SimError(f"wave {w.id}: unaligned {4 * n_dw}-byte LDS access")
         idx0 = (byte_addr // 4).astype(np.int64)
         out = np.zeros((n_dw, NL), np.uint32)
         for k in range(n_dw):
@@ -473,8 +484,9 @@ class Sim:
             return None
         if k == "lds_w":
             addr = self._rv(w, a["addr"]).astype(np.int64) + a["off"]
-            data = np.stack([self._rv(w, a["data"], r4) for r4 in range(4)])
-            self._lds_access(w, addr, 4, True, data)
+            n_dw = a["data"].n
+            data = np.stack([self._rv(w, a["data"], r4) for r4 in range(n_dw)])
+            self._lds_access(w, addr, n_dw, True, data)
             w.lds_q.append(set())
             return None
         if k == "vmem":
@@ -537,8 +549,8 @@ class Sim:
             self._wv(w, a["a"], nx, masked=False)
             self._wv(w, a["b"], ny, masked=False)
             return
-        if op == "v_cmp_lt_u32":
-            r = self._val(w, a["a"]) < self._val(w, a["b"])
+        if op in ("v_cmp_lt_u32", "v_cmp_gt_u32"):
+            r = self._val(w, a["a"]) < self._val(w, a["b"]) if op == "v_cmp_lt_u32" else self._val(w, a["a"]) > self._val(w, a["b"])
             bits = 0
             for l in range(NL):
                 if r[l] and w.exec[l]:
@@ -556,6 +568,8 @@ class Sim:
             out = (f32(s[1]) - halfs_of(s[0])[1]).astype(np.float32).view(np.uint32)
         elif op == "v_mov_b32":
             out = s[0]
+        elif op == "v_add_f32":
+            out = (f32(s[0]) + f32(s[1])).astype(np.float32).view(np.uint32)
         elif op == "v_add_u32":
             out = s[0] + s[1]
         elif op == "v_sub_u32":
