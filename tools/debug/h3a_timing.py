@@ -10,7 +10,7 @@ import scenes
 import nsff_pl_amd as A
 from nsff_pl_amd import _lib, config
 
-which = sys.argv[1] if len(sys.argv) > 1 else "static"       # static: fine launch (first 256 workgroups run the static trunk)
+which = sys.argv[1] if len(sys.argv) > 1 else "static"       # static | dynamic | dynamic_tb: a launch of that trunk alone (131 072 x 1.5 points)
 config.set_precision("f16x3"); config.set_tile_points(130)
 dev = torch.device("cuda:0")
 cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024, seed=0)
@@ -26,7 +26,7 @@ freqs = [float(f) for f in emb["xyz"].freqs]
 sm = 2 if which == "static" else 0                            # dynamic: the warp launch shape (dynamic trunk only)
 tb = _lib.time_bias([(model, t_rows)])[0] if which == "dynamic_tb" else None     # dynamic_tb: time code folded into bias rows
 for _ in range(3):
-    _lib.field_query(model, raw, P, S, sm, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows, t_bias=tb)
+    _lib.field_query(model, raw, P, S, sm, 0 if which == "static" else 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows, t_bias=tb)
 torch.cuda.synchronize()
 lib = _lib.load()
 TBASE = 256 * 8 * 32 * 6
