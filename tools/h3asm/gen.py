@@ -150,12 +150,14 @@ class Stream:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+NOSWAP_STORES = os.environ.get("H3A_NOSWAP_STORES", "1") == "1"    # 0: the v_permlane32_swap + 16-byte store form (A/B builds)
 EXP = os.environ.get("H3A_EXP", "")          # timing experiments (results are garbage): nomix, noswap, nowrite, noride, andsub
 
 
 def epilogue_unit(half, u, tset):
-    """ReLU -> hi / lo split -> lanes i, i+32 trade halves -> two 16-byte LDS stores of (tile u>>1, quad pair p = u&1) of
-    `half`'s accumulators.  In place on the accumulator registers; 8 temporaries from set `tset`."""
+    """ReLU -> hi / lo split -> four 8-byte LDS stores (two per plane) of (tile u>>1, quad pair p = u&1) of `half`'s accumulators.
+    In place on the accumulator registers; 8 temporaries from set `tset`.  (Until late in round 4: lanes i, i+32 traded halves with
+    v_permlane32_swap for two 16-byte stores -- two instructions more per unit, +0.6 % on the C2 step.)"""
     t, p = u >> 1, u & 1
     mt, nt = t >> 1, t & 1
     a = acc(half, mt, nt)
@@ -167,10 +169,16 @@ def epilogue_unit(half, u, tset):
     for k in range(4):
         out += [I_v_sub_lo_half(x[2 * k], H[k], x[2 * k]), I_v_sub_hi_half(x[2 * k + 1], H[k], x[2 * k + 1])]
     out += [I_v_cvt_pkrtz(L[k], x[2 * k], x[2 * k + 1]) for k in range(4)]
-    out += [I_v_permlane32_swap(H[0], H[2]), I_v_permlane32_swap(H[1], H[3]),
-            I_v_permlane32_swap(L[0], L[2]), I_v_permlane32_swap(L[1], L[3])]
     off = half_off(half) + NT_B * nt + 64 * mt + 16 * p
-    out += [I_ds_write_b128(V_WR_H, V(H[0].i, 4), off), I_ds_write_b128(V_WR_L, V(L[0].i, 4), off)]
+    if NOSWAP_STORES:
+        # a lane holds neurons 8 p + 4 h .. + 3 and 16 + 8 p + 4 h .. + 3 of the 32-neuron tile (h = lane >> 5): four 8-byte stores
+        # (write base + 8 h) instead of four v_permlane32_swap + two 16-byte stores (write base + 32 h)
+        out += [I_ds_write_b64(V_WR_H, V(H[0].i, 2), off), I_ds_write_b64(V_WR_H, V(H[2].i, 2), off + 32),
+                I_ds_write_b64(V_WR_L, V(L[0].i, 2), off), I_ds_write_b64(V_WR_L, V(L[2].i, 2), off + 32)]
+    else:
+        out += [I_v_permlane32_swap(H[0], H[2]), I_v_permlane32_swap(H[1], H[3]),
+                I_v_permlane32_swap(L[0], L[2]), I_v_permlane32_swap(L[1], L[3])]
+        out += [I_ds_write_b128(V_WR_H, V(H[0].i, 4), off), I_ds_write_b128(V_WR_L, V(L[0].i, 4), off)]
     if "nomix" in EXP:
         out = [I_valu("v_mov_b32", i.args["d"], i.args["s"][1]) if i.op.startswith("v_fma_mix") else i for i in out]
     if "noswap" in EXP:
@@ -648,7 +656,7 @@ def prologue():
     e(I_valu("v_add_u32", V_RD_L, PLANE_B, V_RD_H, text=f"v_add_u32_e32 {V_RD_L}, {PLANE_B}, {V_RD_H}"))
     # wr_h = lds + l31 * 528 + 128 wave + 32 h ; wr_l = wr_h + PLANE
     e(I_valu("v_mul_u32_u24", V_WR_H, LDH_B, l31))
-    e(I_valu("v_lshlrev_b32", V(T0 + 3), 5, h)); e(I_valu("v_add_u32", V_WR_H, V_WR_H, V(T0 + 3)))
+    e(I_valu("v_lshlrev_b32", V(T0 + 3), 3 if NOSWAP_STORES else 5, h)); e(I_valu("v_add_u32", V_WR_H, V_WR_H, V(T0 + 3)))
     e(I_salu("s_lshl_b32", S_T0, S_WAVE, 7, scc=True))
     e(I_salu("s_add_u32", S_T0, S_T0, S_LDS, scc=True))
     e(I_valu("v_add_u32", V_WR_H, S_T0, V_WR_H, text=f"v_add_u32_e32 {V_WR_H}, {S_T0}, {V_WR_H}"))
@@ -792,7 +800,8 @@ def main():
         sys.exit(f"{len(errs)} hazard(s)")
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "nsff_pl_amd", "csrc",
                        "field_h3a_body_timing.inc" if TIMING else (f"field_h3a_body_{EXP}.inc" if EXP else
-                       (f"field_h3a_body_cap{RIDE_CAP}.inc" if "H3A_RIDE_CAP" in os.environ else "field_h3a_body.inc")))
+                       (f"field_h3a_body_cap{RIDE_CAP}.inc" if "H3A_RIDE_CAP" in os.environ else
+                        ("field_h3a_body_swap.inc" if not NOSWAP_STORES else "field_h3a_body.inc"))))
     clob = ", ".join([f'"v{i}"' for i in range(24, 256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(40, 100)] +
                      ['"vcc"', '"scc"', '"memory"'])
     pre_wr = sorted({r for i in pre for r in i.wr if r[0] in ("v", "a") or (r[0] == "s" and r[1] < 100)})

@@ -96,6 +96,12 @@ def I_ds_write_b128(addr, data, off=0):
                 dict(addr=addr, data=data, off=off))
 
 
+def I_ds_write_b64(addr, data, off=0):
+    assert 0 <= off < 65536 and data.n == 2
+    return Inst("ds_write_b64", f"ds_write_b64 {addr}, {data} offset:{off}", [addr, data], [], "lds_w",
+                dict(addr=addr, data=data, off=off))
+
+
 def I_ds_write_b32(addr, data, off=0):
     assert 0 <= off < 65536 and data.n == 1
     return Inst("ds_write_b32", f"ds_write_b32 {addr}, {data} offset:{off}", [addr, data], [], "lds_w",
