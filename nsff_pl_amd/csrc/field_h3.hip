@@ -1480,6 +1480,7 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
             if (t == 0 || !pending_b) return false;
             ok = ok && put(H3A_BODY_A16R, g.bias >= 0 ? H3A_F_INIT : 0u, g.bias_b, 16, g, g);   // (an A phase's tail initialises acc_B)
             if (g.relu) {
+                if (nxt && nxt->nks != 16) return false;      // (B16R requests from ONE stream: a 16-k-step segment follows)
                 ok = ok && put(nxt ? H3A_BODY_B16R : H3A_BODY_B16L, init_next, nbias, n1, r1, r2);   // (the last segment requests nothing)
                 pending_b = true;
             } else {
@@ -1490,6 +1491,7 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
         } else {
             if (pending_b || !g.relu) return false;
             if (t > 0 && (!g.rebuild || g.bias >= 0)) return false;
+            if (nxt && nxt->nks != 16) return false;          // (its B phase requests from ONE stream)
             if (t == 0)     // slots 0..7 were requested in front of the encoder (H3A_PRE, descriptor 0), 8..15 ride in this A phase
                 ok = ok && put(g.nks == 4 ? H3A_BODY_A4F : H3A_BODY_A8F, 0u, 0, g.nks, g, n > 1 ? segs[1] : g);
             else
