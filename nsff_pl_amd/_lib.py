@@ -325,8 +325,12 @@ def time_rows_backward(g_cur, g_next, g_prev, ts, max_t, n_table):
 def time_rows(table, ts, max_t, want_next=True, want_prev=True):
     """(E[clamp(ts + 1, max=max_t)], E[clamp(ts - 1, min=0)]) of an embedding table in one launch (rendering.py:218,224)."""
     n, width = ts.shape[0], table.shape[1]
-    nxt = torch.empty(n, width, device=table.device) if want_next else None
-    prv = torch.empty(n, width, device=table.device) if want_prev else None
+    if want_next and want_prev:     # (one buffer: the two re-queries of a call can then run as ONE field launch over 2 n rays)
+        both = torch.empty(2, n, width, device=table.device)
+        nxt, prv = both[0], both[1]
+    else:
+        nxt = torch.empty(n, width, device=table.device) if want_next else None
+        prv = torch.empty(n, width, device=table.device) if want_prev else None
     assert ts.dtype == torch.int64 and ts.is_cuda and ts.is_contiguous()
     _check(load().nsff_time_rows(_ptr(table), table.shape[0], width, C.c_void_p(ts.data_ptr()), n, int(max_t),
                                  _ptr(nxt), _ptr(prv), _stream()), "nsff_time_rows")
@@ -386,7 +390,7 @@ def time_bias(jobs):
     jobs); field_query(..., t_bias=) then multiplies no time-code column."""
     assert 1 <= len(jobs) <= MAX_TIME_BIAS_JOBS
     arr = (TimeBiasJob * len(jobs))()
-    keep, outs, per_model = [], [], {}
+    keep, outs, per_model, pair = [], [], {}, None
     n_rays = int(jobs[0][1].shape[0])
     for j, (model, t_rows) in enumerate(jobs):
         if id(model) not in per_model:
@@ -398,7 +402,14 @@ def time_bias(jobs):
             per_model[id(model)] = (desc, C.pointer(desc), wb)
         desc, pdesc, wb = per_model[id(model)]
         assert t_rows.shape == (n_rays, desc.in_t)
-        out = torch.empty(n_rays, len(wb), 256, device=t_rows.device, dtype=torch.float32)
+        # (consecutive jobs of one model get adjacent halves of one buffer: see rendering._inference's merged re-query)
+        if j + 1 < len(jobs) and jobs[j + 1][0] is model and pair is None:
+            pair = torch.empty(2, n_rays, len(wb), 256, device=t_rows.device, dtype=torch.float32)
+            out = pair[0]
+        elif pair is not None:
+            out, pair = pair[1], None
+        else:
+            out = torch.empty(n_rays, len(wb), 256, device=t_rows.device, dtype=torch.float32)
         arr[j].desc = pdesc
         for i, (w, b) in enumerate(wb):
             arr[j].w[i], arr[j].b[i] = w.data_ptr(), b.data_ptr()

@@ -13,6 +13,8 @@ on the current stream:
 The eval-time frustum-visibility mask (rendering.py:190-200) is part of the compositing kernel;
 :mod:`nsff_pl_amd.ray_geometry` only prepares its camera table (once per dataset, no host sync per call).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -113,11 +115,11 @@ def _plan_time_bias(ctx, models, t_embedded, N_samples, N_importance, output_tra
             continue
         if t_embedded.shape != (n_rays, model.in_channels_t):
             continue
-        jobs.append((model, t_embedded)); tags.append((typ, 't'))
         if typ == 'fine' and flows and not ctx.test_time and hasattr(model, "transient_flow_fw"):
             ctx.neighbour_rows = _neighbour_time_rows(ctx.embeddings, ctx.ts, ctx.max_t)
-            jobs.append((model, ctx.neighbour_rows[0])); tags.append((typ, 'fw'))
+            jobs.append((model, ctx.neighbour_rows[0])); tags.append((typ, 'fw'))      # (fw, bw adjacent: one buffer, see time_bias)
             jobs.append((model, ctx.neighbour_rows[1])); tags.append((typ, 'bw'))
+        jobs.append((model, t_embedded)); tags.append((typ, 't'))
     if jobs:
         for tag, out in zip(tags, _lib.time_bias(jobs)):
             ctx.tbias[tag] = out
@@ -198,18 +200,33 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
     if warps:
         # points pushed along their own scene flow, re-queried one frame later / earlier
         ts = ctx.ts
-        xyz_fw = out('xyzs_fw', n_rays, S, 3)
-        xyz_bw = _new(zs, n_rays, S, 3)
-        raw_fw = _new(zs, P, _lib.RAW_STRIDE)
-        raw_bw = _new(zs, P, _lib.RAW_STRIDE)
+        # the two re-queries are ONE launch over 2 n_rays rays when nothing is kept for a backward pass (same kernel, same
+        # per-point arithmetic; one launch boundary less): the warped points, their records, the t +- 1 rows and their bias rows
+        # are the two halves of one buffer each
+        xyz_w = _new(zs, 2, n_rays, S, 3)
+        xyz_fw, xyz_bw = xyz_w[0], xyz_w[1]
+        results['xyzs_fw'] = xyz_fw
+        raw_w = _new(zs, 2 * P, _lib.RAW_STRIDE)
+        raw_fw, raw_bw = raw_w[:P], raw_w[P:]
         tp1, tm1 = ctx.neighbour_rows if ctx.neighbour_rows is not None else _neighbour_time_rows(ctx.embeddings, ts, ctx.max_t)
+        tb_fw, tb_bw = ctx.tbias.get((typ, 'fw')), ctx.tbias.get((typ, 'bw'))
+        merged = (ctx.rec is None and P > 0 and not os.environ.get('NSFF_NO_MERGED_REQUERY') and tp1.data_ptr() + tp1.numel() * 4 == tm1.data_ptr()
+                  and (tb_fw is None) == (tb_bw is None)
+                  and (tb_fw is None or tb_fw.data_ptr() + tb_fw.numel() * 4 == tb_bw.data_ptr()))
         if P:
             _lib.warp_points(raw, xyz, zs, Z_FAR, xyz_fw, xyz_bw)
-            query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1, which='fw')
+            if merged:
+                ctx.tbias[(typ, 'fwbw')] = None if tb_fw is None else torch.as_strided(tb_fw, (2 * n_rays,) + tuple(tb_fw.shape[1:]),
+                                                                                         tb_fw.stride())
+                _lib.field_query(model, raw_w, 2 * P, S, static_mode=0, transient_mode=2, flow_heads=1, xyz=xyz_w,
+                                 freqs=ctx.freqs_xyz, t_emb=torch.as_strided(tp1, (2 * n_rays, tp1.shape[1]), tp1.stride()),
+                                 t_bias=ctx.tbias[(typ, 'fwbw')])
+            else:
+                query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1, which='fw')
         noise_fw = torch.randn(n_rays, S, device=zs.device)
         out('rgb_fw', n_rays, 3)
         results['xyzs_bw'] = xyz_bw
-        if P:
+        if P and not merged:
             query(f"{typ}_warp_bw", raw_bw, xyz_bw, 0, 2, 1, tm1, which='bw')
         noise_bw = torch.randn(n_rays, S, device=zs.device)
         if ctx.rec is not None and nstd != 0:
