@@ -417,6 +417,31 @@ def test_ragged_and_empty_batches(hip_lib):
             parity.assert_close(k, out[k], want[k])
 
 
+def test_merged_requery_launch_equals_two_launches(hip_lib, precision, monkeypatch):
+    """Inference calls issue the two scene-flow re-queries (x + fw at t + 1, x + bw at t - 1) as ONE field launch over 2 N rays;
+    NSFF_NO_MERGED_REQUERY=1 issues them separately.  Per-point arithmetic does not depend on which tile a point sits in: every
+    key is bit-identical -- for a ray count whose point count is not a multiple of the 128-point tile, and at the C2 size."""
+    cfg = dict(scenes.CASES["g3_nsff_train"])
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    kw = scenes.render_kwargs(cfg)
+    for n in (37, 1024):
+        rays, ts = scenes.synthetic_rays(n, 7)
+        outs = []
+        for off in ("", "1"):
+            if off:
+                monkeypatch.setenv("NSFF_NO_MERGED_REQUERY", off)
+            else:
+                monkeypatch.delenv("NSFF_NO_MERGED_REQUERY", raising=False)
+            torch.manual_seed(3)
+            with torch.no_grad():
+                outs.append(_np(A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 1, 1, 64, 32768, test_time=False, **kw)))
+        assert set(outs[0]) == set(outs[1]) and "rgb_fw" in outs[0]
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], outs[1][k]), (n, k)
+    monkeypatch.delenv("NSFF_NO_MERGED_REQUERY", raising=False)
+
+
 def test_native_library_is_the_one_loaded(hip_lib):
     with open("/proc/self/maps") as f:
         assert any("libnsff_hip.so" in line for line in f), "HIP extension not loaded in this process"
