@@ -1094,6 +1094,15 @@ __device__ __forceinline__ float fast_tanh(float v) {
 #else
 #include "field_h3a_body.inc"
 #endif
+// The heads evaluated on a trunk's last activation (HEAD_* of its last step): tile / bias offsets in the packed buffer (words),
+// rows, first float of the raw record, activation kinds (two bits per row).
+struct H3AHeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
+__host__ __device__ __forceinline__ H3AHeadSel h3a_head_sel(const NsffLayoutH3& L, int head) {
+    if (head == HEAD_S_FOLD) return H3AHeadSel{L.s_fold_w, L.s_fold_b, 4, 0, 0x15u};
+    if (head == HEAD_T_FOLD) return H3AHeadSel{L.t_fold_w, L.t_fold_b, (int)L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
+    return H3AHeadSel{L.s_sigma_w, L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
+}
+
 constexpr int H3A_MAX_PHASES = 36, H3A_MAX_BIAS = 16;
 constexpr uint32_t H3A_TB_ROW = 0x80000000u, H3A_TB_HALF_B = 0x100u;    // bias_off entry: row (entry & 0xff) of the per-ray table, of the ray of half A / B
 struct H3APhase { uint32_t d[8]; };     // body, flags, bias table offset, n1, r1 offset / wave stride, r2 offset / wave stride (bytes)
@@ -1103,17 +1112,9 @@ struct H3AArgs {
     __attribute__((aligned(16))) uint32_t bias_off[2][H3A_MAX_BIAS]; // packed word offset of bias table row i, or H3A_TB_ROW | [H3A_TB_HALF_B] | row of H3KArgs::t_bias
     int n_bias[2];
     int head[2];                        // HEAD_* evaluated on the trunk's last activation
+    H3AHeadSel hsel[2];                 // ... and what that means (h3a_head_sel of the host): one scalar load in the kernel
 };
 static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
-
-// The heads evaluated on a trunk's last activation (HEAD_* of its last step): tile / bias offsets in the packed buffer (words),
-// rows, first float of the raw record, activation kinds (two bits per row).
-struct H3AHeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
-__host__ __device__ __forceinline__ H3AHeadSel h3a_head_sel(const NsffLayoutH3& L, int head) {
-    if (head == HEAD_S_FOLD) return H3AHeadSel{L.s_fold_w, L.s_fold_b, 4, 0, 0x15u};
-    if (head == HEAD_T_FOLD) return H3AHeadSel{L.t_fold_w, L.t_fold_b, (int)L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
-    return H3AHeadSel{L.s_sigma_w, L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
-}
 
 // Weight slots 0..7 (the first segment and the start of the second), requested in front of / inside the encoder: statement K
 // loads slot K's 4 KiB of this wave from (K < n1 ? r1 : r2) + 4096 K -- the fields of phase descriptor 0, as the body's refills.
@@ -1278,13 +1279,15 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 #pragma unroll
         for (int r = 0; r < H3A_MAX_BIAS; ++r) {
             const uint32_t off = r < nb ? boff[r] : 0u;
-            const long long at = (off & H3A_TB_ROW) ? tb_at[(off & H3A_TB_HALF_B) ? 1 : 0] + (long long)((off & 0xffu) * (NSFF_W * 4))
-                                                    : (long long)off * 4;
+            // (selects as mask arithmetic: the compiler turns the conditional form into two scalar branches per row)
+            const long long per_ray = -(long long)(off >> 31), half_b = -(long long)((off >> 8) & 1u);
+            const long long at_ray = tb_at[0] + (half_b & (tb_at[1] - tb_at[0])) + (long long)((off & 0xffu) * (NSFF_W * 4));
+            const long long at = (at_ray & per_ray) | ((long long)off * 4 & ~per_ray);
             bv[r] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + at)[threadIdx.x];
         }
     }
     // (the heads' biases -- 32 floats -- travel with the table: the records loop below reads them from LDS)
-    const H3AHeadSel hs = h3a_head_sel(a.L, aa.head[tr]);
+    const H3AHeadSel hs = aa.hsel[tr];
     const float hbias = reinterpret_cast<const float*>(pk)[hs.b_off + (threadIdx.x & 31)];
     H3A_TSTAMP(52);
     H3APre pre;
@@ -2084,6 +2087,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         }
         const long long tiles = (g.n_points + 127) / 128;
         if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
+        ka.hsel[0] = h3a_head_sel(k.L, ka.head[0]); ka.hsel[1] = h3a_head_sel(k.L, ka.head[1]);
         if (asm_body && static_uncovered) {
             // (1) static trunk: the first half of a split launch's grid = static workgroups only
             k.grid_tiles = tiles;
