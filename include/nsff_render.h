@@ -182,7 +182,9 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed,
  * (i = 0 .. nsff_time_bias_rows(desc) - 1), in fp32.  nsff_field_query takes the result as NsffFieldArgs::t_bias.
  * Up to NSFF_MAX_TIME_BIAS_JOBS (model, time rows) pairs per launch: a render_rays call needs the coarse model at t and the fine
  * model at t, t + 1, t - 1.  w[i] / b[i]: weight (256, in_xyz + in_t [+ 256 for a skip layer]) and bias (256) of
- * transient_xyz_encoding_{l_i + 1}, the parameters themselves (PyTorch Linear layout, no pack needed). */
+ * transient_xyz_encoding_{l_i + 1}, the parameters themselves (PyTorch Linear layout, no pack needed).
+ * Time codes wider than 64 columns or with in_t % 4 != 0 are refused (NSFF_ERR_INVALID): the kernel stages 64 columns per ray
+ * as float4s, and such models keep their time-code columns on the matrix pipe (nsff_field_query ignores t_bias for them). */
 #define NSFF_MAX_TIME_BIAS_JOBS 4
 typedef struct NsffTimeBiasJob {
     const NsffModelDesc* desc;

@@ -679,16 +679,20 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
         recs.swap(g_prof);
     }
     double ms = 0, fl = 0, ex = 0, ticks = 0, tms = 0;
+    // every launch first: the span pool is copied once, when ALL profiled launches are complete (a copy taken behind the first
+    // record's event would read the slots of later launches -- on non-blocking streams hipMemcpy does not wait for them -- half-written)
     for (auto& r : recs) {
         hipError_t e = hipEventSynchronize(r.e1);
         if (e != hipSuccess) return nsff_hip_fail(e);
+    }
+    for (auto& r : recs) {
         float t = 0;
-        e = hipEventElapsedTime(&t, r.e0, r.e1);
+        hipError_t e = hipEventElapsedTime(&t, r.e0, r.e1);
         if (e != hipSuccess) return nsff_hip_fail(e);
         ms += t; fl += r.flops; ex += r.executed;
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
         if (r.span_slot >= 0 && g_span_pool) {
-            if (spans.empty()) {                   // (every event above is complete: the stamps of those launches are too)
+            if (spans.empty()) {                   // (every event of this collection is complete: so is every stamp)
                 spans.resize((size_t)SPAN_SLOTS * NSFF_SPAN_WORDS);
                 if (hipMemcpy(spans.data(), g_span_pool, spans.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) spans.clear();
             }

@@ -1965,6 +1965,9 @@ extern "C" int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64
         TimeBiasJobK& k = a.job[q];
         k.rows = nsff_time_bias_rows(&d);
         if (k.rows < 1) return NSFF_ERR_INVALID;
+        // (the kernel stages 64 time-code columns per ray as float4s: wider or odd-width time codes are not its job -- such
+        //  models keep their time-code columns on the matrix pipe, the field dispatcher never asks for rows here)
+        if (d.in_t > 64 || (d.in_t & 3) != 0) return NSFF_ERR_INVALID;
         k.in_xyz = d.in_xyz; k.in_t = d.in_t; k.t_rows = jb.t_rows; k.out = jb.out;
         const uint32_t skips = nsff_skip_layers(&d);
         int i = 0;

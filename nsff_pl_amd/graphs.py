@@ -8,7 +8,10 @@ it; what a caller on a slow or busy host gains is the launch overhead of the who
 
 Contract: results are the graph's own output tensors -- valid until the next call with the same batch size (copy what must
 outlive it; ``evaluate.render_frame(graph=...)`` does).  Weights may change between calls: the packed weight buffers keep their
-addresses and are refreshed eagerly before the replay.  Per-ray keyword tensors (``view_dir``, ``t_embedded``, ``a_embedded``) are
+addresses and are refreshed eagerly before the replay.  The graph also holds RAW PARAMETER ADDRESSES (``nsff_time_bias`` reads the
+dynamic trunk's input-layer weights, the embedding gathers read their tables): the addresses of every model / embedding parameter
+are part of the cache key, so a caller that re-points parameters (``FlatAdam.adopt``, ``model.to()``, ``load_state_dict(assign=True)``)
+gets a fresh capture instead of a replay that reads freed memory.  Per-ray keyword tensors (``view_dir``, ``t_embedded``, ``a_embedded``) are
 not supported -- they would have to be static buffers too; pass the plain arguments.
 """
 import torch
@@ -26,7 +29,12 @@ class GraphedRender:
         self.models, self.embeddings = models, embeddings
         self.args = (max_t, N_samples, perturb, noise_std, N_importance, chunk)
         self.test_time, self.kwargs = bool(test_time), dict(kwargs)
-        self._graphs = {}                # (n_rays, has_ts, precision, tile) -> (graph, rays, ts, results)
+        self._graphs = {}                # (n_rays, has_ts, precision, tile, parameter addresses) -> (graph, rays, ts, results)
+
+    def _param_addresses(self):
+        """Addresses of every parameter a captured launch may read directly (not through the refreshed packs)."""
+        mods = list(self.models.values()) + [m for m in self.embeddings.values() if isinstance(m, torch.nn.Module)]
+        return tuple(p.data_ptr() for m in mods for p in m.parameters())
 
     def _refresh_packs(self):
         """Packed weights live in buffers whose addresses the graphs hold: re-pack (eagerly, in place) whatever changed."""
@@ -57,9 +65,12 @@ class GraphedRender:
     def __call__(self, rays, ts=None):
         if not rays.is_cuda:
             raise RuntimeError("GraphedRender needs GPU tensors (there is no CPU path)")
-        key = (int(rays.shape[0]), ts is not None, config.get_precision(), config.get_tile_points())
+        shape_key = (int(rays.shape[0]), ts is not None, config.get_precision(), config.get_tile_points())
+        key = shape_key + (self._param_addresses(),)
         entry = self._graphs.get(key)
         if entry is None:
+            for stale in [k for k in self._graphs if k[:4] == shape_key]:      # captured against parameters that moved since
+                del self._graphs[stale]
             entry = self._capture(key, rays, ts)
         graph, s_rays, s_ts, results = entry
         s_rays.copy_(rays)

@@ -15,7 +15,13 @@ Where this differs from ``torch.optim.Adam`` -- read before swapping it in elsew
   With ``weight_decay > 0`` a parameter that never receives a gradient (an unused head) must NOT be decayed, so the step
   runs in its segment form (``nsff_adam_step_segments``): a parameter tensor whose gradient slice is identically zero this
   step keeps its value and its moments, which is what torch does for ``grad is None``.  ``decay_unused=True`` selects the
-  plain every-element step instead (one launch fewer).
+  plain every-element step instead (one launch fewer).  Known deviation of that test: "unused" is decided from gradient VALUES,
+  so a parameter whose true gradient is exactly zero everywhere (a dead ReLU layer, a fully masked loss) is skipped too,
+  where torch -- which sees a zero-valued ``.grad`` tensor, not ``None`` -- would still decay it and its moments.
+* **One step counter.**  The bias corrections use one global step count (``state[0]``), not torch's per-parameter counts: a
+  tensor that receives its first gradient at step N is corrected as at step N, not as at step 1.  The two agree whenever
+  every parameter is used from the first step on (the reference's training loop) or ``weight_decay == 0`` with gradients
+  that start at step 1; ``load_torch_state_dict`` refuses per-parameter counts that differ.
 * **HIP device only.**  There is no CPU implementation (tests drive CPU runs with a torch-op twin, tests/common.py).
 * **Shared storage.**  ``module.state_dict()`` tensors are views of the one flat buffer: ``torch.save`` of such a dict
   writes the whole buffer once per file.  Use :func:`detached_state` (or ``NSFFTrainer.checkpoint``) to get clones.

@@ -25,13 +25,6 @@ from . import ray_geometry
 
 Z_FAR = 0.95  # flows are zeroed beyond this depth (reference rendering.py:316)
 
-# Test seam, per call and explicit: ``render_rays(..., **{FINE_DEPTHS_KW: zs})`` evaluates the fine pass at the given
-# (N_rays, S_fine) depths instead of the ones it sampled -- the inverse-CDF draw is ill-conditioned in near-empty bins
-# (tests/parity.py), so per-sample fine keys of two correct fp32 implementations are only comparable at identical depths.
-# Only tests/common.py::fine_depths_kw builds this keyword; there is no module state a product call could inherit.
-FINE_DEPTHS_KW = "_parity_test_fine_depths"
-
-
 def _new(ref, *shape):
     return torch.empty(*shape, device=ref.device, dtype=torch.float32)
 
@@ -112,6 +105,8 @@ def _plan_time_bias(ctx, models, t_embedded, N_samples, N_importance, output_tra
     for typ, S in passes:
         model = models[typ]
         if not model.encode_transient or S % 64 or (n_rays * S < 32768 and config.get_tile_points() == 0):
+            continue
+        if model.in_channels_t > 64 or model.in_channels_t % 4:       # (nsff_time_bias stages 64 columns as float4s; refused there)
             continue
         if t_embedded.shape != (n_rays, model.in_channels_t):
             continue
@@ -210,9 +205,12 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         raw_fw, raw_bw = raw_w[:P], raw_w[P:]
         tp1, tm1 = ctx.neighbour_rows if ctx.neighbour_rows is not None else _neighbour_time_rows(ctx.embeddings, ts, ctx.max_t)
         tb_fw, tb_bw = ctx.tbias.get((typ, 'fw')), ctx.tbias.get((typ, 'bw'))
-        merged = (ctx.rec is None and P > 0 and not os.environ.get('NSFF_NO_MERGED_REQUERY') and tp1.data_ptr() + tp1.numel() * 4 == tm1.data_ptr()
-                  and (tb_fw is None) == (tb_bw is None)
-                  and (tb_fw is None or tb_fw.data_ptr() + tb_fw.numel() * 4 == tb_bw.data_ptr()))
+        # (halves of ONE allocation: the same storage AND adjacent -- two separate allocations may be adjacent by accident)
+        def halves(a, b):
+            return (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                    and a.data_ptr() + a.numel() * 4 == b.data_ptr())
+        merged = (ctx.rec is None and P > 0 and not os.environ.get('NSFF_NO_MERGED_REQUERY') and halves(tp1, tm1)
+                  and (tb_fw is None) == (tb_bw is None) and (tb_fw is None or halves(tb_fw, tb_bw)))
         if P:
             _lib.warp_points(raw, xyz, zs, Z_FAR, xyz_fw, xyz_bw)
             if merged:
@@ -297,6 +295,16 @@ def render_rays(models,
     ``test_time=False`` and parameters that require grad, the results carry a graph to the model /
     embedding parameters (see :mod:`nsff_pl_amd.autograd`).
     """
+    return _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_std, N_importance, chunk, test_time, kwargs)
+
+
+def _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_std, N_importance, chunk, test_time, kwargs,
+                 fine_points=None):
+    """The body of :func:`render_rays`.  ``fine_points`` (None in every product call) is an injection point between the fine
+    sampling stage and the fine field pass: a callable ``(rays, zs_fine, xyz_fine) -> (zs_fine, xyz_fine)``.  The parity tests use
+    it (tests/common.py::render_rays_at) to evaluate the fine pass at the reference's depths -- the inverse-CDF draw is
+    ill-conditioned in near-empty bins (tests/parity.py), so per-sample fine keys of two correct fp32 implementations are only
+    comparable at identical depths; the arithmetic of that substitution lives in the tests, not here."""
     _lib.require_gpu_tensor(rays, "rays")
     _lib.load()
     # Gradients (training): forward values still come from the kernels below; the autograd graph of native
@@ -309,8 +317,8 @@ def render_rays(models,
         # activations) in the parity-grade f16x3 arithmetic
         config.set_precision("f16x3")
         try:
-            return render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_std, N_importance, chunk,
-                               test_time, **kwargs)
+            return _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_std, N_importance, chunk,
+                                test_time, kwargs, fine_points)
         finally:
             config.set_precision("f16")
     with torch.cuda.device(rays.device), torch.no_grad():
@@ -371,11 +379,10 @@ def render_rays(models,
                 results['static_zs_fine'] = zs_static
                 if output_transient:
                     results['transient_zs_fine'] = zs_transient
-            if kwargs.get(FINE_DEPTHS_KW) is not None:
-                zs_fine = torch.as_tensor(kwargs[FINE_DEPTHS_KW]).to(rays.device).contiguous().float()
-                if tuple(zs_fine.shape) != (n_rays, S_fine):
-                    raise ValueError(f"{FINE_DEPTHS_KW}: expected shape {(n_rays, S_fine)}, got {tuple(zs_fine.shape)}")
-                xyz_fine = (rays[:, None, 0:3] + rays[:, None, 3:6] * zs_fine[..., None]).contiguous()
+            if fine_points is not None:
+                zs_fine, xyz_fine = fine_points(rays, zs_fine, xyz_fine)
+                if tuple(zs_fine.shape) != (n_rays, S_fine) or tuple(xyz_fine.shape) != (n_rays, S_fine, 3):
+                    raise ValueError(f"fine_points: expected shapes {(n_rays, S_fine)} / {(n_rays, S_fine, 3)}")
             zs, xyz = zs_fine, xyz_fine
         else:
             xyz = xyz_coarse

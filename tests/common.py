@@ -19,13 +19,25 @@ CHAINED_KEYS = ("xyzs_fw_bw", "xyzs_bw_fw", "rgb_fw", "rgb_bw", "disocc_fw", "di
 SAMPLE_KEYS = ("static_zs_fine", "transient_zs_fine", "zs_fine", "xyzs_fine")
 
 
-def fine_depths_kw(zs_fine):
-    """Keyword arguments that make ONE nsff_pl_amd.render_rays call evaluate its fine pass at the given (N_rays, S_fine)
-    depths (numpy / tensor; None = {} = free-running).  sample_pdf is ill-conditioned in near-empty bins
-    (tests/parity.py), so per-sample fine keys of two correct fp32 implementations are only comparable at identical
-    depths.  The seam is this explicit per-call keyword: nothing is patched, no state outlives the call."""
+def render_rays_at(zs_fine):
+    """``nsff_pl_amd.render_rays`` with the fine pass of ONE call evaluated at the given (N_rays, S_fine) depths (numpy / tensor;
+    None = the plain function, free-running).  sample_pdf is ill-conditioned in near-empty bins (tests/parity.py), so per-sample
+    fine keys of two correct fp32 implementations are only comparable at identical depths.  The substitution (and the point
+    arithmetic o + d z that goes with it) lives here: the product's body only offers the injection point between its fine
+    sampling stage and its fine field pass (rendering._render_rays(fine_points=)); nothing is patched, no state outlives the call."""
     import nsff_pl_amd.rendering as R
-    return {} if zs_fine is None else {R.FINE_DEPTHS_KW: torch.as_tensor(zs_fine)}
+    if zs_fine is None:
+        return R.render_rays
+
+    def at_depths(rays, zs_sampled, xyz_sampled):
+        zs = torch.as_tensor(zs_fine).to(rays.device).contiguous().float()
+        return zs, (rays[:, None, 0:3] + rays[:, None, 3:6] * zs[..., None]).contiguous()
+
+    def call(models, embeddings, rays, ts, max_t, N_samples=64, perturb=0, noise_std=0, N_importance=0, chunk=1024 * 32,
+             test_time=False, **kwargs):
+        return R._render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_std, N_importance, chunk, test_time,
+                              kwargs, fine_points=at_depths)
+    return call
 
 
 def load_golden(name):

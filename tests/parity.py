@@ -15,7 +15,7 @@ i.e. they carry ~1e-7 of ABSOLUTE rounding (1-exp(-x) is quantised to 6e-8 for t
 when a whole ray is near-empty (sum(w+eps) ~ 6e-4, e.g. behind the eval visibility mask)
 that noise is a percent-level perturbation of the pdf.  ``sample_tolerance`` returns the
 first-order bound of both effects per sample; everywhere else the plain 1e-4 applies.  For the same reason the
-end-to-end fine-pass keys are compared at identical depths (``tests/common.py::fine_depths_kw``).
+end-to-end fine-pass keys are compared at identical depths (``tests/common.py::render_rays_at``).
 """
 import numpy as np
 

@@ -187,9 +187,9 @@ def test_render_rays_backward_matches_reference(name, precision, hip_lib, monkey
             import nsff_pl_amd.rendering as R
             monkeypatch.setattr(R.torch, "rand", replay.rand)
             monkeypatch.setattr(R.torch, "randn", replay.randn)
-        res = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
+        res = common.render_rays_at(want["zs_fine"])(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), scenes.N_FRAMES - 1,
                             cfg["N_samples"], cfg.get("perturb", 0), cfg.get("noise_std", 0),
-                            cfg["N_importance"], 1024 * 32, test_time=False, **kw, **common.fine_depths_kw(want["zs_fine"]))
+                            cfg["N_importance"], 1024 * 32, test_time=False, **kw)
         monkeypatch.undo()
         assert res["rgb_fine"].requires_grad and not res["zs_fine"].requires_grad
         for k in want:                                # values still come from the HIP kernels
@@ -236,8 +236,8 @@ def test_native_compositing_backward_equals_torch_expression(name, hip_lib, monk
                     replay = _Replay(cfg, draws)
                     monkeypatch.setattr(R.torch, "rand", replay.rand)
                     monkeypatch.setattr(R.torch, "randn", replay.randn)
-                res = A.render_rays(models, emb, rd, td, scenes.N_FRAMES - 1, cfg["N_samples"], cfg.get("perturb", 0),
-                                    cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32, test_time=False, **kw, **common.fine_depths_kw(want["zs_fine"]))
+                res = common.render_rays_at(want["zs_fine"])(models, emb, rd, td, scenes.N_FRAMES - 1, cfg["N_samples"], cfg.get("perturb", 0),
+                                    cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32, test_time=False, **kw)
                 monkeypatch.undo()
             else:
                 rec = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in _record(cfg, want, draws, rays).items()}

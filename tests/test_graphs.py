@@ -7,7 +7,7 @@ import torch
 import common
 import scenes
 import nsff_pl_amd as A
-from nsff_pl_amd import evaluate
+from nsff_pl_amd import config, evaluate
 from nsff_pl_amd.graphs import GraphedRender
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +40,39 @@ def test_graphed_render_equals_the_eager_call(hip_lib):
     after = g(rays, ts)
     ref = A.render_rays(models, emb, rays, ts, scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, cfg["N_importance"], test_time=True, **kw)
     assert torch.equal(after["rgb_fine"], ref["rgb_fine"]) and not torch.equal(ref["rgb_fine"], eager["rgb_fine"])
+
+
+def test_graph_is_recaptured_when_parameters_move(hip_lib):
+    """The captured launches hold raw parameter addresses (nsff_time_bias reads the input-layer weights, the embedding gathers
+    their tables): FlatAdam.adopt() re-points every parameter at a slice of its flat buffer -- the next call must re-capture, not
+    replay against freed memory, and must follow the optimizer step."""
+    from nsff_pl_amd.optim import FlatAdam
+    cfg, rays, ts, models, emb = _scene("g3_nsff_train")
+    # the C2-like launch mix: force the hand-scheduled body with per-ray time-bias rows also on this small batch
+    config.set_tile_points(130)
+    try:
+        kw = scenes.render_kwargs(cfg)
+        g = GraphedRender(models, emb, scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, cfg["N_importance"], test_time=False, **kw)
+        before = {k: v.clone() for k, v in g(rays, ts).items()}
+        old_ptr = models["fine"].transient_xyz_encoding_1[0].weight.data_ptr()
+        params = [p for m in list(models.values()) + [emb["t"]] for p in m.parameters()]
+        opt = FlatAdam(params, lr=1e-2)                       # adopt(): every parameter now lives in the flat buffer
+        assert models["fine"].transient_xyz_encoding_1[0].weight.data_ptr() != old_ptr
+        again = g(rays, ts)                                   # same values, new addresses: a fresh capture
+        assert len(g._graphs) == 1
+        for k in before:
+            assert torch.equal(again[k], before[k]), k
+        opt.flat_grad.normal_(0, 1e-2)
+        opt.step()
+        got = {k: v.clone() for k, v in g(rays, ts).items()}
+        with torch.no_grad():
+            want = A.render_rays(models, emb, rays, ts, scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, cfg["N_importance"],
+                                 test_time=False, **kw)
+        assert not torch.equal(got["rgb_fine"], before["rgb_fine"])
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    finally:
+        config.set_tile_points(0)
 
 
 def test_graphed_train_mode_call_with_draws(hip_lib):

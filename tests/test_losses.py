@@ -184,9 +184,9 @@ def test_training_step_matches_reference(name, precision, hip_lib, monkeypatch):
             import nsff_pl_amd.rendering as R
             monkeypatch.setattr(R.torch, "rand", replay.rand)
             monkeypatch.setattr(R.torch, "randn", replay.randn)
-        res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
+        res = common.render_rays_at(want["zs_fine"])(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
                             cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
-                            test_time=False, **kw, **common.fine_depths_kw(want["zs_fine"]))
+                            test_time=False, **kw)
         monkeypatch.undo()
         loss_fn, targets = _loss_module(name, DEV)
         terms = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)

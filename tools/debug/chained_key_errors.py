@@ -19,8 +19,8 @@ for name in ("g3b_nsff_train_gain3", "g18_wide_inputs_train", "g3_nsff_train", "
         for grad in (True, False):
             config.set_precision(prec); config.set_tile_points(tile)
             with torch.set_grad_enabled(grad):
-                out = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, cfg["N_importance"],
-                                    1024 * 32, test_time=cfg["test_time"], **kw, **common.fine_depths_kw(want["zs_fine"]))
+                out = common.render_rays_at(want["zs_fine"])(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, cfg["N_importance"],
+                                    1024 * 32, test_time=cfg["test_time"], **kw)
             for k in want:
                 if k in ("static_zs_fine", "transient_zs_fine"):
                     continue

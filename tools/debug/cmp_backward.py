@@ -21,9 +21,9 @@ for native in ("0", "1"):
     if cfg.get("perturb", 0) or cfg.get("noise_std", 0):
         rp = _Replay(cfg, draws)
         R.torch.rand, R.torch.randn = rp.rand, rp.randn
-    res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
+    res = common.render_rays_at(want["zs_fine"])(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"],
                         cfg.get("perturb", 0), cfg.get("noise_std", 0), cfg["N_importance"], 1024 * 32,
-                        test_time=False, **kw, **common.fine_depths_kw(want["zs_fine"]))
+                        test_time=False, **kw)
     R.torch.rand, R.torch.randn = orig
     scenes.cotangent_loss(res).backward()
     out[native] = {n: p.grad.detach().double().cpu() for n, p in scenes.named_grad_params(models, emb) if p.grad is not None}
