@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      22
+#define NSFF_ABI_VERSION      23
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -170,6 +170,14 @@ typedef struct NsffFieldArgs {
     const float* t_bias;
     int32_t t_bias_rows;     /* nsff_time_bias_rows(desc), or 0                     */
     int32_t reserved0;
+    /* inference (F16X3, input A, use_viewdir models, static_mode 2), optional: what [dir | a] contributes to
+     * static_dir_encoding, computed once per ray by nsff_side_bias from the same dir_emb / a_emb rows: (n_rays, 1, 256) fp32.
+     * With it -- and pts_per_ray a multiple of 64 -- the static trunk of a view-direction model runs on the hand-scheduled
+     * kernel: static_dir_encoding becomes one more 256-wide layer with per-ray bias rows, sigma is accumulated in the epilogue
+     * of the last trunk layer.  dir_emb / a_emb must be given either way (every other kernel variant reads them). */
+    const float* s_bias;
+    int32_t s_bias_rows;     /* 1, or 0                                             */
+    int32_t reserved1;
 } NsffFieldArgs;
 
 int nsff_field_query(const NsffModelDesc* desc, const void* packed,
@@ -195,6 +203,15 @@ typedef struct NsffTimeBiasJob {
 } NsffTimeBiasJob;
 int nsff_time_bias_rows(const NsffModelDesc* desc);      /* 0: the model has no dynamic trunk */
 int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64_t n_rays, void* stream);
+
+/* ---- a3: the same for a view-direction model's per-ray inputs (reference nerf.py:183-185, rendering.py:153-172 repeat the
+ * direction embedding and the appearance code over a ray's samples):
+ *     out[ray][n] = b_fold[n] + sum_j W_dir[n][256 + j] * [dir_rows[ray] | a_rows[ray]][j]
+ * with W_dir = static_dir_encoding's weight (256, 256 + in_dir + in_a), the parameter itself, and b_fold = W_dir[:, :256] b_final
+ * + b_dir from the F16X3 packed buffer of an inference pack (nsff_pack_weights / nsff_fold_heads).  fp32, columns in ascending
+ * order.  a_rows may be NULL iff in_a == 0.  nsff_field_query takes the result as NsffFieldArgs::s_bias. */
+int nsff_side_bias(const NsffModelDesc* desc, const void* packed_f16x3, const float* w_dir, const float* dir_rows,
+                   const float* a_rows, int64_t n_rays, float* out, void* stream);
 
 /* ---- N1: backward of the field query (training).  Mixed precision: fp16 MFMA operands, fp32 accumulation;
  * every point's gradient row is normalised by its own power of two (block floating point), weight-gradient
@@ -539,6 +556,7 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
 #define NSFF_KERNEL_H3_SAVE   5   /* f16x3 training forward (keeps activations)                                      */
 #define NSFF_KERNEL_F16_FAST  6   /* single-product fast mode                                                        */
 #define NSFF_KERNEL_H3A_TBIAS 7   /* NSFF_KERNEL_H3A with the time code folded into per-ray bias rows (NsffFieldArgs::t_bias) */
+#define NSFF_KERNEL_H3A_SIDE  8   /* NSFF_KERNEL_H3A[_TBIAS] whose static trunk has the view-direction branch (NsffFieldArgs::s_bias) */
 int         nsff_last_field_kernel(void);
 /* Host-only (no GPU work): the f16x3 step program of an inference launch with these modes -- steps[n][4] = {weight segment
  * offset (words), bias offset (words; 0xFFFFFFFF = accumulate), nks | pre << 8 | post << 16 | head << 24, 0} -- and the phase

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 22
+ABI_VERSION = 23
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -44,7 +44,8 @@ class FieldArgs(C.Structure):
                 ("x_emb", _fp), ("ld_emb", C.c_int32),
                 ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
                 ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp), ("save_masks", _fp),
-                ("save_side", _fp), ("t_bias", _fp), ("t_bias_rows", C.c_int32), ("reserved0", C.c_int32)]
+                ("save_side", _fp), ("t_bias", _fp), ("t_bias_rows", C.c_int32), ("reserved0", C.c_int32),
+                ("s_bias", _fp), ("s_bias_rows", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class TimeBiasJob(C.Structure):
@@ -143,6 +144,7 @@ _SIGNATURES = {
                                    C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "nsff_time_bias_rows": (C.c_int, [C.POINTER(ModelDesc)]),
     "nsff_time_bias": (C.c_int, [C.POINTER(TimeBiasJob), C.c_int32, C.c_int64, C.c_void_p]),
+    "nsff_side_bias": (C.c_int, [C.POINTER(ModelDesc), _fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_void_p]),
     "nsff_last_hip_error": (C.c_char_p, []),
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
     "nsff_param_count": (C.c_int, [C.POINTER(ModelDesc)]),
@@ -346,7 +348,7 @@ def posenc(x, freqs, out):
 def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
                 xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
                 x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, save_masks=None, save_side=None,
-                precision=None, t_bias=None):
+                precision=None, t_bias=None, s_bias=None):
     from . import config
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
@@ -376,7 +378,24 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     a.save_side = None if save_side is None else save_side.data_ptr()
     if t_bias is not None:                      # (n_rays, rows, 256) from time_bias(): the time code's part of the input layers
         a.t_bias, a.t_bias_rows = _ptr(t_bias), int(t_bias.shape[1])
+    if s_bias is not None:                      # (n_rays, 1, 256) from side_bias(): [dir | a]'s part of static_dir_encoding
+        a.s_bias, a.s_bias_rows = _ptr(s_bias), int(s_bias.shape[1])
     _check(load().nsff_field_query(C.byref(desc), _ptr(packed), C.byref(a), _stream()), "nsff_field_query")
+
+
+def side_bias(model, dir_rows, a_rows=None):
+    """(n_rays, 1, 256) fp32: per ray, the folded bias + the [dir | a] columns' product of static_dir_encoding (nsff_side_bias);
+    field_query(..., s_bias=) then runs the view-direction static trunk on the hand-scheduled kernel."""
+    from . import config
+    desc = model_desc(model)
+    n_rays = int(dir_rows.shape[0])
+    assert dir_rows.shape == (n_rays, desc.in_dir) and (desc.in_a == 0 or (a_rows is not None and a_rows.shape == (n_rays, desc.in_a)))
+    packed = model.packed(config.PRECISIONS["f16x3"], inference=True)      # (the folded bias row lives in the inference pack)
+    w = model.static_dir_encoding[0].weight.detach()
+    out = torch.empty(n_rays, 1, 256, device=dir_rows.device, dtype=torch.float32)
+    _check(load().nsff_side_bias(C.byref(desc), _ptr(packed), _ptr(w), _ptr(dir_rows), _ptr(a_rows) if desc.in_a > 0 else None,
+                                 n_rays, _ptr(out), _stream()), "nsff_side_bias")
+    return out
 
 
 def time_bias_rows(model):
@@ -635,7 +654,7 @@ def mpi_composite(H, W, S, dt, accum_fw, accum_bw, static_rgb, static_alpha, zs,
     _check(load().nsff_mpi_composite(C.byref(a), _stream()), "nsff_mpi_composite")
 
 
-KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast", 7: "h3a_tb"}
+KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast", 7: "h3a_tb", 8: "h3a_side"}
 
 
 def last_field_kernel():
@@ -643,15 +662,16 @@ def last_field_kernel():
     return KERNEL_NAMES[load().nsff_last_field_kernel()]
 
 
-def h3a_program(model, static_mode, transient_mode, fold_t=False):
+def h3a_program(model, static_mode, transient_mode, fold_t=False, side_fold=False):
     """(steps, n_static_steps, phases_static, phases_dynamic) of an f16x3 inference launch, from the host-side builders alone
     (no GPU): steps = [(w_off_words, bias_off_words or None, nks, pre, post, head)], phases_* = [[8 dwords]] or [].
-    fold_t: the dynamic trunk's program of a launch that is given t_bias (time code folded into per-ray bias rows)."""
+    fold_t: the dynamic trunk's program of a launch that is given t_bias (time code folded into per-ray bias rows);
+    side_fold: the static trunk's program of a view-direction launch that is given s_bias ([dir | a] folded into per-ray rows)."""
     desc = model_desc(model)
     steps = (C.c_uint32 * (28 * 4))()
     ps, pd = (C.c_uint32 * (36 * 8))(), (C.c_uint32 * (36 * 8))()
     n, ns, nph = C.c_int(0), C.c_int(0), (C.c_int * 2)()
-    _check(load().nsff_field_phase_program(C.byref(desc), int(static_mode), int(transient_mode), int(fold_t), steps, C.byref(n), C.byref(ns), ps, pd, nph),
+    _check(load().nsff_field_phase_program(C.byref(desc), int(static_mode), int(transient_mode), int(bool(fold_t)) | (2 if side_fold else 0), steps, C.byref(n), C.byref(ns), ps, pd, nph),
            "nsff_field_phase_program")
     out = []
     for i in range(n.value):

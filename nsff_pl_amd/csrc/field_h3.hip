@@ -97,6 +97,8 @@ struct H3KArgs {
     const float* t_emb;
     const float* t_bias;       // (rays, tb_rows, 256) fp32: bias + time-code part of the dynamic trunk's input layers (nsff_time_bias), or null
     int tb_rows;
+    const float* s_bias;       // (rays, sb_rows, 256) fp32: bias + [dir | a] part of static_dir_encoding (nsff_side_bias), or null
+    int sb_rows;
     float* raw;
     // training forward (SAVE variant), all fragment-major so that the weight-gradient GEMM streams them:
     _Float16* save_acts;       // (slots, tiles, 4 ks, 256 rows, 16 pts) fp16 post-activation values, or null
@@ -1100,6 +1102,7 @@ struct H3AHeadSel { uint32_t w_off, b_off; int n_rows, slot0; unsigned kinds; };
 __host__ __device__ __forceinline__ H3AHeadSel h3a_head_sel(const NsffLayoutH3& L, int head) {
     if (head == HEAD_S_FOLD) return H3AHeadSel{L.s_fold_w, L.s_fold_b, 4, 0, 0x15u};
     if (head == HEAD_T_FOLD) return H3AHeadSel{L.t_fold_w, L.t_fold_b, (int)L.t_head_rows, 4, 0x15u | (0xAAAu << 8)};
+    if (head == HEAD_S_RGB) return H3AHeadSel{L.s_rgb_w, L.s_rgb_b, 3, 0, 0x15u};
     return H3AHeadSel{L.s_sigma_w, L.s_sigma_b, 1, 3, (unsigned)ACT_NONE};
 }
 
@@ -1113,6 +1116,9 @@ struct H3AArgs {
     int n_bias[2];
     int head[2];                        // HEAD_* evaluated on the trunk's last activation
     H3AHeadSel hsel[2];                 // ... and what that means (h3a_head_sel of the host): one scalar load in the kernel
+    int sig_ride;                       // static trunk with the view-direction branch: sigma = sum of the 8 partial sums the body's
+                                        // sigma ride left at floats 4..11 of the record image + the bias at packed word sig_b_off
+    uint32_t sig_b_off;
 };
 static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
 
@@ -1224,7 +1230,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     constexpr int M = 128, THREADS = 256;
     __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
     __shared__ __attribute__((aligned(16))) float sRaw[M * NSFF_RAW_STRIDE];
-    __shared__ __attribute__((aligned(16))) float sBias[(H3A_MAX_BIAS + 1) * NSFF_W];      // (+ one row: the heads' biases)
+    __shared__ __attribute__((aligned(16))) float sBias[(H3A_MAX_BIAS + 1) * NSFF_W];      // (+ one row: the heads' biases [0, 32), sigma's bias [32])
     for (int i = threadIdx.x; i < M * NSFF_RAW_STRIDE; i += THREADS) sRaw[i] = 0.f;
     _Float16* sXh = sX;
     _Float16* sXl = sX + M * LDH;
@@ -1257,6 +1263,9 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     // (dynamic trunk with the time code folded in: the rows of its input layers are per ray -- every 64-point half of the tile
     // lies inside one ray, the host checked pts_per_ray % 64 == 0 and n_points < 2^31 -- and the body never sees a time-code column)
     const bool tb = tr == 1 && a.t_bias != nullptr;
+    // (the static trunk of a view-direction model has per-ray rows of its own: static_dir_encoding's [dir | a] part, nsff_side_bias)
+    const float* rowtab = tr == 1 ? a.t_bias : a.s_bias;
+    const int rowtab_rows = tr == 1 ? a.tb_rows : a.sb_rows;
     float bv[H3A_MAX_BIAS];
     const int nb = aa.n_bias[tr];
     {
@@ -1264,11 +1273,11 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
         // scalar loads): a plain row is a word offset, a per-ray row lies tb_delta = t_bias - packed further on, at the ray of
         // its half.  Rows past the table's end read the buffer's first words (never stored).
         long long tb_at[2] = {0, 0};
-        if (tb) {
+        if (rowtab != nullptr) {
             const unsigned last = (unsigned)(a.n_points - 1), q0 = (unsigned)p0, ppr = (unsigned)a.pts_per_ray;
-            const long long delta = reinterpret_cast<const char*>(a.t_bias) - reinterpret_cast<const char*>(pk);
-            tb_at[0] = delta + (long long)((q0 < last ? q0 : last) / ppr) * (a.tb_rows * NSFF_W * 4);
-            tb_at[1] = delta + (long long)((q0 + 64u < last ? q0 + 64u : last) / ppr) * (a.tb_rows * NSFF_W * 4);
+            const long long delta = reinterpret_cast<const char*>(rowtab) - reinterpret_cast<const char*>(pk);
+            tb_at[0] = delta + (long long)((q0 < last ? q0 : last) / ppr) * (rowtab_rows * NSFF_W * 4);
+            tb_at[1] = delta + (long long)((q0 + 64u < last ? q0 + 64u : last) / ppr) * (rowtab_rows * NSFF_W * 4);
         }
         uint32_t boff[H3A_MAX_BIAS];
 #pragma unroll
@@ -1289,6 +1298,8 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     // (the heads' biases -- 32 floats -- travel with the table: the records loop below reads them from LDS)
     const H3AHeadSel hs = aa.hsel[tr];
     const float hbias = reinterpret_cast<const float*>(pk)[hs.b_off + (threadIdx.x & 31)];
+    const bool sig_ride = tr == 0 && aa.sig_ride != 0;
+    const float sig_b = reinterpret_cast<const float*>(pk)[sig_ride ? aa.sig_b_off : 0u];
     H3A_TSTAMP(52);
     H3APre pre;
     {
@@ -1305,6 +1316,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     for (int r = 0; r < H3A_MAX_BIAS; ++r)
         if (r < nb) sBias[r * NSFF_W + threadIdx.x] = bv[r];
     if (threadIdx.x < 32) sBias[H3A_MAX_BIAS * NSFF_W + threadIdx.x] = hbias;
+    if (threadIdx.x == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
     H3A_TSTAMP(53);
     const bool lean = a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb);
@@ -1393,6 +1405,16 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
                     const float y = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hc[e] * x)), ya[e], yb[e]);
                     ve[e] = plain[e] ? x : y;
                 }
+                if (sig_ride) {
+                    // sigma of a view-direction static trunk: the 8 partial sums of the body's sigma ride (wave, lane half) in a
+                    // fixed order + the bias; the floats that carried them leave as zeros (a static-only launch stores whole records)
+                    if (q4 == 0) {
+                        const float4 s1 = reinterpret_cast<const float4*>(sRaw)[i + 1], s2 = reinterpret_cast<const float4*>(sRaw)[i + 2];
+                        v.w = ((((s1.x + s1.y) + (s1.z + s1.w)) + ((s2.x + s2.y) + (s2.z + s2.w)))) + sBias[H3A_MAX_BIAS * NSFF_W + 32];
+                    } else if (q4 != 3) {
+                        v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
                 reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = v;
             }
         }
@@ -1409,21 +1431,32 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 // fold_t (dynamic trunk, H3KArgs::t_bias given): the time-code part of every input segment is not executed -- its product is in
 // the per-ray rows of the bias table (H3A_TB_ROW entries: one row per half for the layer's first segment) -- so an input
 // segment runs its position part only (k0s / 16 of its k-steps; the waves' blocks of the packed segment keep their stride).
+// side_fold (static trunk of a view-direction model, H3KArgs::s_bias given; the step program of h3_step_program(side_fold)):
+// static_dir_encoding is the trunk's last 256-wide segment, its bias rows are per ray like the folded time code's, and the
+// sigma head of the step before it (static_sigma reads the last TRUNK layer, nerf.py:169) is not a HEAD phase but the SIGMA RIDE
+// of that layer's epilogues (tools/h3asm/gen.py: B16RS / A16RS); *sig_ride tells the kernel's records loop to add the partial sums up.
 static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bool fold_t, H3APhase* ph, uint32_t* bias_off,
-                              int& n_bias, int& head, int* n_phases = nullptr) {
+                              int& n_bias, int& head, int* n_phases = nullptr, bool side_fold = false, int* sig_ride = nullptr) {
     struct Seg { uint32_t off, stride; int nks, bias, bias_b; bool relu, rebuild; };
     Seg segs[MAX_STEPS];
     int n = 0;
     n_bias = 0;
     head = HEAD_NONE;
+    if (sig_ride) *sig_ride = 0;
+    if (side_fold && (dynamic || fold_t || s1 - s0 < 3)) return false;
     for (int i = s0; i < s1; ++i) {
         const H3Step& st = k.steps[i];
         if (st.nks != 4 && st.nks != 8 && st.nks != 16) return false;
         if (st.post != POST_RELU && st.post != POST_NONE) return false;
         if (st.pre == PRE_SIDE) return false;         // (st.save only names an activation slot: this path is never a saving launch)
         if (st.head != HEAD_NONE) {
-            if (i != s1 - 1 || (st.head != HEAD_S_FOLD && st.head != HEAD_T_FOLD && st.head != HEAD_S_SIGMA)) return false;
-            head = st.head;
+            if (side_fold && i == s1 - 2) {
+                if (st.head != HEAD_S_SIGMA) return false;          // (the sigma ride, see below)
+            } else {
+                if (i != s1 - 1) return false;
+                if (side_fold ? st.head != HEAD_S_RGB : (st.head != HEAD_S_FOLD && st.head != HEAD_T_FOLD && st.head != HEAD_S_SIGMA)) return false;
+                head = st.head;
+            }
         }
         Seg& g = segs[n++];
         g.off = st.w_off * 4u; g.nks = st.nks; g.relu = st.post == POST_RELU;
@@ -1455,6 +1488,21 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
         }
         if (row != k.tb_rows) return false;
     }
+    int sig_row = -1;
+    if (side_fold) {
+        // the last segment = static_dir_encoding on the last trunk layer: 256-wide, ReLU, rows of the per-ray table; the segment
+        // in front of it = the last trunk layer, whose epilogues carry the sigma ride: a plain 256-wide ReLU layer
+        Seg& dirl = segs[n - 1];
+        const Seg& last = segs[n - 2];
+        if (k.sb_rows != 1 || dirl.nks != 16 || !dirl.relu || dirl.bias < 0 || dirl.rebuild) return false;
+        if (last.nks != 16 || !last.relu) return false;
+        if (n_bias + 2 > H3A_MAX_BIAS) return false;
+        bias_off[dirl.bias] = H3A_TB_ROW | 0u;
+        dirl.bias_b = n_bias;
+        bias_off[n_bias++] = H3A_TB_ROW | H3A_TB_HALF_B | 0u;
+        sig_row = n_bias;
+        bias_off[n_bias++] = k.L.s_sigma_f32;            // (a plain row: the sigma weights, read by the ride as a bias-table row)
+    }
     int np = 0;
     auto put = [&](uint32_t body, uint32_t flags, int bias, int n1, const Seg& r1, const Seg& r2) {
         if (np >= H3A_MAX_PHASES) return false;
@@ -1481,10 +1529,14 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
         bool ok = true;
         if (g.nks == 16) {
             if (t == 0 || !pending_b) return false;
-            ok = ok && put(H3A_BODY_A16R, g.bias >= 0 ? H3A_F_INIT : 0u, g.bias_b, 16, g, g);   // (an A phase's tail initialises acc_B)
+            const bool sig_a = side_fold && t == n - 1, sig_b = side_fold && t == n - 2;    // (the ride on half B's / half A's epilogue)
+            ok = ok && put(sig_a ? H3A_BODY_A16RS : H3A_BODY_A16R, g.bias >= 0 ? H3A_F_INIT : 0u, g.bias_b, 16, g, g);   // (an A phase's tail initialises acc_B)
             if (g.relu) {
                 if (nxt && nxt->nks != 16) return false;      // (B16R requests from ONE stream: a 16-k-step segment follows)
-                ok = ok && put(nxt ? H3A_BODY_B16R : H3A_BODY_B16L, init_next, nbias, n1, r1, r2);   // (the last segment requests nothing)
+                if (sig_b)      // ... and loads the sigma weights from table row (flags >> 16)
+                    ok = ok && put(H3A_BODY_B16RS, init_next | ((1024u * (uint32_t)sig_row) << 16), nbias, n1, r1, r2);
+                else
+                    ok = ok && put(nxt ? H3A_BODY_B16R : H3A_BODY_B16L, init_next, nbias, n1, r1, r2);   // (the last segment requests nothing)
                 pending_b = true;
             } else {
                 if (!nxt || !nxt->rebuild || nxt->bias >= 0 || nxt->nks == 16) return false;
@@ -1515,6 +1567,7 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
     if (done) ph[np - 1].d[2] = 4u * (uint32_t)hd.slot0;
     done = done && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]) && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]);
     if (n_phases) *n_phases = np;
+    if (sig_ride) *sig_ride = side_fold ? 1 : 0;
     return done;
 }
 
@@ -1664,7 +1717,8 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
         tiled(w, L.dir_x, ld, (int)L.side_k, d.in_dir + d.in_a, NSFF_W, 0, 0, 0);
         flat(b, L.dir_b, NSFF_W);
     }
-    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_sigma_w, 0, 1); flat(b, L.s_sigma_b, 1); }
+    { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_sigma_w, 0, 1); flat(b, L.s_sigma_b, 1);
+      flat(w, L.s_sigma_f32, NSFF_W); }
     { const float* w = params[pi++]; const float* b = params[pi++]; head(w, L.s_rgb_w, 0, 3); flat(b, L.s_rgb_b, 3); }
     if (d.has_transient) {
         trunk(L.tr, d.in_t);
@@ -1783,7 +1837,9 @@ int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, vo
 
 // Step program of a launch (reference nerf.py:162-208): fills k.steps / k.n_steps / k.n_static_steps from the layout k.L.
 // fold: an inference launch (nothing saved for a backward pass).
-static int h3_step_program(const NsffModelDesc& d, int static_mode, int transient_mode, bool fold, H3KArgs& k) {
+// side_fold: a view-direction static trunk whose [dir | a] columns arrive as per-ray bias rows (H3KArgs::s_bias): the program
+// the hand-scheduled kernel runs -- static_dir_encoding as ONE folded 256-wide ReLU segment, no side-input tile.
+static int h3_step_program(const NsffModelDesc& d, int static_mode, int transient_mode, bool fold, H3KArgs& k, bool side_fold = false) {
     int n = 0;
     auto push = [&](uint32_t w, uint32_t b, uint32_t kcols, int pre, int post, int head, int slot = -1) {
         H3Step& s = k.steps[n++];
@@ -1809,6 +1865,9 @@ static int h3_step_program(const NsffModelDesc& d, int static_mode, int transien
     // layers: the heads that read them are evaluated on the last trunk activation with pre-multiplied rows (NsffLayoutH3).
     if (static_mode == 2 && fold && !d.use_viewdir) {
         trunk(k.L.st, PRE_INPUT, HEAD_S_FOLD, 0);
+    } else if (static_mode == 2 && fold && side_fold) {
+        trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
+        push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
     } else if (static_mode == 2 && fold) {               // view directions: *_final folded into static_dir_encoding
         trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
         push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
@@ -1846,7 +1905,10 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
     H3KArgs k{};
     int rc = nsff_make_layout_h3(*desc, k.L);
     if (rc) return rc;
-    rc = h3_step_program(*desc, static_mode, transient_mode, true, k);
+    // fold_t bit 1: the launch is given NsffFieldArgs::s_bias (a view-direction static trunk with per-ray [dir | a] rows)
+    const bool side_fold = (fold_t & 2) != 0 && static_mode == 2 && desc->use_viewdir;
+    fold_t &= 1;
+    rc = h3_step_program(*desc, static_mode, transient_mode, true, k, side_fold);
     if (rc) return rc;
     for (int i = 0; i < k.n_steps; ++i) {
         const H3Step& st = k.steps[i];
@@ -1859,10 +1921,11 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
     H3APhase ph[H3A_MAX_PHASES];
     uint32_t boff[H3A_MAX_BIAS];
     int nb = 0, head = 0;
-    if (k.n_static_steps > 0 && !(static_mode == 2 && desc->use_viewdir)) {
+    if (k.n_static_steps > 0 && (side_fold || !(static_mode == 2 && desc->use_viewdir))) {
         for (auto& p : ph) for (auto& x : p.d) x = 0;
         int np = 0;
-        if (h3a_build_program(k, 0, k.n_static_steps, false, false, ph, boff, nb, head, &np)) {
+        k.sb_rows = side_fold ? 1 : 0;
+        if (h3a_build_program(k, 0, k.n_static_steps, false, false, ph, boff, nb, head, &np, side_fold)) {
             n_phases[0] = np;
             for (int i = 0; i < n_phases[0]; ++i) for (int j = 0; j < 8; ++j) phases_static[8 * i + j] = ph[i].d[j];
         }
@@ -1987,6 +2050,76 @@ extern "C" int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64
     return nsff_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// nsff_side_bias: per-ray rows  b_fold + W_dir[:, 256 : 256 + in_dir + in_a] [dir | a]  of static_dir_encoding (see the header).
+// One thread per neuron, sixteen rays per workgroup; the rays' side inputs and sixteen weight columns at a time are staged in
+// LDS (consecutive lanes read consecutive floats of a weight row; the tile is stored column-major with a one-float pad).
+namespace {
+struct SideBiasArgs { const float* w; const float* b; const float* dir_rows; const float* a_rows; float* out;
+                      int in_dir, in_a, ld; long long n_rays; };
+__global__ __launch_bounds__(256) void nsff_side_bias_kernel(const SideBiasArgs a) {
+    const int n = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * TB_RAYS;
+    const int in = a.in_dir + a.in_a;
+    __shared__ __attribute__((aligned(16))) float st[TB_RAYS][NSFF_W];      // [dir | a] of the workgroup's rays, zero-padded
+    __shared__ float sw[16][NSFF_W + 1];
+    for (int e = threadIdx.x; e < TB_RAYS * NSFF_W; e += 256) {
+        const int r = e >> 8, c = e & 255;
+        const long long ray = r0 + r < a.n_rays ? r0 + r : a.n_rays - 1;
+        float v = 0.f;
+        if (c < a.in_dir) v = a.dir_rows[ray * a.in_dir + c];
+        else if (c < in) v = a.a_rows[ray * a.in_a + (c - a.in_dir)];
+        st[r][c] = v;
+    }
+    float acc[TB_RAYS];
+    const float b = a.b[n];
+#pragma unroll
+    for (int r = 0; r < TB_RAYS; ++r) acc[r] = b;
+    const float* __restrict__ wl = a.w + NSFF_W;          // the [dir | a] columns follow the 256 columns that read *_final
+    for (int c0 = 0; c0 < in; c0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = threadIdx.x + 256 * k, row = e >> 4, c = c0 + (e & 15);
+            sw[e & 15][row] = c < in ? wl[(long long)row * a.ld + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {                   // (columns in ascending order: one fixed summation order per output)
+            const float w0 = sw[u][n], w1 = sw[u + 1][n], w2 = sw[u + 2][n], w3 = sw[u + 3][n];
+#pragma unroll
+            for (int r = 0; r < TB_RAYS; ++r) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&st[r][c0 + u]);
+                acc[r] = fmaf(w3, t4.w, fmaf(w2, t4.z, fmaf(w1, t4.y, fmaf(w0, t4.x, acc[r]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TB_RAYS; ++r)
+        if (r0 + r < a.n_rays) a.out[(r0 + r) * NSFF_W + n] = acc[r];
+}
+}  // namespace
+
+extern "C" int nsff_side_bias(const NsffModelDesc* desc, const void* packed_f16x3, const float* w_dir, const float* dir_rows,
+                              const float* a_rows, int64_t n_rays, float* out, void* stream) {
+    if (!desc || !packed_f16x3 || !w_dir || !dir_rows || !out) return NSFF_ERR_NULL;
+    const NsffModelDesc& d = *desc;
+    NsffLayoutH3 L;
+    const int rc = nsff_make_layout_h3(d, L);
+    if (rc) return rc;
+    if (!d.use_viewdir || d.in_dir < 1 || n_rays < 0) return NSFF_ERR_INVALID;
+    if (d.in_a > 0 && !a_rows) return NSFF_ERR_NULL;
+    if (n_rays == 0) return NSFF_OK;
+    SideBiasArgs a{};
+    a.w = w_dir; a.b = reinterpret_cast<const float*>(packed_f16x3) + L.dir_b_fold;
+    a.dir_rows = dir_rows; a.a_rows = a_rows; a.out = out;
+    a.in_dir = d.in_dir; a.in_a = d.in_a; a.ld = NSFF_W + d.in_dir + d.in_a; a.n_rays = n_rays;
+    const long long gx = (n_rays + TB_RAYS - 1) / TB_RAYS;
+    if (gx > 0x7fffffffLL) return NSFF_ERR_INVALID;
+    hipLaunchKernelGGL(nsff_side_bias_kernel, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return nsff_launch_status();
+}
+
 // which kernel the last f16 / f16x3 launch of this process took (nsff_last_field_kernel: tests assert that large inference
 // launches really run the hand-scheduled body instead of silently falling back)
 int g_nsff_last_h3_kernel = 0;
@@ -2063,34 +2196,56 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         // A launch whose STATIC trunk has the view-direction branch (not covered) next to a dynamic trunk is issued as two
         // launches: the static workgroups on the eight-wave kernel, the dynamic ones on the hand-scheduled kernel -- each
         // writes its own part of the raw records (piece 1 / piece 2), as the workgroups of one split launch do.
-        const bool static_uncovered = g.static_mode == 2 && d.use_viewdir;
-        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 && !(static_uncovered && !g.transient_mode);
+        bool static_uncovered = g.static_mode == 2 && d.use_viewdir;
+        H3AArgs ka{};
+        ka.n_bias[0] = ka.n_bias[1] = 0; ka.head[0] = ka.head[1] = HEAD_NONE;
+        const bool asm_inputs = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64;
+        // A view-direction static trunk is covered when the caller supplied its per-ray rows (nsff_side_bias) and no 64-point half
+        // straddles two rays: the launch then runs the side-fold step program (static_dir_encoding as one folded 256-wide segment
+        // with per-ray bias rows, sigma as a ride of the last trunk layer's epilogues) -- `ks` replaces `k` for this launch.
+        H3KArgs ks = k;
+        bool side = false;
+        if (static_uncovered && asm_inputs && g.s_bias != nullptr && g.s_bias_rows == 1 && g.pts_per_ray > 0 &&
+            g.pts_per_ray % 64 == 0 && g.n_points <= 0x7fffffffLL &&
+            h3_step_program(d, g.static_mode, g.transient_mode, true, ks, true) == NSFF_OK) {
+            ks.s_bias = g.s_bias; ks.sb_rows = 1;
+            side = h3a_build_program(ks, 0, ks.n_static_steps, false, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0], nullptr,
+                                     true, &ka.sig_ride);
+        }
+        if (side) { static_uncovered = false; ka.sig_b_off = k.L.s_sigma_b; }
+        else { ks = k; ka.sig_ride = 0; ka.n_bias[0] = 0; ka.head[0] = HEAD_NONE; }
+        const int ns = ks.n_steps;
+        bool asm_body = asm_inputs && !(static_uncovered && !g.transient_mode);
         if (asm_body && g.transient_mode)
             asm_body = k.L.kt == 64 && (d.in_t & 3) == 0 && ((uintptr_t)g.t_emb & 15) == 0;
-        H3AArgs ka{};
         if (asm_body) {
-            ka.k = k;
-            ka.n_bias[0] = ka.n_bias[1] = 0; ka.head[0] = ka.head[1] = HEAD_NONE;
-            if (k.n_static_steps > 0 && !static_uncovered)
-                asm_body = h3a_build_program(k, 0, k.n_static_steps, false, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0]);
-            if (asm_body && n > k.n_static_steps) {
+            ka.k = ks;
+            if (ks.n_static_steps > 0 && !static_uncovered && !side)
+                asm_body = h3a_build_program(ks, 0, ks.n_static_steps, false, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0]);
+            if (asm_body && ns > ks.n_static_steps) {
                 // the time code as per-ray bias rows (nsff_time_bias): whenever the caller supplied them and a 64-point half
                 // never straddles two rays; otherwise the body multiplies the time-code columns like any other input
                 bool fold_t = g.t_bias != nullptr && g.pts_per_ray > 0 && g.pts_per_ray % 64 == 0 && g.n_points <= 0x7fffffffLL &&
                               g.t_bias_rows == nsff_time_bias_rows(desc);
                 if (fold_t) {
                     ka.k.t_bias = g.t_bias; ka.k.tb_rows = g.t_bias_rows;
-                    fold_t = h3a_build_program(ka.k, k.n_static_steps, n, true, true, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
+                    fold_t = h3a_build_program(ka.k, ks.n_static_steps, ns, true, true, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
                 }
                 if (!fold_t) {
                     ka.k.t_bias = nullptr; ka.k.tb_rows = 0;
-                    asm_body = h3a_build_program(k, k.n_static_steps, n, true, false, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
+                    asm_body = h3a_build_program(ks, ks.n_static_steps, ns, true, false, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1]);
                 }
             }
+        }
+        if (side && !asm_body) {
+            // (the dynamic trunk of this launch is not covered: back to the plain step program, static trunk on the eight-wave kernel)
+            static_uncovered = true; side = false;
+            asm_body = false;
         }
         const long long tiles = (g.n_points + 127) / 128;
         if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
         ka.hsel[0] = h3a_head_sel(k.L, ka.head[0]); ka.hsel[1] = h3a_head_sel(k.L, ka.head[1]);
+        const int which = side ? NSFF_KERNEL_H3A_SIDE : (ka.k.t_bias ? NSFF_KERNEL_H3A_TBIAS : NSFF_KERNEL_H3A);
         if (asm_body && static_uncovered) {
             // (1) static trunk: the first half of a split launch's grid = static workgroups only
             k.grid_tiles = tiles;
@@ -2101,13 +2256,14 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             ka.k.split_trunks = 1;
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)tiles), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
-            g_nsff_last_h3_kernel = ka.k.t_bias ? NSFF_KERNEL_H3A_TBIAS : NSFF_KERNEL_H3A;
+            g_nsff_last_h3_kernel = which;
         } else if (asm_body) {
+            const bool both2 = ns > ks.n_static_steps && ks.n_static_steps > 0;
             ka.k.grid_tiles = tiles;
-            ka.k.split_trunks = both ? 1 : 0;
-            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)(both ? 2 * tiles : tiles)), dim3(256), 0, st, ka);
+            ka.k.split_trunks = both2 ? 1 : 0;
+            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)(both2 ? 2 * tiles : tiles)), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
-            g_nsff_last_h3_kernel = ka.k.t_bias ? NSFF_KERNEL_H3A_TBIAS : NSFF_KERNEL_H3A;
+            g_nsff_last_h3_kernel = which;
         } else {                                  // eight waves of 32 neurons (half the weight stream of the 64-point tiling)
             lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
             g_nsff_last_h3_kernel = NSFF_KERNEL_H3_8WAVE;

@@ -44,6 +44,9 @@ struct NsffLayoutH3 {
     // view-direction models: static_dir_encoding reads [*_final | dir | a]; its *_final part folds the same way,
     // (W_dir[:, :256] W_final) h + (W_dir[:, :256] b_final + b_dir), a full 256 x 256 segment
     uint32_t dir_h_fold, dir_b_fold, dir_fold_f32;
+    // fp32 copy of static_sigma's weight row (256): the hand-scheduled kernel's sigma ride (a view-direction static trunk
+    // evaluates sigma in the epilogue of its last trunk layer, one layer before the trunk's end) reads it as a bias-table row
+    uint32_t s_sigma_f32;
     uint32_t total;                    // words
 };
 
@@ -103,6 +106,7 @@ static inline int nsff_make_layout_h3(const NsffModelDesc& d, NsffLayoutH3& L) {
         L.dir_b_fold = take(NSFF_W);
         L.dir_fold_f32 = take(NSFF_W * NSFF_W);
     }
+    L.s_sigma_f32 = take(NSFF_W);
     L.total = off;
     return NSFF_OK;
 }

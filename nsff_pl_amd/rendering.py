@@ -143,6 +143,15 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
     raw = _new(zs, P, _lib.RAW_STRIDE)
     side = dict(dir_emb=ctx.dir_embedded if model.use_viewdir and not sigma_only else None,
                 a_emb=a_embedded if (model.use_viewdir and model.in_channels_a > 0 and not sigma_only) else None)
+    # View directions and appearance codes are per RAY (rendering.py:153-172 repeat them over the samples): their part of
+    # static_dir_encoding is computed once per ray (one small launch) and handed to the field launch as bias rows -- the static
+    # trunk of a view-direction model then runs on the hand-scheduled f16x3 kernel (inference launches with 128-point tiles and
+    # samples per ray a multiple of 64; the others read dir_emb / a_emb as before).
+    # (`NSFF_NO_SIDE_BIAS=1`: the earlier form for A/B -- static workgroups on the eight-wave kernel as a launch of their own.)
+    if (side["dir_emb"] is not None and ctx.rec is None and P and S % 64 == 0 and config.get_precision() == "f16x3"
+            and (config.get_tile_points() == 130 or (config.get_tile_points() == 0 and P >= 32768))
+            and not os.environ.get('NSFF_NO_SIDE_BIAS')):
+        side["s_bias"] = _lib.side_bias(model, side["dir_emb"], side["a_emb"])
 
     def query(tag, raw_out, pts, static_mode, transient_mode, flow_heads, t_rows, which='t', **extra):
         """One field launch.  When gradients will be taken (ctx.rec) and the configuration allows it, this launch

@@ -144,3 +144,73 @@ def test_view_direction_model_runs_as_two_launches(hip_lib):
     for lo, hi in ((4, 8), (8, 14)):
         assert np.abs(a[:, lo:hi] - b[:, lo:hi]).max() <= 2e-5 * np.abs(b[:, lo:hi]).max()
     assert np.abs(b[:, 4:14]).max() > 0
+
+
+@pytest.mark.parametrize("in_a", [0, 48])
+def test_view_direction_static_trunk_on_the_hand_scheduled_kernel(in_a, hip_lib):
+    """Given the per-ray [dir | a] rows (nsff_side_bias), the static trunk of a view-direction model runs on the hand-scheduled
+    kernel: static_dir_encoding as one more 256-wide layer with a bias row per ray, sigma accumulated by the epilogues of the last
+    trunk layer (fp32 FMA on the ReLU outputs).  Records equal the eight-wave launch's (which multiplies the [dir | a] columns
+    and evaluates sigma as an f16x3 head) to 2e-5 of the record's largest value; split launches (static + dynamic trunk), static-only
+    launches (whole records, zeros where the ride parked its partial sums) and ragged point counts."""
+    torch.manual_seed(21 + in_a)
+    emb, emb_d = A.PosEmbedding(9, 10), A.PosEmbedding(3, 4)
+    m = A.NeRF("fine", use_viewdir=True, encode_appearance=in_a > 0, in_channels_a=max(in_a, 1), encode_transient=True, output_flow=True)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(".weight"):
+                p.mul_(2.5)
+    m.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    freqs = [float(f) for f in emb.freqs]
+    config.set_precision("f16x3")
+    for S, n_rays, sm, tm, fh in ((128, 11, 2, 2, 2), (64, 9, 2, 0, 0), (192, 3, 2, 2, 0), (64, 7, 2, 2, 2)):
+        P = S * n_rays                                          # (11 x 128, 9 x 64, ...: the last 128-point tile is partial)
+        xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
+        t_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
+        a_rows = torch.randn(n_rays, in_a, generator=g).to(DEV) if in_a else None
+        dirs = emb_d(torch.randn(n_rays, 3, generator=g).to(DEV)).contiguous()
+        sb = _lib.side_bias(m, dirs, a_rows)
+        w = m.static_dir_encoding[0].weight.double()
+        fold_b = w[:, :256] @ m.static_xyz_encoding_final.bias.double() + m.static_dir_encoding[0].bias.double()
+        side = dirs.double() if a_rows is None else torch.cat([dirs.double(), a_rows.double()], 1)
+        want_sb = (side @ w[:, 256:].T + fold_b).float()
+        assert sb.shape == (n_rays, 1, 256)
+        assert (sb[:, 0] - want_sb).abs().max().item() <= 3e-6 * want_sb.abs().max().item()
+        out = {}
+        for tile, s_bias in ((130, sb), (131, None)):
+            config.set_tile_points(tile)
+            raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
+            try:
+                _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs,
+                                 a_emb=a_rows, s_bias=s_bias)
+                torch.cuda.synchronize()
+                out[tile] = (raw.cpu().numpy(), _lib.last_field_kernel())
+            finally:
+                config.set_tile_points(0)
+        (a, ka), (b, kb) = out[130], out[131]
+        assert ka == "h3a_side" and kb == "h3_8wave", (ka, kb)
+        if tm == 0:
+            assert np.isfinite(a).all() and not a[:, 4:].any(), "a static-only launch stores whole records: zeros behind the static slots"
+        for lo, hi, what in ((0, 3, "static rgb"), (3, 4, "static sigma"), (4, 8, "dynamic"), (8, 14, "flows")):
+            if hi > 4 and tm == 0:
+                continue
+            scale = max(np.abs(b[:, lo:hi]).max(), 1e-30)
+            err = np.abs(a[:, lo:hi] - b[:, lo:hi]).max() / scale
+            assert err <= 2e-5, f"S={S} rays={n_rays} modes {(sm, tm, fh)} in_a={in_a}: {what} differ by {err:.2e}"
+    # samples per ray not a multiple of 64: a 64-point half may straddle two rays -- the rows are ignored, the old two-launch form runs
+    S, n_rays = 37, 20
+    P = S * n_rays
+    xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
+    t_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
+    a_rows = torch.randn(n_rays, in_a, generator=g).to(DEV) if in_a else None
+    dirs = emb_d(torch.randn(n_rays, 3, generator=g).to(DEV)).contiguous()
+    config.set_tile_points(130)
+    try:
+        raw = torch.empty(P, _lib.RAW_STRIDE, device=DEV)
+        _lib.field_query(m, raw, P, S, 2, 2, 2, xyz=xyz, freqs=freqs, t_emb=t_rows, dir_emb=dirs, a_emb=a_rows,
+                         s_bias=_lib.side_bias(m, dirs, a_rows))
+        torch.cuda.synchronize()
+        assert _lib.last_field_kernel() == "h3a"
+    finally:
+        config.set_tile_points(0)

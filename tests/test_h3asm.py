@@ -45,7 +45,7 @@ def test_stream_passes_the_hazard_lint():
     assert all(i.kind != "mfma" for i in pre)
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic", "dynamic_tb", "twoskips_tb"])
+@pytest.mark.parametrize("kind", ["static", "dynamic", "dynamic_tb", "twoskips_tb", "viewdir"])
 def test_simulated_trunk_matches_numpy(kind):
     assert check.run_case(kind, verbose=False) < 2e-6
 
@@ -116,6 +116,38 @@ def test_cxx_phase_program_equals_the_simulated_builder(arch):
         for i, (w_, g_) in enumerate(zip(want, ph_f)):
             n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else (4 if w_[0] in (B["EPI_B"], B["HEAD"]) else 3)
             assert w_[:n_cmp] == g_[:n_cmp], (ARCHS[arch], sm, tm, "fold_t", i, w_, g_)
+
+
+@pytest.mark.parametrize("arch", [(8, [4], 48), (4, [2], 0), (3, [], 12)])
+def test_cxx_side_fold_program_equals_the_simulated_builder(arch):
+    """a view-direction static trunk given per-ray [dir | a] rows (NsffFieldArgs::s_bias): static_dir_encoding is one more
+    256-wide segment with a row per half, the sigma head is the ride of the last trunk layer's epilogues (B16RS / A16RS)"""
+    import torch
+    import nsff_pl_amd as A
+    from nsff_pl_amd import _lib
+    D, skips, in_a = arch
+    torch.manual_seed(0)
+    m = A.NeRF("fine", D=D, skips=skips, use_viewdir=True, encode_appearance=in_a > 0, in_channels_a=max(in_a, 1), encode_transient=True,
+               in_channels_t=48, output_flow=True)
+    steps, n_static, ph_s, ph_d = _lib.h3a_program(m, 2, 2, fold_t=True, side_fold=True)
+    assert len(ph_s) > 0 and len(ph_d) > 0
+    assert [st[5] for st in steps[:n_static]].count(1) == 1 and steps[n_static - 1][5] == 2       # HEAD_S_SIGMA mid-trunk, HEAD_S_RGB last
+    segs, nb = [], 0
+    for i, (w, b, nks, pre, post, head) in enumerate(steps[:n_static]):
+        segs.append(dict(nks=nks, off=4 * w, bias=None if b is None else nb, post="relu" if post == 1 else "none",
+                         rebuild=i > 0 and pre != 0))
+        nb += b is not None
+    segs[-1]["bias_b"] = nb                       # half B's row of static_dir_encoding, then the sigma weights' row
+    want = [list(map(int, r)) for r in check.build_program(segs, 0, dict(off=0, n_rows=3, slot0=0), sig_row=nb + 1)]
+    B = gen.BODY
+    assert [w_[0] for w_ in want].count(B["B16RS"]) == 1 and [w_[0] for w_ in want].count(B["A16RS"]) == 1
+    assert len(want) == len(ph_s)
+    uses_streams = {B["B16R"], B["B16RS"], B["B16X"], B["B4"], B["B8"], B["A4F"], B["A8F"]}
+    for i, (w_, g_) in enumerate(zip(want, ph_s)):
+        n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else (4 if w_[0] in (B["EPI_B"], B["HEAD"]) else 3)
+        assert w_[:n_cmp] == g_[:n_cmp], (arch, i, w_, g_)
+    # without the rows the static trunk of a view-direction launch is not one the body executes
+    assert _lib.h3a_program(m, 2, 2)[2] == []
 
 
 def test_compiled_kernel_audit():

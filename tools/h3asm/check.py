@@ -69,12 +69,14 @@ def pack_head(W):
     return out.reshape(-1).view(np.uint32), hi, lo
 
 
-def build_program(segs, in_t, head=None):
+def build_program(segs, in_t, head=None, sig_row=None):
     """Phase descriptors for a trunk (the host-side builder in csrc/field_h3a.hip does the same).
     segs: list of dict(nks, off, bias (index or None), post ('relu' | 'none'), rebuild (bool)[, wstride (bytes between the
     waves' blocks of the packed segment, default nks * 4096), bias_b (table row of half B, default = bias)]).
     head: dict(off (bytes of the head tile), n_rows, slot0) -- the last epilogue requests the tile, the HEAD phase leaves the
-    pre-activation sums of rows 0 .. n_rows - 1 at floats slot0 .. of every point's raw record."""
+    pre-activation sums of rows 0 .. n_rows - 1 at floats slot0 .. of every point's raw record.
+    sig_row: bias-table row of the sigma weights -- the sigma ride (gen.SIG) runs on the epilogues of the LAST BUT ONE segment
+    (a view-direction static trunk: static_sigma reads the last trunk layer, static_dir_encoding follows it)."""
     B = gen.BODY
     ph = []
 
@@ -102,10 +104,16 @@ def build_program(segs, in_t, head=None):
         nbias = nxt["bias"] if (nxt is not None and nxt["bias"] is not None) else 0
         if sg["nks"] == 16:
             assert t > 0 and pending_b, "a 16-wide segment rides the epilogue of the one before it"
+            sig_a = sig_row is not None and t == len(segs) - 1      # half B's epilogue of the layer sigma reads rides here
+            sig_b = sig_row is not None and t == len(segs) - 2      # half A's
             # (an A phase's tail initialises acc_B: the segment's row of half B -- they differ when the time code is folded in)
-            ph.append(desc(B["A16R"], (1 << gen.F_INIT) if sg["bias"] is not None else 0, sg.get("bias_b", sg["bias"]) or 0))
+            ph.append(desc(B["A16RS" if sig_a else "A16R"], (1 << gen.F_INIT) if sg["bias"] is not None else 0, sg.get("bias_b", sg["bias"]) or 0))
             if sg["post"] == "relu":
-                ph.append(desc(B["B16R"] if nxt is not None else B["B16L"], init_next, nbias, **refill_fields(t)))
+                if sig_b:
+                    assert nxt is not None and nxt["nks"] == 16 and sg["post"] == "relu"
+                    ph.append(desc(B["B16RS"], init_next | ((1024 * sig_row) << 16), nbias, **refill_fields(t)))
+                else:
+                    ph.append(desc(B["B16R"] if nxt is not None else B["B16L"], init_next, nbias, **refill_fields(t)))
                 pending_b = True
             else:
                 assert nxt is not None and nxt["rebuild"] and nxt["bias"] is None
@@ -136,7 +144,8 @@ def make_case(kind, seed=0):
     in_t = 48 if kind in ("dynamic", "dynamic_tb", "twoskips_tb") else 0
     k0 = 128 if in_t else 64
     D = 8
-    skips = {"static": [4], "dynamic": [4], "noskip": [], "twoskips": [2, 5], "dynamic_tb": [4], "twoskips_tb": [2, 5]}[kind]
+    viewdir = kind == "viewdir"
+    skips = {"static": [4], "dynamic": [4], "noskip": [], "twoskips": [2, 5], "dynamic_tb": [4], "twoskips_tb": [2, 5], "viewdir": [4]}[kind]
     layers = []
     segs = []
     off = 4096                                  # (packed buffer: keep offset 0 unused)
@@ -163,8 +172,14 @@ def make_case(kind, seed=0):
             add_seg((rng.randn(256, k0) * 2.5 / np.sqrt(k0)).astype(np.float32), None, "relu", True)
         else:
             add_seg((rng.randn(256, 256) * scale).astype(np.float32), b, "relu", False)
-    # the heads: 10 rows (dynamic) / 4 rows (static) of a 32-row tile, results at slot 4 / 0 of the raw records
-    n_rows, slot0 = (10, 4) if in_t else (4, 0)
+    sig_w = None
+    if viewdir:
+        # static_dir_encoding behind the trunk: a 256-wide relu layer whose bias rows are per RAY (b + W[:, 256:] [dir | a]):
+        # one row for half A, another for half B; the sigma weights are one more row of the table
+        add_seg((rng.randn(256, 256) * scale).astype(np.float32), (rng.randn(256) * 0.1).astype(np.float32), "relu", False)
+        sig_w = (rng.randn(256) * 0.2).astype(np.float32)
+    # the heads: 10 rows (dynamic) / 4 rows (static) / 3 rows (view directions: rgb only) of a 32-row tile, at slot 4 / 0 of the raw records
+    n_rows, slot0 = (10, 4) if in_t else ((3, 0) if viewdir else (4, 0))
     Wh_ = np.zeros((32, 256), np.float32)
     Wh_[:n_rows] = (rng.randn(n_rows, 256) * 0.3).astype(np.float32)
     hstream, hhi, hlo = pack_head(Wh_)
@@ -201,24 +216,37 @@ def make_case(kind, seed=0):
             tgt["bias_b"] = nrow
             rows[nrow] = (tgt["b"] + part[64]).astype(np.float32)
             nrow += 1
-    return dict(kind=kind, in_t=in_t, k0=k0, segs=segs, pk=pk, x_in=x_in, t_table=t_table, ray_of=ray_of, rows=rows, tb=tb, head=head)
+    sig_row = None
+    if viewdir:
+        last = segs[-1]
+        last["bias_b"] = len(rows)
+        rows[last["bias_b"]] = (last["b"] + (rng.randn(256) * 0.3).astype(np.float32)).astype(np.float32)    # half B lies in another ray
+        sig_row = len(rows)
+        rows[sig_row] = sig_w
+    return dict(kind=kind, in_t=in_t, k0=k0, segs=segs, pk=pk, x_in=x_in, t_table=t_table, ray_of=ray_of, rows=rows, tb=tb, head=head,
+                sig_row=sig_row, sig_w=sig_w)
 
 
-def reference(case):
-    """the same layers in numpy: products Wh.xh + Wh.xl + Wl.xh accumulated in float64, fp32 after every layer"""
+def reference(case, keep=None):
+    """the same layers in numpy: products Wh.xh + Wh.xl + Wl.xh accumulated in float64, fp32 after every layer
+    keep: list that receives the fp32 post-ReLU values of every relu segment"""
     xin_h, xin_l = split_rtz(case["x_in"])
     xh_, xl_ = xin_h.astype(np.float64), xin_l.astype(np.float64)
     acc = None
     for sg in case["segs"]:
+        if sg.get("bias_b") is not None and not case["tb"] and sg["b"] is not None:       # per-half rows (view directions)
+            sg = dict(sg, b=np.where(np.arange(128)[:, None] < 64, case["rows"][sg["bias"]][None, :], case["rows"][sg["bias_b"]][None, :]))
         Wh, Wl = sg["hi"].astype(np.float64), sg["lo"].astype(np.float64)
         if sg["rebuild"]:
             xh_, xl_ = xin_h.astype(np.float64), xin_l.astype(np.float64)
         K = Wh.shape[1]
         prod = xh_[:, :K] @ Wh.T + xl_[:, :K] @ Wh.T + xh_[:, :K] @ Wl.T          # (128, 256)
-        acc = (prod + (sg["b"][None, :] if sg["b"] is not None else acc)).astype(np.float32).astype(np.float64) \
+        acc = (prod + (np.atleast_2d(sg["b"]) if sg["b"] is not None else acc)).astype(np.float32).astype(np.float64) \
             if sg["b"] is not None else (acc + prod).astype(np.float32).astype(np.float64)
         if sg["post"] == "relu":
             v = np.maximum(acc, 0).astype(np.float32)
+            if keep is not None:
+                keep.append(v)
             h, l = split_rtz(v)
             xh_, xl_ = h.astype(np.float64), l.astype(np.float64)
     return (xh_ + xl_).astype(np.float32), xh_, xl_
@@ -243,7 +271,7 @@ def run_case(kind, seed=0, verbose=True):
     sim = Sim(pre + prog)                      # the two asm statements back to back (the encoder between them is C++)
     sim.add_buffer(PK_BASE, case["pk"])
     body_in_t = 0 if case["tb"] else case["in_t"]       # (the body sees no time-code columns when they are folded into the table)
-    phases = build_program(case["segs"], body_in_t, case["head"])
+    phases = build_program(case["segs"], body_in_t, case["head"], case["sig_row"])
     sim.add_buffer(PH_BASE, phases.reshape(-1))
     sim.add_buffer(T_BASE, case["t_table"].reshape(-1).view(np.uint32))
     # LDS: input tile as the encoder leaves it (hi / lo planes), bias table
@@ -281,7 +309,8 @@ def run_case(kind, seed=0, verbose=True):
     for r in range(128):
         base = (LDS_X + r * gen.LDH_B) // 2
         got[r] = lds_h[base:base + 256].astype(np.float32) + lds_h[base + gen.PLANE_B // 2:base + gen.PLANE_B // 2 + 256].astype(np.float32)
-    want, fxh, fxl = reference(case)
+    acts = []
+    want, fxh, fxl = reference(case, acts)
     err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
     # the heads: pre-activation sums in the raw-record image, everything else untouched (zero)
     hd = case["head"]
@@ -289,6 +318,20 @@ def run_case(kind, seed=0, verbose=True):
     hwant = head_reference(case, fxh, fxl)
     herr = float(np.abs(raw[:, hd["slot0"]:hd["slot0"] + hd["n_rows"]] - hwant).max() / max(np.abs(hwant).max(), 1e-30))
     raw[:, hd["slot0"]:hd["slot0"] + hd["n_rows"]] = 0
+    if case["sig_row"] is not None:
+        # the sigma ride: floats 4 + 2 wave + (lane >> 5) of a record = sum over that lane's 32 neurons of w_sigma relu(layer D-1)
+        v = acts[-2].astype(np.float64)
+        for wv in range(4):
+            for hh in range(2):
+                n = np.array([64 * wv + 32 * mt + 8 * q + 4 * hh + e for mt in range(2) for q in range(4) for e in range(4)])
+                part = v[:, n] @ case["sig_w"][n].astype(np.float64)
+                got_p = raw[:, 4 + 2 * wv + hh]
+                serr = float(np.abs(got_p - part).max() / max(np.abs(part).max(), 1e-30))
+                assert serr < 2e-6, (wv, hh, serr)
+                err = max(err, serr)
+        total = raw[:, 4:12].sum(1)
+        assert np.abs(total - v @ case["sig_w"].astype(np.float64)).max() <= 1e-5 * np.abs(v @ case["sig_w"]).max()
+        raw[:, 4:12] = 0
     assert not raw.any(), "the HEAD phase wrote outside its slots"
     assert herr < 2e-6, herr
     err = max(err, herr)
@@ -303,7 +346,7 @@ def run_case(kind, seed=0, verbose=True):
 
 
 if __name__ == "__main__":
-    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips", "dynamic_tb", "twoskips_tb"]
+    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips", "dynamic_tb", "twoskips_tb", "viewdir"]
     for k in kinds:
         try:
             run_case(k)

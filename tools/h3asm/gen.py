@@ -60,7 +60,24 @@ D_BODY, D_FLAGS, D_BIAS, D_N1, D_R1, D_R1W, D_R2, D_R2W = range(8)
 # an input tile at all (A4 / A8 also run the first layer, where the tile is still the encoder's)
 F_INIT, F_REBUILD_T, F_REBUILD = 0, 1, 2
 
-BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12, HEAD=13)
+BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12, HEAD=13, B16RS=14, A16RS=15)
+
+# ---- the sigma ride (view-direction static trunk: static_sigma reads the LAST TRUNK activation, nerf.py:169, one layer before the
+# trunk's end): the epilogues of that layer also accumulate  sum_n w_sigma[n] relu(acc[n])  over this lane's 32 neurons of each
+# point in fp32 (v_fmac on the values the ReLU just produced, weights in the registers of the input stash, which is dead behind
+# the last skip layer) and leave the 8 partial sums per point (4 waves x 2 lane halves) at floats 4..11 of the point's raw record
+# in LDS; the kernel's records loop adds them up.  B16RS = B16R + the ride on half A's epilogue (it also loads the weights from
+# the bias-table row (flags >> 16)), A16RS = A16R + the ride on half B's epilogue.
+SIG = {"A": (V(56), V(57)), "B": (V(58), V(59))}     # [nt] partial sums of the half's two 32-point tiles
+V_SIGADDR = V(60)
+
+
+def ws(mt, q, e):            # sigma weight of neuron 64 wave + 32 mt + 8 q + 4 (lane >> 5) + e: v64..v95 (the stash registers)
+    return V(STASH + 16 * mt + 4 * q + e)
+
+
+def I_v_fmac(d, a, b):
+    return Inst("v_fmac_f32", f"v_fmac_f32_e32 {d}, {a}, {b}", [a, b, d], [d], "valu", dict(d=d, s=[a, b, d]))
 
 
 def xh(b, nt):
@@ -159,7 +176,7 @@ NOSWAP_STORES = os.environ.get("H3A_NOSWAP_STORES", "1") == "1"    # 0: the v_pe
 EXP = os.environ.get("H3A_EXP", "")          # timing experiments (results are garbage): nomix, noswap, nowrite, noride, andsub
 
 
-def epilogue_unit(half, u, tset):
+def epilogue_unit(half, u, tset, sig=False):
     """ReLU -> hi / lo split -> four 8-byte LDS stores (two per plane) of (tile u>>1, quad pair p = u&1) of `half`'s accumulators.
     In place on the accumulator registers; 8 temporaries from set `tset`.  (Until late in round 4: lanes i, i+32 traded halves with
     v_permlane32_swap for two 16-byte stores -- two instructions more per unit, +0.6 % on the C2 step.)"""
@@ -170,6 +187,8 @@ def epilogue_unit(half, u, tset):
     H = [V(T0 + 8 * tset + k) for k in range(4)]
     L = [V(T0 + 8 * tset + 4 + k) for k in range(4)]
     out = [I_v_max0(r, r) for r in x]
+    if sig:                 # x[j] = neuron 8 q + 4 h + e of the tile, q = p + 2 (j >> 2), e = j & 3
+        out += [I_v_fmac(SIG[half][nt], ws(mt, p + 2 * (j >> 2), j & 3), x[j]) for j in range(8)]
     out += [I_v_cvt_pkrtz(H[k], x[2 * k], x[2 * k + 1]) for k in range(4)]
     for k in range(4):
         out += [I_v_sub_lo_half(x[2 * k], H[k], x[2 * k]), I_v_sub_hi_half(x[2 * k + 1], H[k], x[2 * k + 1])]
@@ -199,10 +218,36 @@ def epilogue_unit(half, u, tset):
     return out
 
 
-def epilogue_stream(half):
+def epilogue_stream(half, sig=False, wait_ws=False):
+    """sig: with the sigma ride (see SIG); wait_ws: the phase requested the sigma weights at its start -- the marker
+    ('NEED_LDS', 'ws') in front of the first unit makes the phase wait for them."""
     out = []
+    if sig:
+        out += [I_valu("v_mov_b32", SIG[half][0], 0), I_valu("v_mov_b32", SIG[half][1], 0)]
+        if wait_ws:
+            out.append(("NEED_LDS", "ws"))
     for u in range(8):
-        out += epilogue_unit(half, u, u & 1)
+        out += epilogue_unit(half, u, u & 1, sig)
+    if sig:
+        # record of point 64 hb + 32 nt + (lane & 31): rawlds + 64 point + 16 + 8 wave + 4 (lane >> 5)
+        t0 = V_SIGADDR
+        out += [I_valu("v_and_b32", t0, 0x1f0, V_LANE16), I_valu("v_lshlrev_b32", t0, 2, t0),
+                I_valu("v_lshrrev_b32", V_TMP, 7, V_LANE16), I_valu("v_and_b32", V_TMP, 4, V_TMP),
+                I_valu("v_add_u32", t0, t0, V_TMP),
+                I_salu("s_lshl_b32", S_T0, S_WAVE, 3, scc=True), I_salu("s_add_u32", S_T0, S_T0, S_RAWLDS, scc=True),
+                I_valu("v_add_u32", t0, S_T0, t0, text=f"v_add_u32_e32 {t0}, {S_T0}, {t0}")]
+        hb = 0 if half == "A" else 1
+        out += [I_ds_write_b32(t0, SIG[half][nt], 16 + 4096 * hb + 2048 * nt) for nt in range(2)]
+    return out
+
+
+def sigma_weight_reads():
+    """WS := row (flags >> 16) of the bias table, this lane's 32 neurons in accumulator order (the mapping of init_reads)"""
+    out = [I_salu("s_lshr_b32", S_T0, S(S_CUR + D_FLAGS), 16, scc=True),
+           I_valu("v_add_u32", V_TMP, S_T0, V_BIAS, text=f"v_add_u32_e32 {V_TMP}, {S_T0}, {V_BIAS}")]
+    for mt in range(2):
+        for q in range(4):
+            out.append(I_ds_read_b128(V(STASH + 16 * mt + 4 * q, 4), V_TMP, 128 * mt + 32 * q))
     return out
 
 
@@ -340,7 +385,8 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
     LAST BUT ONE k-step: by then every fragment of this half has been read (the last k-step's lo fragments go to the second
     XL buffer) and the ride's stores are done, and 16 MFMAs remain to cover what follows the barrier -- the bias-table
     reads into the other half's accumulators (flag F_INIT) and the first fragments of the next phase.
-    ride: None | 'epi' (epilogue of the other half in the gaps of k-steps 1 .. barrier)
+    ride: None | 'epi' (epilogue of the other half in the gaps of k-steps 1 .. barrier) | 'epi_sig' (with the sigma ride) |
+          'epi_sig_ws' (... whose weights this phase requests at its start)
     refills: weight slot refills behind every k-step (B phases)
     rebuild: None | half whose input tile is restored by two guarded clusters
     vm_mode: None | 'formula' (A phase behind a B phase that issued its 16 refills in slot order: vmcnt(4 (15 - ks)) in front
@@ -364,7 +410,11 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
         if TIMING:
             s.emit(raw(f"s_memtime s[{78 + 2 * k}:{79 + 2 * k}]"))
     stamp(0)
-    ride_ins = epilogue_stream(oh) if ride == "epi" else []
+    ride_ins = {None: [], "epi": epilogue_stream(oh), "epi_sig": epilogue_stream(oh, sig=True),
+                "epi_sig_ws": epilogue_stream(oh, sig=True, wait_ws=True)}[ride]
+    if ride == "epi_sig_ws":
+        for r in sigma_weight_reads():
+            s.emit(r, "ws")
     rb_parts = rebuild_parts(rebuild, name) if rebuild is not None else None
     ride_gaps = [(ks, m) for ks in range(1, nks) for m in range(12) if (ks, m) < (bar[0], bar[1] - 1)]
     per_gap = dict(zip(ride_gaps, spread(len(ride_ins), len(ride_gaps)))) if ride_ins else {}
@@ -420,7 +470,10 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
                 pi += 1
             gi += 1
             for _ in range(per_gap.get((ks, m), 0)):
-                s.emit(ride_ins[ri], "ride")
+                if isinstance(ride_ins[ri], tuple):         # ('NEED_LDS', tag)
+                    s.need_lds(ride_ins[ri][1])
+                else:
+                    s.emit(ride_ins[ri], "ride")
                 ri += 1
             if (ks, m) == bar:
                 if tail_init:
@@ -730,7 +783,7 @@ def timing_store():
     return o
 
 
-DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B", "HEAD")
+DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B", "HEAD", "B16RS", "A16RS")
 
 
 def dispatcher():
@@ -767,6 +820,9 @@ def build():
         "B8": short_b_body("B8", 8),
         "EPI_B": bare_epilogue("EPI_B", "B"),
         "HEAD": head_body(),
+        # the sigma ride of a view-direction static trunk: the last trunk layer's B phase and the A phase behind it
+        "B16RS": phase_body("B16RS", "B", 16, ride="epi_sig_ws", refills=True, tail_init=True, one_stream=True),
+        "A16RS": phase_body("A16RS", "A", 16, ride="epi_sig", tail_init=True, vm_mode="formula"),
     }
     prog = prologue()
     prog.append(I_branch("s_branch", "L_dispatch"))

@@ -576,6 +576,8 @@ class Sim:
             out = s[0]
         elif op == "v_add_f32":
             out = (f32(s[0]) + f32(s[1])).astype(np.float32).view(np.uint32)
+        elif op == "v_fmac_f32":
+            out = (f32(s[0]).astype(np.float64) * f32(s[1]).astype(np.float64) + f32(s[2]).astype(np.float64)).astype(np.float32).view(np.uint32)
         elif op == "v_add_u32":
             out = s[0] + s[1]
         elif op == "v_sub_u32":
