@@ -150,10 +150,11 @@ typedef struct NsffFieldArgs {
     float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
     /* training forward (F16X3, input A): also keep what nsff_field_backward / nsff_weight_grad need.  T = ceil(P/64) point
      * tiles; any of them may be NULL.  NS = 2*D+2 activation slots (+1 when use_viewdir).  XR / t_row0 / SR: nsff_train_dims.
-     *   save_acts : fp16 (NS, T, 4, 256, 16): slot l = ReLU output of static layer l, slot D = static_xyz_encoding_final
-     *               output, slots D+1.. the same for the transient trunk, slot 2*D+2 = static_dir_encoding output (slots
-     *               of a trunk that is not evaluated stay unwritten).  Inside a tile: [16-point group][neuron][point] =
-     *               the fragment order of the weight-gradient GEMM (K = points);
+     *   save_acts : fp16 (NS, T, 4, 256, 16): slot l = ReLU output of static layer l (l < D), slots D+1 .. 2*D the same for
+     *               the transient trunk, slot 2*D+2 = static_dir_encoding output; slots D and 2*D+1 (the *_xyz_encoding_final
+     *               outputs of earlier ABI versions) are never written: *_final is folded into the heads in training as in
+     *               inference (slots of a trunk that is not evaluated stay unwritten too).  Inside a tile: [16-point
+     *               group][neuron][point] = the fragment order of the weight-gradient GEMM (K = points);
      *   save_xin  : fp16 (T, 4, XR, 16) trunk input, rows [0,in_xyz) xyz embedding, rows [t_row0, t_row0+in_t) time code
      *               (t_row0 = ceil64(in_xyz); XR = 128 or 256); rows from ceil64 of what the launch encodes up stay unwritten;
      *   save_masks: uint64 (NS, T, 256) ReLU sign bits of every trunk activation, in accumulator order;
@@ -220,8 +221,9 @@ int nsff_side_bias(const NsffModelDesc* desc, const void* packed_f16x3, const fl
  * nsff_bwd_packed_bytes / nsff_pack_weights_bwd: the TRANSPOSED fp16 weight tiles the data-gradient chain
  * streams (same parameter order as nsff_pack_weights).
  * nsff_field_backward: d_raw (P,16) -> d(trunk input) and the pre-activation gradients of every layer:
- *   dpre : fp16 (NS, T, 4, 256, 16)  slot t*(D+1)+l = trunk t (0 static, 1 transient) layer l, l = D: *_final,
- *          slot 2*D+2 = static_dir_encoding (use_viewdir); values = true gradient * G, fragment order as save_acts;
+ *   dpre : fp16 (NS, T, 4, 256, 16)  slot t*(D+1)+l = trunk t (0 static, 1 transient) layer l < D (slot l = D, *_final, is
+ *          never written: the layer is folded into the heads), slot 2*D+2 = static_dir_encoding (use_viewdir); values = true
+ *          gradient * G, fragment order as save_acts;
  *   dhead: fp16 (2, T, 4, 32, 16) head pre-activation gradients * G, rows 0..15: static rgb(3) sigma(1);
  *          transient rgb(3) sigma(1) fw(3) bw(3); rows 16..31: the fp16 rounding remainder of rows 0..15 (the head
  *          weight / bias gradients are the sum of both halves);
@@ -232,6 +234,9 @@ int nsff_side_bias(const NsffModelDesc* desc, const void* packed_f16x3, const fl
 int nsff_train_dims(const NsffModelDesc* desc, int32_t* xin_rows, int32_t* t_row0, int32_t* side_rows);
 int nsff_bwd_packed_bytes(const NsffModelDesc* desc, size_t* bytes);
 int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params, void* packed, void* stream);
+/* ... given the F16X3 forward pack of the SAME weights (nsff_pack_weights with folded heads), whose fp32 scratch already holds the
+ * folded products W_head W_final the transposed tiles need (else they are multiplied here); fwd_packed may be NULL. */
+int nsff_pack_weights_bwd_ex(const NsffModelDesc* desc, const float* const* params, void* packed, const void* fwd_packed, void* stream);
 
 typedef struct NsffFieldBwdArgs {
     int64_t n_points;
@@ -285,6 +290,28 @@ typedef struct NsffGradMapEntry {
 } NsffGradMapEntry;
 int nsff_weight_grad_accumulate(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, float* scratch,
                                 const NsffGradMapEntry* map, int64_t n_map, float* grad_base, const float* gmax, void* stream);
+
+/* nsff_weight_grad_accumulate with a second destination: map entries with dst < 0 STORE their value at aux[-(dst + 1)]
+ * -- dense sums of the jobs the FOLDED parameters are made of: *_xyz_encoding_final is never executed as a layer (the heads that
+ * read it are evaluated as (W_head W_final) h), so its gradient and the heads' are small matrix products of the folded heads'
+ * gradient G = sum_p dpre_p (x) h_p:  dW_head = G W_final^T + gb (x) b_final,  dW_final = W_head^T G,  db_final = W_head^T gb. */
+int nsff_weight_grad_accumulate_aux(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, float* scratch,
+                                    const NsffGradMapEntry* map, int64_t n_map, float* grad_base, float* aux, const float* gmax,
+                                    void* stream);
+
+/* One launch that turns the folded heads' gradient into the gradients of *_xyz_encoding_final and of the heads that read it
+ * and ADDS them to the parameters' gradient memory:  g (32, 256) / gb (32): the dense sum / row sums of the heads' job (rows r
+ * and 16 + r = fp16 value + rounding remainder of folded row r < n_rows <= 16);
+ *   d_w_head[r] += G[r] W_final^T + gb[r] b_final,  *d_b_head[r] += gb[r],  d_w_final += W_head^T G,  d_b_final += W_head^T gb. */
+typedef struct NsffFoldGradArgs {
+    int32_t n_rows, pad_;
+    const float* g; const float* gb;
+    const float* w_final; const float* b_final;        /* (256, 256), (256) */
+    const float* w_head[16];                           /* row r of the heads' weights: 256 floats */
+    float* d_w_head[16]; float* d_b_head[16];
+    float* d_w_final; float* d_b_final;
+} NsffFoldGradArgs;
+int nsff_fold_grads(const NsffFoldGradArgs* args, void* stream);
 
 /* out[0] = max |x[i]| (0 for n == 0): the device scalar `gmax` of nsff_field_backward / nsff_weight_grad without a
  * host round trip (replaces d_raw.abs().max()).  x 16-byte aligned.                                                */

@@ -103,6 +103,11 @@ class WgradJob(C.Structure):
     _fields_ = [("a", _fp), ("b", _fp), ("a_rows", C.c_int32), ("b_rows", C.c_int32), ("out_off", C.c_int64)]
 
 
+class FoldGradArgs(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("pad_", C.c_int32), ("g", _fp), ("gb", _fp), ("w_final", _fp), ("b_final", _fp),
+                ("w_head", _fp * 16), ("d_w_head", _fp * 16), ("d_b_head", _fp * 16), ("d_w_final", _fp), ("d_b_final", _fp)]
+
+
 class SplatArgs(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("n_planes", C.c_int32), ("K4", C.c_float * 4),
                 ("P", C.c_float * 12), ("scale", C.c_float),
@@ -175,6 +180,10 @@ _SIGNATURES = {
     "nsff_weight_grad": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "nsff_weight_grad_accumulate": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, C.c_int64,
                                               _fp, _fp, _fp]),
+    "nsff_weight_grad_accumulate_aux": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, C.c_int64,
+                                                  _fp, _fp, _fp, _fp]),
+    "nsff_fold_grads": (C.c_int, [C.POINTER(FoldGradArgs), _fp]),
+    "nsff_pack_weights_bwd_ex": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp, _fp]),
     "nsff_absmax": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "nsff_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double, _fp]),
     "nsff_adam_step_segments": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -353,8 +362,8 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
     saves = not (save_acts is None and save_xin is None and save_masks is None and save_side is None)
-    # the "f16" fast mode reads the f16x3 pack (hi halfs only); training forwards do not need the folded head rows
-    packed = model.packed(1 if prec == 3 else prec, inference=not saves)
+    # the "f16" fast mode reads the f16x3 pack (hi halfs only); training forwards run the folded step program too (f16x3 packs)
+    packed = model.packed(1 if prec == 3 else prec, inference=True)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()
     a.n_points, a.pts_per_ray = int(n_points), int(pts_per_ray)
@@ -508,9 +517,10 @@ def bwd_packed_bytes(desc):
     return n.value
 
 
-def pack_weights_bwd(desc, params, packed):
+def pack_weights_bwd(desc, params, packed, fwd_packed=None):
+    """fwd_packed: the f16x3 forward pack of the same weights (folded heads): its fp32 scratch supplies the folded products."""
     arr = (_fp * len(params))(*[p.data_ptr() for p in params])
-    _check(load().nsff_pack_weights_bwd(C.byref(desc), arr, _ptr(packed), _stream()), "nsff_pack_weights_bwd")
+    _check(load().nsff_pack_weights_bwd_ex(C.byref(desc), arr, _ptr(packed), _ptr(fwd_packed), _stream()), "nsff_pack_weights_bwd_ex")
 
 
 def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side=None):
@@ -554,19 +564,30 @@ def weight_grad(jobs, n_tiles, n_splits, out, bias, gmax):
                                    _ptr(gmax), _stream()), "nsff_weight_grad")
 
 
-def weight_grad_accumulate(jobs, n_tiles, n_splits, grad_map, grad_base_ptr, gmax):
+def weight_grad_accumulate(jobs, n_tiles, n_splits, grad_map, grad_base_ptr, gmax, aux=None):
     """The same GEMMs, accumulated straight into the parameters' gradient memory.  grad_map: (n,4) int32 device tensor of
-    NsffGradMapEntry rows; grad_base_ptr: device address the map's `dst` offsets count from."""
+    NsffGradMapEntry rows; grad_base_ptr: device address the map's `dst` offsets count from; aux: fp32 tensor that receives
+    the entries with dst < 0 (dense sums for the folded parameters)."""
     arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=0) for j in jobs])
     n = load().nsff_weight_grad_scratch(arr, len(jobs), int(n_tiles), int(n_splits))
     if n < 0:
         raise RuntimeError("nsff_weight_grad_scratch failed")
     assert grad_map.dtype == torch.int32 and grad_map.is_contiguous() and grad_map.shape[1] == 4
     scratch = torch.empty(n, device=gmax.device)
-    _check(load().nsff_weight_grad_accumulate(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(scratch),
-                                              C.c_void_p(grad_map.data_ptr()), grad_map.shape[0], C.c_void_p(grad_base_ptr),
-                                              _ptr(gmax), _stream()), "nsff_weight_grad_accumulate")
+    _check(load().nsff_weight_grad_accumulate_aux(arr, len(jobs), int(n_tiles), int(n_splits), _ptr(scratch),
+                                                  C.c_void_p(grad_map.data_ptr()), grad_map.shape[0], C.c_void_p(grad_base_ptr),
+                                                  _ptr(aux), _ptr(gmax), _stream()), "nsff_weight_grad_accumulate_aux")
     return scratch
+
+
+def fold_grads(g, gb, w_final, b_final, head_rows, d_w_final, d_b_final):
+    """nsff_fold_grads: head_rows = [(w_row (256,) tensor, d_w_row (256,) view of .grad, d_b (1,) view of .grad)] per folded row;
+    every tensor fp32 contiguous on the GPU; the d_* are accumulated into."""
+    a = FoldGradArgs(n_rows=len(head_rows), g=_ptr(g), gb=_ptr(gb), w_final=_ptr(w_final), b_final=_ptr(b_final),
+                     d_w_final=_ptr(d_w_final), d_b_final=_ptr(d_b_final))
+    for r, (w, dw, db) in enumerate(head_rows):
+        a.w_head[r], a.d_w_head[r], a.d_b_head[r] = w.data_ptr(), dw.data_ptr(), db.data_ptr()
+    _check(load().nsff_fold_grads(C.byref(a), _stream()), "nsff_fold_grads")
 
 
 def absmax(x):

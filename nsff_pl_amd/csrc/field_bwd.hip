@@ -52,8 +52,13 @@ constexpr int MAX_BSTEPS = 40;
 // as A-operand tiles in streaming order  seg[wave][ks][mt][lane][8 halfs]:
 //     value = Wt[64*wave + 32*mt + (lane&31)][16*ks + 8*(lane>>5) + t]
 struct TrunkLayoutB {
-    uint32_t head;                       // rows = *_final outputs, K = head rows (16, padded to 64)
-    uint32_t fin;                        // rows = last trunk activation, K = 256
+    uint32_t head;                       // rows = the heads' input, K = head rows (16, padded to 64).  The heads' input is the LAST TRUNK
+                                         // ACTIVATION h: *_xyz_encoding_final is a Linear without activation (nerf.py:170,195), so the
+                                         // training forward evaluates W_head (W_final h + b_final) as (W_head W_final) h like the
+                                         // inference launches do, and this tile holds (W_head W_final)^T -- the 256 x 256 *_final layer
+                                         // is executed neither forward nor backward (its gradients: field_grad._folded_grads).
+                                         // View-direction static trunk: static_rgb reads static_dir_encoding -- its own transpose.
+    uint32_t fin;                        // (unused since the fold: rows = last trunk activation, K = 256)
     uint32_t layer[NSFF_MAX_LAYERS];     // l = 1..D-1: rows = activation of layer l-1, K = 256 (pre-activations of l)
     uint32_t x0;                         // rows = trunk input (xin_rows used), K = 256 (pre-activations of layer 0)
     uint32_t xskip[NSFF_MAX_LAYERS];     // the same for every skip layer l (NSFF_NONE elsewhere)
@@ -61,8 +66,9 @@ struct TrunkLayoutB {
 struct LayoutB {
     TrunkLayoutB st, tr;
     uint32_t s_sigma;                    // 256 fp32: static_sigma.weight (rank-1 term of the static head)
-    uint32_t dir_h, dir_side;            // use_viewdir: static_dir_encoding transposed -- rows = *_final outputs (256) /
-                                         // rows = [dir | a] inputs (side_rows used), K = 256 (its pre-activations)
+    uint32_t dir_h, dir_side;            // use_viewdir: static_dir_encoding transposed -- dir_h: rows = last trunk activation (256), the
+                                         // FOLDED product (W_dir[:, :256] W_final)^T / dir_side: rows = [dir | a] inputs (side_rows used);
+                                         // K = 256 (its pre-activations)
     uint32_t total;
     // trunk-input rows as the forward saves them and d_xin returns them: [0, k0s) position embedding, [k0s, k0s + kt) time
     // code, padded to xin_rows = 128 or 256 (the row counts the weight-gradient GEMM is built for); side_rows likewise
@@ -107,7 +113,9 @@ struct PackSegB {
     const float* src[4];     // kind 2: up to four head tensors; otherwise src[0]
     int32_t r0[4], nr[4];    // kind 2: destination K range of each head tensor
     uint32_t dst;
-    int32_t kind;            // 0 flat fp32 copy (count = nks), 1 transposed Linear, 2 heads, 3 trunk-input rows, 4 side-input rows
+    int32_t kind;            // 0 flat fp32 copy (count = nks), 1 transposed Linear, 2 heads, 3 trunk-input rows, 4 side-input rows,
+                             // 5 heads folded with *_final (fin), 6 static_dir_encoding[:, :256] folded with *_final
+    const float* fin;        // kinds 5 / 6: *_xyz_encoding_final.weight (256, 256)
     int32_t ld, c0;          // kind 1: Wt[k][n] = W[n][c0 + k];  kind 3: W[n][xmap(k)]
     int32_t nks;
     int32_t in_xyz, in_t, k0s;
@@ -135,6 +143,19 @@ __global__ void pack_kernel_b(const PackArgsB a) {
         } else if (s.kind == 2) {
             for (int j = 0; j < 4; ++j)
                 if (s.src[j] != nullptr && n >= s.r0[j] && n < s.r0[j] + s.nr[j]) v = s.src[j][(long long)(n - s.r0[j]) * 256 + k];
+        } else if (s.kind == 5) {                          // Wt[k][n] = sum_o W_head[n][o] W_final[o][k]
+            for (int j = 0; j < 4; ++j)
+                if (s.src[j] != nullptr && n >= s.r0[j] && n < s.r0[j] + s.nr[j]) {
+                    const float* wh = s.src[j] + (long long)(n - s.r0[j]) * 256;
+                    float t0 = 0.f;
+                    for (int o = 0; o < 256; ++o) t0 = fmaf(wh[o], s.fin[(long long)o * 256 + k], t0);
+                    v = t0;
+                }
+        } else if (s.kind == 6) {                          // Wt[k][n] = sum_o W_dir[n][o] W_final[o][k]
+            const float* wd = s.src[0] + (long long)n * s.ld;
+            float t0 = 0.f;
+            for (int o = 0; o < 256; ++o) t0 = fmaf(wd[o], s.fin[(long long)o * 256 + k], t0);
+            v = t0;
         } else if (s.kind == 4) {                          // Wt[k][n] = W_dir[n][256 + k], k < in_dir + in_a (passed in in_xyz)
             if (k < s.in_xyz) v = s.src[0][(long long)n * s.ld + 256 + k];
         } else {
@@ -745,6 +766,7 @@ struct GKArgs {
     const float* part; const float* gmax;
     const NsffGradMapEntry* map; float* grad;
     long long n_map; int n_jobs;
+    float* aux;                  // entries with dst < 0: aux[-(dst + 1)] = value (a store: dense sums for the folded parameters)
 };
 
 __global__ __launch_bounds__(256) void nsff_wgrad_accumulate_kernel(const GKArgs a) {
@@ -777,8 +799,43 @@ __global__ __launch_bounds__(256) void nsff_wgrad_accumulate_kernel(const GKArgs
         const NsffGradMapEntry m = a.map[i];
         float t = partial(m.job_a, m.e_a);
         if (m.job_b >= 0) t += partial(m.job_b, m.e_b);
-        a.grad[m.dst] += t * inv_g;
+        if (m.dst >= 0) a.grad[m.dst] += t * inv_g;
+        else if (a.aux != nullptr) a.aux[-(m.dst + 1)] = t * inv_g;
     }
+}
+
+// Gradients of *_xyz_encoding_final and of the heads that read it, from the folded heads' gradient (see the header):
+// one workgroup per output neuron o of *_final, one thread per input column i.
+__global__ __launch_bounds__(256) void fold_grads_kernel(const NsffFoldGradArgs a) {
+    const int o = blockIdx.x, i = threadIdx.x, R = a.n_rows;
+    __shared__ float sRed[4];
+    float gi[16], dwf = 0.f;
+    const float wfi = a.w_final[(long long)o * 256 + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        gi[r] = 0.f;
+        if (r < R) {
+            gi[r] = a.g[r * 256 + i] + a.g[(16 + r) * 256 + i];          // fp16 value + rounding remainder rows
+            dwf = fmaf(a.w_head[r][o], gi[r], dwf);
+        }
+    }
+    a.d_w_final[(long long)o * 256 + i] += dwf;
+    float dbf = 0.f;
+    for (int r = 0; r < R; ++r) {
+        // dW_head[r][o] = sum_i G[r][i] W_final[o][i] + gb[r] b_final[o]
+        float t = gi[r] * wfi;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        __syncthreads();
+        if ((i & 63) == 0) sRed[i >> 6] = t;
+        __syncthreads();
+        if (i == 0) {
+            const float gbr = a.gb[r] + a.gb[16 + r];
+            a.d_w_head[r][o] += ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + gbr * a.b_final[o];
+            dbf = fmaf(a.w_head[r][o], gbr, dbf);
+            if (o == 0) *a.d_b_head[r] += gbr;
+        }
+    }
+    if (i == 0) a.d_b_final[o] += dbf;
 }
 
 // max |x| as a device scalar (the global scale of nsff_field_backward): non-negative floats order like their bits
@@ -809,6 +866,16 @@ extern "C" int nsff_debug_read_bwd_timing(unsigned* host, int n) {
 
 extern "C" {
 
+int nsff_fold_grads(const NsffFoldGradArgs* args, void* stream) {
+    if (!args) return NSFF_ERR_NULL;
+    const NsffFoldGradArgs& a = *args;
+    if (a.n_rows < 1 || a.n_rows > 16) return NSFF_ERR_INVALID;
+    if (!a.g || !a.gb || !a.w_final || !a.b_final || !a.d_w_final || !a.d_b_final) return NSFF_ERR_NULL;
+    for (int r = 0; r < a.n_rows; ++r) if (!a.w_head[r] || !a.d_w_head[r] || !a.d_b_head[r]) return NSFF_ERR_NULL;
+    hipLaunchKernelGGL(fold_grads_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    return nsff_launch_status();
+}
+
 int nsff_absmax(const float* x, int64_t n, float* out, void* stream) {
     if (!out || (n > 0 && !x)) return NSFF_ERR_NULL;
     if (n < 0) return NSFF_ERR_INVALID;
@@ -831,6 +898,13 @@ int nsff_bwd_packed_bytes(const NsffModelDesc* desc, size_t* bytes) {
 }
 
 int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params, void* packed, void* stream) {
+    return nsff_pack_weights_bwd_ex(desc, params, packed, nullptr, stream);
+}
+
+// fwd_packed (or null): the F16X3 pack of the SAME weights with folded heads (nsff_pack_weights): its fp32 scratch already
+// holds W_head W_final (and W_dir[:, :256] W_final) -- the transposed tiles are then packed from there instead of being
+// multiplied again (a 256-long dot product per element: 44 -> 8 us per pack).
+int nsff_pack_weights_bwd_ex(const NsffModelDesc* desc, const float* const* params, void* packed, const void* fwd_packed, void* stream) {
     if (!desc || !params || !packed) return NSFF_ERR_NULL;
     if ((uintptr_t)packed & 15) return NSFF_ERR_ALIGN;
     const NsffModelDesc& d = *desc;
@@ -838,6 +912,9 @@ int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params,
     const int rc = make_layout_b(d, L);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    NsffLayoutH3 F;
+    if (nsff_make_layout_h3(d, F) != NSFF_OK) return NSFF_ERR_INVALID;
+    const float* fold32 = reinterpret_cast<const float*>(fwd_packed);      // fp32 view of the forward pack (word offsets of F)
     std::vector<PackSegB> segs;
     int pi = 0;
     auto lin = [&](const float* w, uint32_t dst, int ld, int c0) {
@@ -847,6 +924,7 @@ int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params,
         PackSegB s{}; s.src[0] = w; s.dst = dst; s.kind = 3; s.ld = ld; s.nks = 16; s.in_xyz = d.in_xyz; s.in_t = in_t; s.k0s = L.k0s;
         segs.push_back(s);
     };
+    const float* fin[2] = {nullptr, nullptr};              // *_xyz_encoding_final.weight of the two trunks
     auto trunk = [&](int t, const TrunkLayoutB& T, int in_t) {
         const int in = d.in_xyz + in_t;
         for (int l = 0; l < d.D; ++l) {
@@ -855,32 +933,40 @@ int nsff_pack_weights_bwd(const NsffModelDesc* desc, const float* const* params,
             else if (is_skip(d, l)) { lin(w, T.layer[l], in + NSFF_W, in); if (T.xskip[l] != NSFF_NONE) xrows(w, T.xskip[l], in + NSFF_W, in_t); }
             else lin(w, T.layer[l], NSFF_W, 0);
         }
-        const float* wf = params[pi]; pi += 2;
-        lin(wf, T.fin, NSFF_W, 0);
+        fin[t] = params[pi]; pi += 2;
     };
     trunk(0, L.st, 0);
     if (d.use_viewdir) {
         const float* wdir = params[pi]; pi += 2;
         const int ld = NSFF_W + d.in_dir + d.in_a;
-        lin(wdir, L.dir_h, ld, 0);
+        if (fold32) lin(fold32 + F.dir_fold_f32, L.dir_h, NSFF_W, 0);
+        else { PackSegB s{}; s.src[0] = wdir; s.dst = L.dir_h; s.kind = 6; s.ld = ld; s.nks = 16; s.fin = fin[0]; segs.push_back(s); }
         PackSegB s{}; s.src[0] = wdir; s.dst = L.dir_side; s.kind = 4; s.ld = ld; s.nks = 16; s.in_xyz = d.in_dir + d.in_a; segs.push_back(s);
     }
     {
         const float* wsig = params[pi]; pi += 2;
         const float* wrgb = params[pi]; pi += 2;
         PackSegB s{}; s.src[0] = wsig; s.dst = L.s_sigma; s.kind = 0; s.nks = 256; segs.push_back(s);
-        PackSegB h{}; h.src[0] = wrgb; h.r0[0] = 0; h.nr[0] = 3; h.dst = L.st.head; h.kind = 2; h.nks = 4; segs.push_back(h);
+        // (the static rgb head reads *_final -- folded -- unless the view-direction layer sits in between)
+        PackSegB h{}; h.src[0] = wrgb; h.r0[0] = 0; h.nr[0] = 3; h.dst = L.st.head; h.kind = d.use_viewdir ? 2 : 5; h.nks = 4; h.fin = fin[0];
+        if (fold32 && !d.use_viewdir) { h.src[0] = fold32 + F.fold_f32; h.kind = 2; }     // (rows 0..2 of the forward's products; row 3 = sigma stays out)
+        segs.push_back(h);
     }
     if (d.has_transient) {
         trunk(1, L.tr, d.in_t);
         const float* ws = params[pi]; pi += 2;
         const float* wc = params[pi]; pi += 2;
-        PackSegB h{}; h.dst = L.tr.head; h.kind = 2; h.nks = 4;
+        PackSegB h{}; h.dst = L.tr.head; h.kind = 5; h.nks = 4; h.fin = fin[1];
         h.src[0] = wc; h.r0[0] = 0; h.nr[0] = 3;
         h.src[1] = ws; h.r0[1] = 3; h.nr[1] = 1;
         if (d.has_flow) {
             h.src[2] = params[pi]; pi += 2; h.r0[2] = 4; h.nr[2] = 3;
             h.src[3] = params[pi]; pi += 2; h.r0[3] = 7; h.nr[3] = 3;
+        }
+        if (fold32) {
+            const float* rows = fold32 + F.fold_f32 + 32 * NSFF_W;
+            h.kind = 2; h.src[0] = rows; h.r0[0] = 0; h.nr[0] = d.has_flow ? 10 : 4;
+            h.src[1] = h.src[2] = h.src[3] = nullptr;
         }
         segs.push_back(h);
     }
@@ -935,13 +1021,21 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
     // activation slots, which are numbered the same way.
     auto trunk = [&](const TrunkLayoutB& T, int t, bool want_xin) {
         const int base = t * (d.D + 1);
+        // *_xyz_encoding_final is never differentiated as a layer: the heads (the view-direction layer) that read it are linear in
+        // the last trunk activation h, so their transposes are FOLDED with *_final's (pack kinds 5 / 6) and the first GEMM of a
+        // trunk already produces d h -- masked by the last trunk layer's ReLU, plus the rank-1 term of static_sigma, which reads h
+        // itself.  What used to be slot base + D (d *_final) no longer exists; *_final's and the heads' weight gradients are
+        // small matrix products of the folded gradients (nsff_pl_amd/field_grad.py::_folded_grads).
+        int stash0 = -1;
+        if (want_xin) for (int l = 1; l < d.D; ++l) if (is_skip(d, l)) { stash0 = l; break; }
+        const int first_flags = (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == stash0) ? F_STASH : 0);
         if (t == 0 && d.use_viewdir) {
             // static_rgb reads static_dir_encoding = relu(W_dir . [*_final | dir | a]) (nerf.py:183-186)
             push(T.head, 4, EPI_MASK, 2 * d.D + 2, 0);
             if (k.d_side != nullptr) push(L.dir_side, 16, EPI_DXIN, 0, (L.side_rows == 128 ? F_HALF_ROWS : 0) | F_TO_SIDE);
-            push(L.dir_h, 16, EPI_LINEAR, base + d.D, 0);
+            push(L.dir_h, 16, EPI_MASK, base + d.D - 1, first_flags);
         } else {
-            push(T.head, 4, EPI_LINEAR, base + d.D, 0);
+            push(T.head, 4, EPI_MASK, base + d.D - 1, first_flags);
         }
         // Trunk-input gradient (dynamic trunk, want_xin): d_xin = Wx_0^T dpre_0 + sum over skip layers l of Wx_l^T dpre_l.
         // The LOWEST skip layer's tile is stashed in LDS and multiplied last, into the accumulators layer 0 leaves (no
@@ -957,7 +1051,6 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
                 wrote = true;
             }
         };
-        push(T.fin, 16, EPI_MASK, base + d.D - 1, (t == 0 ? F_SIGMA : 0) | ((d.D - 1 == stash_l) ? F_STASH : 0));
         after_tile(d.D - 1);
         for (int l = d.D - 1; l >= 1; --l) {
             push(T.layer[l], 16, EPI_MASK, base + l - 1, (l - 1 == stash_l) ? F_STASH : 0);
@@ -1104,13 +1197,19 @@ int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, 
 
 int nsff_weight_grad_accumulate(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, float* scratch,
                                 const NsffGradMapEntry* map, int64_t n_map, float* grad_base, const float* gmax, void* stream) {
+    return nsff_weight_grad_accumulate_aux(jobs, n_jobs, n_tiles, n_splits, scratch, map, n_map, grad_base, nullptr, gmax, stream);
+}
+
+int nsff_weight_grad_accumulate_aux(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits, float* scratch,
+                                    const NsffGradMapEntry* map, int64_t n_map, float* grad_base, float* aux, const float* gmax,
+                                    void* stream) {
     if (!jobs || !scratch || !gmax || (n_map > 0 && (!map || !grad_base))) return NSFF_ERR_NULL;
     if (n_jobs < 0 || n_jobs > MAX_WJOBS || n_tiles < 0 || n_splits < 1 || n_map < 0) return NSFF_ERR_INVALID;
     if ((uintptr_t)map & 15) return NSFF_ERR_ALIGN;
     if (n_jobs == 0 || n_tiles == 0 || n_map == 0) return NSFF_OK;
     hipStream_t st = (hipStream_t)stream;
     GKArgs g{};
-    g.part = scratch; g.gmax = gmax; g.map = map; g.grad = grad_base; g.n_map = n_map; g.n_jobs = n_jobs;
+    g.part = scratch; g.gmax = gmax; g.map = map; g.grad = grad_base; g.n_map = n_map; g.n_jobs = n_jobs; g.aux = aux;
     int max_size = 0;
     const int rc = wgrad_gemms(jobs, n_jobs, n_tiles, n_splits, scratch, g.jobs, &max_size, st);
     if (rc) return rc;

@@ -2156,7 +2156,10 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         if (g.freqs[i + 1] != 2.0f * g.freqs[i]) k.octave_freqs = 0;
     k.ld_emb = g.ld_emb; k.off_xyz = g.off_xyz; k.off_dir = g.off_dir; k.off_a = g.off_a; k.off_t = g.off_t;
 
-    const bool fold = !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
+    // Every f16x3 launch -- inference and training forward alike -- runs the FOLDED step program: the activation-free
+    // *_xyz_encoding_final layers are never executed, the heads that read them are evaluated with pre-multiplied rows.  A
+    // training forward saves the trunk layers' activations only; the backward pass (field_bwd.hip) is folded the same way.
+    const bool fold = true;
     {
         const int prc = h3_step_program(d, g.static_mode, g.transient_mode, fold, k);
         if (prc != NSFF_OK) return prc;

@@ -62,7 +62,9 @@ def supported(model, xyz):
 
 
 def n_slots(model):
-    """Activation / pre-activation-gradient slots: trunk t layer l -> t*(D+1)+l (l = D: *_final), 2D+2: static_dir_encoding."""
+    """Activation / pre-activation-gradient slots: trunk t layer l -> t*(D+1)+l, 2D+2: static_dir_encoding.  (Slot l = D of a
+    trunk -- *_xyz_encoding_final in earlier versions -- keeps its number but is never written: the layer is folded into the
+    heads that read it, forward and backward.)"""
     return 2 * model.D + 2 + (1 if model.use_viewdir else 0)
 
 
@@ -162,14 +164,14 @@ class _FieldFn(torch.autograd.Function):
                 a_, b_, rows = dpre[base + l], xin, (256, xin_rows)
             elif kind == "h":
                 a_, b_, rows = dpre[base + l], acts[base + l - 1], (256, 256)
-            elif kind == "dir_h":
-                a_, b_, rows = dpre[S_DIR], acts[D], (256, 256)
+            elif kind == "dir_h":                                 # (folded with *_final: reads the last trunk activation)
+                a_, b_, rows = dpre[S_DIR], acts[D - 1], (256, 256)
             elif kind == "dir_x":
                 a_, b_, rows = dpre[S_DIR], side, (256, side_rows)
             elif l == 1:                                          # static sigma reads the trunk
                 a_, b_, rows = dhead[0], acts[base + D - 1], (32, 256)
-            else:
-                a_, b_, rows = dhead[t], acts[S_DIR if (t == 0 and viewdir) else base + D], (32, 256)
+            else:                                                 # the (folded) heads read the last trunk activation as well
+                a_, b_, rows = dhead[t], acts[S_DIR if (t == 0 and viewdir) else base + D - 1], (32, 256)
             jobs.append([a_.data_ptr(), b_.data_ptr(), rows[0], rows[1], 0])
             sizes.append(rows[0] * rows[1])
         # requested split-K factor; the library rounds it to whole rounds of the 256 CUs (16 -> one round of 14 splits x 18 jobs:
@@ -194,17 +196,26 @@ class _FieldFn(torch.autograd.Function):
         with torch.cuda.stream(wstream):
             if grad_map is not None:
                 # deferred mode with every .grad in place: the reduction of the split-K partials accumulates straight
-                # into the parameters' gradient memory (no per-parameter tensors, adds or cats)
-                keep = _lib.weight_grad_accumulate([tuple(j) for j in jobs], tiles, n_splits, grad_map[0], grad_map[1], gmax)
+                # into the parameters' gradient memory (no per-parameter tensors, adds or cats) -- except the FOLDED
+                # parameters (*_final, the heads / the view-direction layer that read it): the same launch leaves their jobs'
+                # dense sums in `aux`, one more launch per trunk (nsff_fold_grads) turns them into gradients in place
+                table, base, aux_at, aux_total = grad_map
+                aux = torch.empty(aux_total, device=dev)
+                keep = _lib.weight_grad_accumulate([tuple(j) for j in jobs], tiles, n_splits, table, base, gmax, aux=aux)
+                dense = lambda i: aux[aux_at[i]:aux_at[i] + sizes[i]].view(jobs[i][2], jobs[i][3])
+                dense_bias = lambda i: aux[aux_at[i] + sizes[i]:aux_at[i] + sizes[i] + 256]
+                _fold_in_place(model, static, transient, meta, plist, dense, dense_bias)
+                keep = (keep, aux)
                 grads = None
             else:
                 out = torch.empty(off, device=dev)
                 bias = torch.empty(len(jobs), 256, device=dev)
                 _lib.weight_grad([tuple(j) for j in jobs], tiles, n_splits, out, bias, gmax)  # summed and unscaled in there
                 keep = (out, bias)
-                grads = _assemble(model, static, transient, meta, plist,
-                                  lambda i: out[jobs[i][4]:jobs[i][4] + sizes[i]].view(jobs[i][2], jobs[i][3]),
-                                  lambda i: bias[i], torch.cat)
+                result = lambda i: out[jobs[i][4]:jobs[i][4] + sizes[i]].view(jobs[i][2], jobs[i][3])
+                grads = _assemble(model, static, transient, meta, plist, result, lambda i: bias[i], torch.cat)
+                for i, g_ in _folded_grads(model, static, transient, meta, plist, result, lambda i: bias[i]).items():
+                    grads[i] = g_
 
         d_xyz = d_t = d_a = None
         if d_xin is not None:              # derivative of the positional encoding + per-ray sum of the time-code rows
@@ -234,8 +245,10 @@ def _skips(model):
 
 def _wgrad_jobs(model, static, transient):
     """The weight-gradient GEMMs of one node as (kind, trunk, layer) tags: 'x' = trunk-input part of layer l (layer 0 and
-    every skip layer), 'h' = hidden part of layer l (l == D: *_final), 'dir_h' / 'dir_x' = the two parts of
-    static_dir_encoding, 'head' = the output heads (layer 1: static_sigma, which reads the trunk instead of *_final)."""
+    every skip layer), 'h' = hidden part of layer l, 'dir_h' / 'dir_x' = the two parts of static_dir_encoding, 'head' = the
+    output heads (layer 1: static_sigma of a view-direction model -- its rgb head reads static_dir_encoding, sigma the trunk;
+    without view directions both read the last trunk activation and share ONE job).  *_xyz_encoding_final has no job: it is
+    folded into the heads / into 'dir_h', whose jobs therefore multiply with the LAST TRUNK activation (_folded_grads)."""
     D, skips = model.D, _skips(model)
     viewdir = bool(model.use_viewdir and static)
     meta = []
@@ -247,11 +260,10 @@ def _wgrad_jobs(model, static, transient):
                 meta.append(("h", t, l))
                 if l in skips:
                     meta.append(("x", t, l))
-        meta.append(("h", t, D))
         if t == 0 and viewdir:            # static_dir_encoding: [*_final | dir | a] -> 256, static_rgb reads it
             meta += [("dir_h", 0, 0), ("dir_x", 0, 0)]
         meta.append(("head", t, 0))
-        if t == 0:
+        if t == 0 and viewdir:
             meta.append(("head", 0, 1))
     return meta
 
@@ -287,26 +299,119 @@ def _assemble(model, static, transient, meta, plist, result, bias_of, cat):
             else:
                 i = res[("h", t, l)]
                 put(layer, result(i), bias_of(i))
-        i = res[("h", t, D)]
-        put(_lin(getattr(model, f"{prefix}_xyz_encoding_final")), result(i), bias_of(i))
+        # (*_final, the heads that read it and static_dir_encoding come from _folded_grads: products, not slices)
         i = res[("head", t, 0)]
         hw, hb = result(i), bias_of(i)
         hw, hb = hw[0:16] + hw[16:32], hb[0:16] + hb[16:32]      # fp16 value + rounding remainder rows
-        if t == 0 and viewdir:
-            ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
-            n_side = model.in_channels_dir + model.in_channels_a
-            put(_lin(model.static_dir_encoding), cat([result(ih), result(ix)[:, :n_side]], 1), bias_of(ih))
-        if t == 0:
+        if t == 0 and viewdir:            # static_rgb reads static_dir_encoding, static_sigma the trunk: plain slices
             put(_lin(model.static_rgb), hw[0:3], hb[0:3])
             i2 = res[("head", 0, 1)]
             put(_lin(model.static_sigma), result(i2)[3:4] + result(i2)[19:20], bias_of(i2)[3:4] + bias_of(i2)[19:20])
-        else:
-            put(_lin(model.transient_rgb), hw[0:3], hb[0:3])
-            put(_lin(model.transient_sigma), hw[3:4], hb[3:4])
-            if model.output_flow:
-                put(_lin(model.transient_flow_fw), hw[4:7], hb[4:7])
-                put(_lin(model.transient_flow_bw), hw[7:10], hb[7:10])
+        elif t == 0:                      # static_sigma reads the last trunk activation like the folded rgb rows: row 3 of their job
+            put(_lin(model.static_sigma), hw[3:4], hb[3:4])
     return grads
+
+
+def _fold_job_indices(model, static, transient, meta):
+    """Jobs whose dense sums _folded_grads needs."""
+    viewdir = bool(model.use_viewdir and static)
+    res = {tag: i for i, tag in enumerate(meta)}
+    sel = []
+    for t in ([0] if static else []) + ([1] if transient else []):
+        if t == 0 and viewdir:
+            sel += [res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]]
+        else:
+            sel.append(res[("head", t, 0)])
+    return sel
+
+
+def _fold_heads(model, t):
+    """[(head module, first row, end row)] of the folded heads of trunk t (rows of the heads' job), in row order."""
+    if t == 0:
+        return [(model.static_rgb, 0, 3)]
+    heads = [(model.transient_rgb, 0, 3), (model.transient_sigma, 3, 4)]
+    if model.output_flow:
+        heads += [(model.transient_flow_fw, 4, 7), (model.transient_flow_bw, 7, 10)]
+    return heads
+
+
+def _fold_in_place(model, static, transient, meta, plist, dense, dense_bias):
+    """The folded parameters' gradients ADDED to their .grad (every one exists: the in-place path): one nsff_fold_grads launch
+    per trunk; the view-direction static trunk (two 256^3 products) through torch's GEMMs."""
+    viewdir = bool(model.use_viewdir and static)
+    res = {tag: i for i, tag in enumerate(meta)}
+    torch_trunks = set()
+    for t in ([0] if static else []) + ([1] if transient else []):
+        prefix = "static" if t == 0 else "transient"
+        fin = _lin(getattr(model, f"{prefix}_xyz_encoding_final"))
+        heads = _fold_heads(model, t)
+        involved = [fin.weight, fin.bias] + [q for m, _, _ in heads for q in (_lin(m).weight, _lin(m).bias)]
+        if (t == 0 and viewdir) or not all(q.requires_grad and q.grad is not None for q in involved):
+            torch_trunks.add(t)
+            continue
+        i = res[("head", t, 0)]
+        rows = []
+        for m, a, b in heads:
+            lin = _lin(m)
+            for r in range(b - a):
+                rows.append((lin.weight.detach()[r], lin.weight.grad[r], lin.bias.grad[r:r + 1]))
+        _lib.fold_grads(dense(i), dense_bias(i), fin.weight.detach(), fin.bias.detach(), rows, fin.weight.grad, fin.bias.grad)
+    if torch_trunks:
+        with torch.no_grad():
+            for i, g_ in _folded_grads(model, static, transient, meta, plist, dense, dense_bias, only=torch_trunks).items():
+                if plist[i].requires_grad:
+                    plist[i].grad.add_(g_)
+
+
+def _folded_grads(model, static, transient, meta, plist, result, bias_of, only=None):
+    """{index in plist: gradient} of the parameters the fold touches.  *_xyz_encoding_final is a Linear without activation
+    (reference nerf.py:170,195) that the kernels never execute: a head that reads it is evaluated as (W_head W_final) h + (W_head
+    b_final + b_head) on the last trunk activation h, and the backward kernels differentiate that folded map.  With
+    G = sum_p dpre_p (x) h_p (the folded head's weight gradient, a job of the weight-gradient GEMM) and gb = sum_p dpre_p:
+        dW_head = G W_final^T + gb (x) b_final      db_head = gb
+        dW_final = W_head^T G                       db_final = W_head^T gb
+    -- exactly what autograd of the two layers gives.  The view-direction layer static_dir_encoding (which reads [*_final | dir |
+    a]) takes W_head's place for the static trunk of such a model; its [dir | a] columns are an ordinary job.
+    result(i) / bias_of(i): dense (a_rows, b_rows) sum and row sums of job i (fp32 tensors)."""
+    D = model.D
+    viewdir = bool(model.use_viewdir and static)
+    index = {id(q): i for i, q in enumerate(plist)}
+    res = {tag: i for i, tag in enumerate(meta)}
+    out = {}
+    for t in ([0] if static else []) + ([1] if transient else []):
+        if only is not None and t not in only:
+            continue
+        prefix = "static" if t == 0 else "transient"
+        fin = _lin(getattr(model, f"{prefix}_xyz_encoding_final"))
+        w_f, b_f = fin.weight.detach(), fin.bias.detach()
+        if t == 0 and viewdir:
+            ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
+            g, gb = result(ih), bias_of(ih)                           # (256, 256), (256)
+            layer = _lin(model.static_dir_encoding)
+            w_dh = layer.weight.detach()[:, :256]
+            n_side = model.in_channels_dir + model.in_channels_a
+            out[index[id(layer.weight)]] = torch.cat([torch.addmm(torch.outer(gb, b_f), g, w_f.t()), result(ix)[:, :n_side]], 1)
+            out[index[id(layer.bias)]] = gb.clone()
+            out[index[id(fin.weight)]] = w_dh.t() @ g
+            out[index[id(fin.bias)]] = w_dh.t() @ gb
+            continue
+        i = res[("head", t, 0)]
+        hw, hb = result(i), bias_of(i)
+        g, gb = hw[0:16] + hw[16:32], hb[0:16] + hb[16:32]           # fp16 value + rounding remainder rows
+        heads = _fold_heads(model, t)
+        n_rows = heads[-1][2]                                                      # (the folded rows are rows 0 .. R - 1 of the job)
+        w_h = torch.cat([_lin(m).weight.detach() for m, _, _ in heads], 0)        # (R, 256)
+        g_r, gb_r = g[:n_rows], gb[:n_rows]
+        d_heads = torch.addmm(torch.outer(gb_r, b_f), g_r, w_f.t())               # (R, 256)
+        k = 0
+        for m, a, b in heads:
+            lin = _lin(m)
+            out[index[id(lin.weight)]] = d_heads[k:k + (b - a)]
+            out[index[id(lin.bias)]] = gb[a:b].clone()
+            k += b - a
+        out[index[id(fin.weight)]] = w_h.t() @ g_r
+        out[index[id(fin.bias)]] = w_h.t() @ gb_r
+    return out
 
 
 class _Idx:
@@ -379,10 +484,23 @@ def _grad_map(model, static, transient, meta, jobs, sizes, plist):
         pair = np.stack([src.ja.reshape(-1).astype(np.int16), src.jb.reshape(-1).astype(np.int16)], 1)   # little-endian
         ent[:, 3] = np.ascontiguousarray(pair).view(np.int32).reshape(-1)
         rows.append(ent)
+    # the jobs the folded parameters are made of: their dense sums (matrix, then the 256 row sums) go to `aux` (dst < 0)
+    aux_at, aux_total = {}, 0
+    for j in _fold_job_indices(model, static, transient, meta):
+        n = sizes[j] + 256
+        ent = np.empty((n, 4), np.int32)
+        ent[:, 0] = -(1 + aux_total + np.arange(n, dtype=np.int64))
+        ent[:, 1] = np.arange(n, dtype=np.int32)
+        ent[:, 2] = 0
+        pair = np.stack([np.full(n, j, np.int16), np.full(n, -1, np.int16)], 1)
+        ent[:, 3] = np.ascontiguousarray(pair).view(np.int32).reshape(-1)
+        rows.append(ent)
+        aux_at[j] = aux_total
+        aux_total += n
     table = torch.from_numpy(np.concatenate(rows, 0)).to(plist[0].device)
     if len(_GRAD_MAPS) > 64:
         _GRAD_MAPS.clear()
-    _GRAD_MAPS[key] = (table, base)
+    _GRAD_MAPS[key] = (table, base, aux_at, max(aux_total, 1))
     return _GRAD_MAPS[key]
 
 

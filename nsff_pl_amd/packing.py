@@ -38,7 +38,8 @@ class PackCache:
                 buf = self._buf[precision] = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
                 if precision == _lib.BWD_PACK:
-                    _lib.pack_weights_bwd(desc, params, buf)
+                    # (the folded products W_head W_final come from the forward pack of the same weights)
+                    _lib.pack_weights_bwd(desc, params, buf, self.get(model, 1, True))
                 else:
                     _lib.pack_weights(desc, params, buf, precision, fold=inference)
                     self._folded[precision] = bool(inference)

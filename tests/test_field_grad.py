@@ -223,7 +223,9 @@ def test_a_backward_inside_a_backward_pass_keeps_the_enclosing_pass_entries(hip_
 def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_lib):
     """Deferred mode with .grad tensors in place: nsff_weight_grad_accumulate adds every gradient element straight into
     the parameters' own memory.  Result must be bit-identical to (existing .grad) + (what the node returns through
-    autograd), for scattered .grad tensors and for views of one flat buffer, twice in a row (accumulation)."""
+    autograd), for scattered .grad tensors and for views of one flat buffer, twice in a row (accumulation).  The FOLDED
+    parameters (*_final and the heads / the view-direction layer that read it) are products of the folded heads' gradient --
+    nsff_fold_grads in place, torch GEMMs on the returned path: the same sums in another order, equal to fp32 rounding."""
     dev = torch.device("cuda:0")
     cfg = scenes.CASES[scene]
     models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
@@ -240,6 +242,10 @@ def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_
             side["a_rows"] = torch.randn(n_rays, model.in_channels_a, generator=g).to(dev)
     cot = torch.randn(n_rays * s, 16, generator=g).to(dev)
     params = [p for p in model.parameters() if p.requires_grad]
+    names = {id(p): n for n, p in model.named_parameters()}
+    viewdir = model.use_viewdir and static
+    folded = lambda n: ("xyz_encoding_final" in n or n.startswith(("transient_rgb", "transient_sigma", "transient_flow"))
+                        or (n.startswith("static_dir_encoding") if viewdir else n.startswith("static_rgb")))
 
     def loss():
         return (field_grad.field(model, xyz, freqs, t_rows, s, static, True, **side) * cot).sum()
@@ -261,9 +267,15 @@ def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_
             loss().backward()
         torch.cuda.synchronize()
         assert not field_grad._PENDING
+        n_folded = 0
         for p, t, w in zip(params, start, want):
             expect = t if w is None else (t + w) + w
-            assert torch.equal(p.grad, expect), (layout, tuple(p.shape))
+            if w is not None and folded(names[id(p)]):
+                n_folded += 1
+                assert float((p.grad - expect).abs().max()) <= 4e-6 * float(w.abs().max()), (layout, names[id(p)])
+            else:
+                assert torch.equal(p.grad, expect), (layout, names[id(p)])
+        assert n_folded >= (10 if static or not viewdir else 0)
     assert field_grad._GRAD_MAPS, "the in-place path was not taken"
 
 

@@ -246,6 +246,59 @@ def test_gradient_map_names_the_same_elements_as_the_tensor_assembly(kw, static,
         assert (ix.ja >= 0).all()
         got = fetch(ix.ja, ix.ea) + fetch(ix.jb, ix.eb)
         np.testing.assert_array_equal(got, g.numpy())
+    # every parameter of the evaluated trunks has exactly one source: a slice of the jobs (above) or the fold's products
+    folded = fg._folded_grads(model, static, transient, meta, plist, lambda i: torch.from_numpy(mats[i]), lambda i: torch.from_numpy(rows[i]))
+    direct = {i for i, g in enumerate(tens) if g is not None}
+    assert not (direct & set(folded)) and all(tuple(g.shape) == tuple(plist[i].shape) for i, g in folded.items())
     expect = sum(1 for n, _ in model.named_parameters()
                  if (static and n.startswith("static")) or (transient and n.startswith("transient")))
-    assert n_grads == expect
+    assert n_grads + len(folded) == expect
+    assert sorted(fg._fold_job_indices(model, static, transient, meta)) == sorted(
+        i for i, (k, t, l) in enumerate(meta) if k in ("dir_h", "dir_x") or (k == "head" and l == 0 and not (t == 0 and model.use_viewdir and static)))
+
+
+@pytest.mark.parametrize("viewdir", [False, True])
+def test_folded_gradients_are_autograds(viewdir):
+    """*_xyz_encoding_final is never executed as a layer: field_grad._folded_grads turns the folded heads' weight gradient
+    G = sum_p dpre_p (x) h_p into the gradients of *_final and of the heads (of static_dir_encoding with view directions) --
+    against float64 autograd of the unfolded layers on random activations and cotangents."""
+    from nsff_pl_amd import field_grad as fg
+    torch.manual_seed(3)
+    model = A.NeRF('fine', use_viewdir=viewdir, encode_appearance=viewdir, in_channels_a=48 if viewdir else 0, encode_transient=True,
+                   output_flow=True).double()
+    plist = _lib.param_list(model)
+    meta = fg._wgrad_jobs(model, True, True)
+    res = {tag: i for i, tag in enumerate(meta)}
+    P, n_side = 37, model.in_channels_dir + model.in_channels_a
+    mats = {i: torch.zeros(fg.job_shape(model, k), dtype=torch.float64) for i, (k, _, _) in enumerate(meta)}
+    rows = {i: torch.zeros(256, dtype=torch.float64) for i in mats}
+    for p in model.parameters():
+        p.grad = None
+    loss = 0
+    for t, prefix in ((0, "static"), (1, "transient")):
+        h = torch.randn(P, 256, dtype=torch.float64)
+        final = getattr(model, f"{prefix}_xyz_encoding_final")(h)
+        if t == 0 and viewdir:
+            side = torch.randn(P, n_side, dtype=torch.float64)
+            pre = model.static_dir_encoding[0](torch.cat([final, side], 1))
+            cot = torch.randn_like(pre)                           # d loss / d pre-activation of static_dir_encoding
+            loss = loss + (pre * cot).sum()
+            mats[res[("dir_h", 0, 0)]] = cot.t() @ h
+            rows[res[("dir_h", 0, 0)]] = cot.sum(0)
+            mats[res[("dir_x", 0, 0)]][:, :n_side] = cot.t() @ side
+            continue
+        heads = [model.static_rgb] if t == 0 else [model.transient_rgb, model.transient_sigma, model.transient_flow_fw, model.transient_flow_bw]
+        pre = torch.cat([m[0](final) if isinstance(m, torch.nn.Sequential) else m(final) for m in heads], 1)
+        cot = torch.randn_like(pre)
+        loss = loss + (pre * cot).sum()
+        i = res[("head", t, 0)]
+        mats[i][:pre.shape[1]] = cot.t() @ h                      # rows 0..R-1 (the remainder rows 16.. stay zero)
+        rows[i][:pre.shape[1]] = cot.sum(0)
+    loss.backward()
+    got = fg._folded_grads(model, True, True, meta, plist, lambda i: mats[i], lambda i: rows[i])
+    names = {id(p): n for n, p in model.named_parameters()}
+    assert len(got) == (4 + 8 + 2 if not viewdir else 4 + 8 + 2)          # static: final + (rgb | dir layer); dynamic: final + four heads
+    for i, g in got.items():
+        ref = plist[i].grad
+        assert ref is not None, names[id(plist[i])]
+        np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=1e-10, atol=1e-10, err_msg=names[id(plist[i])])
