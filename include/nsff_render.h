@@ -583,6 +583,7 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
 #define NSFF_KERNEL_H3_SAVE   5   /* f16x3 training forward (keeps activations)                                      */
 #define NSFF_KERNEL_F16_FAST  6   /* single-product fast mode                                                        */
 #define NSFF_KERNEL_H3A_TBIAS 7   /* NSFF_KERNEL_H3A with the time code folded into per-ray bias rows (NsffFieldArgs::t_bias) */
+#define NSFF_KERNEL_H3A_SAVE  9   /* f16x3 training forward on the hand-scheduled body (nsff_field_kernel_h3a_save)          */
 #define NSFF_KERNEL_H3A_SIDE  8   /* NSFF_KERNEL_H3A[_TBIAS] whose static trunk has the view-direction branch (NsffFieldArgs::s_bias) */
 int         nsff_last_field_kernel(void);
 /* Host-only (no GPU work): the f16x3 step program of an inference launch with these modes -- steps[n][4] = {weight segment

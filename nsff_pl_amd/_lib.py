@@ -675,7 +675,7 @@ def mpi_composite(H, W, S, dt, accum_fw, accum_bw, static_rgb, static_alpha, zs,
     _check(load().nsff_mpi_composite(C.byref(a), _stream()), "nsff_mpi_composite")
 
 
-KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast", 7: "h3a_tb", 8: "h3a_side"}
+KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast", 7: "h3a_tb", 8: "h3a_side", 9: "h3a_save"}
 
 
 def last_field_kernel():

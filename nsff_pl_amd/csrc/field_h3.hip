@@ -1225,7 +1225,13 @@ __device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const
     }
 }
 
-__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa) {
+// SAVE: the TRAINING forward (nsff_field_kernel_h3a_save) -- the same trunk program through the SAVE build of the body
+// (H3A_BODY_SAVE: every layer's activation goes to HBM in the weight-gradient GEMM's fragment order and its ReLU sign words in the
+// backward kernel's accumulator order, riding in the phases), an exact sin / cos per embedding column (the gradients are compared
+// with autograd of the reference network: see build_input's OCTAVE note), the time code through the matrix pipe (its columns'
+// weight gradients need the saved input tile) and the encoded input tile saved in front of the trunk.
+template <bool SAVE>
+__device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
     const H3KArgs& a = aa.k;
     constexpr int M = 128, THREADS = 256;
     __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
@@ -1319,12 +1325,12 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
     if (threadIdx.x == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
     H3A_TSTAMP(53);
-    const bool lean = a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb);
+    const bool lean = !SAVE && a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb);
     if (lean) {
         h3a_encode10(sXh, sXl, a, px, threadIdx.x, pre);
     } else {
         pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
-        build_input<M, THREADS, true, true, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
+        build_input<M, THREADS, true, !SAVE, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
     }
     H3A_TSTAMP(57);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
@@ -1340,6 +1346,22 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
         }
     }
     __syncthreads();
+    [[maybe_unused]] unsigned long long sv_act = 0ull, sv_mask = 0ull;
+    [[maybe_unused]] unsigned sv_astride = 0u, sv_mstride = 0u;
+    if constexpr (SAVE) {
+        // the encoded trunk input (the dynamic trunk's tile carries the time code; a static trunk saves it only when it is the
+        // launch's only trunk -- as the eight-wave training forward does), then the destinations of the body's rides: slot 0 of this
+        // trunk at this workgroup's first 64-point tile (both of its tiles exist: the host checked that the tile count is even)
+        const long long tile64 = tile * 2;
+        if (a.save_xin != nullptr && (tr == 1 || a.transient_mode == 0))
+            tile_to_fragments<THREADS, M>(sXh, sXl, a.save_xin + tile64 * (64 * a.xin_rows), a.xin_rows,
+                                          (int)a.L.k0s + (tr == 1 ? (int)a.L.kt : 0), M / 16);
+        const long long slot0 = tr == 0 ? 0 : a.D + 1;
+        sv_act = (unsigned long long)(uintptr_t)(a.save_acts + (slot0 * a.n_tiles + tile64) * (64 * NSFF_W));
+        sv_mask = (unsigned long long)(uintptr_t)(a.save_masks + (slot0 * a.n_tiles + tile64) * 256 + 64 * wave_id);
+        sv_astride = (unsigned)(a.n_tiles * (64 * NSFF_W * 2));
+        sv_mstride = (unsigned)(a.n_tiles * (256 * 8));
+    }
     {
         const unsigned long long phases = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() +
                                           offsetof(H3AArgs, ph) + (size_t)tr * sizeof(aa.ph[0]);
@@ -1356,6 +1378,14 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
         if (lane == 0) { tdbg[0] = (unsigned)span0.t; tdbg[1] = (unsigned)__builtin_amdgcn_s_memtime(); }
         const unsigned long long dbg = (unsigned long long)(uintptr_t)(tdbg + 64);
 #endif
+        if constexpr (SAVE) {
+            asm volatile(H3A_BODY_SAVE
+                         :
+                         : [pk] "s"(pkb), [phases] "s"(phases), [lds] "s"(lds), [biaslds] "s"(biaslds), [rawlds] "s"((unsigned)(uintptr_t)sRaw),
+                           [wave] "s"(wave_id), [in_t] "s"(in_t), [tid] "v"(tid), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1),
+                           [act] "s"(sv_act), [mask] "s"(sv_mask), [astride] "s"(sv_astride), [mstride] "s"(sv_mstride)
+                         : H3A_SAVE_CLOBBERS);
+        } else {
         asm volatile(H3A_BODY
                      :
                      : [pk] "s"(pkb),
@@ -1365,6 +1395,7 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
                        [phases] "s"(phases), [lds] "s"(lds), [biaslds] "s"(biaslds), [rawlds] "s"((unsigned)(uintptr_t)sRaw),
                        [wave] "s"(wave_id), [in_t] "s"(in_t), [tid] "v"(tid), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1)
                      : H3A_CLOBBERS);
+        }
     }
 #ifdef H3_TIMING
     if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
@@ -1425,6 +1456,9 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 #endif
 }
 
+__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa) { h3a_kernel<false>(aa); }
+__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a_save(const H3AArgs aa) { h3a_kernel<true>(aa); }
+
 // Phase program of one trunk = steps [s0, s1) of the step program (see tools/h3asm/check.py::build_program, the reference
 // implementation of this function, which the simulator runs).  Returns false when the trunk's structure is not one the body
 // executes -- the caller then launches the compiler-scheduled kernel instead.
@@ -1435,8 +1469,11 @@ __global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa
 // static_dir_encoding is the trunk's last 256-wide segment, its bias rows are per ray like the folded time code's, and the
 // sigma head of the step before it (static_sigma reads the last TRUNK layer, nerf.py:169) is not a HEAD phase but the SIGMA RIDE
 // of that layer's epilogues (tools/h3asm/gen.py: B16RS / A16RS); *sig_ride tells the kernel's records loop to add the partial sums up.
+// save: the training forward's program (nsff_field_kernel_h3a_save): a SAVE_LAST phase in front of the heads copies the trunk's
+// last activation to its slot (every other activation rides in the phase that multiplies it).
 static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bool fold_t, H3APhase* ph, uint32_t* bias_off,
-                              int& n_bias, int& head, int* n_phases = nullptr, bool side_fold = false, int* sig_ride = nullptr) {
+                              int& n_bias, int& head, int* n_phases = nullptr, bool side_fold = false, int* sig_ride = nullptr,
+                              bool save = false) {
     struct Seg { uint32_t off, stride; int nks, bias, bias_b; bool relu, rebuild; };
     Seg segs[MAX_STEPS];
     int n = 0;
@@ -1563,7 +1600,9 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
     const H3AHeadSel hd = h3a_head_sel(k.L, head);
     Seg tile = segs[0];
     tile.off = hd.w_off * 4u; tile.stride = 0u;
-    bool done = put(H3A_BODY_EPI_B, 0u, 0, hd.n_rows, tile, tile) && put(H3A_BODY_HEAD, 0u, 0, hd.n_rows, tile, tile);
+    if (save && (side_fold || fold_t)) return false;
+    bool done = put(H3A_BODY_EPI_B, 0u, 0, hd.n_rows, tile, tile) && (!save || put(H3A_BODY_SAVE_LAST, 0u, 0, hd.n_rows, tile, tile)) &&
+                put(H3A_BODY_HEAD, 0u, 0, hd.n_rows, tile, tile);
     if (done) ph[np - 1].d[2] = 4u * (uint32_t)hd.slot0;
     done = done && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]) && put(H3A_BODY_END, 0u, 0, 16, segs[0], segs[0]);
     if (n_phases) *n_phases = np;
@@ -2185,9 +2224,41 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     } else if (saves && points_per_block == 64) { // training forward, 64-point tiling (A/B against the default below)
         lrc = launch(nsff_field_kernel_h3<2, 1, true>, 64, 256);
         g_nsff_last_h3_kernel = NSFF_KERNEL_H3_SAVE;
-    } else if (saves) {                           // training forward: 128 points, eight waves of 32 neurons
-        lrc = launch(nsff_field_kernel_h3<4, 1, true, 1>, 128, 512);
-        g_nsff_last_h3_kernel = NSFF_KERNEL_H3_SAVE;
+    } else if (saves) {
+        // Training forward, 128-point tiles.  Default: the hand-scheduled body in its SAVE build (nsff_field_kernel_h3a_save) for
+        // launches it covers -- raw positions, a 64-column position embedding, time codes of at most 64 columns in float4 rows,
+        // no view-direction branch (its [dir | a] input tile is the eight-wave kernel's), activation and sign-word buffers both
+        // given, an EVEN number of 64-point tiles (a workgroup saves both of its tiles) below 4 GiB per slot; otherwise -- and with
+        // points_per_block == 131 -- eight waves of 32 neurons, compiler-scheduled.
+        H3AArgs ka{};
+        ka.n_bias[0] = ka.n_bias[1] = 0; ka.head[0] = ka.head[1] = HEAD_NONE;
+        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 && !(g.static_mode == 2 && d.use_viewdir) &&
+                        k.save_acts != nullptr && k.save_masks != nullptr && k.save_side == nullptr && (k.n_tiles & 1) == 0 &&
+                        k.n_tiles * (64LL * NSFF_W * 2) < 0x100000000LL && g.n_points <= 0x7fffffffLL;
+        if (asm_body && g.transient_mode)
+            asm_body = k.L.kt == 64 && (d.in_t & 3) == 0 && ((uintptr_t)g.t_emb & 15) == 0;
+        if (asm_body) {
+            ka.k = k;
+            if (k.n_static_steps > 0)
+                asm_body = h3a_build_program(k, 0, k.n_static_steps, false, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0],
+                                             nullptr, false, nullptr, true);
+            if (asm_body && n > k.n_static_steps)
+                asm_body = h3a_build_program(k, k.n_static_steps, n, true, false, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1],
+                                             nullptr, false, nullptr, true);
+        }
+        if (asm_body) {
+            const long long tiles = (g.n_points + 127) / 128;
+            if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
+            ka.hsel[0] = h3a_head_sel(k.L, ka.head[0]); ka.hsel[1] = h3a_head_sel(k.L, ka.head[1]);
+            ka.k.grid_tiles = tiles;
+            ka.k.split_trunks = both ? 1 : 0;
+            hipLaunchKernelGGL(nsff_field_kernel_h3a_save, dim3((unsigned)(both ? 2 * tiles : tiles)), dim3(256), 0, st, ka);
+            lrc = NSFF_OK;
+            g_nsff_last_h3_kernel = NSFF_KERNEL_H3A_SAVE;
+        } else {                                  // eight waves of 32 neurons
+            lrc = launch(nsff_field_kernel_h3<4, 1, true, 1>, 128, 512);
+            g_nsff_last_h3_kernel = NSFF_KERNEL_H3_SAVE;
+        }
     } else if (points_per_block == 64) {
         lrc = launch(nsff_field_kernel_h3<2, 1>, 64, 256);
         g_nsff_last_h3_kernel = NSFF_KERNEL_H3_64;

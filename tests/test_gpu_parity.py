@@ -371,7 +371,7 @@ def test_c2_full_size_properties(hip_lib, precision):
 def test_large_inference_launches_run_the_hand_scheduled_kernel(hip_lib, precision):
     """No silent fallback: a C2-sized f16x3 call (every launch >= 32768 points, no view-direction branch) must take
     nsff_field_kernel_h3a by default and with tile_points = 130, the eight-wave kernel with 131, the 64-point tiling below the
-    size threshold, and the activation-saving kernel when gradients are wanted."""
+    size threshold, and the activation-saving kernels when gradients are wanted (the hand-scheduled body in its SAVE build)."""
     if not precision.startswith("f16x3"):
         pytest.skip("f16x3 kernels only")
     cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024)
@@ -388,7 +388,7 @@ def test_large_inference_launches_run_the_hand_scheduled_kernel(hip_lib, precisi
         A.render_rays(models, emb, rays[:16].to(DEV), ts[:16].to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)
     assert _lib.last_field_kernel() == ("h3_64" if precision == "f16x3" else want)
     A.render_rays(models, emb, rays[:256].to(DEV), ts[:256].to(DEV), 29, 64, 0, 0, 64, 32768, test_time=False, **kw)   # autograd on
-    assert _lib.last_field_kernel() == "h3_save"
+    assert _lib.last_field_kernel() == ("h3_save" if precision.endswith("131") else "h3a_save")     # (the training forward's body)
 
 
 def test_ragged_and_empty_batches(hip_lib):

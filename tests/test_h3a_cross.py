@@ -214,3 +214,63 @@ def test_view_direction_static_trunk_on_the_hand_scheduled_kernel(in_a, hip_lib)
         assert _lib.last_field_kernel() == "h3a"
     finally:
         config.set_tile_points(0)
+
+
+@pytest.mark.parametrize("arch", [0, 1, 2, 4])
+def test_training_forward_on_the_hand_scheduled_kernel(arch, hip_lib):
+    """nsff_field_kernel_h3a_save (the SAVE build of the body: activation copies and ReLU sign words riding in the phases) against
+    the eight-wave training forward: the same records (2e-5), the same encoded input tile (bit for bit: one exact sin / cos per
+    column in both), every layer's saved activation equal up to one fp16 rounding on a fraction of a per cent of the values (the
+    two kernels add the same products in different orders), sign words that differ only where the activation is a rounding
+    error away from zero -- and nothing written outside the evaluated trunks' slots."""
+    from nsff_pl_amd import field_grad
+    D, skips, n_freqs, n_tau = ARCHS[arch]
+    torch.manual_seed(300 + arch)
+    emb = A.PosEmbedding(n_freqs - 1, n_freqs)
+    m = A.NeRF("fine", D=D, skips=skips, in_channels_xyz=3 + 6 * n_freqs, use_viewdir=False, encode_transient=True,
+               in_channels_t=n_tau, output_flow=True)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(".weight"):
+                p.mul_(2.5)
+    m.to(DEV)
+    freqs = [float(f) for f in emb.freqs]
+    g = torch.Generator().manual_seed(arch)
+    config.set_precision("f16x3")
+    for S, n_rays, sm, tm in ((64, 10, 2, 2), (192, 4, 0, 2), (128, 3, 2, 0)):
+        P = S * n_rays                                      # an even number of 64-point tiles, not always a multiple of 128 points...
+        xyz = (torch.rand(P, 3, generator=g) * 2.4 - 1.2).to(DEV)
+        t_rows = torch.randn(n_rays, n_tau, generator=g).to(DEV)
+        out = {}
+        for tile in (130, 131):
+            config.set_tile_points(tile)
+            raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
+            acts, xin, masks, _ = field_grad.alloc_saves(m, P, DEV, bool(tm), bool(sm))
+            acts.view(torch.int16).fill_(0x7e01); masks.fill_(-2)             # (fill patterns: what the launch does not write keeps them)
+            try:
+                _lib.field_query(m, raw, P, S, sm, tm, 2 if tm else 0, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None,
+                                 save_acts=acts, save_xin=xin, save_masks=masks)
+                torch.cuda.synchronize()
+                out[tile] = (raw.cpu().numpy(), acts.cpu(), xin.cpu(), masks.cpu(), _lib.last_field_kernel())
+            finally:
+                config.set_tile_points(0)
+        (a, acts_a, xin_a, masks_a, ka), (b, acts_b, xin_b, masks_b, kb) = out[130], out[131]
+        assert ka == "h3a_save" and kb == "h3_save", (ka, kb)
+        for lo, hi in ((0, 4), (4, 8), (8, 14)):
+            scale = max(np.abs(b[:, lo:hi]).max(), 1e-30)
+            assert np.abs(a[:, lo:hi] - b[:, lo:hi]).max() <= 2e-5 * scale, (ARCHS[arch], S, sm, tm, lo)
+        assert torch.equal(xin_a.view(torch.int16), xin_b.view(torch.int16))
+        written = [t * (D + 1) + l for t, on in ((0, sm), (1, tm)) if on for l in range(D)]
+        for slot in range(acts_a.shape[0]):
+            xa, xb = acts_a[slot].float(), acts_b[slot].float()
+            if slot not in written:
+                assert torch.equal(acts_a[slot].view(torch.int16), acts_b[slot].view(torch.int16)) and (masks_a[slot] == -2).all()
+                assert (acts_a[slot].view(torch.int16) == 0x7e01).all()
+                continue
+            dif = (xa - xb).abs()
+            assert bool((dif <= xb.abs() * 2.0 ** -9 + 4e-6 * float(xb.abs().max())).all()), (ARCHS[arch], S, slot, float(dif.max()))
+            assert float((dif > 0).float().mean()) < 0.01
+            # sign words: [tile][thread] x 64 bits; a differing bit belongs to an activation that is ~0 in one of the kernels
+            diff_bits = (masks_a[slot] ^ masks_b[slot])
+            n_diff = sum(bin(int(v) & 0xFFFFFFFFFFFFFFFF).count("1") for v in diff_bits.reshape(-1)[diff_bits.reshape(-1) != 0].tolist())
+            assert n_diff <= 2e-4 * masks_a[slot].numel() * 64, (ARCHS[arch], S, slot, n_diff)

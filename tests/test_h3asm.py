@@ -45,7 +45,7 @@ def test_stream_passes_the_hazard_lint():
     assert all(i.kind != "mfma" for i in pre)
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic", "dynamic_tb", "twoskips_tb", "viewdir"])
+@pytest.mark.parametrize("kind", ["static", "dynamic", "dynamic_tb", "twoskips_tb", "viewdir", "static_save", "dynamic_save", "twoskips_save"])
 def test_simulated_trunk_matches_numpy(kind):
     assert check.run_case(kind, verbose=False) < 2e-6
 

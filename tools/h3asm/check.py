@@ -23,6 +23,9 @@ from isa import Sim, SimError, halfs_of, f16_rtz_pack
 PK_BASE = 0x1_0000_0000
 PH_BASE = 0x2_0000_0000
 T_BASE = 0x3_0000_0000
+ACT_BASE = 0x4_0000_0000                   # SAVE build: activation slots (slot, tile64, 4 ks, 256 rows, 16 points) fp16
+MASK_BASE = 0x5_0000_0000                  # SAVE build: sign words (slot, tile64, 256 threads) uint64
+N_TILES64 = 6                              # the simulated workgroup is 128-point tile 1 of 3: 64-point tiles 2 and 3
 LDS_X = 0
 LDS_RAW = 2 * gen.PLANE_B                  # raw-record image: 128 points x 16 floats
 LDS_BIAS = LDS_RAW + 8192                  # behind the two planes and the raw-record image
@@ -69,7 +72,7 @@ def pack_head(W):
     return out.reshape(-1).view(np.uint32), hi, lo
 
 
-def build_program(segs, in_t, head=None, sig_row=None):
+def build_program(segs, in_t, head=None, sig_row=None, save=False):
     """Phase descriptors for a trunk (the host-side builder in csrc/field_h3a.hip does the same).
     segs: list of dict(nks, off, bias (index or None), post ('relu' | 'none'), rebuild (bool)[, wstride (bytes between the
     waves' blocks of the packed segment, default nks * 4096), bias_b (table row of half B, default = bias)]).
@@ -130,6 +133,8 @@ def build_program(segs, in_t, head=None, sig_row=None):
     assert pending_b
     hd = head or dict(off=segs[0]["off"], n_rows=0, slot0=0)
     ph.append([B["EPI_B"], 0, 0, hd["n_rows"], hd["off"], 0, hd["off"], 0])
+    if save:                # the last activation goes to its slot before the heads read it
+        ph.append([B["SAVE_LAST"], 0, 0, hd["n_rows"], hd["off"], 0, hd["off"], 0])
     ph.append([B["HEAD"], 0, 4 * hd["slot0"], hd["n_rows"], hd["off"], 0, hd["off"], 0])
     ph.append(desc(B["END"]))
     ph.append(desc(B["END"]))
@@ -227,6 +232,9 @@ def make_case(kind, seed=0):
                 sig_row=sig_row, sig_w=sig_w)
 
 
+PRE_RELU = []
+
+
 def reference(case, keep=None):
     """the same layers in numpy: products Wh.xh + Wh.xl + Wl.xh accumulated in float64, fp32 after every layer
     keep: list that receives the fp32 post-ReLU values of every relu segment"""
@@ -247,6 +255,7 @@ def reference(case, keep=None):
             v = np.maximum(acc, 0).astype(np.float32)
             if keep is not None:
                 keep.append(v)
+                PRE_RELU.append(acc.astype(np.float32))
             h, l = split_rtz(v)
             xh_, xl_ = h.astype(np.float64), l.astype(np.float64)
     return (xh_ + xl_).astype(np.float32), xh_, xl_
@@ -266,12 +275,21 @@ def head_reference(case, xh_, xl_):
 
 
 def run_case(kind, seed=0, verbose=True):
-    case = make_case(kind, seed)
-    pre, prog, _ = gen.build()
+    save = kind.endswith("_save")
+    case = make_case(kind[:-5] if save else kind, seed)
+    pre, prog, _ = gen.build(save=save)
     sim = Sim(pre + prog)                      # the two asm statements back to back (the encoder between them is C++)
     sim.add_buffer(PK_BASE, case["pk"])
     body_in_t = 0 if case["tb"] else case["in_t"]       # (the body sees no time-code columns when they are folded into the table)
-    phases = build_program(case["segs"], body_in_t, case["head"], case["sig_row"])
+    phases = build_program(case["segs"], body_in_t, case["head"], case["sig_row"], save=save)
+    n_relu = sum(1 for sg in case["segs"] if sg["post"] == "relu")
+    if save:
+        # slots 0 .. n_relu - 1 of this trunk, two spare slots in front (the trunk's first slot is not slot 0 of the buffers)
+        acts = np.full((n_relu + 2) * N_TILES64 * 64 * 256 // 2, 0xFFFFFFFF, np.uint32)
+        masks = np.full((n_relu + 2) * N_TILES64 * 256 * 2, 0xFFFFFFFF, np.uint32)
+        sim.add_buffer(ACT_BASE, acts)
+        sim.add_buffer(MASK_BASE, masks)
+        sim.mem_written = {ACT_BASE: np.zeros(acts.size, bool), MASK_BASE: np.zeros(masks.size, bool)}
     sim.add_buffer(PH_BASE, phases.reshape(-1))
     sim.add_buffer(T_BASE, case["t_table"].reshape(-1).view(np.uint32))
     # LDS: input tile as the encoder leaves it (hi / lo planes), bias table
@@ -294,6 +312,12 @@ def run_case(kind, seed=0, verbose=True):
         for name, val in (("lds", LDS_X), ("biaslds", LDS_BIAS), ("wave", w.id), ("in_t", body_in_t), ("rawlds", LDS_RAW), ("n1", phases[0][3]),
                           ("r1", phases[0][4]), ("r1w", phases[0][5]), ("r2", phases[0][6]), ("r2w", phases[0][7])):
             w.s[I_S[name].i] = int(val)
+        if save:            # the first slot of this trunk = slot 2; half A = 64-point tile 2
+            act0 = ACT_BASE + (2 * N_TILES64 + 2) * 64 * 256 * 2
+            msk0 = MASK_BASE + ((2 * N_TILES64 + 2) * 256 + 64 * w.id) * 8
+            for name, val in (("act", act0), ("mask", msk0)):
+                w.s[I_S[name].i], w.s[I_S[name].i + 1] = val & 0xFFFFFFFF, val >> 32
+            w.s[I_S["astride"].i], w.s[I_S["mstride"].i] = N_TILES64 * 64 * 256 * 2, N_TILES64 * 256 * 8
         w.v[I_V["tid"].i] = tid
         row, q = tid >> 2, tid & 3
         for names, rows in ((("tpa0", "tpa1"), row), (("tpb0", "tpb1"), row + 64)):
@@ -309,8 +333,10 @@ def run_case(kind, seed=0, verbose=True):
     for r in range(128):
         base = (LDS_X + r * gen.LDH_B) // 2
         got[r] = lds_h[base:base + 256].astype(np.float32) + lds_h[base + gen.PLANE_B // 2:base + gen.PLANE_B // 2 + 256].astype(np.float32)
-    acts = []
-    want, fxh, fxl = reference(case, acts)
+    acts_relu = []
+    del PRE_RELU[:]
+    want, fxh, fxl = reference(case, acts_relu)
+    pre_relu = list(PRE_RELU)
     err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
     # the heads: pre-activation sums in the raw-record image, everything else untouched (zero)
     hd = case["head"]
@@ -320,7 +346,7 @@ def run_case(kind, seed=0, verbose=True):
     raw[:, hd["slot0"]:hd["slot0"] + hd["n_rows"]] = 0
     if case["sig_row"] is not None:
         # the sigma ride: floats 4 + 2 wave + (lane >> 5) of a record = sum over that lane's 32 neurons of w_sigma relu(layer D-1)
-        v = acts[-2].astype(np.float64)
+        v = acts_relu[-2].astype(np.float64)
         for wv in range(4):
             for hh in range(2):
                 n = np.array([64 * wv + 32 * mt + 8 * q + 4 * hh + e for mt in range(2) for q in range(4) for e in range(4)])
@@ -335,6 +361,39 @@ def run_case(kind, seed=0, verbose=True):
     assert not raw.any(), "the HEAD phase wrote outside its slots"
     assert herr < 2e-6, herr
     err = max(err, herr)
+    if save:
+        # every ReLU layer's output: fp16(hi + lo) in fragment order [16-point group][neuron][point], sign words in accumulator order
+        # a tile = [16-point group ks][32-neuron block rb][lane = (neuron & 31) + 32 (8-point group)][8 points]: 1 KiB blocks, each one
+        # MFMA operand fragment of the weight-gradient GEMM in lane order
+        a16 = acts.view(np.float16).reshape(n_relu + 2, N_TILES64, 4, 8, 2, 32, 8)
+        m64 = masks.view(np.uint64).reshape(n_relu + 2, N_TILES64, 256)
+        assert len(acts_relu) == n_relu
+        for l, v in enumerate(acts_relu):
+            h_, l_ = split_rtz(v)
+            want16 = (h_.astype(np.float32) + l_.astype(np.float32)).astype(np.float16)       # (128, 256)
+            for hb in range(2):
+                got16 = a16[2 + l, 2 + hb].transpose(0, 2, 4, 1, 3).reshape(64, 256)          # [16 ks + 8 g + t][32 rb + r]
+                # (the reference accumulates in float64, the MFMAs in fp32: a value whose fp32 bits differ in the last place may
+                #  round to the neighbouring half -- one fp16 ulp, on a fraction of a per cent of the values; values near zero differ by the
+                #  layer's absolute accumulation noise)
+                w16 = want16[64 * hb:64 * hb + 64].astype(np.float32)
+                dif = np.abs(got16.astype(np.float32) - w16)
+                assert (dif <= np.abs(w16) * 2.0 ** -9 + 2e-6 * np.abs(w16).max()).all() and (dif > 0).mean() < 0.01, (l, hb, dif.max(), (dif > 0).mean())
+                for wv in range(4):
+                    for lane in range(64):
+                        word = int(m64[2 + l, 2 + hb, 64 * wv + lane])
+                        for mt in range(2):
+                            for nt in range(2):
+                                pt = 64 * hb + 32 * nt + (lane & 31)
+                                for q in range(4):
+                                    for e_ in range(4):
+                                        n = 64 * wv + 32 * mt + 8 * q + 4 * (lane >> 5) + e_
+                                        bit = (word >> (32 * mt + 16 * nt + 4 * q + e_)) & 1
+                                        assert bit == int(v[pt, n] > 0) or abs(pre_relu[l][pt, n]) < 1e-5, (l, hb, wv, lane, mt, nt, q, e_)
+        # nothing else was written: the spare slots and the other tiles keep their fill
+        keep = np.ones(a16.shape[:2], bool); keep[2:2 + n_relu, 2:4] = False
+        assert (a16.view(np.uint16)[keep] == 0xFFFF).all() and (m64[keep] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        assert sim.mem_written[ACT_BASE].reshape(n_relu + 2, N_TILES64, -1)[2:, 2:4].all()
     n_mf = sim.waves[0].n_mfma
     want_mf = sum(sg["nks"] for sg in case["segs"]) * 24 + 48
     if verbose:
@@ -346,7 +405,8 @@ def run_case(kind, seed=0, verbose=True):
 
 
 if __name__ == "__main__":
-    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips", "dynamic_tb", "twoskips_tb", "viewdir"]
+    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips", "dynamic_tb", "twoskips_tb", "viewdir",
+                             "static_save", "dynamic_save", "twoskips_save"]
     for k in kinds:
         try:
             run_case(k)

@@ -60,7 +60,27 @@ D_BODY, D_FLAGS, D_BIAS, D_N1, D_R1, D_R1W, D_R2, D_R2W = range(8)
 # an input tile at all (A4 / A8 also run the first layer, where the tile is still the encoder's)
 F_INIT, F_REBUILD_T, F_REBUILD = 0, 1, 2
 
-BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12, HEAD=13, B16RS=14, A16RS=15)
+BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12, HEAD=13, B16RS=14, A16RS=15,
+            SAVE_LAST=16)
+
+# ---- the SAVE build (build(save=True) -> H3A_BODY_SAVE, the body of nsff_field_kernel_h3a_save: the TRAINING forward).  The
+# same phases; additionally
+#   * every phase over a trunk activation (A16R, B16R, B16X, B16L) copies ITS OWN half's input tile -- the activation the
+#     backward pass needs -- to HBM in the fragment order of the weight-gradient GEMM: 8 one-KiB blocks per wave, each = four
+#     transposing LDS reads (ds_read_b64_tr_b16, two per plane), four packed adds (hi + lo, rounded to nearest) and one 16-byte
+#     store, riding in the phase's MFMA gaps between the epilogue's instructions (the tile is complete -- the barrier in front
+#     of the phase -- and stays untouched until the next phase's ride overwrites it); the LAST activation, which no MFMA phase
+#     reads, is copied by a phase of its own (SAVE_LAST) in front of the heads;
+#   * every epilogue also collects the ReLU sign bits (bit 16 nt + 4 q + e of word mt, the order nsff_field_backward reads) --
+#     v_min_u32 1, x and v_lshl_or_b32 per value -- and stores the two words per lane.
+# Destinations are running pointers (asm-owned SGPRs): S_ACT / S_MASK point at the current activation slot of the tile of
+# half A (half B: + 32 KiB / + 2 KiB) and advance by one slot (S_ASTRIDE / S_MSTRIDE bytes) when half B's copy / sign words
+# of a layer are out.  Registers v14..v23 are the body's too in this build.
+SAVE = False
+V_CP_H, V_CP_L, V_CPOFF, V_MSKW = V(14), V(15), V(16), V(17)
+S_ACT, S_MASK, S_ASTRIDE, S_MSTRIDE = S(88, 2), S(90, 2), S(92), S(93)
+CPT = 18                    # v18..v23: the copy's temporaries (v40..v63 belong to the epilogue and to the skip layer's rebuild)
+
 
 # ---- the sigma ride (view-direction static trunk: static_sigma reads the LAST TRUNK activation, nerf.py:169, one layer before the
 # trunk's end): the epilogues of that layer also accumulate  sum_n w_sigma[n] relu(acc[n])  over this lane's 32 neurons of each
@@ -187,6 +207,11 @@ def epilogue_unit(half, u, tset, sig=False):
     H = [V(T0 + 8 * tset + k) for k in range(4)]
     L = [V(T0 + 8 * tset + 4 + k) for k in range(4)]
     out = [I_v_max0(r, r) for r in x]
+    if SAVE:                # sign bits of the eight values: bit 16 nt + 4 q + e of word mt (one word at a time: V_MSKW)
+        if u in (0, 4):
+            out.append(I_valu("v_mov_b32", V_MSKW, 0))
+        for j in range(8):
+            out += [I_valu("v_min_u32", V_TMP, 1, x[j]), I_v_lshl_or(V_MSKW, V_TMP, 16 * nt + 4 * (p + 2 * (j >> 2)) + (j & 3), V_MSKW)]
     if sig:                 # x[j] = neuron 8 q + 4 h + e of the tile, q = p + 2 (j >> 2), e = j & 3
         out += [I_v_fmac(SIG[half][nt], ws(mt, p + 2 * (j >> 2), j & 3), x[j]) for j in range(8)]
     out += [I_v_cvt_pkrtz(H[k], x[2 * k], x[2 * k + 1]) for k in range(4)]
@@ -215,6 +240,42 @@ def epilogue_unit(half, u, tset, sig=False):
         out = [i for i in out if i.op != "v_max_f32"]
     if "noride" in EXP:
         out = []
+    if SAVE and u in (3, 7):   # word mt complete: lane's 4 bytes at S_MASK + 8 (lane) + 4 mt (+ 2 KiB: the tile of half B)
+        out += [I_valu("v_lshrrev_b32", V_TMP, 1, V_LANE16),
+                I_gstore_s(V_TMP, V_MSKW, S_MASK, 4 * mt + (2048 if half == "B" else 0))]
+    return out
+
+
+def copy_groups(half):
+    """The HBM copy of X_<half> (see SAVE) as a list of GROUPS of ride items -- the caller spreads them between other riding
+    instructions so that an LDS round trip lies between a group's reads and the next group's ('NEED_LDS', tag) marker."""
+    hb = 0 if half == "A" else 1
+    t = [V(CPT + k) for k in range(6)]
+    groups = [[I_salu("s_lshl_b32", S_T0, S_WAVE, 10, scc=True),
+               I_valu("v_add_u32", V_CPOFF, S_T0, V_LANE16, text=f"v_add_u32_e32 {V_CPOFF}, {S_T0}, {V_LANE16}")] +
+              ([I_valu("v_add_u32", V_CPOFF, 32768, V_CPOFF, text=f"v_add_u32_e32 {V_CPOFF}, 0x8000, {V_CPOFF}")] if hb else [])]
+    for b in range(8):      # block wave + 4 b = (16-point group b >> 1, 32-neuron block wave + 4 (b & 1))
+        imm = half_off(half) + (b >> 1) * 16 * LDH_B + (b & 1) * 256
+        groups[-1] += [(I_ds_read_tr(V(t[0].i, 2), V_CP_H, imm), ("cp", b, 0)), (I_ds_read_tr(V(t[2].i, 2), V_CP_L, imm), ("cp", b, 0))]
+        groups.append([("NEED_LDS", ("cp", b, 0)), I_v_pk_add_f16(t[0], t[0], t[2]), I_v_pk_add_f16(t[1], t[1], t[3]),
+                       (I_ds_read_tr(V(t[2].i, 2), V_CP_H, imm + 4 * LDH_B), ("cp", b, 1)),
+                       (I_ds_read_tr(V(t[4].i, 2), V_CP_L, imm + 4 * LDH_B), ("cp", b, 1))])
+        groups.append([("NEED_LDS", ("cp", b, 1)), I_v_pk_add_f16(t[2], t[2], t[4]), I_v_pk_add_f16(t[3], t[3], t[5]),
+                       I_gstore_s(V_CPOFF, V(t[0].i, 4), S_ACT, 0),
+                       I_valu("v_add_u32", V_CPOFF, 4096, V_CPOFF, text=f"v_add_u32_e32 {V_CPOFF}, 0x1000, {V_CPOFF}")])
+    if hb:                  # both halves of this slot are out: the pointer moves on to the next slot
+        groups[-1] += [I_salu("s_add_u32", S(S_ACT.i), S(S_ACT.i), S_ASTRIDE, scc=True), I_salu("s_addc_u32", S(S_ACT.i + 1), S(S_ACT.i + 1), 0, scc=True)]
+    return groups
+
+
+def merge_ride(main, groups):
+    """`groups` spread evenly through the list `main` (each group stays contiguous)"""
+    if not groups:
+        return list(main)
+    out, n, g = [], len(main), len(groups)
+    for k in range(g):
+        out += groups[k]
+        out += main[k * n // g:(k + 1) * n // g]
     return out
 
 
@@ -238,6 +299,8 @@ def epilogue_stream(half, sig=False, wait_ws=False):
                 I_valu("v_add_u32", t0, S_T0, t0, text=f"v_add_u32_e32 {t0}, {S_T0}, {t0}")]
         hb = 0 if half == "A" else 1
         out += [I_ds_write_b32(t0, SIG[half][nt], 16 + 4096 * hb + 2048 * nt) for nt in range(2)]
+    if SAVE and half == "B":  # the sign words of both halves of this layer are out: next slot
+        out += [I_salu("s_add_u32", S(S_MASK.i), S(S_MASK.i), S_MSTRIDE, scc=True), I_salu("s_addc_u32", S(S_MASK.i + 1), S(S_MASK.i + 1), 0, scc=True)]
     return out
 
 
@@ -379,8 +442,18 @@ def emit_rebuild(s, part, first):
             s.emit(r, "rebuild", group="rebuild_x" if (first and r.kind == "lds_w") else "rebuild_t")
 
 
+def emit_ride(s, item):
+    """a riding item: an instruction, (instruction, tag) or the marker ('NEED_LDS', tag)"""
+    if isinstance(item, tuple) and item[0] == "NEED_LDS":
+        s.need_lds(item[1])
+    elif isinstance(item, tuple):
+        s.emit(item[0], item[1])
+    else:
+        s.emit(item, "ride")
+
+
 def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebuild=None, vm_mode=None, stream_slots=None,
-               one_stream=False):
+               one_stream=False, copy=False):
     """One phase: `nks` k-steps of MFMAs on acc_<half> from X_<half>.  The phase's barrier sits in front of MFMA 8 of the
     LAST BUT ONE k-step: by then every fragment of this half has been read (the last k-step's lo fragments go to the second
     XL buffer) and the ride's stores are done, and 16 MFMAs remain to cover what follows the barrier -- the bias-table
@@ -415,6 +488,8 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
     if ride == "epi_sig_ws":
         for r in sigma_weight_reads():
             s.emit(r, "ws")
+    if copy:                # (SAVE) this half's input tile goes to HBM while the phase multiplies it
+        ride_ins = merge_ride(ride_ins, copy_groups(half))
     rb_parts = rebuild_parts(rebuild, name) if rebuild is not None else None
     ride_gaps = [(ks, m) for ks in range(1, nks) for m in range(12) if (ks, m) < (bar[0], bar[1] - 1)]
     per_gap = dict(zip(ride_gaps, spread(len(ride_ins), len(ride_gaps)))) if ride_ins else {}
@@ -435,7 +510,8 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
             # ---- in front of the MFMA
             if m == 0:
                 if vm_mode == "formula":
-                    s.wait(vm=min(4 * (15 - ks), 63))
+                    # (+ the stores this phase has issued so far: they are younger entries of the same in-order queue)
+                    s.wait(vm=min(4 * (15 - ks) + sum(1 for i_ in s.ins if i_.op == "gstore_s"), 63))
                 elif vm_mode == "model":
                     s.need_vm(("w", ks))
                 s.need_lds(("xh", ks))
@@ -470,10 +546,7 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
                 pi += 1
             gi += 1
             for _ in range(per_gap.get((ks, m), 0)):
-                if isinstance(ride_ins[ri], tuple):         # ('NEED_LDS', tag)
-                    s.need_lds(ride_ins[ri][1])
-                else:
-                    s.emit(ride_ins[ri], "ride")
+                emit_ride(s, ride_ins[ri])
                 ri += 1
             if (ks, m) == bar:
                 if tail_init:
@@ -533,13 +606,13 @@ def short_b_body(name, nks):
             if ks >= 1:
                 for _ in range(RIDE_CAP if not (3 <= m <= 7) else RIDE_CAP - 1):
                     if ri < len(ride_ins):
-                        s.emit(ride_ins[ri], "ride")
+                        emit_ride(s, ride_ins[ri])
                         ri += 1
     for r in refill_flat(last, True):
         s.emit(r, ("w", last))
     stamp(2)
     while ri < len(ride_ins):
-        s.emit(ride_ins[ri], "ride")
+        emit_ride(s, ride_ins[ri])
         ri += 1
     s.wait(vm=0, lgkm=0)
     s.emit(I_barrier())
@@ -648,13 +721,19 @@ def bare_epilogue(name, half):
     g = 2
     for u in range(0, 8, 2):
         n = len(units[u])
-        for k, (x, y) in enumerate(zip(units[u], units[u + 1])):
+        # (the SAVE build's units share the sign-word registers: one after the other there)
+        pairs = list(zip(units[u], units[u + 1])) if not SAVE else [(x, None) for x in units[u]] + [(y, None) for y in units[u + 1]]
+        for k, (x, y) in enumerate(pairs):
             if k == n // 2 or (k == 0 and u > 0):
                 if g < len(hl):
                     for i in hl[g]:
                         s.emit(i, "head")
                     g += 1
-            s.emit(x, "ride"); s.emit(y, "ride")
+            s.emit(x, "ride")
+            if y is not None:
+                s.emit(y, "ride")
+    if SAVE:                # (the sign words of half B of the last layer were the slot's last: epilogue_stream's pointer step is not needed)
+        pass
     while g < len(hl):
         for i in hl[g]:
             s.emit(i, "head")
@@ -665,13 +744,27 @@ def bare_epilogue(name, half):
     return s.ins
 
 
+def save_last_body():
+    """SAVE build: the trunk's last activation (both halves, complete behind EPI_B's barrier, read next by the HEAD phase) goes to
+    its slot -- a phase of its own, nothing to ride on."""
+    s = Stream()
+    s.emit(I_label("L_SAVE_LAST"))
+    for half in ("A", "B"):
+        for grp in copy_groups(half):
+            for item in grp:
+                emit_ride(s, item)
+    s.wait(lgkm=0)
+    s.emit(I_branch("s_branch", "L_dispatch"))
+    return s.ins
+
+
 def raw(text, wr=(), rd=()):
     return Inst("raw", text, rd, wr, "other")
 
 
 # Inline-asm operands and the registers the simulator's harness presets in their place
 IN_S = dict(pk=S(0, 2), phases=S(2, 2), lds=S(4), biaslds=S(5), wave=S(6), in_t=S(7), r1=S(8), r1w=S(9), r2=S(10), r2w=S(11), n1=S(12),
-            rawlds=S(13))
+            rawlds=S(13), act=S(14, 2), mask=S(16, 2), astride=S(18), mstride=S(19))
 IN_V = dict(tid=V(0), tpa0=V(1), tpa1=V(2), tpb0=V(3), tpb1=V(4))
 
 
@@ -752,6 +845,21 @@ def prologue():
     e(I_valu("v_min_u32", V(T0 + 5), V(T0 + 5), V_N4))                        # min(16 q, in_t)
     e(I_valu("v_sub_u32", V_N4, V_N4, V(T0 + 5)))                             # in_t - min(16 q, in_t) >= 0
     e(I_valu("v_lshrrev_b32", V_N4, 2, V_N4)); e(I_valu("v_min_u32", V_N4, 4, V_N4))
+    if SAVE:
+        # %[act] / %[mask] s64: this tile's (half A's) first activation slot / sign words of THIS WAVE (+ 512 wave);
+        # %[astride] / %[mstride] s32: bytes per slot.  Copy addresses: lane i of a 16-lane group g reads 4 neurons of point
+        # 8 (g >> 1) + (i >> 2): cp_h = lds + that row * 528 + 32 (g & 1) + 8 (i & 3) + 64 wave
+        e(in_s(S_ACT, "act")); e(in_s(S_MASK, "mask")); e(in_s(S_ASTRIDE, "astride")); e(in_s(S_MSTRIDE, "mstride"))
+        a_, b_ = V(T0 + 3), V(T0 + 4)
+        e(I_valu("v_and_b32", a_, 15, lane)); e(I_valu("v_lshrrev_b32", a_, 2, a_))             # i >> 2
+        e(I_valu("v_lshrrev_b32", b_, 5, lane)); e(I_valu("v_lshlrev_b32", b_, 3, b_))          # 8 (g >> 1)
+        e(I_valu("v_add_u32", a_, a_, b_)); e(I_valu("v_mul_u32_u24", V_CP_H, LDH_B, a_))
+        e(I_valu("v_lshrrev_b32", a_, 4, lane)); e(I_valu("v_and_b32", a_, 1, a_)); e(I_valu("v_lshlrev_b32", a_, 5, a_))   # 32 (g & 1)
+        e(I_valu("v_and_b32", b_, 3, lane)); e(I_valu("v_lshlrev_b32", b_, 3, b_))              # 8 (i & 3)
+        e(I_valu("v_add_u32", a_, a_, b_)); e(I_valu("v_add_u32", V_CP_H, V_CP_H, a_))
+        e(I_salu("s_lshl_b32", S_T0, S_WAVE, 6, scc=True)); e(I_salu("s_add_u32", S_T0, S_T0, S_LDS, scc=True))
+        e(I_valu("v_add_u32", V_CP_H, S_T0, V_CP_H, text=f"v_add_u32_e32 {V_CP_H}, {S_T0}, {V_CP_H}"))
+        e(I_valu("v_add_u32", V_CP_L, PLANE_B, V_CP_H, text=f"v_add_u32_e32 {V_CP_L}, {PLANE_B}, {V_CP_H}"))
     # stash of the input tile (the C++ encoder built it and synchronised the workgroup before this statement)
     for hb in range(2):
         st, ho = STASH + 16 * hb, hb * HALF_B
@@ -783,7 +891,7 @@ def timing_store():
     return o
 
 
-DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B", "HEAD", "B16RS", "A16RS")
+DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B", "HEAD", "B16RS", "A16RS", "SAVE_LAST")
 
 
 def dispatcher():
@@ -799,19 +907,31 @@ def dispatcher():
     e(I_salu("s_mul_i32", S_T0, S_WAVE, S(S_CUR + D_R1W))); e(I_salu("s_add_u32", S_R1, S(S_CUR + D_R1), S_T0, scc=True))
     e(I_salu("s_mul_i32", S_T0, S_WAVE, S(S_CUR + D_R2W))); e(I_salu("s_add_u32", S_R2, S(S_CUR + D_R2), S_T0, scc=True))
     for name in DISPATCH_ORDER:
+        if name not in dispatcher.bodies:
+            continue
         e(I_s_cmp("s_cmp_eq_u32", S(S_CUR + D_BODY), BODY[name]))
         e(I_branch("s_cbranch_scc1", f"L_{name}"))
     e(I_branch("s_branch", "L_end"))
     return o
 
 
-def build():
-    """-> (pre-issue statement, main statement, bodies)"""
+def build(save=False):
+    """-> (pre-issue statement, main statement, bodies); save: the training-forward body (see SAVE)"""
+    global SAVE
+    SAVE = bool(save)
+    try:
+        return _build()
+    finally:
+        SAVE = False
+
+
+def _build():
+    cp = SAVE
     bodies = {
-        "A16R": phase_body("A16R", "A", 16, ride="epi", tail_init=True, vm_mode="formula"),
-        "B16R": phase_body("B16R", "B", 16, ride="epi", refills=True, tail_init=True, one_stream=True),
-        "B16L": phase_body("B16L", "B", 16, ride="epi"),        # the trunk's last segment: nothing left to request
-        "B16X": phase_body("B16X", "B", 16, refills=True, rebuild="A"),
+        "A16R": phase_body("A16R", "A", 16, ride="epi", tail_init=True, vm_mode="formula", copy=cp),
+        "B16R": phase_body("B16R", "B", 16, ride="epi", refills=True, tail_init=True, one_stream=True, copy=cp),
+        "B16L": phase_body("B16L", "B", 16, ride="epi", copy=cp),        # the trunk's last segment: nothing left to request
+        "B16X": phase_body("B16X", "B", 16, refills=True, rebuild="A", copy=cp),
         "A4": phase_body("A4", "A", 4, rebuild="B", vm_mode="formula"),
         "A8": phase_body("A8", "A", 8, rebuild="B", vm_mode="formula"),
         "A4F": phase_body("A4F", "A", 4, vm_mode="model", stream_slots=list(range(8, 16))),
@@ -820,10 +940,14 @@ def build():
         "B8": short_b_body("B8", 8),
         "EPI_B": bare_epilogue("EPI_B", "B"),
         "HEAD": head_body(),
-        # the sigma ride of a view-direction static trunk: the last trunk layer's B phase and the A phase behind it
-        "B16RS": phase_body("B16RS", "B", 16, ride="epi_sig_ws", refills=True, tail_init=True, one_stream=True),
-        "A16RS": phase_body("A16RS", "A", 16, ride="epi_sig", tail_init=True, vm_mode="formula"),
     }
+    if SAVE:
+        bodies["SAVE_LAST"] = save_last_body()
+    else:
+        # the sigma ride of a view-direction static trunk: the last trunk layer's B phase and the A phase behind it
+        bodies["B16RS"] = phase_body("B16RS", "B", 16, ride="epi_sig_ws", refills=True, tail_init=True, one_stream=True)
+        bodies["A16RS"] = phase_body("A16RS", "A", 16, ride="epi_sig", tail_init=True, vm_mode="formula")
+    dispatcher.bodies = set(bodies)
     prog = prologue()
     prog.append(I_branch("s_branch", "L_dispatch"))
     for name in bodies:
@@ -871,7 +995,10 @@ def main():
     global TIMING
     TIMING = "--timing" in sys.argv
     pre, prog, bodies = build()
-    errs = lint(bodies, prog)
+    timing, TIMING = TIMING, False               # (the stamps are the inference body's: `make timing` measures that one)
+    _, prog_save, bodies_save = build(save=True)
+    TIMING = timing
+    errs = lint(bodies, prog) + lint(bodies_save, prog_save)
     for e_ in errs[:40]:
         print("LINT:", e_)
     if errs:
@@ -882,6 +1009,8 @@ def main():
                         ("field_h3a_body_swap.inc" if not NOSWAP_STORES else "field_h3a_body.inc"))))
     clob = ", ".join([f'"v{i}"' for i in range(24, 256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(40, 100)] +
                      ['"vcc"', '"scc"', '"memory"'])
+    clob_save = ", ".join([f'"v{i}"' for i in range(14, 256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(40, 100)] +
+                          ['"vcc"', '"scc"', '"memory"'])
     pre_wr = sorted({r for i in pre for r in i.wr if r[0] in ("v", "a") or (r[0] == "s" and r[1] < 100)})
     pre_clob = ", ".join([f'"{f}{i}"' for f, i in pre_wr] + ['"scc"', '"memory"'])
     consts = "".join(f"#define H3A_BODY_{k} {v}\n" for k, v in BODY.items())
@@ -898,17 +1027,21 @@ def main():
         slots += f"#define H3A_PRE_SLOT{k}_CLOBBERS " + ", ".join(['"v32"'] + [f'"a{16 * k + j}"' for j in range(16)] + ['"memory"']) + "\n"
     text = ("// GENERATED by tools/h3asm/gen.py -- do not edit.  The hand-scheduled trunk body of nsff_field_kernel_h3a:\n"
             "// H3A_PRE (weight slots 0..7 requested in front of the encoder; H3A_PRE_SLOT0..7: the same loads one slot per statement)\n"
-            "// and H3A_BODY (the trunk; registers v24..v255, a0..a255, s40..s99 are its own while it runs).\n" + consts +
+            "// and H3A_BODY (the trunk; registers v24..v255, a0..a255, s40..s99 are its own while it runs); H3A_BODY_SAVE: the training\n"
+            "// forward's body (activation copies + ReLU sign words riding in the phases; v14..v23 are its own too).\n" + consts +
             "#define H3A_PRE_CLOBBERS " + pre_clob + "\n" + macro("H3A_PRE", pre) + slots +
-            "#define H3A_CLOBBERS " + clob + "\n" + macro("H3A_BODY", prog))
+            "#define H3A_CLOBBERS " + clob + "\n" + macro("H3A_BODY", prog) +
+            "#define H3A_SAVE_CLOBBERS " + clob_save + "\n" + macro("H3A_BODY_SAVE", prog_save))
     with open(out, "w") as f:
         f.write(text)
     n_m = sum(1 for i in prog if i.kind == "mfma")
     n_all = sum(1 for i in prog if i.kind not in ("label", "other"))
     print(f"wrote {os.path.normpath(out)}: {n_all} instructions, {n_m} MFMAs")
     for name, ins in bodies.items():
-        print(f"  {name:6s} {sum(1 for i in ins if i.kind not in ('label', 'other')):5d} instructions, "
-              f"{sum(1 for i in ins if i.kind == 'mfma'):4d} MFMAs")
+        sv = bodies_save.get(name)
+        print(f"  {name:9s} {sum(1 for i in ins if i.kind not in ('label', 'other')):5d} instructions, "
+              f"{sum(1 for i in ins if i.kind == 'mfma'):4d} MFMAs" +
+              (f"   (save build: {sum(1 for i in sv if i.kind not in ('label', 'other'))})" if sv is not None else ""))
 
 
 if __name__ == "__main__":

@@ -108,6 +108,30 @@ def I_ds_write_b32(addr, data, off=0):
                 dict(addr=addr, data=data, off=off))
 
 
+def I_ds_read_tr(d, addr, off=0):
+    """ds_read_b64_tr_b16 d[2], addr offset: within each group of 16 lanes, lane i supplies the address of 4 consecutive halfs
+    (one row of a 16 x 4 block); lane l receives element j = the half (l & 3) of the row supplied by lane 4 j + ((l & 15) >> 2) --
+    a transposing read (tools/debug/probes/tr_read_probe.hip prints the mapping on the part)."""
+    assert 0 <= off < 65536 and d.n == 2
+    return Inst("ds_read_b64_tr_b16", f"ds_read_b64_tr_b16 {d}, {addr} offset:{off}", [addr], [d], "lds_r", dict(d=d, addr=addr, off=off))
+
+
+def I_gstore_s(voff, data, sbase, off=0):
+    """global_store_dword[x2|x4] voff, data, s[base:base+1] offset  (address = sbase + zext(voff) + off)"""
+    assert 0 <= off <= 4095 and data.n in (1, 2, 4) and sbase.n == 2
+    suffix = {1: "dword", 2: "dwordx2", 4: "dwordx4"}[data.n]
+    return Inst("gstore_s", f"global_store_{suffix} {voff}, {data}, {sbase} offset:{off}", [voff, data, sbase], [], "vmem",
+                dict(data=data, voff=voff, sbase=sbase, off=off))
+
+
+def I_v_pk_add_f16(d, a, b):
+    return Inst("v_pk_add_f16", f"v_pk_add_f16 {d}, {a}, {b}", [a, b], [d], "valu", dict(d=d, s=[a, b]))
+
+
+def I_v_lshl_or(d, a, sh, c):            # d = (a << sh) | c
+    return Inst("v_lshl_or_b32", f"v_lshl_or_b32 {d}, {a}, {sh}, {c}", [x for x in (a, c) if _is_reg(x)], [d], "valu", dict(d=d, s=[a, sh, c]))
+
+
 def I_gload_x4_s(d, voff, sbase, off=0):
     """global_load_dwordx4 d, voff, s[base:base+1] offset  (address = sbase + zext(voff) + off)"""
     assert -4096 <= off <= 4095 and d.n == 4 and sbase.n == 2
@@ -325,6 +349,7 @@ class Sim:
         self.lds_w_wave = np.full(lds_bytes // 4, -1, np.int64)
         self.lds_r_epoch = np.full((4, lds_bytes // 4), -1, np.int64)
         self.mem = {}            # base address -> np.uint32 array
+        self.mem_written = None  # {base: bool array}: set by the harness to catch a global dword stored twice
         self.waves = [Wave(w) for w in range(4)]
         self.trace = None
 
@@ -478,6 +503,24 @@ class Sim:
                     acc[32 * hb:32 * hb + 32] = (acc[32 * hb:32 * hb + 32].astype(np.float64) + prod[i, :]).astype(np.float32)
                 self._wv(w, d, acc.view(np.uint32), r, masked=False)       # (MFMA ignores EXEC)
             return None
+        if k == "lds_r" and ins.op == "ds_read_b64_tr_b16":
+            addr = self._rv(w, a["addr"]).astype(np.int64) + a["off"]
+            raw = self._lds_access(w, addr, 2, False)                  # (2, NL) dwords = 4 halfs per lane
+            halfs = np.zeros((NL, 4), np.uint16)
+            halfs[:, 0], halfs[:, 1] = raw[0] & 0xFFFF, raw[0] >> 16
+            halfs[:, 2], halfs[:, 3] = raw[1] & 0xFFFF, raw[1] >> 16
+            got = np.zeros((NL, 4), np.uint16)
+            for l in range(NL):
+                g0 = l & ~15
+                for j in range(4):
+                    got[l, j] = halfs[g0 + 4 * j + ((l & 15) >> 2), l & 3]
+            self._wv(w, a["d"], got[:, 0].astype(np.uint32) | (got[:, 1].astype(np.uint32) << 16), 0)
+            self._wv(w, a["d"], got[:, 2].astype(np.uint32) | (got[:, 3].astype(np.uint32) << 16), 1)
+            regs = set(a["d"].regs())
+            w.lds_q.append(regs)
+            for r in regs:
+                w.pending[r] = "LDS"
+            return None
         if k == "lds_r":
             addr = self._rv(w, a["addr"]).astype(np.int64) + a["off"]
             out = self._lds_access(w, addr, 4, False)
@@ -494,6 +537,30 @@ class Sim:
             data = np.stack([self._rv(w, a["data"], r4) for r4 in range(n_dw)])
             self._lds_access(w, addr, n_dw, True, data)
             w.lds_q.append(set())
+            return None
+        if k == "vmem" and ins.op == "gstore_s":
+            base = int(w.s[a["sbase"].i]) | (int(w.s[a["sbase"].i + 1]) << 32)
+            addr = base + self._rv(w, a["voff"]).astype(np.uint64) + np.uint64(a["off"])
+            n_dw = a["data"].n
+            for l in range(NL):
+                if not w.exec[l]:
+                    continue
+                hit = False
+                for b0, arr in self.mem.items():
+                    if b0 <= int(addr[l]) and int(addr[l]) + 4 * n_dw <= b0 + arr.size * 4:
+                        if (int(addr[l]) - b0) % (4 * n_dw):
+                            raise SimError(f"unaligned global store ({ins.text})")
+                        o = (int(addr[l]) - b0) // 4
+                        if self.mem_written is not None:
+                            if self.mem_written[b0][o:o + n_dw].any():
+                                raise SimError(f"wave {w.id}: `{ins.text}` writes global dword {o} of buffer {b0:#x} a second time")
+                            self.mem_written[b0][o:o + n_dw] = True
+                        for kk in range(n_dw):
+                            arr[o + kk] = self._rv(w, a["data"], kk)[l]
+                        hit = True
+                if not hit:
+                    raise SimError(f"wave {w.id} pc {w.pc}: `{ins.text}` writes unmapped global memory (lane {l}, address {int(addr[l]):#x})")
+            w.vm_q.append(set())
             return None
         if k == "vmem":
             if ins.op == "gload_s":
@@ -576,6 +643,12 @@ class Sim:
             out = s[0]
         elif op == "v_add_f32":
             out = (f32(s[0]) + f32(s[1])).astype(np.float32).view(np.uint32)
+        elif op == "v_pk_add_f16":
+            lo = (halfs_of(s[0])[0] + halfs_of(s[1])[0]).astype(np.float16)       # (the exact fp32 sum of two halfs, rounded to nearest even)
+            hi = (halfs_of(s[0])[1] + halfs_of(s[1])[1]).astype(np.float16)
+            out = lo.view(np.uint16).astype(np.uint32) | (hi.view(np.uint16).astype(np.uint32) << 16)
+        elif op == "v_lshl_or_b32":
+            out = ((s[0] << (s[1] & 31)) | s[2]).astype(np.uint32)
         elif op == "v_fmac_f32":
             out = (f32(s[0]).astype(np.float64) * f32(s[1]).astype(np.float64) + f32(s[2]).astype(np.float64)).astype(np.float32).view(np.uint32)
         elif op == "v_add_u32":
