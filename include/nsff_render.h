@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      23
+#define NSFF_ABI_VERSION      24
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -199,8 +199,17 @@ typedef struct NsffTimeBiasJob {
     const NsffModelDesc* desc;
     const float* w[NSFF_MAX_LAYERS];
     const float* b[NSFF_MAX_LAYERS];
-    const float* t_rows;     /* (n_rays, in_t)                                      */
+    const float* t_rows;     /* (n_rays, in_t), or NULL: index mode (below)         */
     float* out;              /* (n_rays, nsff_time_bias_rows(desc), 256)            */
+    /* index mode (t_rows == NULL): the job gathers its rows itself, t_rows[r] = table[clamp(ts[r] + delta)] -- the reference's
+     * embedding_t(ts), embedding_t(clamp(ts + 1, max=max_t)), embedding_t(clamp(ts - 1, min=0)) (rendering.py:153,218,224) for
+     * delta = 0, +1, -1 (the index is also kept inside the table) -- and leaves them in rows_out (n_rays, in_t) when that is
+     * given: one launch instead of a gather, the neighbour-row kernel and this one. */
+    const float* table;      /* (n_table, in_t) time-code table                     */
+    const int64_t* ts;       /* (n_rays) frame indices                              */
+    int64_t n_table, max_t;
+    int32_t delta, pad_;
+    float* rows_out;         /* (n_rays, in_t) or NULL                              */
 } NsffTimeBiasJob;
 int nsff_time_bias_rows(const NsffModelDesc* desc);      /* 0: the model has no dynamic trunk */
 int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64_t n_rays, void* stream);

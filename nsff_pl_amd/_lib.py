@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 23
+ABI_VERSION = 24
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -49,7 +49,9 @@ class FieldArgs(C.Structure):
 
 
 class TimeBiasJob(C.Structure):
-    _fields_ = [("desc", C.POINTER(ModelDesc)), ("w", _fp * 8), ("b", _fp * 8), ("t_rows", _fp), ("out", _fp)]
+    _fields_ = [("desc", C.POINTER(ModelDesc)), ("w", _fp * 8), ("b", _fp * 8), ("t_rows", _fp), ("out", _fp),
+                ("table", _fp), ("ts", _fp), ("n_table", C.c_int64), ("max_t", C.c_int64), ("delta", C.c_int32), ("pad_", C.c_int32),
+                ("rows_out", _fp)]
 
 
 MAX_TIME_BIAS_JOBS = 4
@@ -412,14 +414,31 @@ def time_bias_rows(model):
     return load().nsff_time_bias_rows(C.byref(model_desc(model)))
 
 
-def time_bias(jobs):
+def time_bias(jobs, index=None):
     """jobs: [(model, t_rows (n_rays, in_t))] (at most MAX_TIME_BIAS_JOBS, one n_rays) -> [(n_rays, rows, 256) fp32]: per ray,
     bias + time-code columns' product of the dynamic trunk's layer 0 and skip layers (nsff_time_bias: ONE launch for all
-    jobs); field_query(..., t_bias=) then multiplies no time-code column."""
+    jobs); field_query(..., t_bias=) then multiplies no time-code column.
+    index = (table (n_table, in_t), ts (n_rays,) int64, max_t): jobs are [(model, delta)], delta in (0, +1, -1) -- the launch
+    gathers table[clamp(ts + delta)] itself (no separate gather / neighbour-row launches) and ALSO returns the gathered rows:
+    -> (outs, {delta: (n_rays, in_t)}); the rows of +1 and -1 are the two halves of one buffer."""
     assert 1 <= len(jobs) <= MAX_TIME_BIAS_JOBS
     arr = (TimeBiasJob * len(jobs))()
     keep, outs, per_model, pair = [], [], {}, None
-    n_rays = int(jobs[0][1].shape[0])
+    rows_of = {}
+    if index is not None:
+        table, ts, max_t = index
+        assert ts.dtype == torch.int64 and ts.is_cuda and ts.is_contiguous()
+        n_rays, width = int(ts.shape[0]), int(table.shape[1])
+        deltas = sorted({int(d) for _, d in jobs})
+        if 1 in deltas and -1 in deltas:
+            both = torch.empty(2, n_rays, width, device=table.device, dtype=torch.float32)
+            rows_of[1], rows_of[-1] = both[0], both[1]
+        for d in deltas:
+            if d not in rows_of:
+                rows_of[d] = torch.empty(n_rays, width, device=table.device, dtype=torch.float32)
+        written = set()
+    else:
+        n_rays = int(jobs[0][1].shape[0])
     for j, (model, t_rows) in enumerate(jobs):
         if id(model) not in per_model:
             desc = model_desc(model)
@@ -429,23 +448,34 @@ def time_bias(jobs):
                 _ptr(w), _ptr(b)                # (contiguous fp32 GPU tensors, or an assertion)
             per_model[id(model)] = (desc, C.pointer(desc), wb)
         desc, pdesc, wb = per_model[id(model)]
-        assert t_rows.shape == (n_rays, desc.in_t)
+        if index is not None:
+            delta, t_rows = int(t_rows), None
+            assert width == desc.in_t
+        else:
+            assert t_rows.shape == (n_rays, desc.in_t)
         # (consecutive jobs of one model get adjacent halves of one buffer: see rendering._inference's merged re-query)
+        dev = wb[0][0].device
         if j + 1 < len(jobs) and jobs[j + 1][0] is model and pair is None:
-            pair = torch.empty(2, n_rays, len(wb), 256, device=t_rows.device, dtype=torch.float32)
+            pair = torch.empty(2, n_rays, len(wb), 256, device=dev, dtype=torch.float32)
             out = pair[0]
         elif pair is not None:
             out, pair = pair[1], None
         else:
-            out = torch.empty(n_rays, len(wb), 256, device=t_rows.device, dtype=torch.float32)
+            out = torch.empty(n_rays, len(wb), 256, device=dev, dtype=torch.float32)
         arr[j].desc = pdesc
         for i, (w, b) in enumerate(wb):
             arr[j].w[i], arr[j].b[i] = w.data_ptr(), b.data_ptr()
         arr[j].t_rows, arr[j].out = _ptr(t_rows), _ptr(out)
+        if index is not None:
+            arr[j].table, arr[j].ts = _ptr(table), ts.data_ptr()
+            arr[j].n_table, arr[j].max_t, arr[j].delta = int(table.shape[0]), int(max_t), delta
+            if delta not in written:                # (the first job of a delta leaves the gathered rows behind)
+                arr[j].rows_out = _ptr(rows_of[delta])
+                written.add(delta)
         outs.append(out)
     keep.append(per_model)
     _check(load().nsff_time_bias(arr, len(jobs), n_rays, _stream()), "nsff_time_bias")
-    return outs
+    return outs if index is None else (outs, rows_of)
 
 
 def coarse_samples(rays, z_lin, perturb, perturb_rand, zs, xyz):

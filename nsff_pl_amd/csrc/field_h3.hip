@@ -1986,7 +1986,8 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
 // One thread per neuron, sixteen rays per workgroup; weights and time codes are staged in LDS.  ~75 MFLOP per C2 call -- its cost is the launch.
 namespace {
 struct TimeBiasJobK { const float* w[NSFF_MAX_LAYERS]; const float* b[NSFF_MAX_LAYERS]; int ld[NSFF_MAX_LAYERS];
-                      const float* t_rows; float* out; int rows, in_xyz, in_t; };
+                      const float* t_rows; float* out; int rows, in_xyz, in_t;
+                      const float* table; const long long* ts; long long n_table, max_t; int delta; float* rows_out; };
 struct TimeBiasArgs { TimeBiasJobK job[NSFF_MAX_TIME_BIAS_JOBS]; long long n_rays; };
 constexpr int TB_RAYS = 16;
 __global__ __launch_bounds__(256) void nsff_time_bias_kernel(const TimeBiasArgs a) {
@@ -2007,7 +2008,16 @@ __global__ __launch_bounds__(256) void nsff_time_bias_kernel(const TimeBiasArgs 
     for (int k = 0; k < TB_RAYS / 4; ++k) {
         const int e = threadIdx.x + 256 * k, r = e >> 6, c = e & 63;
         const long long ray = r0 + r < a.n_rays ? r0 + r : a.n_rays - 1;
-        tv[k] = c < in_t ? j.t_rows[ray * in_t + c] : 0.f;
+        const float* row = j.t_rows != nullptr ? j.t_rows + ray * in_t : nullptr;
+        if (row == nullptr) {                        // index mode: the row of the (clamped) neighbouring frame, rendering.py:153,218,224
+            long long t = j.ts[ray] + j.delta;
+            if (j.delta > 0) t = t < j.max_t ? t : j.max_t;
+            if (j.delta < 0) t = t > 0 ? t : 0;
+            t = t < 0 ? 0 : (t > j.n_table - 1 ? j.n_table - 1 : t);
+            row = j.table + t * in_t;
+        }
+        tv[k] = c < in_t ? row[c] : 0.f;
+        if (j.rows_out != nullptr && i == 0 && c < in_t && r0 + r < a.n_rays) j.rows_out[(r0 + r) * in_t + c] = tv[k];
     }
     const float b = j.b[i][n];
 #pragma unroll
@@ -2059,7 +2069,8 @@ extern "C" int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64
     int max_rows = 0;
     for (int q = 0; q < n_jobs; ++q) {
         const NsffTimeBiasJob& jb = jobs[q];
-        if (!jb.desc || !jb.t_rows || !jb.out) return NSFF_ERR_NULL;
+        if (!jb.desc || !jb.out) return NSFF_ERR_NULL;
+        if (!jb.t_rows && (!jb.table || !jb.ts || jb.n_table < 1 || jb.delta < -1 || jb.delta > 1)) return NSFF_ERR_NULL;
         const NsffModelDesc& d = *jb.desc;
         NsffLayoutH3 L;
         const int rc = nsff_make_layout_h3(d, L);
@@ -2071,6 +2082,8 @@ extern "C" int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64
         //  models keep their time-code columns on the matrix pipe, the field dispatcher never asks for rows here)
         if (d.in_t > 64 || (d.in_t & 3) != 0) return NSFF_ERR_INVALID;
         k.in_xyz = d.in_xyz; k.in_t = d.in_t; k.t_rows = jb.t_rows; k.out = jb.out;
+        k.table = jb.table; k.ts = reinterpret_cast<const long long*>(jb.ts); k.n_table = jb.n_table; k.max_t = jb.max_t;
+        k.delta = jb.delta; k.rows_out = jb.t_rows ? nullptr : jb.rows_out;
         const uint32_t skips = nsff_skip_layers(&d);
         int i = 0;
         for (int l = 0; l < d.D; ++l) {

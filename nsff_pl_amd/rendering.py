@@ -83,41 +83,56 @@ def _neighbour_time_rows(embeddings, ts, max_t):
             _embed_rows(embeddings, 't', torch.clamp(ts - 1, min=0)))
 
 
-def _plan_time_bias(ctx, models, t_embedded, N_samples, N_importance, output_transient, flows):
-    """The time code enters the dynamic trunk at layer 0 and at the skip layers, and every sample of a ray shares it
-    (rendering.py:153,168,221,227 repeat the row): its product with those layers' time-code columns is computed here once per
-    RAY -- one launch for every (model, time rows) pair of this call -- and handed to the field launches as bias rows
+def _time_codes(ctx, models, kwargs, N_samples, N_importance, output_transient, flows):
+    """The (n_rays, in_t) time codes of this call -- kwargs['t_embedded'] or embeddings['t'](ts) (rendering.py:153) -- and, for the
+    launches that can use them, the time code's part of the dynamic trunk as per-RAY bias rows.
+
+    The time code enters the dynamic trunk at layer 0 and at the skip layers, and every sample of a ray shares it
+    (rendering.py:153,168,221,227 repeat the row): its product with those layers' time-code columns is computed once per RAY --
+    one launch for every (model, time rows) pair of this call -- and handed to the field launches as bias rows
     (`_lib.time_bias`); the hand-scheduled f16x3 kernel then multiplies no time-code column.  Fills ctx.tbias[(typ, which)],
     which in 't' | 'fw' | 'bw', for the launches that can use it (inference in f16x3, 128-point tiles, samples per ray a
-    multiple of 64); the others run as before."""
+    multiple of 64); the others run as before.  With a plain nn.Embedding table and integer frame indices the SAME launch also
+    gathers the rows -- E_t[ts] and the neighbour rows E_t[clamp(ts +- 1)] of the re-queries (rendering.py:218,224) -- instead
+    of a gather, a neighbour-row kernel and the bias kernel."""
     ctx.tbias, ctx.neighbour_rows = {}, None
-    n_rays = ctx.n_rays
-    if (not output_transient or t_embedded is None or ctx.rec is not None or n_rays == 0
-            or config.get_precision() != "f16x3" or config.get_tile_points() not in (0, 130)):
-        return
-    passes = []
-    if N_importance > 0:
-        passes.append(('coarse', N_samples))
-        passes.append(('fine', N_samples + 2 * N_importance))
-    else:
-        passes.append(('fine', N_samples))
-    jobs, tags = [], []
-    for typ, S in passes:
-        model = models[typ]
-        if not model.encode_transient or S % 64 or (n_rays * S < 32768 and config.get_tile_points() == 0):
-            continue
-        if model.in_channels_t > 64 or model.in_channels_t % 4:       # (nsff_time_bias stages 64 columns as float4s; refused there)
-            continue
-        if t_embedded.shape != (n_rays, model.in_channels_t):
-            continue
-        if typ == 'fine' and flows and not ctx.test_time and hasattr(model, "transient_flow_fw"):
-            ctx.neighbour_rows = _neighbour_time_rows(ctx.embeddings, ctx.ts, ctx.max_t)
-            jobs.append((model, ctx.neighbour_rows[0])); tags.append((typ, 'fw'))      # (fw, bw adjacent: one buffer, see time_bias)
-            jobs.append((model, ctx.neighbour_rows[1])); tags.append((typ, 'bw'))
-        jobs.append((model, t_embedded)); tags.append((typ, 't'))
-    if jobs:
-        for tag, out in zip(tags, _lib.time_bias(jobs)):
-            ctx.tbias[tag] = out
+    if not output_transient:
+        return None
+    n_rays, ts, m = ctx.n_rays, ctx.ts, ctx.embeddings.get('t')
+    override = kwargs.get('t_embedded') if 't_embedded' in kwargs else None
+    plan = []
+    if not (ctx.rec is not None or n_rays == 0 or config.get_precision() != "f16x3" or config.get_tile_points() not in (0, 130)):
+        passes = [('coarse', N_samples), ('fine', N_samples + 2 * N_importance)] if N_importance > 0 else [('fine', N_samples)]
+        for typ, S in passes:
+            model = models[typ]
+            if not model.encode_transient or S % 64 or (n_rays * S < 32768 and config.get_tile_points() == 0):
+                continue
+            if model.in_channels_t > 64 or model.in_channels_t % 4:   # (nsff_time_bias stages 64 columns as float4s; refused there)
+                continue
+            if typ == 'fine' and flows and not ctx.test_time and hasattr(model, "transient_flow_fw"):
+                plan += [(typ, 'fw', model, 1), (typ, 'bw', model, -1)]      # (fw, bw adjacent: one buffer, see time_bias)
+            plan.append((typ, 't', model, 0))
+    plain = (override is None and isinstance(m, torch.nn.Embedding) and m.padding_idx is None and m.max_norm is None
+             and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()
+             and torch.is_tensor(ts) and ts.is_cuda and ts.dtype == torch.int64)
+    if (plan and plain and all(mod.in_channels_t == m.weight.shape[1] for _, _, mod, _ in plan)
+            and not os.environ.get('NSFF_NO_TIME_INDEX')):          # (`NSFF_NO_TIME_INDEX=1`: separate gather / neighbour-row launches, A/B)
+        outs, rows = _lib.time_bias([(mod, d) for _, _, mod, d in plan], index=(m.weight.detach(), ts.contiguous(), ctx.max_t))
+        for (typ, which, _, _), out in zip(plan, outs):
+            ctx.tbias[(typ, which)] = out
+        if 1 in rows:
+            ctx.neighbour_rows = (rows[1], rows[-1])
+        return rows[0]
+    t_embedded = override if override is not None else ctx.embeddings['t'](ts)
+    t_embedded = t_embedded.detach().contiguous().float()
+    plan = [p for p in plan if t_embedded.shape == (n_rays, p[2].in_channels_t)]
+    if plan:
+        if any(w == 'fw' for _, w, _, _ in plan):
+            ctx.neighbour_rows = _neighbour_time_rows(ctx.embeddings, ts, ctx.max_t)
+        src = {0: t_embedded, 1: ctx.neighbour_rows[0] if ctx.neighbour_rows else None, -1: ctx.neighbour_rows[1] if ctx.neighbour_rows else None}
+        for (typ, which, _, _), out in zip(plan, _lib.time_bias([(mod, src[d]) for _, _, mod, d in plan])):
+            ctx.tbias[(typ, which)] = out
+    return t_embedded
 
 
 def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
@@ -359,11 +374,8 @@ def _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_
         if N_importance > 0:  # coarse to fine
             model = models['coarse']
             output_transient = bool(kwargs.get('output_transient', True) and model.encode_transient)
-            if output_transient:
-                t_embedded = kwargs['t_embedded'] if 't_embedded' in kwargs else embeddings['t'](ts)
-                t_embedded = t_embedded.detach().contiguous().float()
-            _plan_time_bias(ctx, models, t_embedded, N_samples, N_importance, output_transient,
-                            kwargs.get('output_transient_flow', []))
+            t_embedded = _time_codes(ctx, models, kwargs, N_samples, N_importance, output_transient,
+                                     kwargs.get('output_transient_flow', []))
             _inference(results, ctx, model, xyz_coarse, zs, output_transient, [], t_embedded, None)
 
             det = perturb == 0
@@ -403,10 +415,7 @@ def _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_
             a_embedded = a_embedded.detach().contiguous().float()
         if N_importance == 0:
             output_transient = bool(kwargs.get('output_transient', True) and model.encode_transient)
-            if output_transient:
-                t_embedded = kwargs['t_embedded'] if 't_embedded' in kwargs else embeddings['t'](ts)
-                t_embedded = t_embedded.detach().contiguous().float()
-            _plan_time_bias(ctx, models, t_embedded, N_samples, 0, output_transient, kwargs.get('output_transient_flow', []))
+            t_embedded = _time_codes(ctx, models, kwargs, N_samples, 0, output_transient, kwargs.get('output_transient_flow', []))
         output_transient_flow = [] if not output_transient else kwargs.get('output_transient_flow', [])
         _inference(results, ctx, model, xyz, zs, output_transient, output_transient_flow,
                    t_embedded, a_embedded)
