@@ -712,16 +712,39 @@ __global__ __launch_bounds__(256, 1) void nsff_wgrad_head_kernel(const WKArgs a)
     const h2 ones = {(_Float16)1.f, (_Float16)1.f};
     const _Float16* ap = job.a + lane * 8;
     const _Float16* bp = job.b + (NB * wave) * 512 + lane * 8;
-#pragma unroll 2
-    for (long long s = t0 * 4; s < t1 * 4; ++s) {
-        const h8 af = *reinterpret_cast<const h8*>(ap + s * 512);
+    // The loop is one memory latency per step unless the fragments of the next steps are in flight: DEPTH steps (a tile = four)
+    // are requested ahead (round 5: 49 -> see EXPERIMENTS R5 us per launch; the B fragments come from HBM, nobody else reads them)
+    constexpr int DEPTH = 8;
+    const long long s_begin = t0 * 4, s_end = t1 * 4;
+    h8 fa[DEPTH], fb[DEPTH][NB];
+    auto fetch = [&](int slot, long long s) {
+        const long long c = s < s_end ? s : s_end - 1;          // (past the end: a valid address, never multiplied)
+        fa[slot] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(ap + c * 512));
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            acc[nb] = MFMA_H(af, *reinterpret_cast<const h8*>(bp + s * (B_ROWS * 16) + nb * 512), acc[nb]);
-        bsum = __builtin_amdgcn_fdot2(h2{af[0], af[1]}, ones, bsum, false);
-        bsum = __builtin_amdgcn_fdot2(h2{af[2], af[3]}, ones, bsum, false);
-        bsum = __builtin_amdgcn_fdot2(h2{af[4], af[5]}, ones, bsum, false);
-        bsum = __builtin_amdgcn_fdot2(h2{af[6], af[7]}, ones, bsum, false);
+        for (int nb = 0; nb < NB; ++nb) fb[slot][nb] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(bp + c * (B_ROWS * 16) + nb * 512));
+    };
+    if (s_end > s_begin) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d, s_begin + d);
+#pragma unroll 1
+        for (long long s = s_begin; s < s_end; s += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const h8 af = fa[d];
+                h8 bf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bf[nb] = fb[d][nb];
+                fetch(d, s + DEPTH + d);
+                if (s + d < s_end) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_H(af, bf[nb], acc[nb]);
+                    bsum = __builtin_amdgcn_fdot2(h2{af[0], af[1]}, ones, bsum, false);
+                    bsum = __builtin_amdgcn_fdot2(h2{af[2], af[3]}, ones, bsum, false);
+                    bsum = __builtin_amdgcn_fdot2(h2{af[4], af[5]}, ones, bsum, false);
+                    bsum = __builtin_amdgcn_fdot2(h2{af[6], af[7]}, ones, bsum, false);
+                }
+            }
+        }
     }
     float* out = a.out + job.out_off + (long long)split * (32 * B_ROWS);
 #pragma unroll
