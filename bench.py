@@ -23,8 +23,7 @@ Extra objects on the JSON line:
                   workload (rank 0, N=1 only).
   aux          -- (N=1, default workload) the other BASELINE.json configurations, measured in the same run
                   AFTER the headline timed region, a few steps each: training step (C4 per GPU), full-frame
-                  evaluation (C3), time interpolation (C5 inner loop), and the single-product "f16" FAST
-                  MODE of the headline workload (clearly labelled: it is not parity-grade and never `value`).
+                  evaluation (C3), the reference's README configuration, time interpolation (C5 inner loop).
 """
 import argparse
 import json
@@ -40,13 +39,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_RAYS, N_SAMPLES, N_IMPORTANCE = 1024, 64, 64
 # MI355X_MICROARCH.md dense peaks: fp32 MFMA (v_mfma_f32_32x32x2_f32) and f16 MFMA (32x32x16)
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
-MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "f16": 1}
-KERNEL_NAME = {"f32": "nsff_field_kernel", "f16x3": "nsff_field_kernel_h3a", "f16": "nsff_field_kernel_h3<4,1,false,2,false>"}
-TRAIN_KERNEL_NAME = {"f16x3": "nsff_field_kernel_h3<4,1,true,1,true>"}
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
+MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3}
+KERNEL_NAME = {"f32": "nsff_field_kernel", "f16x3": "nsff_field_kernel_h3a"}
+TRAIN_KERNEL_NAME = {"f16x3": "nsff_field_kernel_h3a_save"}
 DTYPE_TEXT = {"f32": "f32",
-              "f16x3": "f16x3 (fp32 operands split into 2 halfs, 3 f16 MFMAs per product, fp32 accumulate; same 1e-4 parity as f32)",
-              "f16": "f16 FAST MODE (operands rounded once to fp16, 1 MFMA per product, fp32 accumulate; NOT parity-grade)"}
+              "f16x3": "f16x3 (fp32 operands split into 2 halfs, 3 f16 MFMAs per product, fp32 accumulate; same 1e-4 parity as f32)"}
 FLOP_PER_RAY_C2_TRAIN = 1031.80e6
 
 
@@ -326,7 +324,7 @@ def roofline_block(precision, kern):
             "executed": executed,
             "mfma_issue_frac": executed * MFMA_PER_PRODUCT[precision] / PEAK_TFLOPS[precision],
             "note": "achieved = algorithmic FLOPs of the reference network (2*MACs of its fp32 Linear layers) / kernel time; "
-                    "executed = what the kernel actually multiplies: inference launches of the f16 kernels fold the two "
+                    "executed = what the kernel actually multiplies: the f16 kernels (inference AND training forward) fold the two "
                     "activation-free *_xyz_encoding_final layers (nerf.py:170,195) into pre-multiplied head rows, i.e. skip "
                     "2 of the 18 256x256 layers; the f16x3 mode issues 3 f16 MFMAs per executed product (mfma_issue_frac)",
             "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
@@ -418,29 +416,21 @@ def aux_block(bench, args):
     from nsff_pl_amd import config
     aux = {"note": "measured in this run after the headline timed region; steps/warmup per entry"}
     dev = bench.device
-    # (1) single-product fast mode of the SAME C2 workload: labelled, never the headline
-    config.set_precision("f16")
-    config.set_tile_points(0)
-    t, kern, _ = timed(bench.render_step(), 10, 2, 1, dev, prof=True)
-    rf = roofline_block("f16", kern)
-    aux["fast_mode_f16"] = {"label": "FAST MODE, not parity-grade (one f16 MFMA per product; ~5e-3 max-norm error, see DESIGN.md 8)",
-                            "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 10 / t, "ms_per_step": t / 10 * 1e3,
-                            "steps": 10, "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "clock_ghz",
-                                                                         "frac_at_clock", "avg_launch_ms", "launches")}}
-    config.set_precision(args.precision)
-    config.set_tile_points(args.tile_points if args.precision == "f16x3" else 0)
     # (1a) the headline call as ONE replayed hipGraph (nsff_pl_amd.graphs.GraphedRender): same kernels, no per-launch host work
     from nsff_pl_amd.graphs import GraphedRender
     gr = GraphedRender(bench.models, bench.emb, bench.scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0, N_IMPORTANCE, test_time=False, **bench.kw)
     gr(bench.rays, bench.ts)
     t, _, _ = timed(lambda: gr(bench.rays, bench.ts), 20, 3, 1, dev)
     aux["render_as_hip_graph"] = {"ms_per_step": t / 20 * 1e3, "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 20 / t,
-                                  "note": "the C2 call captured once and replayed (23 kernel nodes incl. the generator kernels)"}
+                                  "note": "the C2 call captured once and replayed (17 kernel nodes incl. the generator kernels); a replay has a fixed "
+                                          "cost of ~10 us (a one-node graph: 9.8 us, an eager launch 4.4 us -- tools/debug/graph_vs_eager.py) that "
+                                          "the eager path, whose host runs ahead of the GPU, never pays"}
     # (1b) the TRAINING forward of the same C2 call (what a training step launches: every layer executed, activations and
     # ReLU sign bits kept for the backward pass) next to the headline's inference launches
     t, kern, _ = timed(bench.render_step(train_forward=True), 10, 2, 1, dev, prof=True)
     rf = roofline_block(args.precision, kern)
-    aux["train_forward"] = {"label": "C2 forward as a training step runs it (autograd on): activation-saving kernels, no folded layers",
+    aux["train_forward"] = {"label": "C2 forward as a training step runs it (autograd on): the SAVE build of the hand-scheduled body -- every trunk "
+                                     "layer's activation and ReLU sign words go to HBM while the phases multiply; *_final folded into the heads as in inference",
                             "ms_per_step": t / 10 * 1e3, "ray_samples_per_s": N_RAYS * (N_SAMPLES + N_IMPORTANCE) * 10 / t,
                             "roofline": dict({k: rf[k] for k in ("achieved", "executed", "peak", "unit", "frac", "clock_ghz", "frac_at_clock",
                                                                  "avg_launch_ms", "launches")},
@@ -495,7 +485,7 @@ def main():
                     help="untimed steps run for this long BEFORE the W warm-up steps: the part comes out of its idle state (95 MHz "
                          "while the CPU baseline runs) and its power management settles; 0 = none.  Reported in config.settle_ms")
     ap.add_argument("--no-aux", action="store_true", help="skip the aux block (other configurations after the headline)")
-    ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16"],
+    ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3"],
                     help="arithmetic of the dense layers; f32 and f16x3 pass the same 1e-4 parity tests, f16 is the "
                          "labelled fast mode")
     ap.add_argument("--workload", default="render", choices=["render", "train", "eval", "eval_interp"],
@@ -613,6 +603,8 @@ def main():
             line["config"]["parallelism"] = f"data-parallel x{world}, one flat gradient all-reduce per step"
             line["config"]["hip_graph"] = bool(bench.trainer.graph)
             line["config"].pop("mlp_tflops_whole_step")
+            if "roofline" in line:      # (the field launches of a training step are the training forward's)
+                line["roofline"]["kernel"] = TRAIN_KERNEL_NAME.get(args.precision, line["roofline"]["kernel"])
         if per_rank is not None:
             line["per_rank"] = per_rank
         if cpu is not None:

@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      24
+#define NSFF_ABI_VERSION      25
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -70,13 +70,10 @@ static inline uint32_t nsff_skip_layers(const NsffModelDesc* d) {
  *   NSFF_PREC_F16X3 fp32 operands split into two halfs, three f16 MFMAs per product,
  *                   fp32 accumulate (v_mfma_f32_32x32x16_f16), activations staged in LDS;
  *                   agrees with F32 to fp32 rounding level (same 1e-4 parity tests)
- *   NSFF_PREC_F16   FAST MODE, not parity-grade: operands rounded once to fp16, one f16 MFMA per product,
- *                   fp32 accumulate (~5e-3 max-norm on rendered values).  Reads the F16X3 packed buffer
- *                   (hi halfs only); inference only (the save_* outputs are refused).
+ * (Value 3 was the single-product fast mode of earlier ABI versions: not parity-grade, removed -- NSFF_ERR_INVALID now.)
  */
 #define NSFF_PREC_F32        0
 #define NSFF_PREC_F16X3      1
-#define NSFF_PREC_F16        3
 
 /* Size in bytes of the packed-weight buffer for `desc` at `precision`. */
 int nsff_packed_bytes(const NsffModelDesc* desc, int precision, size_t* bytes);
@@ -590,7 +587,7 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
 #define NSFF_KERNEL_H3_8WAVE  3   /* f16x3, 128-point tiles, eight waves of 32 neurons, compiler-scheduled           */
 #define NSFF_KERNEL_H3A       4   /* f16x3, 128-point tiles, hand-scheduled body (nsff_field_kernel_h3a)             */
 #define NSFF_KERNEL_H3_SAVE   5   /* f16x3 training forward (keeps activations)                                      */
-#define NSFF_KERNEL_F16_FAST  6   /* single-product fast mode                                                        */
+/*      (6: the single-product fast mode of earlier ABI versions, removed) */
 #define NSFF_KERNEL_H3A_TBIAS 7   /* NSFF_KERNEL_H3A with the time code folded into per-ray bias rows (NsffFieldArgs::t_bias) */
 #define NSFF_KERNEL_H3A_SAVE  9   /* f16x3 training forward on the hand-scheduled body (nsff_field_kernel_h3a_save)          */
 #define NSFF_KERNEL_H3A_SIDE  8   /* NSFF_KERNEL_H3A[_TBIAS] whose static trunk has the view-direction branch (NsffFieldArgs::s_bias) */

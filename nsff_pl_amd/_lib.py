@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 24
+ABI_VERSION = 25
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -364,8 +364,8 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
     saves = not (save_acts is None and save_xin is None and save_masks is None and save_side is None)
-    # the "f16" fast mode reads the f16x3 pack (hi halfs only); training forwards run the folded step program too (f16x3 packs)
-    packed = model.packed(1 if prec == 3 else prec, inference=True)
+    # (training forwards run the folded step program too: one pack form)
+    packed = model.packed(prec, inference=True)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()
     a.n_points, a.pts_per_ray = int(n_points), int(pts_per_ray)
@@ -705,7 +705,7 @@ def mpi_composite(H, W, S, dt, accum_fw, accum_bw, static_rgb, static_alpha, zs,
     _check(load().nsff_mpi_composite(C.byref(a), _stream()), "nsff_mpi_composite")
 
 
-KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 6: "f16_fast", 7: "h3a_tb", 8: "h3a_side", 9: "h3a_save"}
+KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_save", 7: "h3a_tb", 8: "h3a_side", 9: "h3a_save"}
 
 
 def last_field_kernel():

@@ -5,15 +5,11 @@ precision
                accumulation; agrees with "f32" to fp32-rounding level and passes the same 1e-4 parity tests,
                ~2.7x faster.
     "f32"   -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
-    "f16"   -- FAST MODE, not parity-grade: operands rounded once to fp16, ONE f16 MFMA per product, fp32
-               accumulation.  ~5e-3 max-norm error on rendered values (measured per key in
-               tests/test_fast_mode.py, PSNR delta in DESIGN.md section 8); inference only -- gradients are always
-               taken through the f16x3 training forward.
 Select with ``set_precision`` or the environment variable ``NSFF_PRECISION``.
 """
 import os
 
-PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 3}
+PRECISIONS = {"f32": 0, "f16x3": 1}
 DEFAULT_PRECISION = "f16x3"
 
 

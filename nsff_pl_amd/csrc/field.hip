@@ -423,7 +423,7 @@ const char* nsff_last_hip_error(void) { return hipGetErrorString(g_nsff_last_err
 
 int nsff_packed_bytes(const NsffModelDesc* desc, int precision, size_t* bytes) {
     if (!desc || !bytes) return NSFF_ERR_NULL;
-    if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16) return nsff_h3_packed_bytes(desc, bytes);
+    if (precision == NSFF_PREC_F16X3) return nsff_h3_packed_bytes(desc, bytes);
     if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
     NsffLayout L;
     const int rc = nsff_make_layout(*desc, L);
@@ -447,7 +447,7 @@ int nsff_pack_weights(const NsffModelDesc* desc, int precision, const float* con
 int nsff_fold_heads(const NsffModelDesc* desc, int precision, const float* const* params, void* packed_v, void* stream) {
     if (!desc || !params || !packed_v) return NSFF_ERR_NULL;
     if ((uintptr_t)packed_v & 15) return NSFF_ERR_ALIGN;
-    if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16)
+    if (precision == NSFF_PREC_F16X3)
         return nsff_h3_fold_heads(desc, params, packed_v, (hipStream_t)stream);
     if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
     NsffLayout L;
@@ -464,7 +464,7 @@ int nsff_pack_weights_ex(const NsffModelDesc* desc, int precision, const float* 
     if (!desc || !params || !packed_v) return NSFF_ERR_NULL;
     if ((uintptr_t)packed_v & 15) return NSFF_ERR_ALIGN;
     if (flags & ~NSFF_PACK_SKIP_FOLD) return NSFF_ERR_INVALID;
-    if (precision == NSFF_PREC_F16X3 || precision == NSFF_PREC_F16)      // one packed layout serves both
+    if (precision == NSFF_PREC_F16X3)
         return nsff_h3_pack_weights(desc, params, packed_v, !(flags & NSFF_PACK_SKIP_FOLD), (hipStream_t)stream);
     if (precision != NSFF_PREC_F32) return NSFF_ERR_INVALID;
     float* packed = reinterpret_cast<float*>(packed_v);
@@ -570,7 +570,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     if (g.static_mode < 0 || g.static_mode > 2 || g.transient_mode < 0 || g.transient_mode > 2) return NSFF_ERR_INVALID;
     if (g.static_mode == 0 && g.transient_mode == 0) return NSFF_ERR_INVALID;
     if (g.flow_heads < 0 || g.flow_heads > 2 || (g.flow_heads && !d.has_flow)) return NSFF_ERR_INVALID;
-    if (g.precision != NSFF_PREC_F32 && g.precision != NSFF_PREC_F16X3 && g.precision != NSFF_PREC_F16) return NSFF_ERR_INVALID;
+    if (g.precision != NSFF_PREC_F32 && g.precision != NSFF_PREC_F16X3) return NSFF_ERR_INVALID;
     if (g.tile_points != 0 && g.tile_points != 64 && g.tile_points != 130 && g.tile_points != 131) return NSFF_ERR_INVALID;
     if (g.transient_mode && !d.has_transient) return NSFF_ERR_INVALID;
     if (g.n_points == 0) return NSFF_OK;
@@ -630,9 +630,6 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
         const int tile_default = g.n_points >= 128LL * 256 ? 130 : 64;
         const int rc3 = nsff_h3_field_query(desc, packed_v, args, g.tile_points ? g.tile_points : tile_default, st, span);
         if (rc3 != NSFF_OK) return rc3;
-    } else if (g.precision == NSFF_PREC_F16) {
-        const int rc3 = nsff_h3_field_query(desc, packed_v, args, NSFF_H3_FAST, st, span);
-        if (rc3 != NSFF_OK) return rc3;
     } else {
         hipLaunchKernelGGL(nsff_field_kernel, dim3((unsigned)tiles), dim3(NTHREADS), 0, st, k);
         e = hipGetLastError();
@@ -643,9 +640,10 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
         hipEventRecord(pr.e1, st);
         pr.flops = field_flops_per_point(d, g.static_mode, g.transient_mode,
                                          g.transient_mode == 2 ? g.flow_heads : 0) * (double)g.n_points;
-        // the f16 kernels' inference launches fold the activation-free *_final layers into their head rows
-        const bool h3 = g.precision == NSFF_PREC_F16X3 || g.precision == NSFF_PREC_F16;
-        const bool folds = !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
+        // the f16 kernels fold the activation-free *_final layers into their head rows -- training forwards too (they are f16x3
+        // launches); the exact-fp32 kernel folds in its inference launches (it has no saving form)
+        const bool h3 = g.precision == NSFF_PREC_F16X3;
+        const bool folds = h3 || !(g.save_acts || g.save_xin || g.save_masks || g.save_side);
         const int folded = folds ? ((g.static_mode == 2 && (h3 || !d.use_viewdir)) ? 1 : 0) + (g.transient_mode ? 1 : 0) : 0;
         pr.executed = pr.flops - 2.0 * d.W * d.W * folded * (double)g.n_points;
         std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -17,10 +17,6 @@
 //     epilogue packs them to fp16 and lanes i / i+32 trade halves (v_permlane32_swap) so that every
 //     lane owns 8 consecutive neurons = one 16-byte, bank-conflict-free ds_write_b128 per plane
 //     (the direct 8-byte stores are 2-way conflicted with 528-byte rows).
-// SPLIT = false is the FAST MODE ("f16", not parity-grade): the same kernel with every operand rounded once to
-// fp16 (round-to-nearest-even, clamped to the fp16 range) and ONE MFMA per product -- only the hi halfs of the
-// packed weights are fetched, the LDS tile is a single fp16 plane (so a 128-point workgroup needs 67.6 KB and two
-// of them share a CU) and the epilogue is one v_med3 + half a v_cvt_pk_f16_f32 per value.
 // Wave w owns neurons [64w, 64w+64) for all points of the tile: 2 x NT accumulator tiles.
 // NT = 4 (128 points, one workgroup per CU) halves the weight stream per FLOP; NT = 2
 // (64 points, two workgroups per CU) hides epilogues behind the other workgroup's MFMAs.
@@ -145,34 +141,22 @@ __device__ __forceinline__ void span_end(unsigned long long* span, const SpanT& 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H3_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <bool SPLIT = true>
 __device__ __forceinline__ void split_store(_Float16* xh, _Float16* xl, int idx, float v) {
     const _Float16 hi = (_Float16)v;
     xh[idx] = hi;
-    if constexpr (SPLIT) xl[idx] = (_Float16)(v - (float)hi);
+    xl[idx] = (_Float16)(v - (float)hi);
 }
 
 // MTW = 32-neuron tiles per wave: 2 (four waves x 64 neurons) or 1 (eight waves x 32 neurons, kernel variant <4,1,*,1>)
-template <int MTW, bool SPLIT = true> struct WFrag { h8 wh[MTW], wl[MTW]; };   // weights (A operand) of one k-step: 8*MTW VGPRs
-template <int MTW> struct WFrag<MTW, false> { h8 wh[MTW]; };
-template <int NT, bool SPLIT = true> struct XFrag { h8 xh[NT], xl[NT]; };  // activations (B operand) of one k-step
-template <int NT> struct XFrag<NT, false> { h8 xh[NT]; };
-template <int MTW, bool SPLIT = true> struct WRing { WFrag<MTW, SPLIT> r[4]; };       // four k-steps of weights in flight (L2 latency)
+template <int MTW> struct WFrag { h8 wh[MTW], wl[MTW]; };   // weights (A operand) of one k-step: 8*MTW VGPRs
+template <int NT> struct XFrag { h8 xh[NT], xl[NT]; };      // activations (B operand) of one k-step
+template <int MTW> struct WRing { WFrag<MTW> r[4]; };       // four k-steps of weights in flight (L2 latency)
 template <int MTW> struct BiasRegs { float4 b[MTW][4]; };
 
 // Weights are read through a bumped pointer so that every load is base + small immediate
 // ([ks][mt][part][lane] 16-byte chunks = 4 KiB per k-step; the lane offset is in the pointer).
 template <int MTW>
-__device__ __forceinline__ void load_w(WFrag<MTW, false>& f, const uint4* __restrict__& wp) {
-    // fast mode: only the hi halfs ([part 0] chunks) of the same packed stream are touched
-    static_assert(MTW == 2, "fast mode runs the 64-neuron-per-wave tiling");
-    const uint4 a0 = wp[0], a2 = wp[128];
-    wp += 256;
-    f.wh[0] = __builtin_bit_cast(h8, a0); f.wh[1] = __builtin_bit_cast(h8, a2);
-}
-
-template <int MTW>
-__device__ __forceinline__ void load_w(WFrag<MTW, true>& f, const uint4* __restrict__& wp) {
+__device__ __forceinline__ void load_w(WFrag<MTW>& f, const uint4* __restrict__& wp) {
     if constexpr (MTW == 2) {
         const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
         wp += 256;
@@ -195,20 +179,20 @@ __device__ __forceinline__ BRows<NT> b_rows(const _Float16* bh, const _Float16* 
     return b;
 }
 
-template <int NT, bool SPLIT>
-__device__ __forceinline__ void load_x(XFrag<NT, SPLIT>& f, const BRows<NT>& b, int ks) {
+template <int NT>
+__device__ __forceinline__ void load_x(XFrag<NT>& f, const BRows<NT>& b, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f.xh[nt] = lds_h8(b.h[nt] + ks * 16);
-        if constexpr (SPLIT) f.xl[nt] = lds_h8(b.l[nt] + ks * 16);
+        f.xl[nt] = lds_h8(b.l[nt] + ks * 16);
     }
 }
 
 // Issue the weight loads of the first four k-steps of a segment (called BEFORE the barriers /
 // epilogue that precede the segment's GEMM, so the L2 round trip hides behind them).
 // Returns the pointer of k-step 4.
-template <int MTW, bool SPLIT>
-__device__ __forceinline__ const uint4* prefetch_w(WRing<MTW, SPLIT>& ring, const uint4* __restrict__ w) {
+template <int MTW>
+__device__ __forceinline__ const uint4* prefetch_w(WRing<MTW>& ring, const uint4* __restrict__ w) {
     const uint4* __restrict__ wp = w;
     load_w(ring.r[0], wp);
     load_w(ring.r[1], wp);
@@ -218,15 +202,7 @@ __device__ __forceinline__ const uint4* prefetch_w(WRing<MTW, SPLIT>& ring, cons
 }
 
 template <int NT, int MTW>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW, false>& w, const XFrag<NT, false>& x) {
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA_H(w.wh[mt], x.xh[nt], acc[mt][nt]);
-}
-
-template <int NT, int MTW>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW, true>& w, const XFrag<NT, true>& x) {
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MTW][NT], const WFrag<MTW>& w, const XFrag<NT>& x) {
     // three passes so that consecutive MFMAs never touch the same accumulator
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -253,40 +229,40 @@ struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
 // layer boundary (requested in one burst after the GEMM, 8 waves x 12 loads of 1 KiB serialise on the CU's 64 B/clk
 // vector-memory path for ~1.5k cycles in front of the barrier -- round-3 stamps).  Returns the pointer of k-step 4 of `next`.
 // NEXT_STRIDE: uint4s per k-step of that stream (256 trunk segments, 128 head tiles).
-template <int NT, int MTW, bool SPLIT, class Side = NoSide, class Rest = NoSide>
-__device__ __forceinline__ const uint4* gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW, SPLIT>& ring, const uint4* __restrict__ wp,
+template <int NT, int MTW, class Side = NoSide, class Rest = NoSide>
+__device__ __forceinline__ const uint4* gemm_seg(f32x16 (&acc)[MTW][NT], WRing<MTW>& ring, const uint4* __restrict__ wp,
                                                  BRows<NT> b, int nks, Side&& side = Side{}, Rest&& side_rest = Rest{},
                                                  const uint4* __restrict__ next = nullptr, int next_stride = 256) {
     // nks is a multiple of 4 (every K-segment is zero-padded to 64 columns): no per-step branches.
-    XFrag<NT, SPLIT> x0, x1;
-    load_x<NT, SPLIT>(x0, b, 0);
+    XFrag<NT> x0, x1;
+    load_x<NT>(x0, b, 0);
     int j = 0;
 #pragma unroll 1
     for (int ks = 4; ks < nks; ks += 4) {        // every group but the last: refill the ring
         // sched_barrier pins each weight refill right behind the MFMAs that free its ring slot (left alone hipcc sinks all
         // 16 loads to the end of the group and the ring never runs ahead)
-        load_x<NT, SPLIT>(x1, b, 1);
+        load_x<NT>(x1, b, 1);
         mma_step<NT, MTW>(acc, ring.r[0], x0);
         load_w(ring.r[0], wp);
         H3_PIN();
-        load_x<NT, SPLIT>(x0, b, 2);
+        load_x<NT>(x0, b, 2);
         mma_step<NT, MTW>(acc, ring.r[1], x1);
         load_w(ring.r[1], wp);
         H3_PIN();
-        load_x<NT, SPLIT>(x1, b, 3);
+        load_x<NT>(x1, b, 3);
         mma_step<NT, MTW>(acc, ring.r[2], x0);
         load_w(ring.r[2], wp);
         H3_PIN();
-        load_x<NT, SPLIT>(x0, b, 4);
+        load_x<NT>(x0, b, 4);
         mma_step<NT, MTW>(acc, ring.r[3], x1);
         load_w(ring.r[3], wp);
         H3_PIN();
         if constexpr (!__is_same(Side, NoSide)) { side(j++); H3_PIN(); }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { b.h[nt] += 64; if constexpr (SPLIT) b.l[nt] += 64; }      // four k-steps of 16 halfs
+        for (int nt = 0; nt < NT; ++nt) { b.h[nt] += 64; b.l[nt] += 64; }      // four k-steps of 16 halfs
     }
     // (the refill of a slot is pinned behind the MFMAs that read it, like in the loop)
-    auto refill = [&](WFrag<MTW, SPLIT>& f) __attribute__((always_inline)) {
+    auto refill = [&](WFrag<MTW>& f) __attribute__((always_inline)) {
         if (next != nullptr) {
             const uint4* __restrict__ p = next;
             load_w(f, p);                                       // (advances by a trunk segment's 256)
@@ -294,13 +270,13 @@ __device__ __forceinline__ const uint4* gemm_seg(f32x16 (&acc)[MTW][NT], WRing<M
         }
         H3_PIN();
     };
-    load_x<NT, SPLIT>(x1, b, 1);
+    load_x<NT>(x1, b, 1);
     mma_step<NT, MTW>(acc, ring.r[0], x0);
     refill(ring.r[0]);
-    load_x<NT, SPLIT>(x0, b, 2);
+    load_x<NT>(x0, b, 2);
     mma_step<NT, MTW>(acc, ring.r[1], x1);
     refill(ring.r[1]);
-    load_x<NT, SPLIT>(x1, b, 3);
+    load_x<NT>(x1, b, 3);
     mma_step<NT, MTW>(acc, ring.r[2], x0);
     refill(ring.r[2]);
     mma_step<NT, MTW>(acc, ring.r[3], x1);
@@ -350,34 +326,6 @@ __device__ __forceinline__ u4v pair_halves(h4 a, h4 b) {
 }
 // column (halfs) of the 16-byte group pair_halves() leaves in this lane
 __device__ __forceinline__ int pair_col(int p, int lane) { return 8 * p + 16 * (lane >> 5); }
-
-// fast mode: clamp to the fp16 range (one v_med3 that is also the ReLU), round to nearest, one 8-byte store
-template <int NT, bool RELU, int MTW>
-__device__ __forceinline__ void acc_store_f16(_Float16* sXh, const f32x16 (&acc)[MTW][NT], int nb0, int nt0, int lane) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    h4 hq[4];
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f2 a, b;
-                a[0] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 0], RELU ? 0.0f : -65504.0f, 65504.0f);
-                a[1] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 1], RELU ? 0.0f : -65504.0f, 65504.0f);
-                b[0] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 2], RELU ? 0.0f : -65504.0f, 65504.0f);
-                b[1] = __builtin_amdgcn_fmed3f(acc[mt][nt][4 * q + 3], RELU ? 0.0f : -65504.0f, 65504.0f);
-                const h2f h01 = __builtin_convertvector(a, h2f), h23 = __builtin_convertvector(b, h2f);
-                h4 hv;
-                hv[0] = h01[0]; hv[1] = h01[1]; hv[2] = h23[0]; hv[3] = h23[1];
-                hq[q] = hv;
-                if (q == 3) {
-                    const int row = (32 * (nt0 + nt) + (lane & 31)) * LDH + nb0 + 32 * mt;
-                    *reinterpret_cast<u4v*>(sXh + row + pair_col(0, lane)) = pair_halves(hq[0], hq[2]);
-                    *reinterpret_cast<u4v*>(sXh + row + pair_col(1, lane)) = pair_halves(hq[1], hq[3]);
-                }
-            }
-}
 
 // v - (float)h[0] / v - (float)h[1] in one instruction each (v_fma_mix_f32 converts the f16 source on the fly)
 __device__ __forceinline__ float minus_lo_half(h2 h, float v) {
@@ -515,12 +463,11 @@ __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Fl
 }
 
 // four consecutive columns of one row -> one 8-byte store per plane
-template <bool SPLIT>
 __device__ __forceinline__ void split_store4(_Float16* xh, _Float16* xl, int idx, const float4 v) {
     h4 hv, lv;
     hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
     *reinterpret_cast<h4*>(xh + idx) = hv;
-    if constexpr (SPLIT) {
+    {
         lv[0] = (_Float16)(v.x - (float)hv[0]); lv[1] = (_Float16)(v.y - (float)hv[1]);
         lv[2] = (_Float16)(v.z - (float)hv[2]); lv[3] = (_Float16)(v.w - (float)hv[3]);
         *reinterpret_cast<h4*>(xl + idx) = lv;
@@ -545,12 +492,10 @@ __device__ __forceinline__ int build_part(int tid) {
 }
 
 // two consecutive columns (idx even) -> one 4-byte store per plane
-template <bool SPLIT>
 __device__ __forceinline__ void split_store2(_Float16* xh, _Float16* xl, int idx, float v0, float v1) {
     const h2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
     *reinterpret_cast<h2*>(xh + idx) = h;
-    if constexpr (SPLIT)
-        *reinterpret_cast<h2*>(xl + idx) = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h, v0), minus_hi_half(h, v1));
+    *reinterpret_cast<h2*>(xl + idx) = __builtin_amdgcn_cvt_pkrtz(minus_lo_half(h, v0), minus_hi_half(h, v1));
 }
 
 // OCTAVE: allow the angle-doubling encoder (inference).  The training forward keeps one exact sincos per column: its
@@ -579,7 +524,7 @@ __device__ __forceinline__ void sincos_cw(float a, float* s, float* c) {
 // ILP: the hand-scheduled kernel's encoder -- one wave per SIMD with the whole register file to itself, dependent VALU chains are
 // what it waits for: the three axes' range reductions may interleave and use sincos_cw; the eight-wave kernels keep the library
 // call, one reduction at a time, for their register budget
-template <int M, int THREADS, bool SPLIT, bool OCTAVE = true, bool ILP = false>
+template <int M, int THREADS, bool OCTAVE = true, bool ILP = false>
 __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
                                             const float (&x)[3], int tid) {
     constexpr int G = THREADS / M;               // threads per point row
@@ -627,13 +572,13 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
         for (int k = 0; k < OPP; ++k) {
             if (f0 + k >= a.n_freqs) { sn[0] = sn[1] = sn[2] = cs[0] = cs[1] = cs[2] = 0.f; }   // (zero padding up to k0s)
             const int ck = c0 + 6 * k;                              // [sin x3 | cos x3] of octave f0 + k
-            if (k == 0) split_store<SPLIT>(sXh, sXl, base + ck, sn[0]);
-            else if (ck - 1 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck - 1, carry, sn[0]);
-            if (ck + 1 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck + 1, sn[1], sn[2]);
-            if (ck + 3 < k0s) split_store2<SPLIT>(sXh, sXl, base + ck + 3, cs[0], cs[1]);
+            if (k == 0) split_store(sXh, sXl, base + ck, sn[0]);
+            else if (ck - 1 < k0s) split_store2(sXh, sXl, base + ck - 1, carry, sn[0]);
+            if (ck + 1 < k0s) split_store2(sXh, sXl, base + ck + 1, sn[1], sn[2]);
+            if (ck + 3 < k0s) split_store2(sXh, sXl, base + ck + 3, cs[0], cs[1]);
             carry = cs[2];
             if (k + 1 < OPP) {
-                if (SPLIT && k == 2 && f0 + 3 < a.n_freqs) {        // (five octaves per part only)
+                if (k == 2 && f0 + 3 < a.n_freqs) {        // (five octaves per part only)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         if constexpr (ILP) sincos_cw(a.freqs[f0 + 3] * x[c], &sn[c], &cs[c]);
@@ -648,34 +593,34 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
                 }
             }
         }
-        if (c0 + 6 * OPP - 1 < k0s) split_store<SPLIT>(sXh, sXl, base + c0 + 6 * OPP - 1, carry);
+        if (c0 + 6 * OPP - 1 < k0s) split_store(sXh, sXl, base + c0 + 6 * OPP - 1, carry);
         if (q == G - 1)                                             // columns past the last part's range (G = 2: column 63)
-            for (int c = 3 + 6 * OPP * G; c < k0s; ++c) split_store<SPLIT>(sXh, sXl, base + c, 0.f);
+            for (int c = 3 + 6 * OPP * G; c < k0s; ++c) split_store(sXh, sXl, base + c, 0.f);
         if (q == 0) {
-            split_store2<SPLIT>(sXh, sXl, base + 0, x[0], x[1]);
-            split_store<SPLIT>(sXh, sXl, base + 2, x[2]);
+            split_store2(sXh, sXl, base + 0, x[0], x[1]);
+            split_store(sXh, sXl, base + 2, x[2]);
         }
     } else if (a.xyz != nullptr) {
         if (q == 0) {
-            split_store<SPLIT>(sXh, sXl, base + 0, x[0]); split_store<SPLIT>(sXh, sXl, base + 1, x[1]);
-            split_store<SPLIT>(sXh, sXl, base + 2, x[2]);
-            for (int c = a.in_xyz; c < k0s; ++c) split_store<SPLIT>(sXh, sXl, base + c, 0.f);
+            split_store(sXh, sXl, base + 0, x[0]); split_store(sXh, sXl, base + 1, x[1]);
+            split_store(sXh, sXl, base + 2, x[2]);
+            for (int c = a.in_xyz; c < k0s; ++c) split_store(sXh, sXl, base + c, 0.f);
         }
         const int nf3 = 3 * a.n_freqs;
         for (int j = q; j < nf3; j += G) {
             const int f = j / 3, c = j - 3 * f;
             float s, co;
             sincosf(a.freqs[f] * x[c], &s, &co);
-            split_store<SPLIT>(sXh, sXl, base + 3 + 6 * f + c, s);
-            split_store<SPLIT>(sXh, sXl, base + 3 + 6 * f + 3 + c, co);
+            split_store(sXh, sXl, base + 3 + 6 * f + c, s);
+            split_store(sXh, sXl, base + 3 + 6 * f + 3 + c, co);
         }
     } else {
         const float* src = a.x_emb + p * a.ld_emb + a.off_xyz;
-        for (int c = q; c < k0s; c += G) split_store<SPLIT>(sXh, sXl, base + c, (valid && c < a.in_xyz) ? src[c] : 0.f);
+        for (int c = q; c < k0s; c += G) split_store(sXh, sXl, base + c, (valid && c < a.in_xyz) ? src[c] : 0.f);
     }
     if (vec_t) {
 #pragma unroll
-        for (int j = 0; j < CH0; ++j) split_store4<SPLIT>(sXh, sXl, base + k0s + 4 * (q + j * G), tv[j]);
+        for (int j = 0; j < CH0; ++j) split_store4(sXh, sXl, base + k0s + 4 * (q + j * G), tv[j]);
         if constexpr (CH > CH0) {                     // two threads per row: the second half of the 16 chunks
 #pragma unroll
             for (int j = CH0; j < CH; ++j) {
@@ -683,15 +628,15 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
                 tv[j - CH0] = (valid && c < a.in_t) ? *reinterpret_cast<const float4*>(tsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int j = CH0; j < CH; ++j) split_store4<SPLIT>(sXh, sXl, base + k0s + 4 * (q + j * G), tv[j - CH0]);
+            for (int j = CH0; j < CH; ++j) split_store4(sXh, sXl, base + k0s + 4 * (q + j * G), tv[j - CH0]);
         }
     } else if (with_t) {
         for (int c = q; c < kt; c += G)
-            split_store<SPLIT>(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? tsrc[c] : 0.f);
+            split_store(sXh, sXl, base + k0s + c, (valid && c < a.in_t) ? tsrc[c] : 0.f);
     }
 }
 
-template <int M, int THREADS, bool SPLIT>
+template <int M, int THREADS>
 __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, int tid) {
     constexpr int G = THREADS / M;
     const int r = build_row<M, THREADS>(tid), q = build_part<M, THREADS>(tid);
@@ -715,7 +660,7 @@ __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H
             if (c < a.in_dir) v = sd[c];
             else if (c < a.in_dir + a.in_a) v = sa[c - a.in_dir];
         }
-        split_store<SPLIT>(sXh, sXl, r * LDH + c, v);
+        split_store(sXh, sXl, r * LDH + c, v);
     }
 }
 
@@ -730,25 +675,25 @@ enum { ACT_NONE = 0, ACT_SIGMOID = 1, ACT_FLOW = 2 };
 // the three product terms run as three independent accumulator chains; one chain makes every MFMA wait for the one
 // before it (24 x the full MFMA latency), which the 64-neuron tilings accept: three chains spill 14 VGPRs there.
 // out row = (r&3) + 8*(r>>2) + 4*(lane>>5); only r < 8 (rows < 16) can be live.
-template <int NPT, int NW, bool SPLIT, int MTW>
+template <int NPT, int NW, int MTW>
 __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, float* sRed, const uint32_t* __restrict__ pk,
                                       uint32_t w_off, uint32_t b_off, int n_rows, unsigned kinds, float flow_scale,
                                       float* sRaw, int slot0, int wave, int lane,
-                                      const WRing<MTW, SPLIT>& pre, bool use_pre, const uint4* __restrict__ wrest) {
+                                      const WRing<MTW>& pre, bool use_pre, const uint4* __restrict__ wrest) {
     constexpr int KS = NW / NPT;                 // k-splits (waves beyond NPT * KS idle)
     constexpr int NK = 16 / KS;                  // k-steps per wave
     static_assert(KS == 1 || KS == 2, "heads: 1 or 2 waves per point tile");
     const int pt = wave % NPT, kh = wave / NPT;
     if (KS == 1 && wave >= NPT) return;
-    constexpr int CH = (SPLIT && MTW == 1) ? 3 : 1;      // accumulator chains
+    constexpr int CH = MTW == 1 ? 3 : 1;                 // accumulator chains
     f32x16 acc0[CH];
     H3_HSTAMP(0);
     // the biases of this lane's (up to) eight rows: requested now, used behind the MFMAs and the k-split exchange (round-3 head
     // stamps of the last head call: weights + MFMAs 3.4 k cycles, k-split exchange 1.0 k, bias + activations + record image 2.4 k,
     // final barrier 1.7 k, records 0.8 k; -1.7 % per launch on one box, +-0 on another.  Requesting the second half of the
     // head weights behind the last GEMM as well costs 19 spilled registers: +2.5 %, not kept)
-    // (32-neuron waves only: the 64-neuron tilings have no registers to spare -- the fast mode lost 3.7 % to 12 more spills)
-    constexpr bool EARLY_BIAS = SPLIT && MTW == 1;
+    // (32-neuron waves only: the 64-neuron tilings have no registers to spare)
+    constexpr bool EARLY_BIAS = MTW == 1;
     const float* bias = reinterpret_cast<const float*>(pk + b_off);
     [[maybe_unused]] float bv[8];
     if constexpr (EARLY_BIAS) {
@@ -770,23 +715,21 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
     for (int half = 0; half < NK / 8; ++half) {
         h8 whv[8], wlv[8];
         bool have = false;
-        if constexpr (SPLIT) {
-            if (half == 0 && use_pre) {
-                have = true;
-                if constexpr (MTW == 1) {
+        if (half == 0 && use_pre) {
+            have = true;
+            if constexpr (MTW == 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { whv[j] = pre.r[j].wh[0]; wlv[j] = pre.r[j].wl[0]; }
+                for (int j = 0; j < 4; ++j) { whv[j] = pre.r[j].wh[0]; wlv[j] = pre.r[j].wl[0]; }
 #pragma unroll
-                    for (int j = 4; j < 8; ++j) {
-                        whv[j] = __builtin_bit_cast(h8, wrest[((j - 4) * 2 + 0) * 64]);
-                        wlv[j] = __builtin_bit_cast(h8, wrest[((j - 4) * 2 + 1) * 64]);
-                    }
-                } else {
+                for (int j = 4; j < 8; ++j) {
+                    whv[j] = __builtin_bit_cast(h8, wrest[((j - 4) * 2 + 0) * 64]);
+                    wlv[j] = __builtin_bit_cast(h8, wrest[((j - 4) * 2 + 1) * 64]);
+                }
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        whv[2 * j] = pre.r[j].wh[0]; wlv[2 * j] = pre.r[j].wl[0];
-                        whv[2 * j + 1] = pre.r[j].wh[1]; wlv[2 * j + 1] = pre.r[j].wl[1];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    whv[2 * j] = pre.r[j].wh[0]; wlv[2 * j] = pre.r[j].wl[0];
+                    whv[2 * j + 1] = pre.r[j].wh[1]; wlv[2 * j + 1] = pre.r[j].wl[1];
                 }
             }
         }
@@ -801,14 +744,10 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
         for (int j = 0; j < 8; ++j) {
             const int ks = half * 8 + j;
             const h8 xh = lds_h8(bh + ks * 16);
-            acc0[0] = MFMA_H(wlv[j], xh, acc0[0]);         // the narrow heads keep the weights' lo halfs in both modes
-            if constexpr (SPLIT) {
-                const h8 xl = lds_h8(bl + ks * 16);
-                acc0[CH > 1 ? 1 : 0] = MFMA_H(whv[j], xl, acc0[CH > 1 ? 1 : 0]);
-                acc0[CH > 1 ? 2 : 0] = MFMA_H(whv[j], xh, acc0[CH > 1 ? 2 : 0]);
-            } else {
-                acc0[0] = MFMA_H(whv[j], xh, acc0[0]);
-            }
+            const h8 xl = lds_h8(bl + ks * 16);
+            acc0[0] = MFMA_H(wlv[j], xh, acc0[0]);
+            acc0[CH > 1 ? 1 : 0] = MFMA_H(whv[j], xl, acc0[CH > 1 ? 1 : 0]);
+            acc0[CH > 1 ? 2 : 0] = MFMA_H(whv[j], xh, acc0[CH > 1 ? 2 : 0]);
         }
     }
     float part[8];
@@ -852,15 +791,12 @@ __device__ __forceinline__ void heads(const _Float16* sXh, const _Float16* sXl, 
 // SAVE: training forward -- epilogues also write their activations (fp16) to HBM for the backward pass.
 //   <4,1,*,1>: 128 points, EIGHT waves of 32 neurons each (MTW = 1): every weight byte is fetched once per 128
 //          points (half the L2 stream of <2,1>) by exactly one wave, and two waves per SIMD hide each other's epilogues.
-//   <4,1,false,2,false>: FAST MODE -- 128 points, four waves of 64 neurons x 128 points, single fp16 plane (67.6 KB), two
-//          workgroups per CU, one MFMA per product.
-template <int NT, int WM, bool SAVE = false, int MTW = 2, bool SPLIT = true>
-__global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
+template <int NT, int WM, bool SAVE = false, int MTW = 2>
+__global__ __launch_bounds__(256 * WM * (3 - MTW), (NT == 2 ? 2 : 1)) void nsff_field_kernel_h3(const H3KArgs a) {
     constexpr int M = 32 * NT * WM;
     constexpr int THREADS = 256 * WM * (3 - MTW);
     static_assert(MTW == 2 || WM == 1, "the 32-neuron-per-wave variant has a single row of point tiles");
-    static_assert(SPLIT || !SAVE, "the training forward keeps fp32-grade activations: f16x3 only");
-    __shared__ __attribute__((aligned(16))) _Float16 sX[(SPLIT ? 2 : 1) * M * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
     constexpr int NPT = M / 32, NW = THREADS / 64;                       // heads: point tiles, waves
     __shared__ float sRed[NW > NPT ? NPT * 8 * 64 : 1];                  // k-split partial sums of the heads
     // raw records of the tile (16 floats per point): the heads fill them in, the kernel's last act writes them out as
@@ -868,7 +804,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     __shared__ __attribute__((aligned(16))) float sRaw[M * NSFF_RAW_STRIDE];
     for (int i = threadIdx.x; i < M * NSFF_RAW_STRIDE; i += THREADS) sRaw[i] = 0.f;
     _Float16* sXh = sX;
-    _Float16* sXl = SPLIT ? sX + M * LDH : sX;        // (never dereferenced when !SPLIT)
+    _Float16* sXl = sX + M * LDH;
     const int lane = threadIdx.x & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = MTW == 2 ? (wave_id & 3) : (wave_id >> 1);   // 64-neuron block of the packed weight stream
@@ -891,7 +827,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     const _Float16* sBl = sXl + (32 * nt0 + (lane & 31)) * LDH + 8 * (lane >> 5);
 
     f32x16 acc[MTW][NT];
-    WRing<MTW, SPLIT> ring;
+    WRing<MTW> ring;
     BiasRegs<MTW> br;
     auto seg = [&](uint32_t off, int nks) {
         return reinterpret_cast<const uint4*>(pk + off) + (wave * nks) * 4 * 64 + mt0 * 128 + lane;
@@ -900,7 +836,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
 
     // raw-position mode: this thread's point, read once (it is re-encoded up to four times: both trunks, layer 0 + skip)
     // (the 128-point fast kernel has no registers to spare for it and re-reads the point in every build instead)
-    constexpr bool KEEP_POINT = SPLIT;
+    constexpr bool KEEP_POINT = true;
     float px[3] = {0.f, 0.f, 0.f};
     auto read_point = [&]() {
         const long long bp = p0 + build_row<M, THREADS>(threadIdx.x);
@@ -947,7 +883,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
     H3_SPAN(0);
     const SpanT span0 = span_begin(a.span);
     const H3Step s0 = step_at(s_begin);
-    const uint4* wnext = prefetch_w<MTW, SPLIT>(ring, seg(s0.w_off, s0.nks));
+    const uint4* wnext = prefetch_w<MTW>(ring, seg(s0.w_off, s0.nks));
     load_bias<MTW>(br, fbias(s0.bias_off), nb0, lane);
 #pragma unroll 1
     for (int i = s_begin; i < s_end; ++i) {
@@ -957,10 +893,10 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             pend_flush();                          // (a tile nobody multiplied after it was saved: the last one of a trunk)
             __syncthreads();                       // everyone is done reading the previous tile
             if (st.pre == PRE_SIDE) {
-                build_side<M, THREADS, SPLIT>(sXh, sXl, a, p0, threadIdx.x);
+                build_side<M, THREADS>(sXh, sXl, a, p0, threadIdx.x);
             } else {
                 if constexpr (!KEEP_POINT) read_point();
-                build_input<M, THREADS, SPLIT, !SAVE>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px, threadIdx.x);
+                build_input<M, THREADS, !SAVE>(sXh, sXl, a, p0, st.pre == PRE_INPUT_T, px, threadIdx.x);
             }
             __syncthreads();
             if constexpr (SAVE) {
@@ -983,7 +919,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         const bool has_next = i + 1 < s_end;
         const H3Step nx = step_at(has_next ? i + 1 : i);
         const HeadSel hs = head_sel(st.head);
-        constexpr bool HEAD_PREFETCH = SPLIT && NW / NPT == 2;           // (k-split heads of the f16x3 kernels)
+        constexpr bool HEAD_PREFETCH = NW / NPT == 2;                    // (k-split heads)
         const bool head_next = HEAD_PREFETCH && st.head != HEAD_NONE;
         const uint4* nextp = nullptr;
         if (head_next) nextp = reinterpret_cast<const uint4*>(pk + hs.w_off) + lane + (wave_id / NPT) * 8 * 2 * 64;
@@ -991,7 +927,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
         if constexpr (SAVE) {
             // (one instantiation of the GEMM loop; the copy is switched by a wave-uniform flag)
             const bool copy = H3_SAVE_INTERLEAVE && pend_dst != nullptr;
-            const uint4* wafter = gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks,
+            const uint4* wafter = gemm_seg<NT, MTW>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks,
                 [&](int j) {                     // two blocks per wave behind each group of four k-steps (64 blocks, NW * 4 calls)
 #pragma unroll
                     for (int u = 2 * j; u < 2 * j + 2; ++u) {
@@ -1012,11 +948,11 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
             wnext = wafter;
             if (copy) pend_dst = nullptr;
         } else {
-            wnext = gemm_seg<NT, MTW, SPLIT>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks, NoSide{}, NoSide{}, nextp, nstride);
+            wnext = gemm_seg<NT, MTW>(acc, ring, wnext, b_rows<NT>(sBh, sBl, LDH), st.nks, NoSide{}, NoSide{}, nextp, nstride);
         }
         H3_STAMP(2);
         if (has_next) {                            // next segment's weights + bias fly during the epilogue
-            if (!head_next) wnext = prefetch_w<MTW, SPLIT>(ring, seg(nx.w_off, nx.nks));
+            if (!head_next) wnext = prefetch_w<MTW>(ring, seg(nx.w_off, nx.nks));
             if (nx.bias_off != NSFF_NONE) load_bias<MTW>(br, fbias(nx.bias_off), nb0, lane);
         }
         if (st.post != POST_NONE) {
@@ -1028,10 +964,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                 if (st.save && a.save_masks != nullptr && st.post == POST_RELU)
                     mk = a.save_masks + ((long long)(st.save - 1) * a.n_tiles + tile64) * 256;   // (per-thread slot: acc_store)
             }
-            if constexpr (!SPLIT) {
-                if (st.post == POST_RELU) acc_store_f16<NT, true, MTW>(sXh, acc, nb0, nt0, lane);
-                else acc_store_f16<NT, false, MTW>(sXh, acc, nb0, nt0, lane);
-            } else if (st.post == POST_RELU) {
+            if (st.post == POST_RELU) {
                 if (SAVE && mk != nullptr) acc_store<NT, true, MTW, SAVE>(sXh, sXl, acc, nb0, nt0, lane, mk, ks_end > 4);
                 else acc_store<NT, true, MTW>(sXh, sXl, acc, nb0, nt0, lane);
             } else acc_store<NT, false, MTW>(sXh, sXl, acc, nb0, nt0, lane);
@@ -1043,11 +976,11 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), ((NT == 2 || !SPLIT) ? 2 : 1)
                     pend_set(a.save_acts + (long long)(st.save - 1) * a.save_stride + tile64 * (64 * NSFF_W), NSFF_W, NSFF_W);
             }
             if (st.head != HEAD_NONE) {
-                heads<NPT, NW, SPLIT, MTW>(sXh, sXl, sRed, pk, hs.w_off, hs.b_off, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0,
+                heads<NPT, NW, MTW>(sXh, sXl, sRed, pk, hs.w_off, hs.b_off, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0,
                                            wave_id, lane, ring, head_next, wnext);
                 // (a head in the middle of a trunk -- training forward, view directions: the ring carried its weights, so the
                 //  next segment's first k-steps are requested here, beside the head's activation arithmetic)
-                if (has_next && head_next) wnext = prefetch_w<MTW, SPLIT>(ring, seg(nx.w_off, nx.nks));
+                if (has_next && head_next) wnext = prefetch_w<MTW>(ring, seg(nx.w_off, nx.nks));
             }
         }
     }
@@ -1330,7 +1263,7 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
         h3a_encode10(sXh, sXl, a, px, threadIdx.x, pre);
     } else {
         pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
-        build_input<M, THREADS, true, !SAVE, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
+        build_input<M, THREADS, !SAVE, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
     }
     H3A_TSTAMP(57);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
@@ -2230,11 +2163,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     };
     int lrc;
     const bool saves = k.save_acts || k.save_xin || k.save_masks || k.save_side;
-    if (points_per_block == NSFF_H3_FAST) {       // "f16": one product per MAC, 128-point tiles, two workgroups per CU
-        if (saves) return NSFF_ERR_INVALID;
-        lrc = launch(nsff_field_kernel_h3<4, 1, false, 2, false>, 128, 256);
-        g_nsff_last_h3_kernel = NSFF_KERNEL_F16_FAST;
-    } else if (saves && points_per_block == 64) { // training forward, 64-point tiling (A/B against the default below)
+    if (saves && points_per_block == 64) { // training forward, 64-point tiling (A/B against the default below)
         lrc = launch(nsff_field_kernel_h3<2, 1, true>, 64, 256);
         g_nsff_last_h3_kernel = NSFF_KERNEL_H3_SAVE;
     } else if (saves) {

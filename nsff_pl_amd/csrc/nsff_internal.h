@@ -9,9 +9,7 @@ int nsff_h3_pack_weights(const NsffModelDesc* desc, const float* const* params, 
 int nsff_h3_fold_heads(const NsffModelDesc* desc, const float* const* params, void* packed, hipStream_t st);
 int nsff_fold_rows_f32(const NsffModelDesc* desc, const float* const* params, float* s_w, float* s_b, float* t_w, float* t_b,
                        hipStream_t st);
-// args already validated by nsff_field_query; points_per_block is 64 / 128 / 129 / 130 (f16x3 tilings) or
-// NSFF_H3_FAST (the single-product "f16" fast mode on the same packed weights)
-#define NSFF_H3_FAST 1
+// args already validated by nsff_field_query; points_per_block is 64 / 130 / 131 (the f16x3 tilings of NsffFieldArgs::tile_points)
 // span (or null, profiling): NSFF_SPAN_WORDS zeroed uint64 that receive the summed lifetimes of a sample of the launch's
 // workgroups in shader-clock ticks [0] and in wall-clock ticks [1]
 #define NSFF_SPAN_WORDS 2

@@ -40,7 +40,7 @@ class GraphedRender:
         """Packed weights live in buffers whose addresses the graphs hold: re-pack (eagerly, in place) whatever changed."""
         prec = config.PRECISIONS[config.get_precision()]
         for m in self.models.values():
-            m.packed(1 if prec == 3 else prec, inference=True)
+            m.packed(prec, inference=True)
 
     def _capture(self, key, rays, ts):
         dev = rays.device

@@ -336,15 +336,6 @@ def _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_
     want_grad = (torch.is_grad_enabled() and not test_time and
                  bool(autograd.grad_parameters(models, embeddings)))
     rec = {} if want_grad else None
-    if want_grad and config.get_precision() == "f16":
-        # the single-product fast mode is inference only: a call that will be differentiated runs (and saves its
-        # activations) in the parity-grade f16x3 arithmetic
-        config.set_precision("f16x3")
-        try:
-            return _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_std, N_importance, chunk,
-                                test_time, kwargs, fine_points)
-        finally:
-            config.set_precision("f16")
     with torch.cuda.device(rays.device), torch.no_grad():
         results = {}
         rays = rays.contiguous().float()

@@ -179,3 +179,30 @@ def test_bench_in_its_torchrun_form_on_one_gpu(hip_lib):
     assert p.returncode == 0, p.stderr[-3000:]
     line = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")][0]
     assert "per_rank" not in line and line["config"]["hip_graph"] is True
+
+
+@pytest.mark.parametrize("extra", [["--workload", "train"], ["--workload", "train", "--graph"], ["--workload", "eval"]])
+def test_bench_other_workloads_in_their_torchrun_form_on_one_gpu(extra, hip_lib):
+    """The three forms the driver may start under the launcher besides the headline: the C4 training step (the flat-gradient
+    RCCL all-reduce between the step's two hipGraphs / between backward and Adam) and the strong-scaling evaluation frame
+    (ray shards + the overlapped pixel all-gather) -- world size 1 over RCCL on the one GPU there is; rank 0 prints ONE line
+    that carries per_rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            ndist.INIT_ENV)}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29673", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-aux", "--no-cpu-baseline", "--settle-ms", "0"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 1e5
+    assert line["per_rank"]["ms_per_step_max"] <= line["ms_per_step"] * 1.001
+    if "train" in extra:
+        assert "all-reduce" in line["config"]["parallelism"] and line["config"]["hip_graph"] is ("--graph" in extra)
+        assert line["roofline"]["kernel"] == "nsff_field_kernel_h3a_save"
+        if "--graph" not in extra:       # (a replayed graph does not pass through the C-ABI's launch profiler)
+            assert line["roofline"]["frac"] > 0.05
+    else:
+        assert line["scaling"] == "strong" and line["per_rank"]["gather_ms_per_step_max"] > 0

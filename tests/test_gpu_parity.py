@@ -28,8 +28,7 @@ def precision(request):
     every form the library has: what it picks by launch size ("f16x3": 64-point tiles for the small golden scenes, 128-point
     tiles for the full-size tests), 128-point tiles forced ("f16x3-130": the HAND-SCHEDULED body nsff_field_kernel_h3a
     wherever a launch's trunks qualify -- every scene without a view-direction branch -- else the compiler-scheduled
-    eight-wave kernel) and the compiler-scheduled eight-wave kernel forced ("f16x3-131").  The single-product "f16" fast
-    mode has its own error-reporting test (tests/test_fast_mode.py)."""
+    eight-wave kernel) and the compiler-scheduled eight-wave kernel forced ("f16x3-131")."""
     from nsff_pl_amd import config
     name, _, tile = request.param.partition("-")
     config.set_precision(name)

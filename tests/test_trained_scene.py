@@ -1,5 +1,5 @@
-"""A TRAINED synthetic scene (SURVEY.md 8f row N1 end to end): the native training step really fits a scene, and the parity /
-fast-mode error figures hold on trained weights, not only on the seeded "sharp" initialisations of the golden scenes.
+"""A TRAINED synthetic scene (SURVEY.md 8f row N1 end to end): the native training step really fits a scene, and the parity
+figures hold on trained weights, not only on the seeded "sharp" initialisations of the golden scenes.
 
 A teacher field renders 1024 rays (exact fp32); a student with another seed and plain torch initialisation is trained on the
 teacher's colours by NSFFTrainer -- HIP training forward, fused loss, native backward, native Adam (reference train.py:174-198).
@@ -49,12 +49,11 @@ def test_student_fits_the_teacher_and_precisions_agree_on_trained_weights(hip_li
     for _ in range(STEPS):
         log = tr.step(batch)
     assert torch.isfinite(log["train/loss"]).all() if torch.is_tensor(log["train/loss"]) else True
-    out = {p: _render(student, emb_s, rays, ts, cfg, p) for p in ("f32", "f16x3", "f16")}
+    out = {p: _render(student, emb_s, rays, ts, cfg, p) for p in ("f32", "f16x3")}
     after = _psnr(out["f16x3"]["rgb_fine"], target)
     # measured: 18.3 dB untrained -> 33.9 dB after 300 steps (37-40 dB after 600)
     assert after > before + 10.0 and after > 28.0, (before, after)
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     for key in ("rgb_fine", "depth_fine"):
         assert rel(out["f16x3"][key], out["f32"][key]) <= 1e-4, key          # measured 7e-7 / 1e-6: the parity bar on trained weights
-        assert rel(out["f16"][key], out["f32"][key]) <= 5e-3, key            # fast mode, measured 3e-4
-    assert abs(_psnr(out["f16"]["rgb_fine"], target) - _psnr(out["f32"]["rgb_fine"], target)) < 0.1
+    assert abs(_psnr(out["f16x3"]["rgb_fine"], target) - _psnr(out["f32"]["rgb_fine"], target)) < 0.01

@@ -24,13 +24,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--tile-points", type=int, default=0)
     args = ap.parse_args()
     from nsff_pl_amd import config
     config.set_precision(args.precision)
     config.set_tile_points(args.tile_points)
-    peak = {"f32": 157.3e12, "f16x3": 2500e12, "f16": 2500e12}[args.precision]
+    peak = {"f32": 157.3e12, "f16x3": 2500e12}[args.precision]
     dev = "cuda:0"
     cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=args.rays, seed=0)
     models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)

@@ -1,6 +1,6 @@
 """Debug / evidence: a TRAINED synthetic scene.  A teacher field (seeded "sharp" init) renders 1024 rays; a student with another
 seed and plain torch init is trained on the teacher's colours with NSFFTrainer (native forward / loss / backward / Adam).
-Prints the PSNR trajectory and, on the trained weights, parity-grade f16x3 vs exact f32 vs the f16 fast mode.
+Prints the PSNR trajectory and, on the trained weights, parity-grade f16x3 vs exact f32.
     python tools/debug/teacher_student.py [steps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,10 +56,10 @@ def main():
         log = tr.step(batch)
         if i % 50 == 0 or i == STEPS - 1:
             print(f"step {i:4d}  loss {float(log['train/loss']):.5f}  train/psnr {float(log['train/psnr']):.2f} dB", flush=True)
-    out = {p: render(student, emb_s, rays, ts, p) for p in ("f32", "f16x3", "f16")}
+    out = {p: render(student, emb_s, rays, ts, p) for p in ("f32", "f16x3")}
     for p, o in out.items():
         print(f"trained student, {p:6s}: PSNR vs teacher {psnr(o['rgb_fine'], target):.3f} dB", flush=True)
-    for p in ("f16x3", "f16"):
+    for p in ("f16x3",):
         d = (out[p]["rgb_fine"] - out["f32"]["rgb_fine"]).abs().max() / out["f32"]["rgb_fine"].abs().max()
         dd = (out[p]["depth_fine"] - out["f32"]["depth_fine"]).abs().max() / out["f32"]["depth_fine"].abs().max()
         print(f"trained student, {p:6s} vs f32: rgb_fine max-norm rel {float(d):.2e}, depth_fine {float(dd):.2e}", flush=True)
