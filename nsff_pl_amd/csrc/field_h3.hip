@@ -636,6 +636,26 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
     }
 }
 
+// the time-code columns [k0s, k0s + kt) of the trunk input tile alone (the position part is someone else's): float4 rows
+template <int M, int THREADS>
+__device__ __forceinline__ void build_time_part(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, int tid) {
+    constexpr int G = THREADS / M;
+    constexpr int CH = 16 / G;
+    const int r = build_row<M, THREADS>(tid), q = build_part<M, THREADS>(tid);
+    const long long p = p0 + r;
+    const bool valid = p < a.n_points;
+    const int k0s = (int)a.L.k0s;
+    const float* tsrc = a.t_emb + ((valid ? p : a.n_points - 1) / a.pts_per_ray) * a.in_t;
+    float4 tv[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = 4 * (q + j * G);
+        tv[j] = (valid && c < a.in_t) ? *reinterpret_cast<const float4*>(tsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) split_store4(sXh, sXl, r * LDH + k0s + 4 * (q + j * G), tv[j]);
+}
+
 template <int M, int THREADS>
 __device__ __forceinline__ void build_side(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, int tid) {
     constexpr int G = THREADS / M;
@@ -1092,7 +1112,10 @@ __device__ __forceinline__ void h3a_store8(_Float16* rh, _Float16* rl, int col, 
 // back to back they hold every wave at the issue stage for that long.  Slots 0..2 are the caller's: requested behind its own
 // loads (the point, the bias rows) and landed with them -- the compiler's wait for the point cannot see the statements' loads
 // and waits for everything in flight, so what is requested in front of it shares the point's memory latency.
-template <class Pre>
+// EXACT (the training forward): no angle doubling -- one range-reduced sin / cos per column (sincos_cw: ~1e-7 absolute, the accuracy
+// class of the library call at a third of its instructions), because the gradients are compared with autograd of the reference
+// network, whose ReLU pattern answers a 4-ulp change of the encoding with per-cent changes of single weight gradients.
+template <bool EXACT, class Pre>
 __device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const H3KArgs& a, const float (&x)[3], int tid, const Pre& pre) {
     const int r = tid & 127;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 7);
@@ -1107,7 +1130,13 @@ __device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const
         for (int c = 0; c < 3; ++c) { v[6 * k + c] = sn[c]; v[6 * k + 3 + c] = cs[c]; }
         if (k == 0) pre.template slot<4>();
         if (k == 3) pre.template slot<5>();
-        if (k == 2) {
+        if constexpr (EXACT) {
+            if (k < 4) {
+                const float fk = a.freqs[5 * q + k + 1];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sincos_cw(fk * x[c], &sn[c], &cs[c]);
+            }
+        } else if (k == 2) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) sincos_cw(fb * x[c], &sn[c], &cs[c]);
         } else if (k < 4) {
@@ -1258,9 +1287,12 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
     if (threadIdx.x == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
     H3A_TSTAMP(53);
-    const bool lean = !SAVE && a.octave_freqs && a.n_freqs == 10 && !(tr == 1 && !tb);
+    // (the lean encoder builds the position part; the dynamic trunk's time-code columns -- when they go through the matrix pipe:
+    //  no folded rows, and every training forward -- are appended by build_time_part)
+    const bool lean = a.octave_freqs && a.n_freqs == 10 && (SAVE || !(tr == 1 && !tb));
     if (lean) {
-        h3a_encode10(sXh, sXl, a, px, threadIdx.x, pre);
+        h3a_encode10<SAVE>(sXh, sXl, a, px, threadIdx.x, pre);
+        if (SAVE && tr == 1 && !tb) build_time_part<M, THREADS>(sXh, sXl, a, p0, threadIdx.x);
     } else {
         pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
         build_input<M, THREADS, !SAVE, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);

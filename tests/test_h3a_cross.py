@@ -219,8 +219,8 @@ def test_view_direction_static_trunk_on_the_hand_scheduled_kernel(in_a, hip_lib)
 @pytest.mark.parametrize("arch", [0, 1, 2, 4])
 def test_training_forward_on_the_hand_scheduled_kernel(arch, hip_lib):
     """nsff_field_kernel_h3a_save (the SAVE build of the body: activation copies and ReLU sign words riding in the phases) against
-    the eight-wave training forward: the same records (2e-5), the same encoded input tile (bit for bit: one exact sin / cos per
-    column in both), every layer's saved activation equal up to one fp16 rounding on a fraction of a per cent of the values (the
+    the eight-wave training forward: the same records (2e-5), the same encoded input tile (one range-reduced sin / cos per column
+    in both: equal up to fp16 rounding flips), every layer's saved activation equal up to one fp16 rounding on a fraction of a per cent of the values (the
     two kernels add the same products in different orders), sign words that differ only where the activation is a rounding
     error away from zero -- and nothing written outside the evaluated trunks' slots."""
     from nsff_pl_amd import field_grad
@@ -259,7 +259,10 @@ def test_training_forward_on_the_hand_scheduled_kernel(arch, hip_lib):
         for lo, hi in ((0, 4), (4, 8), (8, 14)):
             scale = max(np.abs(b[:, lo:hi]).max(), 1e-30)
             assert np.abs(a[:, lo:hi] - b[:, lo:hi]).max() <= 2e-5 * scale, (ARCHS[arch], S, sm, tm, lo)
-        assert torch.equal(xin_a.view(torch.int16), xin_b.view(torch.int16))
+        # the encoded input tile: one range-reduced sin / cos per column in both kernels (Cody-Waite here, the library call there):
+        # equal after the rounding to fp16 except where an fp32 last-place difference straddles a rounding boundary
+        dx = (xin_a.float() - xin_b.float()).abs()
+        assert float(dx.max()) <= 2.0 ** -10 and float((dx > 0).float().mean()) < 0.01, (float(dx.max()), float((dx > 0).float().mean()))
         written = [t * (D + 1) + l for t, on in ((0, sm), (1, tm)) if on for l in range(D)]
         for slot in range(acts_a.shape[0]):
             xa, xb = acts_a[slot].float(), acts_b[slot].float()
