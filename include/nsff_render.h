@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      25
+#define NSFF_ABI_VERSION      26
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -592,6 +592,13 @@ int nsff_prof_collect_clock(int64_t* launches, double* total_ms, double* total_f
 #define NSFF_KERNEL_H3A_SAVE  9   /* f16x3 training forward on the hand-scheduled body (nsff_field_kernel_h3a_save)          */
 #define NSFF_KERNEL_H3A_SIDE  8   /* NSFF_KERNEL_H3A[_TBIAS] whose static trunk has the view-direction branch (NsffFieldArgs::s_bias) */
 int         nsff_last_field_kernel(void);
+/* Workgroups of that launch when it ran the hand-scheduled inference kernel (0 otherwise).  Large launches of that kernel are
+ * PERSISTENT: one workgroup per compute unit, each walking tiles  first, first + stride, ...  of one trunk (both trunks: the
+ * workgroups of XCDs 0..3 take the static trunk, 4..7 the dynamic one -- taken when both trunks cost the same number of matrix
+ * steps); the plain bias rows are loaded once per workgroup and the next tile's first eight weight slots are requested while the
+ * current tile's records are stored.  Results are bit-identical to the one-workgroup-per-tile form (environment
+ * NSFF_NO_PERSIST=1, read per launch, selects that form for A/B measurements). */
+int         nsff_last_field_grid(void);
 /* Host-only (no GPU work): the f16x3 step program of an inference launch with these modes -- steps[n][4] = {weight segment
  * offset (words), bias offset (words; 0xFFFFFFFF = accumulate), nks | pre << 8 | post << 16 | head << 24, 0} -- and the phase
  * programs (8-dword descriptors, 36 at most per trunk) the hand-scheduled kernel would execute for its static / dynamic trunk;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 25
+ABI_VERSION = 26
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -147,6 +147,7 @@ class FlowGradArgs(C.Structure):
 _SIGNATURES = {
     "nsff_abi_version": (C.c_int, []),
     "nsff_last_field_kernel": (C.c_int, []),
+    "nsff_last_field_grid": (C.c_int, []),
     "nsff_field_phase_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "nsff_time_bias_rows": (C.c_int, [C.POINTER(ModelDesc)]),
@@ -711,6 +712,12 @@ KERNEL_NAMES = {0: None, 1: "f32", 2: "h3_64", 3: "h3_8wave", 4: "h3a", 5: "h3_s
 def last_field_kernel():
     """name of the kernel the last field_query of this process launched (include/nsff_render.h: NSFF_KERNEL_*)"""
     return KERNEL_NAMES[load().nsff_last_field_kernel()]
+
+
+def last_field_grid():
+    """Workgroups of the last field launch when it ran the hand-scheduled inference kernel (0 otherwise): the CU count for a
+    persistent launch, one (two: both trunks) per 128-point tile otherwise (include/nsff_render.h::nsff_last_field_grid)."""
+    return int(load().nsff_last_field_grid())
 
 
 def h3a_program(model, static_mode, transient_mode, fold_t=False, side_fold=False):

@@ -373,7 +373,7 @@ __global__ void nsff_posenc_kernel(const PosencArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-int g_last_field_kernel = 0;
+int g_last_field_kernel = 0, g_last_field_grid = 0;
 struct ProfRec { hipEvent_t e0, e1; double flops, executed; int span_slot; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -636,6 +636,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
         g_last_field_kernel = NSFF_KERNEL_F32;
     }
     if (g.precision != NSFF_PREC_F32) g_last_field_kernel = g_nsff_last_h3_kernel;
+    g_last_field_grid = g.precision != NSFF_PREC_F32 ? g_nsff_last_h3_grid : 0;
     if (prof) {
         hipEventRecord(pr.e1, st);
         pr.flops = field_flops_per_point(d, g.static_mode, g.transient_mode,
@@ -653,6 +654,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
 }
 
 int nsff_last_field_kernel(void) { return g_last_field_kernel; }
+int nsff_last_field_grid(void) { return g_last_field_grid; }
 
 int nsff_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

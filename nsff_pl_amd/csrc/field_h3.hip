@@ -22,6 +22,7 @@
 // (64 points, two workgroups per CU) hides epilogues behind the other workgroup's MFMAs.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "nsff_layout_h3.h"
 #include "nsff_common.h"
@@ -524,8 +525,8 @@ __device__ __forceinline__ void sincos_cw(float a, float* s, float* c) {
 // ILP: the hand-scheduled kernel's encoder -- one wave per SIMD with the whole register file to itself, dependent VALU chains are
 // what it waits for: the three axes' range reductions may interleave and use sincos_cw; the eight-wave kernels keep the library
 // call, one reduction at a time, for their register budget
-template <int M, int THREADS, bool OCTAVE = true, bool ILP = false>
-__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, bool with_t,
+template <int M, int THREADS, bool OCTAVE = true, bool ILP = false, class KA = H3KArgs>
+__device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const KA& a, long long p0, bool with_t,
                                             const float (&x)[3], int tid) {
     constexpr int G = THREADS / M;               // threads per point row
     constexpr int CH = 16 / G;                   // float4 chunks of a 64-column time-code segment per thread
@@ -637,8 +638,8 @@ __device__ __forceinline__ void build_input(_Float16* sXh, _Float16* sXl, const 
 }
 
 // the time-code columns [k0s, k0s + kt) of the trunk input tile alone (the position part is someone else's): float4 rows
-template <int M, int THREADS>
-__device__ __forceinline__ void build_time_part(_Float16* sXh, _Float16* sXl, const H3KArgs& a, long long p0, int tid) {
+template <int M, int THREADS, class KA = H3KArgs>
+__device__ __forceinline__ void build_time_part(_Float16* sXh, _Float16* sXl, const KA& a, long long p0, int tid) {
     constexpr int G = THREADS / M;
     constexpr int CH = 16 / G;
     const int r = build_row<M, THREADS>(tid), q = build_part<M, THREADS>(tid);
@@ -1069,6 +1070,14 @@ struct H3AArgs {
     int n_bias[2];
     int head[2];                        // HEAD_* evaluated on the trunk's last activation
     H3AHeadSel hsel[2];                 // ... and what that means (h3a_head_sel of the host): one scalar load in the kernel
+    // PERSISTENT launch (p_mode != 0): the grid is one workgroup per CU and a workgroup walks tiles tile0, tile0 + stride, ... of ONE
+    // trunk -- everything that does not depend on the tile (the plain bias rows, the head biases, the record image's zeros) is set
+    // up once, and the next tile's first eight weight slots are requested behind the body, so that they cross the CU's vector-memory
+    // path while the records of this tile are stored.  1: one trunk in the launch (whole records); 2: both trunks -- workgroup b runs
+    // on XCD b % 8 (observed, not promised: only L2 locality depends on it), XCDs 0..3 take the static trunk, 4..7 the dynamic one,
+    // each trunk's 2.3 MB of weights stay in its XCDs' L2s; 3: the dynamic trunk of a launch whose static trunk is another kernel's.
+    int p_mode;
+    long long p_tiles;                  // 128-point tiles of the launch
     int sig_ride;                       // static trunk with the view-direction branch: sigma = sum of the 8 partial sums the body's
                                         // sigma ride left at floats 4..11 of the record image + the bias at packed word sig_b_off
     uint32_t sig_b_off;
@@ -1080,7 +1089,9 @@ static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kern
 struct H3APre {
     unsigned long long pk;
     unsigned r1, r2, n1, lane16;
+    bool on;          // (wave-uniform) false: the slots of this tile were requested behind the previous tile's body (persistent launch)
     template <int K> __device__ __forceinline__ void slot() const {
+        if (!on) return;
         const unsigned off = (K < (int)n1 ? r1 : r2) + 4096u * K;
 #define H3A_SLOT_CASE(k) if constexpr (K == k) asm volatile(H3A_PRE_SLOT##k : : [pk] "s"(pk), [off] "s"(off), [lane16] "v"(lane16) : H3A_PRE_SLOT##k##_CLOBBERS)
         H3A_SLOT_CASE(0); H3A_SLOT_CASE(1); H3A_SLOT_CASE(2); H3A_SLOT_CASE(3);
@@ -1115,8 +1126,8 @@ __device__ __forceinline__ void h3a_store8(_Float16* rh, _Float16* rl, int col, 
 // EXACT (the training forward): no angle doubling -- one range-reduced sin / cos per column (sincos_cw: ~1e-7 absolute, the accuracy
 // class of the library call at a third of its instructions), because the gradients are compared with autograd of the reference
 // network, whose ReLU pattern answers a 4-ulp change of the encoding with per-cent changes of single weight gradients.
-template <bool EXACT, class Pre>
-__device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const H3KArgs& a, const float (&x)[3], int tid, const Pre& pre) {
+template <bool EXACT, class Pre, class KA = H3KArgs>
+__device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const KA& a, const float (&x)[3], int tid, const Pre& pre) {
     const int r = tid & 127;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 7);
     const float fa = a.freqs[5 * q], fb = a.freqs[5 * q + 3];
@@ -1192,9 +1203,18 @@ __device__ __forceinline__ void h3a_encode10(_Float16* sXh, _Float16* sXl, const
 // backward kernel's accumulator order, riding in the phases), an exact sin / cos per embedding column (the gradients are compared
 // with autograd of the reference network: see build_input's OCTAVE note), the time code through the matrix pipe (its columns'
 // weight gradients need the saved input tile) and the encoded input tile saved in front of the trunk.
+// The arguments are read through the kernel-argument segment pointer, made opaque once per tile and once behind the body: the body
+// leaves the compiler 40 scalar and 24 (SAVE: 14) vector registers, and what it would keep of the arguments across the body -- or
+// hoist out of the tile loop -- it would have to spill; re-read, they are scalar loads that hit the constant cache.
+typedef const __attribute__((address_space(4))) H3AArgs H3AKernArgs;
+__device__ __forceinline__ H3AKernArgs* h3a_args() {
+    H3AKernArgs* p = (H3AKernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 template <bool SAVE>
-__device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
-    const H3KArgs& a = aa.k;
+__device__ __forceinline__ void h3a_kernel() {
     constexpr int M = 128, THREADS = 256;
     __shared__ __attribute__((aligned(16))) _Float16 sX[2 * M * LDH];
     __shared__ __attribute__((aligned(16))) float sRaw[M * NSFF_RAW_STRIDE];
@@ -1202,17 +1222,38 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
     for (int i = threadIdx.x; i < M * NSFF_RAW_STRIDE; i += THREADS) sRaw[i] = 0.f;
     _Float16* sXh = sX;
     _Float16* sXl = sX + M * LDH;
-    const int lane = threadIdx.x & 63;
-    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    long long tile = blockIdx.x;
-    int tr = a.n_static_steps > 0 ? 0 : 1, piece = 0;
-    if (a.split_trunks) {
+    long long tile = blockIdx.x, tile_stride = 0x7fffffffffffLL, tile_end = 0x7fffffffffffLL;
+    int tr, piece = 0;
+    SpanT span0;
+  {
+    H3AKernArgs& aa = *h3a_args();
+    const auto& a = aa.k;
+    tr = a.n_static_steps > 0 ? 0 : 1;
+    if (aa.p_mode != 0) {
+        tile_end = aa.p_tiles;
+        tile_stride = gridDim.x;
+        if (aa.p_mode == 2) {                       // trunk by XCD, tile j of the trunk's gridDim.x / 2 workgroups
+            const int x = blockIdx.x & 7;
+            tr = x >> 2; piece = tr + 1;
+            tile = (long long)(blockIdx.x >> 3) * 4 + (x & 3);
+            tile_stride = gridDim.x >> 1;
+        } else if (aa.p_mode == 3) { tr = 1; piece = 2; }
+    } else if (a.split_trunks) {
         if (tile < a.grid_tiles) { tr = 0; piece = 1; }
         else { tile -= a.grid_tiles; tr = 1; piece = 2; }
     }
-    const long long p0 = tile * M;
+    span0 = span_begin(a.span);
+  }
+#pragma unroll 1
+  for (int it = 0; tile < tile_end; ++it, tile += tile_stride) {
+    H3AKernArgs& aa = *h3a_args();
+    const auto& a = aa.k;
     const uint32_t* __restrict__ pk = a.packed;
-    const SpanT span0 = span_begin(a.span);
+    unsigned tid_ = threadIdx.x;            // (opaque per tile: nothing derived from the thread index is carried across the body)
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const long long p0 = tile * M;
 #ifdef H3_TIMING
 #define H3A_TSTAMP(k) do { if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1224,7 +1265,7 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
     float px[3];
     {
         const long long last = a.n_points - 1;
-        const long long bp = p0 + build_row<M, THREADS>(threadIdx.x) < last ? p0 + build_row<M, THREADS>(threadIdx.x) : last;
+        const long long bp = p0 + build_row<M, THREADS>(tid_) < last ? p0 + build_row<M, THREADS>(tid_) : last;
         px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2];      // (rows past the end: the last point)
     }
     // bias table of this trunk (fp32 rows of 256): the body initialises its accumulators from it with ds_read_b128.
@@ -1250,59 +1291,79 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
         uint32_t boff[H3A_MAX_BIAS];
 #pragma unroll
         for (int r4 = 0; r4 < H3A_MAX_BIAS / 4; ++r4) {
-            const u4v q = reinterpret_cast<const u4v*>(&aa.bias_off[tr][0])[r4];
+            const u4v q = reinterpret_cast<const __attribute__((address_space(4))) u4v*>(&aa.bias_off[tr][0])[r4];
             boff[4 * r4] = q[0]; boff[4 * r4 + 1] = q[1]; boff[4 * r4 + 2] = q[2]; boff[4 * r4 + 3] = q[3];
         }
+        if (it == 0) {
 #pragma unroll
-        for (int r = 0; r < H3A_MAX_BIAS; ++r) {
-            const uint32_t off = r < nb ? boff[r] : 0u;
-            // (selects as mask arithmetic: the compiler turns the conditional form into two scalar branches per row)
-            const long long per_ray = -(long long)(off >> 31), half_b = -(long long)((off >> 8) & 1u);
-            const long long at_ray = tb_at[0] + (half_b & (tb_at[1] - tb_at[0])) + (long long)((off & 0xffu) * (NSFF_W * 4));
-            const long long at = (at_ray & per_ray) | ((long long)off * 4 & ~per_ray);
-            bv[r] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + at)[threadIdx.x];
+            for (int r = 0; r < H3A_MAX_BIAS; ++r) {
+                const uint32_t off = r < nb ? boff[r] : 0u;
+                // (selects as mask arithmetic: the compiler turns the conditional form into two scalar branches per row)
+                const long long per_ray = -(long long)(off >> 31), half_b = -(long long)((off >> 8) & 1u);
+                const long long at_ray = tb_at[0] + (half_b & (tb_at[1] - tb_at[0])) + (long long)((off & 0xffu) * (NSFF_W * 4));
+                const long long at = (at_ray & per_ray) | ((long long)off * 4 & ~per_ray);
+                bv[r] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + at)[tid_];
+            }
+        } else {
+            // a later tile of a persistent launch: only the per-ray rows change (at most six: one scalar branch per table row)
+#pragma unroll
+            for (int r = 0; r < H3A_MAX_BIAS; ++r) {
+                const uint32_t off = r < nb ? boff[r] : 0u;
+                bv[r] = 0.f;
+                if (off >> 31) {
+                    const long long at = tb_at[(off >> 8) & 1u] + (long long)((off & 0xffu) * (NSFF_W * 4));
+                    bv[r] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + at)[tid_];
+                }
+            }
         }
     }
     // (the heads' biases -- 32 floats -- travel with the table: the records loop below reads them from LDS)
-    const H3AHeadSel hs = aa.hsel[tr];
-    const float hbias = reinterpret_cast<const float*>(pk)[hs.b_off + (threadIdx.x & 31)];
+    const H3AHeadSel hs = {aa.hsel[tr].w_off, aa.hsel[tr].b_off, aa.hsel[tr].n_rows, aa.hsel[tr].slot0, aa.hsel[tr].kinds};
+    const float hbias = reinterpret_cast<const float*>(pk)[hs.b_off + (tid_ & 31)];
     const bool sig_ride = tr == 0 && aa.sig_ride != 0;
     const float sig_b = reinterpret_cast<const float*>(pk)[sig_ride ? aa.sig_b_off : 0u];
     H3A_TSTAMP(52);
     H3APre pre;
     {
-        const H3APhase& d0 = aa.ph[tr][0];
+        const auto& d0 = aa.ph[tr][0];
         pre.pk = (unsigned long long)(uintptr_t)pk;
         pre.n1 = d0.d[3];
         pre.r1 = d0.d[4] + (unsigned)wave_id * d0.d[5];
         pre.r2 = d0.d[6] + (unsigned)wave_id * d0.d[7];
         pre.lane16 = (unsigned)lane << 4;
+        pre.on = it == 0;
     }
     pre.slot<0>(); pre.slot<1>(); pre.slot<2>();
     // the one wait for this workgroup's own loads (and the three slots behind them): the bias rows go to LDS, the point is pinned as landed
+    if (it == 0) {
 #pragma unroll
-    for (int r = 0; r < H3A_MAX_BIAS; ++r)
-        if (r < nb) sBias[r * NSFF_W + threadIdx.x] = bv[r];
-    if (threadIdx.x < 32) sBias[H3A_MAX_BIAS * NSFF_W + threadIdx.x] = hbias;
-    if (threadIdx.x == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
+        for (int r = 0; r < H3A_MAX_BIAS; ++r)
+            if (r < nb) sBias[r * NSFF_W + tid_] = bv[r];
+        if (tid_ < 32) sBias[H3A_MAX_BIAS * NSFF_W + tid_] = hbias;
+        if (tid_ == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
+    } else {
+#pragma unroll
+        for (int r = 0; r < H3A_MAX_BIAS; ++r)
+            if (r < nb && (aa.bias_off[tr][r] >> 31)) sBias[r * NSFF_W + tid_] = bv[r];
+    }
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
     H3A_TSTAMP(53);
     // (the lean encoder builds the position part; the dynamic trunk's time-code columns -- when they go through the matrix pipe:
     //  no folded rows, and every training forward -- are appended by build_time_part)
     const bool lean = a.octave_freqs && a.n_freqs == 10 && (SAVE || !(tr == 1 && !tb));
     if (lean) {
-        h3a_encode10<SAVE>(sXh, sXl, a, px, threadIdx.x, pre);
-        if (SAVE && tr == 1 && !tb) build_time_part<M, THREADS>(sXh, sXl, a, p0, threadIdx.x);
+        h3a_encode10<SAVE>(sXh, sXl, a, px, tid_, pre);
+        if (SAVE && tr == 1 && !tb) build_time_part<M, THREADS>(sXh, sXl, a, p0, tid_);
     } else {
         pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
-        build_input<M, THREADS, !SAVE, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, threadIdx.x);
+        build_input<M, THREADS, !SAVE, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, tid_);
     }
     H3A_TSTAMP(57);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
     const float* tpa = reinterpret_cast<const float*>(pk);
     const float* tpb = tpa;
     if (tr == 1 && !tb) {
-        const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const int row = tid_ >> 2, q = tid_ & 3;
         const long long last = a.n_points - 1;
         const long long pa = p0 + row < last ? p0 + row : last, pb = p0 + 64 + row < last ? p0 + 64 + row : last;
         if (16 * q < a.in_t) {
@@ -1335,7 +1396,7 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
         const unsigned in_t = (tr == 1 && !tb) ? (unsigned)a.in_t : 0u;
         const unsigned tpa0 = (unsigned)((uintptr_t)tpa), tpa1 = (unsigned)((uintptr_t)tpa >> 32);
         const unsigned tpb0 = (unsigned)((uintptr_t)tpb), tpb1 = (unsigned)((uintptr_t)tpb >> 32);
-        const unsigned tid = threadIdx.x;
+        const unsigned tid = tid_;
 #ifdef H3_TIMING
         // 256 dwords per (workgroup & 255, wave): [0] kernel entry, [1] input built, [52..] C++ stamps, [62] body left, [63] records
         // stored, [64 + 6 i ..] the body's records: dispatcher visit i and the five stamps of the phase before it
@@ -1363,16 +1424,37 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
         }
     }
 #ifdef H3_TIMING
-    if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + (threadIdx.x >> 6)) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
     // The body's HEAD phase left the heads' pre-activation sums in the raw-record image; bias and activation are applied where
     // the records leave: a thread always handles the same 16-byte quarter of a record (256 threads, 4 quarters per point).
     __syncthreads();
+   {
+    H3AKernArgs& aa = *h3a_args();
+    const auto& a = aa.k;
+    unsigned tix = threadIdx.x;
+    asm volatile("" : "+v"(tix));       // (nothing of the thread index kept alive across the body: it has 24 registers)
+    [[maybe_unused]] const int lane = tix & 63;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tix >> 6);
+    const H3AHeadSel hs = {aa.hsel[tr].w_off, aa.hsel[tr].b_off, aa.hsel[tr].n_rows, aa.hsel[tr].slot0, aa.hsel[tr].kinds};
+    const bool sig_ride = tr == 0 && aa.sig_ride != 0;
+    const long long p0 = tile * M;
+    if (tile + tile_stride < tile_end) {
+        H3APre pre;
+        const auto& d0 = aa.ph[tr][0];
+        pre.pk = (unsigned long long)(uintptr_t)a.packed;
+        pre.n1 = d0.d[3];
+        pre.r1 = d0.d[4] + (unsigned)wave_id * d0.d[5];
+        pre.r2 = d0.d[6] + (unsigned)wave_id * d0.d[7];
+        pre.lane16 = (unsigned)lane << 4;
+        // persistent launch: the next tile's weight slots 0..7 -- the accumulation registers are free again -- are in flight while
+        // the records below are stored and the next point is fetched and encoded
+        pre.on = true;
+        pre.slot<0>(); pre.slot<1>(); pre.slot<2>(); pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
+    }
     H3A_TSTAMP(54);
     H3A_TSTAMP(55);
     H3A_TSTAMP(56);
-    unsigned tix = threadIdx.x;
-    asm volatile("" : "+v"(tix));       // (no 64-bit multiple of the thread index kept alive across the body: it has 24 registers)
     {
         // per thread, for its four record floats: bias, and the activation as  y = fma(1 / (1 + 2^(c x)), ya, yb)  -- sigmoid:
         // c = -log2 e, (ya, yb) = (1, 0); flow: c = 2 log2 e, (-2 s, s) = s tanh(x); none: x itself -- branch-free
@@ -1415,14 +1497,17 @@ __device__ __forceinline__ void h3a_kernel(const H3AArgs& aa) {
             }
         }
     }
-    span_end(a.span, span0);
+   }
+    if constexpr (SAVE) break;      // (the training forward is never launched in the persistent form: no loop for the compiler to keep state around)
+  }     // (tiles of this workgroup)
+    span_end(h3a_args()->k.span, span0);
 #ifdef H3_TIMING
-    if (lane == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + wave_id) * 256 + 63] = (unsigned)__builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + (threadIdx.x >> 6)) * 256 + 63] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
 }
 
-__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs aa) { h3a_kernel<false>(aa); }
-__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a_save(const H3AArgs aa) { h3a_kernel<true>(aa); }
+__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a(const H3AArgs) { h3a_kernel<false>(); }
+__global__ __launch_bounds__(256, 1) void nsff_field_kernel_h3a_save(const H3AArgs) { h3a_kernel<true>(); }
 
 // Phase program of one trunk = steps [s0, s1) of the step program (see tools/h3asm/check.py::build_program, the reference
 // implementation of this function, which the simulator runs).  Returns false when the trunk's structure is not one the body
@@ -2140,11 +2225,13 @@ extern "C" int nsff_side_bias(const NsffModelDesc* desc, const void* packed_f16x
 // which kernel the last f16 / f16x3 launch of this process took (nsff_last_field_kernel: tests assert that large inference
 // launches really run the hand-scheduled body instead of silently falling back)
 int g_nsff_last_h3_kernel = 0;
+int g_nsff_last_h3_grid = 0;          // workgroups of that launch when it was a hand-scheduled inference launch (nsff_last_field_grid)
 
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
                         int points_per_block, hipStream_t st, unsigned long long* span) {
     const NsffModelDesc& d = *desc;
     const NsffFieldArgs& g = *args;
+    g_nsff_last_h3_grid = 0;
     H3KArgs k{};
     const int rc = nsff_make_layout_h3(d, k.L);
     if (rc) return rc;
@@ -2294,6 +2381,23 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
         ka.hsel[0] = h3a_head_sel(k.L, ka.head[0]); ka.hsel[1] = h3a_head_sel(k.L, ka.head[1]);
         const int which = side ? NSFF_KERNEL_H3A_SIDE : (ka.k.t_bias ? NSFF_KERNEL_H3A_TBIAS : NSFF_KERNEL_H3A);
+        // Persistent form (H3AArgs::p_mode): one workgroup per CU walking its tiles -- for launches that give every workgroup at
+        // least one tile; both trunks only when their phase programs cost the same (each workgroup keeps ONE trunk, so an
+        // imbalance idles half of the chip: the view-direction static trunk is 23 % longer than the dynamic one -- those launches
+        // keep one workgroup per tile and the dispatcher's own balancing).  NSFF_NO_PERSIST=1: one workgroup per tile (A/B).
+        static const int n_cus = [] { int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+            return n; }();
+        const bool no_persist = getenv("NSFF_NO_PERSIST") != nullptr;       // (read per launch: tests flip it)
+        const bool can_persist = !no_persist && n_cus >= 8 && n_cus % 8 == 0;
+        auto cost = [&](const H3APhase* ph) {
+            int c = 0;
+            for (int i = 1; i < H3A_MAX_PHASES && !(i > 1 && ph[i].d[0] == H3A_BODY_END); ++i) {
+                const uint32_t b = ph[i].d[0];
+                c += (b == H3A_BODY_A16R || b == H3A_BODY_A16RS) ? 16 : ((b == H3A_BODY_A4 || b == H3A_BODY_A4F) ? 4 : ((b == H3A_BODY_A8 || b == H3A_BODY_A8F) ? 8 : 0));
+            }
+            return c;
+        };
         if (asm_body && static_uncovered) {
             // (1) static trunk: the first half of a split launch's grid = static workgroups only
             k.grid_tiles = tiles;
@@ -2302,16 +2406,26 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             // (2) dynamic trunk: a split launch whose static half is empty (grid_tiles = 0: every workgroup is a dynamic one)
             ka.k.grid_tiles = 0;
             ka.k.split_trunks = 1;
-            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)tiles), dim3(256), 0, st, ka);
+            unsigned grid = (unsigned)tiles;
+            if (can_persist && tiles >= n_cus) { ka.p_mode = 3; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
+            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3(grid), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
             g_nsff_last_h3_kernel = which;
+            g_nsff_last_h3_grid = (int)grid;
         } else if (asm_body) {
             const bool both2 = ns > ks.n_static_steps && ks.n_static_steps > 0;
             ka.k.grid_tiles = tiles;
             ka.k.split_trunks = both2 ? 1 : 0;
-            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3((unsigned)(both2 ? 2 * tiles : tiles)), dim3(256), 0, st, ka);
+            unsigned grid = (unsigned)(both2 ? 2 * tiles : tiles);
+            if (can_persist && !both2 && tiles >= n_cus) { ka.p_mode = 1; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
+            if (can_persist && both2 && !side && tiles >= n_cus / 2) {
+                const int cs = cost(ka.ph[0]), cd = cost(ka.ph[1]);
+                if (25 * std::abs(cs - cd) <= std::max(cs, cd)) { ka.p_mode = 2; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
+            }
+            hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3(grid), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
             g_nsff_last_h3_kernel = which;
+            g_nsff_last_h3_grid = (int)grid;
         } else {                                  // eight waves of 32 neurons (half the weight stream of the 64-point tiling)
             lrc = launch(nsff_field_kernel_h3<4, 1, false, 1>, 128, 512);
             g_nsff_last_h3_kernel = NSFF_KERNEL_H3_8WAVE;

@@ -17,3 +17,4 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
                         int points_per_block, hipStream_t st, unsigned long long* span = nullptr);
 
 extern int g_nsff_last_h3_kernel;
+extern int g_nsff_last_h3_grid;

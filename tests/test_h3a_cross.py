@@ -277,3 +277,58 @@ def test_training_forward_on_the_hand_scheduled_kernel(arch, hip_lib):
             diff_bits = (masks_a[slot] ^ masks_b[slot])
             n_diff = sum(bin(int(v) & 0xFFFFFFFFFFFFFFFF).count("1") for v in diff_bits.reshape(-1)[diff_bits.reshape(-1) != 0].tolist())
             assert n_diff <= 2e-4 * masks_a[slot].numel() * 64, (ARCHS[arch], S, slot, n_diff)
+
+
+def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, monkeypatch):
+    """Large launches of the hand-scheduled kernel are persistent (include/nsff_render.h::nsff_last_field_grid): one workgroup per
+    compute unit walks tiles of ONE trunk -- both trunks when they cost the same (time code as per-ray bias rows), one trunk
+    (static-only / dynamic-only launches, and the dynamic half of a view-direction model without its per-ray rows) otherwise.
+    Every tile is computed by the same instruction stream from the same inputs whichever workgroup runs it: the records are
+    bit-identical to the one-workgroup-per-tile form (NSFF_NO_PERSIST=1), including a ragged last tile; the grid tells which form ran."""
+    torch.manual_seed(5)
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    emb, emb_d = A.PosEmbedding(9, 10), A.PosEmbedding(3, 4)
+    freqs = [float(f) for f in emb.freqs]
+    g = torch.Generator().manual_seed(9)
+    plain = A.NeRF("fine", use_viewdir=False, encode_transient=True, in_channels_t=48, output_flow=True).to(DEV)
+    viewdir = A.NeRF("fine", use_viewdir=True, encode_transient=True, in_channels_t=48, output_flow=True).to(DEV)
+    config.set_precision("f16x3")
+    S = 64
+    cases = [  # model, rays, (static, transient, flow heads), per-ray time rows?, grid of the persistent form (None: never persistent)
+        (plain, 2 * n_cus + 3, (2, 2, 2), True, n_cus),            # both trunks, equal cost: trunk by XCD
+        (plain, 2 * n_cus + 3, (2, 2, 2), False, None),            # time code through the matrix pipe: the dynamic trunk is 7 % longer
+        (plain, 2 * n_cus + 5, (2, 0, 0), False, n_cus),           # static only
+        (plain, 2 * n_cus + 5, (0, 2, 1), True, n_cus),            # dynamic only
+        (viewdir, 2 * n_cus + 1, (2, 2, 2), True, n_cus),          # static trunk on the eight-wave kernel, dynamic one persistent
+        (plain, n_cus // 8, (2, 2, 2), True, None),                # fewer tiles than workgroups
+    ]
+    for m, n_rays, (sm, tm, fh), rows, grid_p in cases:
+        P = S * n_rays
+        tiles = (P + 127) // 128
+        xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
+        t_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
+        dirs = emb_d(torch.randn(n_rays, 3, generator=g).to(DEV)).contiguous() if m is viewdir else None
+        tb = _lib.time_bias([(m, t_rows)])[0] if (rows and tm) else None
+        got = {}
+        config.set_tile_points(130)
+        try:
+            for form in ("persistent", "tile"):
+                if form == "tile":
+                    monkeypatch.setenv("NSFF_NO_PERSIST", "1")
+                else:
+                    monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
+                raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
+                _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs, t_bias=tb)
+                torch.cuda.synchronize()
+                got[form] = (raw.cpu().numpy(), _lib.last_field_grid(), _lib.last_field_kernel())
+        finally:
+            config.set_tile_points(0)
+            monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
+        (a, ga, ka), (b, gb, kb) = got["persistent"], got["tile"]
+        both = sm and tm and m is not viewdir
+        assert ka == kb and ka.startswith("h3a"), (ka, kb)
+        assert gb == (2 * tiles if both else tiles), (gb, tiles)
+        assert ga == (grid_p if grid_p is not None else gb), (ga, grid_p, gb)
+        used = slice(0, 4) if tm == 0 else (slice(4, 4 + 4 + 3 * fh) if sm == 0 else slice(0, 4 + 4 + 3 * fh))
+        assert np.isfinite(a[:, used]).all()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"rays={n_rays} modes {(sm, tm, fh)} rows={rows}"

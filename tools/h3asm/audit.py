@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Audit of the compiled nsff_field_kernel_h3a (run by `make -C nsff_pl_amd/csrc audit`): the body between #ASMSTART / #ASMEND owns
 v24..v255, a0..a255 and s40..s99 only WHILE IT RUNS -- hipcc may use them before and after (the clobber list tells it that nothing
-of its own survives the statement).  What must hold: no spilled VGPRs, no scratch, 512 registers allocated, one asm statement,
+of its own survives the statement).  What must hold: no spilled VGPRs, no scratch (scalars parked in lanes of a VGPR the
+body leaves alone -- the persistent tile loop's invariants -- are reported, not refused), 512 registers allocated, one asm statement,
 and between the kernel's entry and the asm no compiler code may leave a value in the asm-owned range that it reads back after
 the asm (the clobber list guarantees it; the audit reports the count of compiler instructions and the descriptor fields)."""
 import re
