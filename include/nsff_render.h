@@ -595,8 +595,8 @@ int         nsff_last_field_kernel(void);
 /* Workgroups of that launch when it ran the hand-scheduled inference kernel (0 otherwise).  Large launches of that kernel are
  * PERSISTENT: one workgroup per compute unit, each walking tiles  first, first + stride, ...  of one trunk (both trunks: the
  * workgroups of XCDs 0..3 take the static trunk, 4..7 the dynamic one -- taken when both trunks cost the same number of matrix
- * steps); the plain bias rows are loaded once per workgroup and the next tile's first eight weight slots are requested while the
- * current tile's records are stored.  Results are bit-identical to the one-workgroup-per-tile form (environment
+ * steps); the plain bias rows are loaded once per workgroup, the next tile's first eight weight slots are requested by the last
+ * trunk phase of the current one and its point by the body's first instructions.  Results are bit-identical to the one-workgroup-per-tile form (environment
  * NSFF_NO_PERSIST=1, read per launch, selects that form for A/B measurements). */
 int         nsff_last_field_grid(void);
 /* Host-only (no GPU work): the f16x3 step program of an inference launch with these modes -- steps[n][4] = {weight segment
@@ -605,7 +605,10 @@ int         nsff_last_field_grid(void);
  * n_phases[t] = 0 when trunk t is absent or not covered by that kernel.  Used by the tests that pin the host-side program
  * builder to the one the simulator runs (tools/h3asm/check.py).  steps: room for 28 x 4, phases_*: room for 36 x 8.
  * fold_t != 0: the dynamic trunk's program of a launch that was given NsffFieldArgs::t_bias (bias fields of its descriptors
- * then index a table whose per-ray rows follow the plain ones: half A's row replaces the layer's bias row, half B's is appended). */
+ * then index a table whose per-ray rows follow the plain ones: half A's row replaces the layer's bias row, half B's is appended).
+ * fold_t bit 1: the static trunk's program of a view-direction launch given NsffFieldArgs::s_bias; bit 2: the programs of a
+ * PERSISTENT launch (nsff_last_field_grid): the last segment's B phase carries descriptor 0's stream fields and requests the
+ * first segments' weight slots 0..7 for the workgroup's next tile (n_phases[t] = 0 for a trunk that ends with a skip layer). */
 int         nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, int fold_t, uint32_t* steps,
                              int* n_steps, int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases);
 

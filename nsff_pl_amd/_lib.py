@@ -720,16 +720,18 @@ def last_field_grid():
     return int(load().nsff_last_field_grid())
 
 
-def h3a_program(model, static_mode, transient_mode, fold_t=False, side_fold=False):
+def h3a_program(model, static_mode, transient_mode, fold_t=False, side_fold=False, persist=False):
     """(steps, n_static_steps, phases_static, phases_dynamic) of an f16x3 inference launch, from the host-side builders alone
     (no GPU): steps = [(w_off_words, bias_off_words or None, nks, pre, post, head)], phases_* = [[8 dwords]] or [].
     fold_t: the dynamic trunk's program of a launch that is given t_bias (time code folded into per-ray bias rows);
-    side_fold: the static trunk's program of a view-direction launch that is given s_bias ([dir | a] folded into per-ray rows)."""
+    side_fold: the static trunk's program of a view-direction launch that is given s_bias ([dir | a] folded into per-ray rows);
+    persist: the programs of a persistent launch (the last segment's B phase requests the next tile's first weight slots; [] for a
+    trunk that does not end with a 256-wide segment)."""
     desc = model_desc(model)
     steps = (C.c_uint32 * (28 * 4))()
     ps, pd = (C.c_uint32 * (36 * 8))(), (C.c_uint32 * (36 * 8))()
     n, ns, nph = C.c_int(0), C.c_int(0), (C.c_int * 2)()
-    _check(load().nsff_field_phase_program(C.byref(desc), int(static_mode), int(transient_mode), int(bool(fold_t)) | (2 if side_fold else 0), steps, C.byref(n), C.byref(ns), ps, pd, nph),
+    _check(load().nsff_field_phase_program(C.byref(desc), int(static_mode), int(transient_mode), int(bool(fold_t)) | (2 if side_fold else 0) | (4 if persist else 0), steps, C.byref(n), C.byref(ns), ps, pd, nph),
            "nsff_field_phase_program")
     out = []
     for i in range(n.value):

@@ -132,12 +132,13 @@ __device__ __forceinline__ SpanT span_begin(const unsigned long long* span) {
     if (span != nullptr && (blockIdx.x & 15) == 0) { s.t = __builtin_amdgcn_s_memtime(); s.r = __builtin_amdgcn_s_memrealtime(); }
     return s;
 }
-__device__ __forceinline__ void span_end(unsigned long long* span, const SpanT& s0) {
-    if (span == nullptr || (blockIdx.x & 15) != 0 || threadIdx.x != 0) return;
+__device__ __forceinline__ void span_end(unsigned long long* span, const SpanT& s0, unsigned tid) {
+    if (span == nullptr || (blockIdx.x & 15) != 0 || tid != 0) return;
     const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
     atomicAdd(span, t - s0.t);
     atomicAdd(span + 1, r - s0.r);
 }
+__device__ __forceinline__ void span_end(unsigned long long* span, const SpanT& s0) { span_end(span, s0, threadIdx.x); }
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H3_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -1244,13 +1245,22 @@ __device__ __forceinline__ void h3a_kernel() {
     }
     span0 = span_begin(a.span);
   }
+    // The point of a tile is requested one tile ahead (a persistent workgroup: by the previous tile's body, into registers it
+    // leaves to the compiler) -- the first one here.  (rows past the end: the last point)
+    float px[3];
+    auto request_point = [&px](const auto& a, long long p0, unsigned tid) {
+        const long long last = a.n_points - 1;
+        const long long bp = p0 + build_row<M, THREADS>(tid) < last ? p0 + build_row<M, THREADS>(tid) : last;
+        px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2];
+    };
+    request_point(h3a_args()->k, tile * M, threadIdx.x);
+    unsigned tid_ = threadIdx.x;            // (the ONE copy of the thread index that crosses the body: an in / out operand of its statement)
 #pragma unroll 1
   for (int it = 0; tile < tile_end; ++it, tile += tile_stride) {
     H3AKernArgs& aa = *h3a_args();
     const auto& a = aa.k;
     const uint32_t* __restrict__ pk = a.packed;
-    unsigned tid_ = threadIdx.x;            // (opaque per tile: nothing derived from the thread index is carried across the body)
-    asm volatile("" : "+v"(tid_));
+    asm volatile("" : "+v"(tid_));          // (opaque per tile: nothing derived from the thread index is carried across the body)
     const int lane = tid_ & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const long long p0 = tile * M;
@@ -1259,15 +1269,10 @@ __device__ __forceinline__ void h3a_kernel() {
 #else
 #define H3A_TSTAMP(k) do {} while (0)
 #endif
+    H3A_TSTAMP(58);                         // (timing build: this tile's start; [59] its end -- the last tile's stamps survive)
     // Everything this workgroup reads before its trunk starts is REQUESTED first and waited for once: the point, the bias-table
     // rows (sixteen loads in flight), then -- the pre-issue statement -- weight slots 0..7: 128 KiB that cross the CU's vector-memory
     // path while the encoder below computes.  The compiler's wait for the point sits behind the statement (its first use).
-    float px[3];
-    {
-        const long long last = a.n_points - 1;
-        const long long bp = p0 + build_row<M, THREADS>(tid_) < last ? p0 + build_row<M, THREADS>(tid_) : last;
-        px[0] = a.xyz[bp * 3 + 0]; px[1] = a.xyz[bp * 3 + 1]; px[2] = a.xyz[bp * 3 + 2];      // (rows past the end: the last point)
-    }
     // bias table of this trunk (fp32 rows of 256): the body initialises its accumulators from it with ds_read_b128.
     // (dynamic trunk with the time code folded in: the rows of its input layers are per ray -- every 64-point half of the tile
     // lies inside one ray, the host checked pts_per_ray % 64 == 0 and n_points < 2^31 -- and the body never sees a time-code column)
@@ -1333,19 +1338,8 @@ __device__ __forceinline__ void h3a_kernel() {
         pre.lane16 = (unsigned)lane << 4;
         pre.on = it == 0;
     }
-    pre.slot<0>(); pre.slot<1>(); pre.slot<2>();
-    // the one wait for this workgroup's own loads (and the three slots behind them): the bias rows go to LDS, the point is pinned as landed
-    if (it == 0) {
-#pragma unroll
-        for (int r = 0; r < H3A_MAX_BIAS; ++r)
-            if (r < nb) sBias[r * NSFF_W + tid_] = bv[r];
-        if (tid_ < 32) sBias[H3A_MAX_BIAS * NSFF_W + tid_] = hbias;
-        if (tid_ == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
-    } else {
-#pragma unroll
-        for (int r = 0; r < H3A_MAX_BIAS; ++r)
-            if (r < nb && (aa.bias_off[tr][r] >> 31)) sBias[r * NSFF_W + tid_] = bv[r];
-    }
+    pre.slot<0>(); pre.slot<1>(); pre.slot<2>();        // (a later tile of a persistent workgroup: the previous tile's B16LP phase requested all eight)
+    // the point is pinned as landed here (first tile: the one wait for the workgroup's own loads and the three slots behind them)
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
     H3A_TSTAMP(53);
     // (the lean encoder builds the position part; the dynamic trunk's time-code columns -- when they go through the matrix pipe:
@@ -1357,6 +1351,27 @@ __device__ __forceinline__ void h3a_kernel() {
     } else {
         pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
         build_input<M, THREADS, !SAVE, true>(sXh, sXl, a, p0, tr == 1 && !tb, px, tid_);
+    }
+    // the bias rows go to LDS behind the encoder (a later tile's per-ray rows were requested in front of it), then the NEXT tile's
+    // point is requested: it lands under the body
+    if (it == 0) {
+#pragma unroll
+        for (int r = 0; r < H3A_MAX_BIAS; ++r)
+            if (r < nb) sBias[r * NSFF_W + tid_] = bv[r];
+        if (tid_ < 32) sBias[H3A_MAX_BIAS * NSFF_W + tid_] = hbias;
+        if (tid_ == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
+    } else {
+#pragma unroll
+        for (int r = 0; r < H3A_MAX_BIAS; ++r)
+            if (r < nb && (aa.bias_off[tr][r] >> 31)) sBias[r * NSFF_W + tid_] = bv[r];
+    }
+    // (the body itself requests the NEXT tile's point into px -- registers the body leaves to the compiler -- from this address;
+    //  the last tile requests its own point again)
+    [[maybe_unused]] unsigned long long nxa;
+    {
+        const long long np0 = (tile + tile_stride < tile_end ? tile + tile_stride : tile) * M, last = a.n_points - 1;
+        const long long bp = np0 + build_row<M, THREADS>(tid_) < last ? np0 + build_row<M, THREADS>(tid_) : last;
+        nxa = (unsigned long long)(uintptr_t)(a.xyz + bp * 3);
     }
     H3A_TSTAMP(57);
     // rows of the time code this thread restores at a skip layer: point row (tid >> 2) of either half, columns [16 q, 16 q + 16)
@@ -1396,7 +1411,6 @@ __device__ __forceinline__ void h3a_kernel() {
         const unsigned in_t = (tr == 1 && !tb) ? (unsigned)a.in_t : 0u;
         const unsigned tpa0 = (unsigned)((uintptr_t)tpa), tpa1 = (unsigned)((uintptr_t)tpa >> 32);
         const unsigned tpb0 = (unsigned)((uintptr_t)tpb), tpb1 = (unsigned)((uintptr_t)tpb >> 32);
-        const unsigned tid = tid_;
 #ifdef H3_TIMING
         // 256 dwords per (workgroup & 255, wave): [0] kernel entry, [1] input built, [52..] C++ stamps, [62] body left, [63] records
         // stored, [64 + 6 i ..] the body's records: dispatcher visit i and the five stamps of the phase before it
@@ -1406,25 +1420,25 @@ __device__ __forceinline__ void h3a_kernel() {
 #endif
         if constexpr (SAVE) {
             asm volatile(H3A_BODY_SAVE
-                         :
+                         : [tid] "+v"(tid_)
                          : [pk] "s"(pkb), [phases] "s"(phases), [lds] "s"(lds), [biaslds] "s"(biaslds), [rawlds] "s"((unsigned)(uintptr_t)sRaw),
-                           [wave] "s"(wave_id), [in_t] "s"(in_t), [tid] "v"(tid), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1),
+                           [wave] "s"(wave_id), [in_t] "s"(in_t), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1),
                            [act] "s"(sv_act), [mask] "s"(sv_mask), [astride] "s"(sv_astride), [mstride] "s"(sv_mstride)
                          : H3A_SAVE_CLOBBERS);
         } else {
         asm volatile(H3A_BODY
-                     :
-                     : [pk] "s"(pkb),
+                     : [nx0] "=&v"(px[0]), [nx1] "=&v"(px[1]), [nx2] "=&v"(px[2]), [tid] "+v"(tid_)
+                     : [nxa] "v"(nxa), [pk] "s"(pkb),
 #ifdef H3_TIMING
                        [dbg] "s"(dbg),
 #endif
                        [phases] "s"(phases), [lds] "s"(lds), [biaslds] "s"(biaslds), [rawlds] "s"((unsigned)(uintptr_t)sRaw),
-                       [wave] "s"(wave_id), [in_t] "s"(in_t), [tid] "v"(tid), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1)
+                       [wave] "s"(wave_id), [in_t] "s"(in_t), [tpa0] "v"(tpa0), [tpa1] "v"(tpa1), [tpb0] "v"(tpb0), [tpb1] "v"(tpb1)
                      : H3A_CLOBBERS);
         }
     }
 #ifdef H3_TIMING
-    if ((threadIdx.x & 63) == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + (threadIdx.x >> 6)) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
+    if ((tid_ & 63) == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + (tid_ >> 6)) * 256 + 62] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
     // The body's HEAD phase left the heads' pre-activation sums in the raw-record image; bias and activation are applied where
     // the records leave: a thread always handles the same 16-byte quarter of a record (256 threads, 4 quarters per point).
@@ -1432,26 +1446,12 @@ __device__ __forceinline__ void h3a_kernel() {
    {
     H3AKernArgs& aa = *h3a_args();
     const auto& a = aa.k;
-    unsigned tix = threadIdx.x;
-    asm volatile("" : "+v"(tix));       // (nothing of the thread index kept alive across the body: it has 24 registers)
+    const unsigned tix = tid_;          // (opaque: an output of the body's statement)
     [[maybe_unused]] const int lane = tix & 63;
-    const int wave_id = __builtin_amdgcn_readfirstlane(tix >> 6);
+    [[maybe_unused]] const int wave_id = __builtin_amdgcn_readfirstlane(tix >> 6);
     const H3AHeadSel hs = {aa.hsel[tr].w_off, aa.hsel[tr].b_off, aa.hsel[tr].n_rows, aa.hsel[tr].slot0, aa.hsel[tr].kinds};
     const bool sig_ride = tr == 0 && aa.sig_ride != 0;
     const long long p0 = tile * M;
-    if (tile + tile_stride < tile_end) {
-        H3APre pre;
-        const auto& d0 = aa.ph[tr][0];
-        pre.pk = (unsigned long long)(uintptr_t)a.packed;
-        pre.n1 = d0.d[3];
-        pre.r1 = d0.d[4] + (unsigned)wave_id * d0.d[5];
-        pre.r2 = d0.d[6] + (unsigned)wave_id * d0.d[7];
-        pre.lane16 = (unsigned)lane << 4;
-        // persistent launch: the next tile's weight slots 0..7 -- the accumulation registers are free again -- are in flight while
-        // the records below are stored and the next point is fetched and encoded
-        pre.on = true;
-        pre.slot<0>(); pre.slot<1>(); pre.slot<2>(); pre.slot<3>(); pre.slot<4>(); pre.slot<5>(); pre.slot<6>(); pre.slot<7>();
-    }
     H3A_TSTAMP(54);
     H3A_TSTAMP(55);
     H3A_TSTAMP(56);
@@ -1497,12 +1497,13 @@ __device__ __forceinline__ void h3a_kernel() {
             }
         }
     }
+    H3A_TSTAMP(59);
    }
     if constexpr (SAVE) break;      // (the training forward is never launched in the persistent form: no loop for the compiler to keep state around)
   }     // (tiles of this workgroup)
-    span_end(h3a_args()->k.span, span0);
+    span_end(h3a_args()->k.span, span0, tid_);
 #ifdef H3_TIMING
-    if ((threadIdx.x & 63) == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + (threadIdx.x >> 6)) * 256 + 63] = (unsigned)__builtin_amdgcn_s_memtime();
+    if ((tid_ & 63) == 0) g_h3_timing[H3A_TBASE + ((blockIdx.x & 255) * 4 + (tid_ >> 6)) * 256 + 63] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
 }
 
@@ -1988,6 +1989,20 @@ static int h3_step_program(const NsffModelDesc& d, int static_mode, int transien
 // steps: [n][4] = {w_off (words), bias_off (words, NSFF_NONE = accumulate), nks | pre << 8 | post << 16 | head << 24, 0};
 // phases_static / phases_dynamic: [H3A_MAX_PHASES][8] descriptors; n_phases[2] = descriptors written (0 = trunk absent or
 // not covered).
+// The phase program of a PERSISTENT workgroup (tools/h3asm/check.py::make_persistent is the simulated reference): the last
+// segment's B phase B16L becomes B16LP with descriptor 0's stream fields -- behind its k-steps 1..8 it requests weight slots 0..7
+// of the trunk's first segments, which the workgroup's next tile finds resident (as a first tile finds what the pre-issue
+// statements requested).  false: the trunk does not end with a 256-wide segment (a skip layer last) -- one workgroup per tile then.
+static bool h3a_make_persistent(H3APhase* ph) {
+    int at = -1;
+    for (int i = 1; i < H3A_MAX_PHASES && !(i > 1 && ph[i].d[0] == H3A_BODY_END); ++i)
+        if (ph[i].d[0] == H3A_BODY_B16L) { if (at >= 0) return false; at = i; }
+    if (at < 0) return false;
+    ph[at].d[0] = H3A_BODY_B16LP;
+    for (int j = 3; j < 8; ++j) ph[at].d[j] = ph[0].d[j];
+    return true;
+}
+
 extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mode, int transient_mode, int fold_t, uint32_t* steps,
                                 int* n_steps, int* n_static_steps, uint32_t* phases_static, uint32_t* phases_dynamic, int* n_phases) {
     if (!desc || !steps || !n_steps || !n_static_steps || !phases_static || !phases_dynamic || !n_phases) return NSFF_ERR_NULL;
@@ -1996,6 +2011,7 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
     if (rc) return rc;
     // fold_t bit 1: the launch is given NsffFieldArgs::s_bias (a view-direction static trunk with per-ray [dir | a] rows)
     const bool side_fold = (fold_t & 2) != 0 && static_mode == 2 && desc->use_viewdir;
+    const bool persist = (fold_t & 4) != 0;       // bit 2: the programs of a persistent launch
     fold_t &= 1;
     rc = h3_step_program(*desc, static_mode, transient_mode, true, k, side_fold);
     if (rc) return rc;
@@ -2014,7 +2030,7 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
         for (auto& p : ph) for (auto& x : p.d) x = 0;
         int np = 0;
         k.sb_rows = side_fold ? 1 : 0;
-        if (h3a_build_program(k, 0, k.n_static_steps, false, false, ph, boff, nb, head, &np, side_fold)) {
+        if (h3a_build_program(k, 0, k.n_static_steps, false, false, ph, boff, nb, head, &np, side_fold) && (!persist || h3a_make_persistent(ph))) {
             n_phases[0] = np;
             for (int i = 0; i < n_phases[0]; ++i) for (int j = 0; j < 8; ++j) phases_static[8 * i + j] = ph[i].d[j];
         }
@@ -2023,7 +2039,7 @@ extern "C" int nsff_field_phase_program(const NsffModelDesc* desc, int static_mo
         for (auto& p : ph) for (auto& x : p.d) x = 0;
         int np = 0;
         k.tb_rows = fold_t ? nsff_time_bias_rows(desc) : 0;
-        if (h3a_build_program(k, k.n_static_steps, k.n_steps, true, fold_t != 0, ph, boff, nb, head, &np)) {
+        if (h3a_build_program(k, k.n_static_steps, k.n_steps, true, fold_t != 0, ph, boff, nb, head, &np) && (!persist || h3a_make_persistent(ph))) {
             n_phases[1] = np;
             for (int i = 0; i < n_phases[1]; ++i) for (int j = 0; j < 8; ++j) phases_dynamic[8 * i + j] = ph[i].d[j];
         }
@@ -2407,7 +2423,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             ka.k.grid_tiles = 0;
             ka.k.split_trunks = 1;
             unsigned grid = (unsigned)tiles;
-            if (can_persist && tiles >= n_cus) { ka.p_mode = 3; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
+            if (can_persist && tiles >= n_cus && h3a_make_persistent(ka.ph[1])) { ka.p_mode = 3; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3(grid), dim3(256), 0, st, ka);
             lrc = NSFF_OK;
             g_nsff_last_h3_kernel = which;
@@ -2417,10 +2433,17 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             ka.k.grid_tiles = tiles;
             ka.k.split_trunks = both2 ? 1 : 0;
             unsigned grid = (unsigned)(both2 ? 2 * tiles : tiles);
-            if (can_persist && !both2 && tiles >= n_cus) { ka.p_mode = 1; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
+            if (can_persist && !both2 && tiles >= n_cus && h3a_make_persistent(ka.ph[ks.n_static_steps > 0 ? 0 : 1])) {
+                ka.p_mode = 1; ka.p_tiles = tiles; grid = (unsigned)n_cus;
+            }
             if (can_persist && both2 && !side && tiles >= n_cus / 2) {
                 const int cs = cost(ka.ph[0]), cd = cost(ka.ph[1]);
-                if (25 * std::abs(cs - cd) <= std::max(cs, cd)) { ka.p_mode = 2; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
+                H3APhase keep[H3A_MAX_PHASES];
+                for (int i = 0; i < H3A_MAX_PHASES; ++i) keep[i] = ka.ph[0][i];
+                if (25 * std::abs(cs - cd) <= std::max(cs, cd) && h3a_make_persistent(ka.ph[0])) {
+                    if (h3a_make_persistent(ka.ph[1])) { ka.p_mode = 2; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
+                    else for (int i = 0; i < H3A_MAX_PHASES; ++i) ka.ph[0][i] = keep[i];
+                }
             }
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3(grid), dim3(256), 0, st, ka);
             lrc = NSFF_OK;

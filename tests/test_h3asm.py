@@ -45,7 +45,8 @@ def test_stream_passes_the_hazard_lint():
     assert all(i.kind != "mfma" for i in pre)
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic", "dynamic_tb", "twoskips_tb", "viewdir", "static_save", "dynamic_save", "twoskips_save"])
+@pytest.mark.parametrize("kind", ["static", "dynamic", "dynamic_tb", "twoskips_tb", "viewdir", "static_save", "dynamic_save", "twoskips_save", "static_persist",
+                                  "dynamic_tb_persist", "viewdir_persist"])
 def test_simulated_trunk_matches_numpy(kind):
     assert check.run_case(kind, verbose=False) < 2e-6
 
@@ -116,6 +117,33 @@ def test_cxx_phase_program_equals_the_simulated_builder(arch):
         for i, (w_, g_) in enumerate(zip(want, ph_f)):
             n_cmp = 8 if (i == 0 or w_[0] in uses_streams) else (4 if w_[0] in (B["EPI_B"], B["HEAD"]) else 3)
             assert w_[:n_cmp] == g_[:n_cmp], (ARCHS[arch], sm, tm, "fold_t", i, w_, g_)
+
+
+@pytest.mark.parametrize("arch", range(len(ARCHS)))
+def test_cxx_persistent_program_equals_the_simulated_patch(arch):
+    """the programs of a persistent launch (fold_t bit 2): the C++ patch (h3a_make_persistent) against check.make_persistent on
+    the C++ builder's own plain program -- B16L -> B16LP with descriptor 0's stream fields, nothing else; a trunk that ends with a
+    skip layer's input part has no such phase and is refused (one workgroup per tile)"""
+    import numpy as np
+    import torch
+    import nsff_pl_amd as A
+    from nsff_pl_amd import _lib
+    D, skips, n_freqs, n_tau = ARCHS[arch]
+    torch.manual_seed(0)
+    m = A.NeRF("fine", D=D, skips=skips, in_channels_xyz=3 + 6 * n_freqs, use_viewdir=False, encode_transient=True,
+               in_channels_t=n_tau, output_flow=True)
+    for fold_t in (False, True):
+        _, _, ph_s, ph_d = _lib.h3a_program(m, 2, 2, fold_t=fold_t)
+        _, _, pp_s, pp_d = _lib.h3a_program(m, 2, 2, fold_t=fold_t, persist=True)
+        for plain, pers in ((ph_s, pp_s), (ph_d, pp_d)):
+            assert plain
+            want = np.array(plain, np.uint32)
+            if check.make_persistent(want):
+                assert [list(map(int, r)) for r in want] == pers
+                at = [i for i, r in enumerate(pers) if r[0] == gen.BODY["B16LP"]]
+                assert len(at) == 1 and pers[at[0]][3:8] == pers[0][3:8] and not any(r[0] == gen.BODY["B16L"] for r in pers)
+            else:
+                assert pers == [] and (D - 1) in skips
 
 
 @pytest.mark.parametrize("arch", [(8, [4], 48), (4, [2], 0), (3, [], 12)])

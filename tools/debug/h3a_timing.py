@@ -44,8 +44,8 @@ if which in ("static", "dynamic_tb"):
 else:
     seq = [11, 7] + [1, 2] * 3 + [1, 3, 5, 7] + [1, 2] * 2 + [1, 12, 9, 13]
 print(f"{which} trunk, mean cycles over 256 workgroups x 4 waves")
-print(f"  kernel entry -> input built   {d(0, 1).mean():8.0f}   = point + bias requests {d(0, 52).mean():.0f}, point landed {d(52, 53).mean():.0f}, "
-      f"weight pre-issue {d(53, 57).mean():.0f}, encoder {d(57, 1).mean():.0f}")
+print(f"  kernel entry -> input built   {d(0, 1).mean():8.0f}   = bias-row + head requests {d(0, 52).mean():.0f}, point pinned {d(52, 53).mean():.0f}, "
+      f"encoder (weight slots 3..7 riding) + bias rows to LDS {d(53, 57).mean():.0f}, time-code pointers + barrier {d(57, 1).mean():.0f}")
 print(f"  body prologue                 {dd(rec[:, :, 0, 0], rec[:, :, 1, 0]).mean():8.0f}   (asm start -> first dispatch)")
 tot = 0.0
 for i, b in enumerate(seq):
@@ -61,4 +61,7 @@ for i, b in enumerate(seq):
 print(f"  phases total                  {tot:8.0f}")
 print(f"  body left    -> records stored {d(62, 63).mean():7.0f}   = barrier {d(62, 54).mean():.0f}, heads {d(54, 55).mean():.0f}, barrier {d(55, 56).mean():.0f}, "
       f"records {d(56, 63).mean():.0f}")
-print(f"  whole workgroup               {d(0, 63).mean():8.0f}")
+print(f"  whole workgroup               {d(0, 63).mean():8.0f}   ({_lib.last_field_grid()} workgroups for {P // 128} tiles)")
+# a persistent workgroup's LAST tile (its stamps overwrite the earlier tiles'): the steady state of the tile loop
+print(f"  last tile of the workgroup    {d(58, 59).mean():8.0f}   = requests {d(58, 52).mean():.0f}, point pinned {d(52, 53).mean():.0f}, encoder + bias rows to LDS {d(53, 57).mean():.0f}, "
+      f"barrier {d(57, 1).mean():.0f}, body {d(1, 62).mean():.0f}, barrier + next tile's slots 0..2 {d(62, 54).mean():.0f}, records {d(56, 59).mean():.0f}")

@@ -72,7 +72,18 @@ def pack_head(W):
     return out.reshape(-1).view(np.uint32), hi, lo
 
 
-def build_program(segs, in_t, head=None, sig_row=None, save=False):
+def make_persistent(ph):
+    """The phase program of a PERSISTENT workgroup (field_h3.hip: h3a_make_persistent does the same): the last segment's B phase
+    B16L becomes B16LP with descriptor 0's stream fields -- it requests the first segments' weight slots 0..7 for the next tile."""
+    at = [i for i in range(1, len(ph)) if ph[i][0] == gen.BODY["B16L"]]
+    if len(at) != 1:
+        return False
+    ph[at[0]][0] = gen.BODY["B16LP"]
+    ph[at[0]][3:8] = ph[0][3:8]
+    return True
+
+
+def build_program(segs, in_t, head=None, sig_row=None, save=False, persist=False):
     """Phase descriptors for a trunk (the host-side builder in csrc/field_h3a.hip does the same).
     segs: list of dict(nks, off, bias (index or None), post ('relu' | 'none'), rebuild (bool)[, wstride (bytes between the
     waves' blocks of the packed segment, default nks * 4096), bias_b (table row of half B, default = bias)]).
@@ -138,7 +149,10 @@ def build_program(segs, in_t, head=None, sig_row=None, save=False):
     ph.append([B["HEAD"], 0, 4 * hd["slot0"], hd["n_rows"], hd["off"], 0, hd["off"], 0])
     ph.append(desc(B["END"]))
     ph.append(desc(B["END"]))
-    return np.array(ph, np.uint32)
+    ph = np.array(ph, np.uint32)
+    if persist:
+        assert make_persistent(ph)
+    return ph
 
 
 def make_case(kind, seed=0):
@@ -276,12 +290,13 @@ def head_reference(case, xh_, xl_):
 
 def run_case(kind, seed=0, verbose=True):
     save = kind.endswith("_save")
-    case = make_case(kind[:-5] if save else kind, seed)
+    persist = kind.endswith("_persist")
+    case = make_case(kind[:-5] if save else (kind[:-8] if persist else kind), seed)
     pre, prog, _ = gen.build(save=save)
     sim = Sim(pre + prog)                      # the two asm statements back to back (the encoder between them is C++)
     sim.add_buffer(PK_BASE, case["pk"])
     body_in_t = 0 if case["tb"] else case["in_t"]       # (the body sees no time-code columns when they are folded into the table)
-    phases = build_program(case["segs"], body_in_t, case["head"], case["sig_row"], save=save)
+    phases = build_program(case["segs"], body_in_t, case["head"], case["sig_row"], save=save, persist=persist)
     n_relu = sum(1 for sg in case["segs"] if sg["post"] == "relu")
     if save:
         # slots 0 .. n_relu - 1 of this trunk, two spare slots in front (the trunk's first slot is not slot 0 of the buffers)
@@ -394,6 +409,17 @@ def run_case(kind, seed=0, verbose=True):
         keep = np.ones(a16.shape[:2], bool); keep[2:2 + n_relu, 2:4] = False
         assert (a16.view(np.uint16)[keep] == 0xFFFF).all() and (m64[keep] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
         assert sim.mem_written[ACT_BASE].reshape(n_relu + 2, N_TILES64, -1)[2:, 2:4].all()
+    if persist:
+        # the next tile's first segments are resident in weight slots 0..7, exactly where the pre-issue statement puts a first tile's
+        n1, r1, r1w, r2, r2w = (int(v) for v in phases[0][3:8])
+        lane = np.arange(64)
+        for w in sim.waves:
+            for k in range(8):
+                base = ((r1 + w.id * r1w) if k < n1 else (r2 + w.id * r2w)) + 4096 * k
+                for c in range(4):
+                    for e_ in range(4):
+                        want_w = case["pk"][(base + 1024 * c + 16 * lane) // 4 + e_]
+                        assert np.array_equal(w.a[16 * k + 4 * c + e_], want_w), (w.id, k, c, e_)
     n_mf = sim.waves[0].n_mfma
     want_mf = sum(sg["nks"] for sg in case["segs"]) * 24 + 48
     if verbose:
@@ -406,7 +432,7 @@ def run_case(kind, seed=0, verbose=True):
 
 if __name__ == "__main__":
     kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips", "dynamic_tb", "twoskips_tb", "viewdir",
-                             "static_save", "dynamic_save", "twoskips_save"]
+                             "static_save", "dynamic_save", "twoskips_save", "static_persist", "dynamic_tb_persist", "viewdir_persist"]
     for k in kinds:
         try:
             run_case(k)

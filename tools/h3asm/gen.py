@@ -61,7 +61,7 @@ D_BODY, D_FLAGS, D_BIAS, D_N1, D_R1, D_R1W, D_R2, D_R2W = range(8)
 F_INIT, F_REBUILD_T, F_REBUILD = 0, 1, 2
 
 BODY = dict(END=0, A16R=1, B16R=2, B16X=3, A4=4, A8=5, B4=6, B8=7, EPI_B=9, A4F=10, A8F=11, B16L=12, HEAD=13, B16RS=14, A16RS=15,
-            SAVE_LAST=16)
+            SAVE_LAST=16, B16LP=17)
 
 # ---- the SAVE build (build(save=True) -> H3A_BODY_SAVE, the body of nsff_field_kernel_h3a_save: the TRAINING forward).  The
 # same phases; additionally
@@ -453,7 +453,7 @@ def emit_ride(s, item):
 
 
 def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebuild=None, vm_mode=None, stream_slots=None,
-               one_stream=False, copy=False):
+               one_stream=False, copy=False, refill_slots=None):
     """One phase: `nks` k-steps of MFMAs on acc_<half> from X_<half>.  The phase's barrier sits in front of MFMA 8 of the
     LAST BUT ONE k-step: by then every fragment of this half has been read (the last k-step's lo fragments go to the second
     XL buffer) and the ride's stores are done, and 16 MFMAs remain to cover what follows the barrier -- the bias-table
@@ -464,7 +464,10 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
     rebuild: None | half whose input tile is restored by two guarded clusters
     vm_mode: None | 'formula' (A phase behind a B phase that issued its 16 refills in slot order: vmcnt(4 (15 - ks)) in front
              of k-step ks) | 'model' (first segment: slots 0..7 were requested before the encoder ran, slots 8..15 ride here)
-    stream_slots: weight slots whose loads ride in this phase, one piece per gap from the first gap on"""
+    stream_slots: weight slots whose loads ride in this phase, one piece per gap from the first gap on
+    refill_slots: the slots a refilling phase requests (default: all sixteen).  B16LP -- the last segment's B phase of a PERSISTENT
+             workgroup -- requests slots 0..7 of the trunk's FIRST segments (its descriptor carries descriptor 0's stream fields):
+             the next tile of the workgroup finds them resident, as a first tile finds what the pre-issue statement requested"""
     s = Stream()
     s.emit(I_label(f"L_{name}"))
     oh = other(half)
@@ -537,7 +540,7 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
                     s.emit(r, ("xl", ks + 1))
             if rebuild is not None and m == 2 and ks in (0, max(1, (nks - 1) // 2)):
                 emit_rebuild(s, rb_parts[0 if ks == 0 else 1], ks == 0)
-            if refills and ks >= 1 and 3 <= m <= 7:
+            if refills and ks >= 1 and 3 <= m <= 7 and (refill_slots is None or ks - 1 in refill_slots):
                 for r in refill(ks - 1, one_stream)[m - 3]:
                     s.emit(r, ("w", ks - 1))
             if pieces and gi % every == 0 and pi < len(pieces):
@@ -556,7 +559,7 @@ def phase_body(name, half, nks, ride=None, refills=False, tail_init=False, rebui
             if ks == last and m == 0:
                 for r in frag_reads_l(oh, 0):
                     s.emit(r, ("xl'", 0))
-            if ks == last and m == 11 and refills:
+            if ks == last and m == 11 and refills and (refill_slots is None or last in refill_slots):
                 for r in refill_flat(last, one_stream):
                     s.emit(r, ("w", last))
     assert ri == len(ride_ins) and pi == len(pieces)
@@ -629,8 +632,9 @@ HEAD_ACC = [V(128 + 16 * c, 16) for c in range(3)]     # three accumulator chain
 
 
 def head_loads():
-    """The head tile [k-step][hi, lo][lane = tile row + 32 k-half][8 halfs] (32 KiB, stream r1 of the descriptor) -> a0..a127,
-    requested in front of the last epilogue: k-step ks' hi fragment in a[8 ks : 8 ks + 3], lo in a[8 ks + 4 : 8 ks + 7].  Only
+    """The head tile [k-step][hi, lo][lane = tile row + 32 k-half][8 halfs] (32 KiB, stream r1 of the descriptor) -> a128..a255
+    (weight slots 8..15: slots 0..7 may already hold the NEXT tile's first segments, B16LP), requested in front of the last
+    epilogue: k-step ks' hi fragment in a[128 + 8 ks : 128 + 8 ks + 3], lo in a[128 + 8 ks + 4 : 128 + 8 ks + 7].  Only
     the lanes whose row (lane & 31) is one of the n1 head rows load (the others keep stale, finite weights: their output rows
     are never read); the last MFMAs of the trunk were issued long before the first load can return.
     Returns [setup (VCC = the loading lanes; nothing of the epilogue touches VCC), group 0, ..., group 7]: a group is four loads
@@ -641,7 +645,7 @@ def head_loads():
     groups = []
     for g in range(8):
         o = [I_s_and_saveexec(S_SAVE), I_valu("v_add_u32", V_OFF, S_R1, V_LANE16, text=f"v_add_u32_e32 {V_OFF}, {S_R1}, {V_LANE16}")]
-        o += [I_gload_x4_s(A(16 * g + 4 * c, 4), V_OFF, S_PK, 1024 * c) for c in range(4)]
+        o += [I_gload_x4_s(A(128 + 16 * g + 4 * c, 4), V_OFF, S_PK, 1024 * c) for c in range(4)]
         o += [I_salu("s_add_u32", S_R1, S_R1, 4096, scc=True), I_s_mov_exec(S_SAVE)]
         groups.append(o)
     return [setup] + groups
@@ -649,7 +653,7 @@ def head_loads():
 
 def head_body():
     """HEAD: the narrow output layers on the trunk's last activation (both planes complete: EPI_B ended with a barrier).  Wave w
-    multiplies the 32-row head tile (a0..a127, see head_loads) with the fragments of points 32 w .. 32 w + 31 -- three
+    multiplies the 32-row head tile (a128..a255, see head_loads) with the fragments of points 32 w .. 32 w + 31 -- three
     accumulator chains Wl.xh, Wh.xl, Wh.xh of sixteen MFMAs -- and leaves  (chain0 + chain1) + chain2  of head row
     r < n1 at float D_BIAS / 4 + r of the point's raw record in LDS; bias and activation are applied where the records are stored."""
     s = Stream()
@@ -674,9 +678,9 @@ def head_body():
     a0, a1, a2 = HEAD_ACC
     for ks in range(16):
         s.need_lds(("x", ks))
-        e(I_mfma(a0, A(8 * ks + 4, 4), fh(ks), a0 if ks else 0))
-        e(I_mfma(a1, A(8 * ks, 4), fl(ks), a1 if ks else 0))
-        e(I_mfma(a2, A(8 * ks, 4), fh(ks), a2 if ks else 0))
+        e(I_mfma(a0, A(128 + 8 * ks + 4, 4), fh(ks), a0 if ks else 0))
+        e(I_mfma(a1, A(128 + 8 * ks, 4), fl(ks), a1 if ks else 0))
+        e(I_mfma(a2, A(128 + 8 * ks, 4), fh(ks), a2 if ks else 0))
         if ks + 3 < 16:                 # (into the registers of k-step ks - 1: its MFMAs were issued 96 cycles ago)
             for r in reads(ks + 3):
                 e(r, ("x", ks + 3))
@@ -809,6 +813,12 @@ def prologue():
     e(in_s(S_PK, "pk")); e(in_s(S_PH, "phases")); e(in_s(S_LDS, "lds")); e(in_s(S_BIASLDS, "biaslds"))
     e(in_s(S_WAVE, "wave")); e(in_s(S_INT, "in_t")); e(in_s(S_RAWLDS, "rawlds")); e(in_v(V_TMP, "tid"))
     e(in_v(V(34), "tpa0")); e(in_v(V(35), "tpa1")); e(in_v(V(36), "tpb0")); e(in_v(V(37), "tpb1"))
+    if not SAVE:
+        # the NEXT tile's point of this thread (a persistent workgroup's tile loop, field_h3.hip): %[nxa] v64 its address, %[nx0..2]
+        # three of the compiler's registers (outputs of the statement, valid behind L_end's vmcnt(0)).  Not in the wait model:
+        # operations the model does not know make a counted wait stricter, never weaker (the queue returns in order).
+        for j in range(3):
+            e(raw(f"global_load_dword %[nx{j}], %[nxa], off" + (f" offset:{4 * j}" if j else "")))
     # descriptor 0 -> cur (bias row of segment 0), descriptor 1 -> nxt (fetched now, valid after the lgkmcnt(0) below)
     e(I_s_load(S(S_CUR, 8), S_PH, 0))
     e(I_s_load(S(S_NXT, 8), S_PH, 32))
@@ -891,7 +901,7 @@ def timing_store():
     return o
 
 
-DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "EPI_B", "HEAD", "B16RS", "A16RS", "SAVE_LAST")
+DISPATCH_ORDER = ("A16R", "B16R", "B16X", "A4", "B4", "A8", "B8", "A4F", "A8F", "B16L", "B16LP", "EPI_B", "HEAD", "B16RS", "A16RS", "SAVE_LAST")
 
 
 def dispatcher():
@@ -947,6 +957,8 @@ def _build():
         # the sigma ride of a view-direction static trunk: the last trunk layer's B phase and the A phase behind it
         bodies["B16RS"] = phase_body("B16RS", "B", 16, ride="epi_sig_ws", refills=True, tail_init=True, one_stream=True)
         bodies["A16RS"] = phase_body("A16RS", "A", 16, ride="epi_sig", tail_init=True, vm_mode="formula")
+        # the last segment's B phase of a persistent workgroup: the next tile's weight slots 0..7 behind its k-steps 1..8
+        bodies["B16LP"] = phase_body("B16LP", "B", 16, ride="epi", refills=True, refill_slots=range(8))
     dispatcher.bodies = set(bodies)
     prog = prologue()
     prog.append(I_branch("s_branch", "L_dispatch"))
