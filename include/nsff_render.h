@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      26
+#define NSFF_ABI_VERSION      27
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -210,6 +210,22 @@ typedef struct NsffTimeBiasJob {
 } NsffTimeBiasJob;
 int nsff_time_bias_rows(const NsffModelDesc* desc);      /* 0: the model has no dynamic trunk */
 int nsff_time_bias(const NsffTimeBiasJob* jobs, int32_t n_jobs, int64_t n_rays, void* stream);
+
+/* ---- a4: the random draws of a render_rays call (reference rendering.py:321 perturb, 207 / 213 noise per pass, 128 the two
+ * warps, 338-340 the inverse-CDF draws) in ONE launch, bit-identical to torch.rand / torch.randn of the same generator state:
+ * job j fills out[0, numel) with what a torch kernel of `grid` blocks of 256 threads -- ATen's launch geometry for numel
+ * elements: min(#CU * (max threads per CU / 256), ceil(numel / 256)) -- started at Philox offset `offset` (a multiple of 4) of
+ * `seed` would write; the caller advances the generator by ((numel - 1) / (1024 grid) + 1) * 4 per job, as torch does.
+ * kind 0: uniform [0, 1) (torch.rand), 1: standard normal (torch.randn).  */
+#define NSFF_MAX_RNG_JOBS 12
+typedef struct NsffRngJob {
+    float*   out;
+    int64_t  numel;
+    uint64_t offset;
+    int32_t  kind;
+    uint32_t grid;
+} NsffRngJob;
+int nsff_rng_draws(const NsffRngJob* jobs, int32_t n_jobs, uint64_t seed, void* stream);
 
 /* ---- a3: the same for a view-direction model's per-ray inputs (reference nerf.py:183-185, rendering.py:153-172 repeat the
  * direction embedding and the appearance code over a ray's samples):

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 26
+ABI_VERSION = 27
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -55,6 +55,13 @@ class TimeBiasJob(C.Structure):
 
 
 MAX_TIME_BIAS_JOBS = 4
+
+
+class RngJob(C.Structure):
+    _fields_ = [("out", _fp), ("numel", C.c_int64), ("offset", C.c_uint64), ("kind", C.c_int32), ("grid", C.c_uint32)]
+
+
+MAX_RNG_JOBS = 12
 
 
 _COMPOSITE_PTRS_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "xyz_fw", "xyz_bw",
@@ -152,6 +159,7 @@ _SIGNATURES = {
                                    C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "nsff_time_bias_rows": (C.c_int, [C.POINTER(ModelDesc)]),
     "nsff_time_bias": (C.c_int, [C.POINTER(TimeBiasJob), C.c_int32, C.c_int64, C.c_void_p]),
+    "nsff_rng_draws": (C.c_int, [C.POINTER(RngJob), C.c_int32, C.c_uint64, C.c_void_p]),
     "nsff_side_bias": (C.c_int, [C.POINTER(ModelDesc), _fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_void_p]),
     "nsff_last_hip_error": (C.c_char_p, []),
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
@@ -408,6 +416,56 @@ def side_bias(model, dir_rows, a_rows=None):
     _check(load().nsff_side_bias(C.byref(desc), _ptr(packed), _ptr(w), _ptr(dir_rows), _ptr(a_rows) if desc.in_a > 0 else None,
                                  n_rays, _ptr(out), _stream()), "nsff_side_bias")
     return out
+
+
+_DEVICE_RNG_GEOMETRY = {}
+
+
+def fused_draws(plan, device, values=True):
+    """The draws ``[(kind, shape)]`` (kind "rand" | "randn") of torch's default generator of `device`, in order, by ONE launch
+    (nsff_rng_draws): bit-identical to calling torch.rand / torch.randn in that order, and the generator is left where those
+    calls would leave it.  values=False for entries whose numbers nobody reads: give a list of booleans -- such a draw only
+    advances the generator (its tensor is None).  -> list of float32 tensors."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _DEVICE_RNG_GEOMETRY:
+        p = torch.cuda.get_device_properties(idx)
+        _DEVICE_RNG_GEOMETRY[idx] = p.multi_processor_count * (p.max_threads_per_multi_processor // 256)
+    max_grid = _DEVICE_RNG_GEOMETRY[idx]
+    gen = torch.cuda.default_generators[idx]
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    wanted = values if isinstance(values, (list, tuple)) else [bool(values)] * len(plan)
+    sizes = []
+    for kind, shape in plan:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        sizes.append(n)
+    total = sum(n for n, w in zip(sizes, wanted) if w)
+    buf = torch.empty(max(total, 1), device=dev, dtype=torch.float32)        # ONE allocation; the draws are views of it
+    outs, jobs, at = [], [], 0
+    for (kind, shape), numel, want in zip(plan, sizes, wanted):
+        if numel == 0:                              # (torch returns before it touches the generator)
+            outs.append(torch.empty(*shape, device=dev, dtype=torch.float32))
+            continue
+        grid = min(max_grid, (numel + 255) // 256)
+        if want:
+            t = buf[at:at + numel].view(*shape)
+            at += numel
+            jobs.append((t, numel, offset, 1 if kind == "randn" else 0, grid))
+            outs.append(t)
+        else:
+            outs.append(None)
+        offset += ((numel - 1) // (1024 * grid) + 1) * 4
+    for k in range(0, len(jobs), MAX_RNG_JOBS):
+        part = jobs[k:k + MAX_RNG_JOBS]
+        arr = (RngJob * len(part))()
+        for j, (t, numel, off, kind, grid) in enumerate(part):
+            arr[j].out, arr[j].numel, arr[j].offset, arr[j].kind, arr[j].grid = t.data_ptr(), numel, off, kind, grid
+        with torch.cuda.device(idx):
+            _check(load().nsff_rng_draws(arr, len(part), seed, _stream()), "nsff_rng_draws")
+    gen.set_offset(offset)
+    return outs
 
 
 def time_bias_rows(model):

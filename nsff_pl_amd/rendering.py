@@ -49,10 +49,68 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
     return out
 
 
+_TORCH_RAND, _TORCH_RANDN = torch.rand, torch.randn
+
+
+class _Draws:
+    """The torch.rand / torch.randn draws of one render_rays call, in the reference's order (rendering.py:321 perturb; per model
+    pass 207, 213 the density noise; 338-340 the inverse-CDF draws between the passes; 128 the two warps' noise).  Their shapes
+    follow from the call's arguments, so ONE launch makes them all when the call starts (_lib.fused_draws: torch's own generator,
+    bit for bit, the generator left where the separate calls leave it); draws whose values nobody reads (noise with
+    noise_std = 0: the reference multiplies them by zero) only advance the generator.  While a hipGraph is captured, with
+    NSFF_TORCH_RNG=1, or when torch.rand / torch.randn are not torch's own (the parity tests replay recorded draws through them)
+    every draw is the torch call it mirrors."""
+
+    def __init__(self, device, n_rays, N_samples, N_importance, perturb, noise_std, test_time, models, kwargs):
+        self.device = device
+        self.fused = (device.type == "cuda" and torch.rand is _TORCH_RAND and torch.randn is _TORCH_RANDN
+                      and not os.environ.get("NSFF_TORCH_RNG") and not torch.cuda.is_current_stream_capturing())
+        self.at = 0
+        if not self.fused:
+            return
+        first = models["coarse"] if N_importance > 0 else models["fine"]
+        transient = bool(kwargs.get("output_transient", True) and first.encode_transient)
+        flows = kwargs.get("output_transient_flow", []) if transient else []
+        noisy = float(noise_std) != 0
+        plan, need = [], []
+
+        def add(kind, need_values, *shape):
+            plan.append((kind, shape))
+            need.append(bool(need_values))
+        if perturb > 0:
+            add("rand", True, n_rays, N_samples)
+        S = N_samples
+        if N_importance > 0:
+            add("randn", noisy, n_rays, S)
+            if transient:
+                add("randn", noisy, n_rays, S)
+            if perturb != 0:
+                add("rand", True, n_rays, N_importance)
+                if transient:
+                    add("rand", True, n_rays, N_importance)
+            S = N_samples + (2 if transient else 1) * N_importance
+        add("randn", noisy, n_rays, S)
+        if transient:
+            add("randn", noisy, n_rays, S)
+            if flows and not test_time:
+                add("randn", noisy, n_rays, S)
+                add("randn", noisy, n_rays, S)
+        self.plan = plan
+        self.values = _lib.fused_draws(plan, device, need)
+
+    def take(self, kind, *shape):
+        if not self.fused:
+            return (torch.rand if kind == "rand" else torch.randn)(*shape, device=self.device)
+        if self.at >= len(self.plan) or self.plan[self.at] != (kind, shape):
+            raise RuntimeError(f"draw {self.at}: {kind}{shape} is not the planned {self.plan[self.at:self.at + 1]}")
+        self.at += 1
+        return self.values[self.at - 1]
+
+
 class _Pass:
     """Inputs shared by the coarse and the fine pass of one render_rays call."""
     __slots__ = ("embeddings", "rays", "ts", "max_t", "noise_std", "test_time", "kwargs",
-                 "freqs_xyz", "dir_embedded", "n_rays", "rec", "tbias", "neighbour_rows")
+                 "freqs_xyz", "dir_embedded", "n_rays", "rec", "tbias", "neighbour_rows", "draws")
 
 
 def _embed_rows(embeddings, key, idx):
@@ -189,8 +247,8 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
 
     # RNG draws, in the reference's order (rendering.py:207, 213, then 128 for fw and bw)
     nstd = float(ctx.noise_std)
-    noise_s = torch.randn(n_rays, S, device=zs.device)
-    noise_t = torch.randn(n_rays, S, device=zs.device) if output_transient else None
+    noise_s = ctx.draws.take("randn", n_rays, S)
+    noise_t = ctx.draws.take("randn", n_rays, S) if output_transient else None
     if ctx.rec is not None and nstd != 0:        # the draws are needed again when gradients are taken
         ctx.rec[f"{typ}_static"], ctx.rec[f"{typ}_transient"] = noise_s, noise_t
 
@@ -245,12 +303,12 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
                                  t_bias=ctx.tbias[(typ, 'fwbw')])
             else:
                 query(f"{typ}_warp_fw", raw_fw, xyz_fw, 0, 2, 1, tp1, which='fw')
-        noise_fw = torch.randn(n_rays, S, device=zs.device)
+        noise_fw = ctx.draws.take("randn", n_rays, S)
         out('rgb_fw', n_rays, 3)
         results['xyzs_bw'] = xyz_bw
         if P and not merged:
             query(f"{typ}_warp_bw", raw_bw, xyz_bw, 0, 2, 1, tm1, which='bw')
-        noise_bw = torch.randn(n_rays, S, device=zs.device)
+        noise_bw = ctx.draws.take("randn", n_rays, S)
         if ctx.rec is not None and nstd != 0:
             ctx.rec[f"{typ}_warp_fw"], ctx.rec[f"{typ}_warp_bw"] = noise_fw, noise_bw
         out('rgb_bw', n_rays, 3)
@@ -355,7 +413,8 @@ def _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_
 
         # coarse depths: one linspace shared by all rays, optional stratified jitter
         z_lin = _unit_linspace(N_samples, rays.device)
-        perturb_rand = torch.rand(n_rays, N_samples, device=rays.device) if perturb > 0 else None
+        ctx.draws = _Draws(rays.device, n_rays, N_samples, N_importance, perturb, noise_std, test_time, models, kwargs)
+        perturb_rand = ctx.draws.take("rand", n_rays, N_samples) if perturb > 0 else None
         zs = _new(rays, n_rays, N_samples)
         xyz_coarse = _new(rays, n_rays, N_samples, 3)
         if n_rays:
@@ -374,8 +433,8 @@ def _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_
                 u_s = _unit_linspace(N_importance, rays.device)
                 u_t = u_s
             else:
-                u_s = torch.rand(n_rays, N_importance, device=rays.device)
-                u_t = torch.rand(n_rays, N_importance, device=rays.device) if output_transient else None
+                u_s = ctx.draws.take("rand", n_rays, N_importance)
+                u_t = ctx.draws.take("rand", n_rays, N_importance) if output_transient else None
             S_fine = N_samples + (2 if output_transient else 1) * N_importance
             zs_static = _new(rays, n_rays, N_importance) if test_time else None
             zs_transient = _new(rays, n_rays, N_importance) if (test_time and output_transient) else None

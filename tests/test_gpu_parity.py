@@ -311,6 +311,65 @@ def test_rng_draw_order_matches_reference_on_device(hip_lib):
     assert torch.equal(after, torch.rand(4, device=DEV))
 
 
+def test_fused_draws_are_torchs(hip_lib):
+    """nsff_rng_draws (one launch for all draws of a call) against torch.rand / torch.randn themselves: the same bits from the same
+    generator state, the same state afterwards -- for sizes below and above one grid-stride pass of torch's launch geometry, odd
+    sizes, empty draws, and draws whose values are skipped (they only advance the generator)."""
+    plan = [("rand", (1024, 64)), ("randn", (1024, 64)), ("randn", (1024, 64)), ("rand", (1024, 64)), ("randn", (1024, 192)),
+            ("randn", (7, 33)), ("rand", (1, 1)), ("randn", (0, 64)), ("rand", (3001, 997)), ("randn", (2100, 1111)), ("rand", (5,)),
+            ("randn", (1024, 192)), ("randn", (1024, 192)), ("rand", (255,)), ("randn", (257,))]
+    for seed in (0, 123456789):
+        torch.manual_seed(seed)
+        torch.rand(3, device=DEV)                                   # (an offset that is not zero)
+        want = [(torch.rand if k == "rand" else torch.randn)(*shape, device=DEV) for k, shape in plan]
+        after = torch.rand(4, device=DEV)
+        torch.manual_seed(seed)
+        torch.rand(3, device=DEV)
+        got = _lib.fused_draws(plan, torch.device(DEV))
+        assert torch.equal(after, torch.rand(4, device=DEV)), "the generator is not where the separate calls leave it"
+        for (k, shape), w, g in zip(plan, want, got):
+            assert g.shape == w.shape and g.dtype == torch.float32
+            assert torch.equal(g, w), (seed, k, shape, (g != w).float().mean().item())
+        # skipped values: None in their place, the others unchanged, the same state afterwards
+        torch.manual_seed(seed)
+        torch.rand(3, device=DEV)
+        need = [i % 3 != 1 for i in range(len(plan))]
+        part = _lib.fused_draws(plan, torch.device(DEV), need)
+        assert torch.equal(after, torch.rand(4, device=DEV))
+        for i, (w, g) in enumerate(zip(want, part)):
+            assert (g is None) == (not need[i] and w.numel() > 0)
+            if g is not None:
+                assert torch.equal(g, w)
+
+
+def test_render_with_fused_draws_equals_render_with_torch_draws(hip_lib, monkeypatch):
+    """the C2 training call (perturb = noise_std = 1, fw / bw warps: nine draws) with its draws made by one launch and by the nine
+    torch calls (NSFF_TORCH_RNG=1): every output bit-identical, the generator in the same state; noise_std = 0: the skipped
+    draws leave the same state too"""
+    cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=256)
+    rays, ts = scenes.synthetic_rays(256, 5)
+    models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+    _to_dev(models, emb)
+    for noise_std in (1.0, 0.0):
+        got = {}
+        for form in ("fused", "torch"):
+            if form == "torch":
+                monkeypatch.setenv("NSFF_TORCH_RNG", "1")
+            else:
+                monkeypatch.delenv("NSFF_TORCH_RNG", raising=False)
+            torch.manual_seed(77)
+            with torch.no_grad():
+                out = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), 29, 64, 1.0, noise_std, 64, 32768, test_time=False,
+                                    **scenes.render_kwargs(cfg))
+            got[form] = ({k: v.clone() for k, v in out.items()}, torch.rand(4, device=DEV))
+        monkeypatch.delenv("NSFF_TORCH_RNG", raising=False)
+        (a, sa), (b, sb) = got["fused"], got["torch"]
+        assert torch.equal(sa, sb)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (noise_std, k)
+
+
 # ---- full-size configuration (BASELINE.json configs[1]): size-independent properties ----
 def test_c2_full_size_properties(hip_lib, precision):
     cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024)

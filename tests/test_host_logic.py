@@ -56,7 +56,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 26
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 27
 
 
 def test_struct_layouts_match_the_header_sizes():
@@ -64,6 +64,7 @@ def test_struct_layouts_match_the_header_sizes():
     assert C.sizeof(_lib.ModelDesc) == 48
     assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 4 * _lib.MAX_FREQS + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8 + 8 + 8 + 16 and _lib.MAX_FREQS == 24
     assert C.sizeof(_lib.TimeBiasJob) == 8 + 64 + 64 + 16 + 16 + 16 + 8 + 8
+    assert C.sizeof(_lib.RngJob) == 32 and _lib.MAX_RNG_JOBS == 12
     assert C.sizeof(_lib.FieldBwdArgs) == 16 + 8 * 8 and C.sizeof(_lib.WgradJob) == 32
     assert C.sizeof(_lib.SplatArgs) == 12 + 16 + 48 + 4 + 5 * 8 + 16 and C.sizeof(_lib.MpiArgs) == 16 + 7 * 8
     assert C.sizeof(_lib.LossArgs) == 24 + 8 + 8 + 8 * (len(_lib._LOSS_IN) + 3 + len(_lib.LOSS_GRADS))
@@ -104,6 +105,13 @@ def test_layout_and_argument_validation_without_gpu():
     jobs = (_lib.TimeBiasJob * 1)()
     assert lib.nsff_time_bias(jobs, 0, 4, None) == -1 and lib.nsff_time_bias(jobs, 5, 4, None) == -1
     assert lib.nsff_time_bias(jobs, 1, 4, None) == -2                          # (null members)
+    rj = (_lib.RngJob * 2)()
+    assert lib.nsff_rng_draws(None, 0, 1, None) == 0 and lib.nsff_rng_draws(None, 1, 1, None) == -2
+    assert lib.nsff_rng_draws(rj, _lib.MAX_RNG_JOBS + 1, 1, None) == -1 and lib.nsff_rng_draws(rj, 1, 1, None) == -2    # (null out)
+    rj[0].out, rj[0].numel, rj[0].grid, rj[0].offset = 64, 1000, 4, 2        # an offset that is not a multiple of 4
+    assert lib.nsff_rng_draws(rj, 1, 1, None) == -1
+    rj[0].offset, rj[0].grid = 4, 5                                          # more blocks than torch launches for 1000 elements
+    assert lib.nsff_rng_draws(rj, 1, 1, None) == -1
     c = _lib.CompositeArgs()
     c.n_rays, c.n_samples = 4, 0
     assert lib.nsff_composite(C.byref(c), None) == -1
