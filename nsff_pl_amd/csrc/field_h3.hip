@@ -1088,9 +1088,9 @@ static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kern
 // Weight slots 0..7 (the first segment and the start of the second), requested in front of / inside the encoder: statement K
 // loads slot K's 4 KiB of this wave from (K < n1 ? r1 : r2) + 4096 K -- the fields of phase descriptor 0, as the body's refills.
 struct H3APre {
-    unsigned long long pk;
-    unsigned r1, r2, n1, lane16;
-    bool on;          // (wave-uniform) false: the slots of this tile were requested behind the previous tile's body (persistent launch)
+    unsigned long long pk = 0;
+    unsigned r1 = 0, r2 = 0, n1 = 0, lane16 = 0;
+    bool on = false;          // (wave-uniform) false: the slots of this tile were requested behind the previous tile's body (persistent launch)
     template <int K> __device__ __forceinline__ void slot() const {
         if (!on) return;
         const unsigned off = (K < (int)n1 ? r1 : r2) + 4096u * K;
@@ -1255,6 +1255,35 @@ __device__ __forceinline__ void h3a_kernel() {
     };
     request_point(h3a_args()->k, tile * M, threadIdx.x);
     unsigned tid_ = threadIdx.x;            // (the ONE copy of the thread index that crosses the body: an in / out operand of its statement)
+    // What every tile's bias-row requests need, read ONCE per workgroup (the compiler parks these scalars in lanes of a register
+    // the body leaves alone: a lane read instead of a dependent scalar load per tile): the bias table's entries, the per-ray
+    // table's position relative to the packed buffer, its row pitch, the launch's last point, points per ray.
+    // (dynamic trunk with the time code folded in: the rows of its input layers are per ray -- every 64-point half of the tile
+    // lies inside one ray, the host checked pts_per_ray % 64 == 0 and n_points < 2^31 -- and the body never sees a time-code column;
+    // the static trunk of a view-direction model has per-ray rows of its own: static_dir_encoding's [dir | a] part, nsff_side_bias)
+    uint32_t boff[H3A_MAX_BIAS];
+    int nb;
+    unsigned has_rows;          // (an integer in a scalar register: a parked bool becomes a lane mask in a vector register)
+    unsigned last_pt, ppr, row_bytes;
+    long long rows_delta;
+    {
+        H3AKernArgs& aa = *h3a_args();
+        const auto& a = aa.k;
+        const float* rowtab = tr == 1 ? a.t_bias : a.s_bias;
+        has_rows = (unsigned)__builtin_amdgcn_readfirstlane(rowtab != nullptr ? 1 : 0);
+        row_bytes = (unsigned)(tr == 1 ? a.tb_rows : a.sb_rows) * (NSFF_W * 4);
+        last_pt = (unsigned)(a.n_points - 1);
+        ppr = (unsigned)a.pts_per_ray;
+        rows_delta = reinterpret_cast<const char*>(rowtab) - reinterpret_cast<const char*>(a.packed);
+        nb = aa.n_bias[tr];
+#pragma unroll
+        for (int r4 = 0; r4 < H3A_MAX_BIAS / 4; ++r4) {
+            const u4v q = reinterpret_cast<const __attribute__((address_space(4))) u4v*>(&aa.bias_off[tr][0])[r4];
+            boff[4 * r4] = q[0]; boff[4 * r4 + 1] = q[1]; boff[4 * r4 + 2] = q[2]; boff[4 * r4 + 3] = q[3];
+        }
+#pragma unroll
+        for (int r = 0; r < H3A_MAX_BIAS; ++r) boff[r] = r < nb ? boff[r] : 0u;
+    }
 #pragma unroll 1
   for (int it = 0; tile < tile_end; ++it, tile += tile_stride) {
     H3AKernArgs& aa = *h3a_args();
@@ -1274,35 +1303,28 @@ __device__ __forceinline__ void h3a_kernel() {
     // rows (sixteen loads in flight), then -- the pre-issue statement -- weight slots 0..7: 128 KiB that cross the CU's vector-memory
     // path while the encoder below computes.  The compiler's wait for the point sits behind the statement (its first use).
     // bias table of this trunk (fp32 rows of 256): the body initialises its accumulators from it with ds_read_b128.
-    // (dynamic trunk with the time code folded in: the rows of its input layers are per ray -- every 64-point half of the tile
-    // lies inside one ray, the host checked pts_per_ray % 64 == 0 and n_points < 2^31 -- and the body never sees a time-code column)
-    const bool tb = tr == 1 && a.t_bias != nullptr;
-    // (the static trunk of a view-direction model has per-ray rows of its own: static_dir_encoding's [dir | a] part, nsff_side_bias)
-    const float* rowtab = tr == 1 ? a.t_bias : a.s_bias;
-    const int rowtab_rows = tr == 1 ? a.tb_rows : a.sb_rows;
+    const bool tb = tr == 1 && has_rows != 0u;
     float bv[H3A_MAX_BIAS];
-    const int nb = aa.n_bias[tr];
-    {
-        // row r's bytes from the packed buffer's start (wave-uniform, branch-free; the table's 16 entries arrive as four 16-byte
-        // scalar loads): a plain row is a word offset, a per-ray row lies tb_delta = t_bias - packed further on, at the ray of
-        // its half.  Rows past the table's end read the buffer's first words (never stored).
-        long long tb_at[2] = {0, 0};
-        if (rowtab != nullptr) {
-            const unsigned last = (unsigned)(a.n_points - 1), q0 = (unsigned)p0, ppr = (unsigned)a.pts_per_ray;
-            const long long delta = reinterpret_cast<const char*>(rowtab) - reinterpret_cast<const char*>(pk);
-            tb_at[0] = delta + (long long)((q0 < last ? q0 : last) / ppr) * (rowtab_rows * NSFF_W * 4);
-            tb_at[1] = delta + (long long)((q0 + 64u < last ? q0 + 64u : last) / ppr) * (rowtab_rows * NSFF_W * 4);
-        }
-        uint32_t boff[H3A_MAX_BIAS];
+    // (opaque copies: what is derived from the parked scalars is derived per tile, not parked as well)
+    uint32_t bo[H3A_MAX_BIAS];
 #pragma unroll
-        for (int r4 = 0; r4 < H3A_MAX_BIAS / 4; ++r4) {
-            const u4v q = reinterpret_cast<const __attribute__((address_space(4))) u4v*>(&aa.bias_off[tr][0])[r4];
-            boff[4 * r4] = q[0]; boff[4 * r4 + 1] = q[1]; boff[4 * r4 + 2] = q[2]; boff[4 * r4 + 3] = q[3];
+    for (int r = 0; r < H3A_MAX_BIAS; ++r) { bo[r] = boff[r]; asm volatile("" : "+s"(bo[r])); }
+    {
+        // row r's bytes from the packed buffer's start (wave-uniform, branch-free): a plain row is a word offset, a per-ray row
+        // lies rows_delta = t_bias - packed further on, at the ray of its half.  Rows past the table's end read the buffer's
+        // first words (never stored).
+        long long tb_at[2] = {0, 0};
+        if (has_rows != 0u) {
+            unsigned q0 = (unsigned)p0, lp = last_pt, pp = ppr, rbytes = row_bytes;
+            long long rd = rows_delta;
+            asm volatile("" : "+s"(lp), "+s"(pp), "+s"(rbytes), "+s"(rd));
+            tb_at[0] = rd + (long long)((q0 < lp ? q0 : lp) / pp) * rbytes;
+            tb_at[1] = rd + (long long)((q0 + 64u < lp ? q0 + 64u : lp) / pp) * rbytes;
         }
         if (it == 0) {
 #pragma unroll
             for (int r = 0; r < H3A_MAX_BIAS; ++r) {
-                const uint32_t off = r < nb ? boff[r] : 0u;
+                const uint32_t off = bo[r];
                 // (selects as mask arithmetic: the compiler turns the conditional form into two scalar branches per row)
                 const long long per_ray = -(long long)(off >> 31), half_b = -(long long)((off >> 8) & 1u);
                 const long long at_ray = tb_at[0] + (half_b & (tb_at[1] - tb_at[0])) + (long long)((off & 0xffu) * (NSFF_W * 4));
@@ -1313,7 +1335,7 @@ __device__ __forceinline__ void h3a_kernel() {
             // a later tile of a persistent launch: only the per-ray rows change (at most six: one scalar branch per table row)
 #pragma unroll
             for (int r = 0; r < H3A_MAX_BIAS; ++r) {
-                const uint32_t off = r < nb ? boff[r] : 0u;
+                const uint32_t off = bo[r];
                 bv[r] = 0.f;
                 if (off >> 31) {
                     const long long at = tb_at[(off >> 8) & 1u] + (long long)((off & 0xffu) * (NSFF_W * 4));
@@ -1323,21 +1345,20 @@ __device__ __forceinline__ void h3a_kernel() {
         }
     }
     // (the heads' biases -- 32 floats -- travel with the table: the records loop below reads them from LDS)
-    const H3AHeadSel hs = {aa.hsel[tr].w_off, aa.hsel[tr].b_off, aa.hsel[tr].n_rows, aa.hsel[tr].slot0, aa.hsel[tr].kinds};
-    const float hbias = reinterpret_cast<const float*>(pk)[hs.b_off + (tid_ & 31)];
-    const bool sig_ride = tr == 0 && aa.sig_ride != 0;
-    const float sig_b = reinterpret_cast<const float*>(pk)[sig_ride ? aa.sig_b_off : 0u];
-    H3A_TSTAMP(52);
+    float hbias = 0.f, sig_b = 0.f;
     H3APre pre;
-    {
+    pre.on = it == 0;
+    if (it == 0) {      // (a later tile of a persistent workgroup finds them in LDS / its weight slots resident)
+        hbias = reinterpret_cast<const float*>(pk)[aa.hsel[tr].b_off + (tid_ & 31)];
+        sig_b = reinterpret_cast<const float*>(pk)[(tr == 0 && aa.sig_ride != 0) ? aa.sig_b_off : 0u];
         const auto& d0 = aa.ph[tr][0];
         pre.pk = (unsigned long long)(uintptr_t)pk;
         pre.n1 = d0.d[3];
         pre.r1 = d0.d[4] + (unsigned)wave_id * d0.d[5];
         pre.r2 = d0.d[6] + (unsigned)wave_id * d0.d[7];
         pre.lane16 = (unsigned)lane << 4;
-        pre.on = it == 0;
     }
+    H3A_TSTAMP(52);
     pre.slot<0>(); pre.slot<1>(); pre.slot<2>();        // (a later tile of a persistent workgroup: the previous tile's B16LP phase requested all eight)
     // the point is pinned as landed here (first tile: the one wait for the workgroup's own loads and the three slots behind them)
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]));
@@ -1363,7 +1384,7 @@ __device__ __forceinline__ void h3a_kernel() {
     } else {
 #pragma unroll
         for (int r = 0; r < H3A_MAX_BIAS; ++r)
-            if (r < nb && (aa.bias_off[tr][r] >> 31)) sBias[r * NSFF_W + tid_] = bv[r];
+            if (bo[r] >> 31) sBias[r * NSFF_W + tid_] = bv[r];
     }
     // (the body itself requests the NEXT tile's point into px -- registers the body leaves to the compiler -- from this address;
     //  the last tile requests its own point again)
