@@ -1076,8 +1076,10 @@ struct H3AArgs {
     // up once, and the next tile's first eight weight slots are requested behind the body, so that they cross the CU's vector-memory
     // path while the records of this tile are stored.  1: one trunk in the launch (whole records); 2: both trunks -- workgroup b runs
     // on XCD b % 8 (observed, not promised: only L2 locality depends on it), XCDs 0..3 take the static trunk, 4..7 the dynamic one,
-    // each trunk's 2.3 MB of weights stay in its XCDs' L2s; 3: the dynamic trunk of a launch whose static trunk is another kernel's.
-    int p_mode;
+    // each trunk's 2.3 MB of weights stay in its XCDs' L2s; 3: the dynamic trunk of a launch whose static trunk is another kernel's;
+    // 4: both trunks of unequal cost (a view-direction static trunk is 23 % longer): workgroups [0, p_split) take the static trunk,
+    // the others the dynamic one -- p_split = the static trunk's share of the matrix steps, so that both kinds finish together.
+    int p_mode, p_split;
     long long p_tiles;                  // 128-point tiles of the launch
     int sig_ride;                       // static trunk with the view-direction branch: sigma = sum of the 8 partial sums the body's
                                         // sigma ride left at floats 4..11 of the record image + the bias at packed word sig_b_off
@@ -1239,6 +1241,11 @@ __device__ __forceinline__ void h3a_kernel() {
             tile = (long long)(blockIdx.x >> 3) * 4 + (x & 3);
             tile_stride = gridDim.x >> 1;
         } else if (aa.p_mode == 3) { tr = 1; piece = 2; }
+        else if (aa.p_mode == 4) {
+            tr = (int)blockIdx.x >= aa.p_split ? 1 : 0; piece = tr + 1;
+            tile = tr ? (long long)blockIdx.x - aa.p_split : (long long)blockIdx.x;
+            tile_stride = tr ? (long long)gridDim.x - aa.p_split : (long long)aa.p_split;
+        }
     } else if (a.split_trunks) {
         if (tile < a.grid_tiles) { tr = 0; piece = 1; }
         else { tile -= a.grid_tiles; tr = 1; piece = 2; }
@@ -2419,9 +2426,9 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         ka.hsel[0] = h3a_head_sel(k.L, ka.head[0]); ka.hsel[1] = h3a_head_sel(k.L, ka.head[1]);
         const int which = side ? NSFF_KERNEL_H3A_SIDE : (ka.k.t_bias ? NSFF_KERNEL_H3A_TBIAS : NSFF_KERNEL_H3A);
         // Persistent form (H3AArgs::p_mode): one workgroup per CU walking its tiles -- for launches that give every workgroup at
-        // least one tile; both trunks only when their phase programs cost the same (each workgroup keeps ONE trunk, so an
-        // imbalance idles half of the chip: the view-direction static trunk is 23 % longer than the dynamic one -- those launches
-        // keep one workgroup per tile and the dispatcher's own balancing).  NSFF_NO_PERSIST=1: one workgroup per tile (A/B).
+        // least one tile.  Each workgroup keeps ONE trunk: trunks of equal cost split the chip by XCD, unequal ones (the
+        // view-direction static trunk is 23 % longer than the dynamic one) by their share of the matrix steps.
+        // NSFF_NO_PERSIST=1: one workgroup per tile (A/B).
         static const int n_cus = [] { int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
             return n; }();
@@ -2457,13 +2464,17 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             if (can_persist && !both2 && tiles >= n_cus && h3a_make_persistent(ka.ph[ks.n_static_steps > 0 ? 0 : 1])) {
                 ka.p_mode = 1; ka.p_tiles = tiles; grid = (unsigned)n_cus;
             }
-            if (can_persist && both2 && !side && tiles >= n_cus / 2) {
+            if (can_persist && both2 && tiles >= n_cus / 2) {
                 const int cs = cost(ka.ph[0]), cd = cost(ka.ph[1]);
+                const bool equal = 25 * std::abs(cs - cd) <= std::max(cs, cd);
+                // (unequal trunks: the static trunk's workgroups by its share of the matrix steps; every workgroup needs a tile)
+                const int split = equal ? n_cus / 2 : (int)(((long long)n_cus * cs + (cs + cd) / 2) / (cs + cd));
                 H3APhase keep[H3A_MAX_PHASES];
                 for (int i = 0; i < H3A_MAX_PHASES; ++i) keep[i] = ka.ph[0][i];
-                if (25 * std::abs(cs - cd) <= std::max(cs, cd) && h3a_make_persistent(ka.ph[0])) {
-                    if (h3a_make_persistent(ka.ph[1])) { ka.p_mode = 2; ka.p_tiles = tiles; grid = (unsigned)n_cus; }
-                    else for (int i = 0; i < H3A_MAX_PHASES; ++i) ka.ph[0][i] = keep[i];
+                if (split >= 1 && split < n_cus && tiles >= std::max(split, n_cus - split) && h3a_make_persistent(ka.ph[0])) {
+                    if (h3a_make_persistent(ka.ph[1])) {
+                        ka.p_mode = equal ? 2 : 4; ka.p_split = split; ka.p_tiles = tiles; grid = (unsigned)n_cus;
+                    } else for (int i = 0; i < H3A_MAX_PHASES; ++i) ka.ph[0][i] = keep[i];
                 }
             }
             hipLaunchKernelGGL(nsff_field_kernel_h3a, dim3(grid), dim3(256), 0, st, ka);

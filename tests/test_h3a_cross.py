@@ -281,8 +281,9 @@ def test_training_forward_on_the_hand_scheduled_kernel(arch, hip_lib):
 
 def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, monkeypatch):
     """Large launches of the hand-scheduled kernel are persistent (include/nsff_render.h::nsff_last_field_grid): one workgroup per
-    compute unit walks tiles of ONE trunk -- both trunks when they cost the same (time code as per-ray bias rows), one trunk
-    (static-only / dynamic-only launches, and the dynamic half of a view-direction model without its per-ray rows) otherwise.
+    compute unit walks tiles of ONE trunk -- both trunks split by XCD when they cost the same (time code as per-ray bias rows), by
+    their share of the matrix steps when they do not (time code through the matrix pipe; a view-direction static trunk with its
+    per-ray rows), one trunk in static-only / dynamic-only launches and for the dynamic half of a view-direction model without rows.
     Every tile is computed by the same instruction stream from the same inputs whichever workgroup runs it: the records are
     bit-identical to the one-workgroup-per-tile form (NSFF_NO_PERSIST=1), including a ragged last tile; the grid tells which form ran."""
     torch.manual_seed(5)
@@ -294,21 +295,24 @@ def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, m
     viewdir = A.NeRF("fine", use_viewdir=True, encode_transient=True, in_channels_t=48, output_flow=True).to(DEV)
     config.set_precision("f16x3")
     S = 64
-    cases = [  # model, rays, (static, transient, flow heads), per-ray time rows?, grid of the persistent form (None: never persistent)
-        (plain, 2 * n_cus + 3, (2, 2, 2), True, n_cus),            # both trunks, equal cost: trunk by XCD
-        (plain, 2 * n_cus + 3, (2, 2, 2), False, None),            # time code through the matrix pipe: the dynamic trunk is 7 % longer
-        (plain, 2 * n_cus + 5, (2, 0, 0), False, n_cus),           # static only
-        (plain, 2 * n_cus + 5, (0, 2, 1), True, n_cus),            # dynamic only
-        (viewdir, 2 * n_cus + 1, (2, 2, 2), True, n_cus),          # static trunk on the eight-wave kernel, dynamic one persistent
-        (plain, n_cus // 8, (2, 2, 2), True, None),                # fewer tiles than workgroups
+    cases = [  # model, rays, (static, transient, flow heads), per-ray time rows?, per-ray [dir | a] rows?, grid of the persistent form (None: never persistent)
+        (plain, 2 * n_cus + 3, (2, 2, 2), True, False, n_cus),     # both trunks, equal cost: trunk by XCD
+        (plain, 2 * n_cus + 3, (2, 2, 2), False, False, n_cus),    # time code through the matrix pipe: the dynamic trunk is 7 % longer
+        (plain, 2 * n_cus + 5, (2, 0, 0), False, False, n_cus),    # static only
+        (plain, 2 * n_cus + 5, (0, 2, 1), True, False, n_cus),     # dynamic only
+        (viewdir, 2 * n_cus + 1, (2, 2, 2), True, False, n_cus),   # static trunk on the eight-wave kernel, dynamic one persistent
+        (viewdir, 2 * n_cus + 7, (2, 2, 2), True, True, n_cus),    # view-direction static trunk (23 % longer) beside the dynamic one
+        (viewdir, 2 * n_cus + 7, (2, 0, 0), False, True, n_cus),   # ... alone
+        (plain, n_cus // 8, (2, 2, 2), True, False, None),         # fewer tiles than workgroups
     ]
-    for m, n_rays, (sm, tm, fh), rows, grid_p in cases:
+    for m, n_rays, (sm, tm, fh), rows, side, grid_p in cases:
         P = S * n_rays
         tiles = (P + 127) // 128
         xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
         t_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
         dirs = emb_d(torch.randn(n_rays, 3, generator=g).to(DEV)).contiguous() if m is viewdir else None
         tb = _lib.time_bias([(m, t_rows)])[0] if (rows and tm) else None
+        sb = _lib.side_bias(m, dirs, None) if side else None
         got = {}
         config.set_tile_points(130)
         try:
@@ -318,14 +322,15 @@ def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, m
                 else:
                     monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
                 raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
-                _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs, t_bias=tb)
+                _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs, t_bias=tb,
+                                 s_bias=sb)
                 torch.cuda.synchronize()
                 got[form] = (raw.cpu().numpy(), _lib.last_field_grid(), _lib.last_field_kernel())
         finally:
             config.set_tile_points(0)
             monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
         (a, ga, ka), (b, gb, kb) = got["persistent"], got["tile"]
-        both = sm and tm and m is not viewdir
+        both = sm and tm and (m is not viewdir or side)
         assert ka == kb and ka.startswith("h3a"), (ka, kb)
         assert gb == (2 * tiles if both else tiles), (gb, tiles)
         assert ga == (grid_p if grid_p is not None else gb), (ga, grid_p, gb)
