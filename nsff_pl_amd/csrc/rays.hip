@@ -118,44 +118,57 @@ struct FineArgs {
     float* zs_fine; float* xyz_fine;
 };
 
+// One ray per workgroup of four waves: the inverse-CDF draws of the static and the transient weights run side by side (wave 0 /
+// wave 1, the arithmetic of either is one wave's as before: the same scan order, the same results), the merge sort ranks one
+// element per thread, and a CU holds eight rays' workgroups at a time -- the one-wave-per-ray form of earlier rounds (four waves
+// per CU, three elements' ranks per lane) took 24 us per 1024 rays, a sequence of exposed latencies.
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void fine_samples_kernel(const FineArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long ray_raw = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
-    const bool active = ray_raw < a.n_rays;
-    const long long ray = active ? ray_raw : a.n_rays - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    constexpr int T = 64 * WAVES_PER_BLOCK;
+    const long long ray = blockIdx.x;
     const int S = a.S, n_imp = a.n_imp;
     const int k_sets = a.w_transient ? 2 : 1;
     const int Sf = S + k_sets * n_imp;
-    float* cdf = smem + wave * (2 * S + Sf);   // S-1 used
-    float* bins = cdf + S;                     // S-1 used: interval mid points (rendering.py:315)
-    float* merged = bins + S;                  // Sf
-    for (int j = lane; j < S - 1; j += 64) bins[j] = 0.5f * (a.z_lin[j] + a.z_lin[j + 1]);
-    for (int j = lane; j < S; j += 64) merged[j] = a.zs_coarse[ray * S + j];
+    float* cdf = smem + wave * S;                              // S-1 used; one scratch per wave (sample_pdf_ray writes it unconditionally)
+    float* bins = smem + WAVES_PER_BLOCK * S;                  // S-1 used: interval mid points (rendering.py:315)
+    float* merged = bins + ((S + 3) & ~3);                     // Sf, 16-byte aligned
+    for (int j = tid; j < S - 1; j += T) bins[j] = 0.5f * (a.z_lin[j] + a.z_lin[j + 1]);
+    for (int j = tid; j < S; j += T) merged[j] = a.zs_coarse[ray * S + j];
     __syncthreads();
-    for (int set = 0; set < k_sets; ++set) {
+    {
+        const bool mine = wave < k_sets;                       // (the other waves go through the function's barriers with nothing to do)
+        const int set = mine ? wave : 0;
         const float* w = (set == 0 ? a.w_static : a.w_transient) + ray * S + 1;   // weights[:, 1:-1]
         const float* ub = set == 0 ? a.u_static : a.u_transient;
         const float* u = a.u_per_ray ? ub + ray * n_imp : ub;
         float* keep = set == 0 ? a.samples_static : a.samples_transient;
         sample_pdf_ray(w, bins, S - 2, 1e-5f, u, n_imp, cdf, merged + S + set * n_imp,
-                       keep ? keep + ray * n_imp : nullptr, lane, active);
+                       keep ? keep + ray * n_imp : nullptr, lane, mine);
     }
-    // torch.sort(cat([zs, zs_static, zs_transient]))[0]: stable rank sort, Sf^2/64 compares per lane
-    for (int i = lane; i < Sf; i += 64) {
+    // torch.sort(cat([zs, zs_static, zs_transient]))[0]: stable rank sort, one element per thread, four candidates per LDS read
+    const float* r = a.rays + ray * 6;
+    const float o0 = r[0], o1 = r[1], o2 = r[2], d0 = r[3], d1 = r[4], d2 = r[5];
+    for (int i = tid; i < Sf; i += T) {
         const float v = merged[i];
         int rank = 0;
-        for (int j = 0; j < Sf; ++j) {
+        int j = 0;
+        for (; j + 4 <= Sf; j += 4) {
+            const float4 o = *reinterpret_cast<const float4*>(merged + j);
+            rank += (o.x < v || (o.x == v && j < i)) ? 1 : 0;
+            rank += (o.y < v || (o.y == v && j + 1 < i)) ? 1 : 0;
+            rank += (o.z < v || (o.z == v && j + 2 < i)) ? 1 : 0;
+            rank += (o.w < v || (o.w == v && j + 3 < i)) ? 1 : 0;
+        }
+        for (; j < Sf; ++j) {
             const float o = merged[j];
             rank += (o < v || (o == v && j < i)) ? 1 : 0;
         }
-        if (active) {
-            const long long dst = ray * Sf + rank;
-            a.zs_fine[dst] = v;
-            const float* r = a.rays + ray * 6;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a.xyz_fine[dst * 3 + c] = r[c] + r[3 + c] * v;
-        }
+        const long long dst = ray * Sf + rank;
+        a.zs_fine[dst] = v;
+        a.xyz_fine[dst * 3 + 0] = o0 + d0 * v;
+        a.xyz_fine[dst * 3 + 1] = o1 + d1 * v;
+        a.xyz_fine[dst * 3 + 2] = o2 + d2 * v;
     }
 }
 
@@ -642,9 +655,9 @@ int nsff_fine_samples(const float* rays, int64_t n_rays, const float* z_lin, con
                weights_static, weights_transient, u_static, u_transient, u_per_ray,
                samples_static, samples_transient, zs_fine, xyz_fine};
     const int Sf = n_samples + (weights_transient ? 2 : 1) * n_importance;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * (2 * n_samples + Sf) * sizeof(float);
-    if (lds > 64 * 1024) return NSFF_ERR_INVALID;
-    const unsigned blocks = (unsigned)((n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    const size_t lds = (size_t)(WAVES_PER_BLOCK * n_samples + ((n_samples + 3) & ~3) + Sf) * sizeof(float);
+    if (lds > 64 * 1024 || n_rays > 0x7fffffffLL) return NSFF_ERR_INVALID;
+    const unsigned blocks = (unsigned)n_rays;                   // one ray per workgroup
     hipLaunchKernelGGL(fine_samples_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds,
                        (hipStream_t)stream, a);
     return nsff_launch_status();
