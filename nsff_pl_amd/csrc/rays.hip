@@ -11,6 +11,7 @@
 // Reference: models/rendering.py:10-49 (sample_pdf), :98-140 (render_transient_warping),
 // :187-188, :202-298 (inference), :314-324, :332-348, :359 (render_rays).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "nsff_common.h"
 
 namespace {
@@ -490,6 +491,219 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_kernel(const N
     }
 }
 
+// The same for 64 < n_samples <= 256 (the fine pass: 192): ONE ray per workgroup, wave c = samples [64 c, 64 c + 64).  The serial
+// form above walks a ray's chunks one after the other -- three exposed memory latencies per ray on four waves per CU; here every
+// chunk's loads are in flight at once.  A chunk's transmittances start at the product of the chunks in front of it: each wave
+// leaves its four products of (1 - alpha) in LDS, a chunk multiplies its predecessors' in the serial form's order (the same
+// weights, bit for bit); the per-ray sums are wave sums per chunk added in chunk order.
+template <int NCH>
+__global__ __launch_bounds__(64 * NCH) void composite_kernel_chunks(const NsffCompositeArgs a) {
+    __shared__ float tot[NCH][4];
+    __shared__ float part[NCH][32];
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const long long ray = blockIdx.x;
+    const int S = a.n_samples;
+    const bool tr = a.has_transient != 0;
+    const bool flows = tr && a.flow_mode >= 1;
+    const bool warps = tr && a.flow_mode >= 2;
+
+    const int i = 64 * c + lane;
+    const bool on = i < S;
+    const long long idx = ray * S + (on ? i : S - 1);
+    const float z = a.zs[idx];
+    const bool last = i >= S - 1;
+    const float dz = last ? 0.f : a.zs[idx + 1] - z;
+    const float d_s = last ? 100.f : dz;        // rendering.py:203
+    const float d_t = last ? 1e-3f : dz;        // rendering.py:204
+    const float* rec = a.raw + idx * RS;
+
+    float sig_s = rec[3];
+    if (a.noise_static) sig_s += a.noise_static[idx] * a.noise_std;
+    sig_s = softplus(sig_s);
+    const float al_s = 1.f - expf(-d_s * sig_s);
+    float rgb_s[3] = {0, 0, 0};
+    if (a.has_rgb) { rgb_s[0] = rec[0]; rgb_s[1] = rec[1]; rgb_s[2] = rec[2]; }
+
+    float sig_t = 0.f, al_t = 0.f, alpha = al_s;
+    float rgb_t[3] = {0, 0, 0};
+    if (tr) {
+        sig_t = rec[7];
+        if (a.visibility && a.visibility[idx] == 0.f) sig_t = -10.f;     // rendering.py:200
+        if (a.vis.w2c && frustum_count(a.vis, a.xyz[idx * 3], a.xyz[idx * 3 + 1], a.xyz[idx * 3 + 2]) == 0.f) sig_t = -10.f;
+        if (a.noise_transient) sig_t += a.noise_transient[idx] * a.noise_std;
+        sig_t = softplus(sig_t);
+        al_t = 1.f - expf(-d_t * sig_t);
+        alpha = 1.f - (1.f - al_s) * (1.f - al_t);
+        if (a.has_rgb) { rgb_t[0] = rec[4]; rgb_t[1] = rec[5]; rgb_t[2] = rec[6]; }
+    }
+    // the chunk's own scans: blend, static field alone (rendering.py:270-278), the two warped renders (rendering.py:98-140)
+    const float inc = wave_scan_mul(on ? 1.f - alpha : 1.f, lane);
+    float incs = 1.f, incw[2] = {1.f, 1.f}, al_tw[2] = {0.f, 0.f};
+    if (a.has_rgb && tr) incs = wave_scan_mul(on ? 1.f - al_s : 1.f, lane);
+    if (a.has_rgb && warps) {
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const float* recw = (dir == 0 ? a.raw_fw : a.raw_bw) + idx * RS;
+            const float* nz = dir == 0 ? a.noise_fw : a.noise_bw;
+            float sg = recw[7];
+            if (nz) sg += nz[idx] * a.noise_std;
+            al_tw[dir] = 1.f - expf(-d_t * softplus(sg));
+            const float al_w = 1.f - (1.f - al_s) * (1.f - al_tw[dir]);
+            incw[dir] = wave_scan_mul(on ? 1.f - al_w : 1.f, lane);
+        }
+    }
+    if (lane == 63) { tot[c][0] = inc; tot[c][1] = incs; tot[c][2] = incw[0]; tot[c][3] = incw[1]; }
+    __syncthreads();
+    float cT = 1.f, cTs = 1.f, cTw[2] = {1.f, 1.f};
+    for (int cc = 0; cc < c; ++cc) { cT *= tot[cc][0]; cTs *= tot[cc][1]; cTw[0] *= tot[cc][2]; cTw[1] *= tot[cc][3]; }
+
+    // exclusive cumprod of (1 - alpha), no epsilon (rendering.py:234-235)
+    float exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = 1.f;
+    const float T = cT * exc;
+    const float w = alpha * T, w_s = al_s * T, w_t = al_t * T;
+    if (on) {
+        if (a.static_sigmas) a.static_sigmas[idx] = sig_s;
+        if (a.has_rgb && a.static_rgbs) {
+            a.static_rgbs[idx * 3 + 0] = rgb_s[0]; a.static_rgbs[idx * 3 + 1] = rgb_s[1];
+            a.static_rgbs[idx * 3 + 2] = rgb_s[2];
+        }
+        if (tr) {
+            if (a.transient_sigmas) a.transient_sigmas[idx] = sig_t;
+            if (a.has_rgb && a.transient_rgbs) {
+                a.transient_rgbs[idx * 3 + 0] = rgb_t[0]; a.transient_rgbs[idx * 3 + 1] = rgb_t[1];
+                a.transient_rgbs[idx * 3 + 2] = rgb_t[2];
+            }
+            if (a.static_alphas) a.static_alphas[idx] = al_s;
+            if (a.transient_alphas) a.transient_alphas[idx] = al_t;
+            if (a.static_weights) a.static_weights[idx] = w_s;
+            if (a.transient_weights) a.transient_weights[idx] = w_t;
+            if (a.weights) a.weights[idx] = w;
+        } else {
+            if (a.static_weights) a.static_weights[idx] = w;     // rendering.py:248
+            if (a.weights) a.weights[idx] = w;
+        }
+    }
+    if (!a.has_rgb) return;     // sigma-only coarse pass stops at the weights (rendering.py:253); uniform: no barrier is skipped by a part of the workgroup
+
+    // this chunk's terms of the per-ray sums (lanes past the ray's end contribute zeros), in the order of part[]'s columns
+    enum { P_DEPTH, P_RGB, P_TRGB = P_RGB + 3, P_TALPHA = P_TRGB + 3, P_SORGB, P_SODEPTH = P_SORGB + 3, P_XYZ, P_FFW = P_XYZ + 3,
+           P_FBW = P_FFW + 3, P_RGBFW = P_FBW + 3, P_RGBBW = P_RGBFW + 3, P_OCCFW = P_RGBBW + 3, P_OCCBW, P_N };
+    static_assert(P_N <= 32, "part[] columns");
+    float p[P_N];
+#pragma unroll
+    for (int k = 0; k < P_N; ++k) p[k] = 0.f;
+    if (on) {
+        p[P_DEPTH] = w * z;
+        if (tr) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { p[P_RGB + k] = w_s * rgb_s[k]; p[P_TRGB + k] = w_t * rgb_t[k]; }
+            p[P_TALPHA] = w_t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[P_RGB + k] = w * rgb_s[k];
+        }
+    }
+    if (tr) {
+        float excs = __shfl_up(incs, 1);
+        if (lane == 0) excs = 1.f;
+        const float wso = al_s * (cTs * excs);
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[P_SORGB + k] = wso * rgb_s[k];
+            p[P_SODEPTH] = wso * z;
+        }
+    }
+    if (flows) {
+        const bool far = z > a.z_far;
+        float ffw[3], fbw[3], x[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ffw[k] = far ? 0.f : rec[8 + k];       // rendering.py:187-188
+            fbw[k] = far ? 0.f : rec[11 + k];
+            x[k] = a.xyz[idx * 3 + k];
+        }
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (a.flows_fw) a.flows_fw[idx * 3 + k] = ffw[k];
+                if (a.flows_bw) a.flows_bw[idx * 3 + k] = fbw[k];
+                p[P_XYZ + k] = w * x[k]; p[P_FFW + k] = w * ffw[k]; p[P_FBW + k] = w * fbw[k];
+            }
+        }
+        if (warps) {
+#pragma unroll
+            for (int dir = 0; dir < 2; ++dir) {
+                const float* recw = (dir == 0 ? a.raw_fw : a.raw_bw) + idx * RS;
+                float excw = __shfl_up(incw[dir], 1);
+                if (lane == 0) excw = 1.f;
+                const float Tw = cTw[dir] * excw;
+                const float ws_w = al_s * Tw, wt_w = al_tw[dir] * Tw;
+                if (on) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[(dir == 0 ? P_RGBFW : P_RGBBW) + k] = ws_w * rgb_s[k] + wt_w * recw[4 + k];
+                    // cycle point: the warped query's flow back (fw warp -> 'bw' head and vice versa)
+                    const float* xw = (dir == 0 ? a.xyz_fw : a.xyz_bw) + idx * 3;
+                    float* cyc = dir == 0 ? a.xyzs_fw_bw : a.xyzs_bw_fw;
+                    const int head = dir == 0 ? 11 : 8;
+                    if (cyc) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) cyc[idx * 3 + k] = xw[k] + (far ? 0.f : recw[head + k]);
+                    }
+                    const float occ = wt_w - w_t;              // rendering.py:290-291
+                    if (dir == 0) { p[P_OCCFW] = occ; if (a.disoccs_fw) a.disoccs_fw[idx] = 1.f - fabsf(occ); }
+                    else          { p[P_OCCBW] = occ; if (a.disoccs_bw) a.disoccs_bw[idx] = 1.f - fabsf(occ); }
+                }
+            }
+        }
+    }
+    const int n_used = warps ? (int)P_N : (flows ? (int)P_RGBFW : (tr ? (int)P_XYZ : (int)P_TRGB));
+#pragma unroll
+    for (int k = 0; k < P_N; ++k) {
+        if (k < n_used) {
+            const float v = wave_sum(p[k]);
+            if (lane == 0) part[c][k] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float s[P_N];
+#pragma unroll
+    for (int k = 0; k < P_N; ++k) {
+        s[k] = 0.f;
+        if (k < n_used) for (int cc = 0; cc < NCH; ++cc) s[k] += part[cc][k];
+    }
+    if (a.depth) a.depth[ray] = s[P_DEPTH];
+    if (!tr) {
+        if (a.rgb) for (int k = 0; k < 3; ++k) a.rgb[ray * 3 + k] = s[P_RGB + k];
+        return;
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (a.rgb) a.rgb[ray * 3 + k] = s[P_RGB + k] + s[P_TRGB + k];                                      // :262
+        if (a.transient_rgb) a.transient_rgb[ray * 3 + k] = s[P_TRGB + k] + 0.8f * (1.f - s[P_TALPHA]);    // :264-265
+        if (a.static_only_rgb) a.static_only_rgb[ray * 3 + k] = s[P_SORGB + k];
+    }
+    if (a.transient_alpha) a.transient_alpha[ray] = s[P_TALPHA];
+    if (a.static_only_depth) a.static_only_depth[ray] = s[P_SODEPTH];
+    if (flows) {
+        for (int k = 0; k < 3; ++k) {
+            if (a.xyz_exp) a.xyz_exp[ray * 3 + k] = s[P_XYZ + k];
+            if (a.flow_fw_exp) a.flow_fw_exp[ray * 3 + k] = s[P_FFW + k];
+            if (a.flow_bw_exp) a.flow_bw_exp[ray * 3 + k] = s[P_FBW + k];
+            if (a.xyz_fw_exp) a.xyz_fw_exp[ray * 3 + k] = s[P_XYZ + k] + s[P_FFW + k];
+            if (a.xyz_bw_exp) a.xyz_bw_exp[ray * 3 + k] = s[P_XYZ + k] + s[P_FBW + k];
+        }
+    }
+    if (warps) {
+        for (int k = 0; k < 3; ++k) {
+            if (a.rgb_fw) a.rgb_fw[ray * 3 + k] = s[P_RGBFW + k];
+            if (a.rgb_bw) a.rgb_bw[ray * 3 + k] = s[P_RGBBW + k];
+        }
+        if (a.disocc_fw) a.disocc_fw[ray] = 1.f - fabsf(s[P_OCCFW]);
+        if (a.disocc_bw) a.disocc_bw[ray] = 1.f - fabsf(s[P_OCCBW]);
+    }
+}
+
 // rows of the time-code table for the neighbouring frames: next[r] = E[min(ts[r] + 1, max_t)], prev[r] = E[max(ts[r] - 1, 0)]
 // (reference rendering.py:218,224: embedding_t(torch.clamp(ts +- 1, ...))) -- one launch instead of two add / clamp / gather
 // triples; either output may be NULL.  One thread per float4 (width % 4 == 0) or per float.
@@ -714,6 +928,15 @@ int nsff_composite(const NsffCompositeArgs* args, void* stream) {
     if (a.flow_mode == 2 && (!a.raw_fw || !a.raw_bw || !a.xyz_fw || !a.xyz_bw)) return NSFF_ERR_NULL;
     if (a.vis.w2c && (!a.vis.ts || !a.xyz)) return NSFF_ERR_NULL;
     if (a.vis.w2c && (a.vis.n_cams < 1 || a.vis.n_frames < 1)) return NSFF_ERR_INVALID;
+    // 65..256 samples per ray: one ray per workgroup, one wave per 64-sample chunk (NSFF_SERIAL_COMPOSITE=1: the serial form, A/B)
+    const int nch = (a.n_samples + 63) / 64;
+    if (nch >= 2 && nch <= 4 && a.n_rays <= 0x7fffffffLL && getenv("NSFF_SERIAL_COMPOSITE") == nullptr) {
+        const dim3 grid((unsigned)a.n_rays);
+        if (nch == 2) hipLaunchKernelGGL(composite_kernel_chunks<2>, grid, dim3(128), 0, (hipStream_t)stream, a);
+        else if (nch == 3) hipLaunchKernelGGL(composite_kernel_chunks<3>, grid, dim3(192), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(composite_kernel_chunks<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        return nsff_launch_status();
+    }
     const unsigned blocks = (unsigned)((a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     hipLaunchKernelGGL(composite_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0,
                        (hipStream_t)stream, a);

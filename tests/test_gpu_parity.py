@@ -370,6 +370,40 @@ def test_render_with_fused_draws_equals_render_with_torch_draws(hip_lib, monkeyp
             assert torch.equal(a[k], b[k]), (noise_std, k)
 
 
+def test_chunk_parallel_composite_equals_the_serial_form(hip_lib, monkeypatch):
+    """65..256 samples per ray: one ray per workgroup, one wave per 64-sample chunk (composite_kernel_chunks) against the one-wave-
+    per-ray form (NSFF_SERIAL_COMPOSITE=1): every per-sample output bit-identical (a chunk's transmittance starts at its
+    predecessors' products, multiplied in the serial form's order), the per-ray sums equal up to their summation order"""
+    for name, n_samples, n_imp in (("g3_nsff_train", 64, 64), ("g5_nsff_test_vis", 64, 32), ("g1_static_c1", 128, 0)):
+        cfg = dict(scenes.CASES[name], n_rays=96)
+        rays, ts = scenes.synthetic_rays(96, 11)
+        models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+        _to_dev(models, emb)
+        got = {}
+        for form in ("chunks", "serial"):
+            if form == "serial":
+                monkeypatch.setenv("NSFF_SERIAL_COMPOSITE", "1")
+            else:
+                monkeypatch.delenv("NSFF_SERIAL_COMPOSITE", raising=False)
+            torch.manual_seed(3)
+            with torch.no_grad():
+                out = A.render_rays(models, emb, rays.to(DEV), None if ts is None else ts.to(DEV), 29, n_samples, cfg.get("perturb", 0),
+                                    cfg.get("noise_std", 0), n_imp, 32768, test_time=cfg["test_time"], **scenes.render_kwargs(cfg))
+            got[form] = {k: v.clone() for k, v in out.items()}
+        monkeypatch.delenv("NSFF_SERIAL_COMPOSITE", raising=False)
+        a, b = got["chunks"], got["serial"]
+        assert a.keys() == b.keys()
+        S_f = n_samples + (2 if cfg["transient"] else 1) * n_imp if n_imp else n_samples
+        assert 64 < S_f <= 256
+        for k in a:
+            per_sample = a[k].dim() >= 2 and a[k].shape[1] in (n_samples, S_f)
+            if per_sample:
+                assert torch.equal(a[k], b[k]), (name, k)
+            else:
+                scale = max(b[k].abs().max().item(), 1e-30)
+                assert (a[k] - b[k]).abs().max().item() <= 3e-6 * scale, (name, k)
+
+
 # ---- full-size configuration (BASELINE.json configs[1]): size-independent properties ----
 def test_c2_full_size_properties(hip_lib, precision):
     cfg = dict(scenes.CASES["g3_nsff_train"], n_rays=1024)
