@@ -337,3 +337,51 @@ def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, m
         used = slice(0, 4) if tm == 0 else (slice(4, 4 + 4 + 3 * fh) if sm == 0 else slice(0, 4 + 4 + 3 * fh))
         assert np.isfinite(a[:, used]).all()
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"rays={n_rays} modes {(sm, tm, fh)} rows={rows}"
+
+
+@pytest.mark.parametrize("arch", range(len(ARCHS)))
+def test_persistent_launch_on_random_architectures(arch, hip_lib, monkeypatch):
+    """the persistent form on every architecture of this file (depth 2..8, any skip set, 4..10 frequencies, 16..64 time-code
+    columns): records bit-identical to one workgroup per tile for a both-trunk launch (time code through the matrix pipe and as
+    per-ray rows) and a dynamic-only one; a trunk that ends with a skip layer's input part has no B16L phase to turn into B16LP
+    and keeps one workgroup per tile (the grid says which form ran)"""
+    D, skips, n_freqs, n_tau = ARCHS[arch]
+    torch.manual_seed(300 + arch)
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    emb = A.PosEmbedding(n_freqs - 1, n_freqs)
+    m = A.NeRF("fine", D=D, skips=skips, in_channels_xyz=3 + 6 * n_freqs, use_viewdir=False, encode_transient=True,
+               in_channels_t=n_tau, output_flow=True).to(DEV)
+    freqs = [float(f) for f in emb.freqs]
+    g = torch.Generator().manual_seed(50 + arch)
+    S, n_rays = 64, 2 * n_cus + 3
+    P = S * n_rays
+    tiles = (P + 127) // 128
+    xyz = (torch.rand(P, 3, generator=g) * 2.4 - 1.2).to(DEV)
+    t_rows = torch.randn(n_rays, n_tau, generator=g).to(DEV)
+    rows_ok = n_tau % 4 == 0 and n_tau <= 64
+    can = (D - 1) not in skips                     # (the trunk ends with a 256-wide segment)
+    config.set_precision("f16x3")
+    for (sm, tm, fh), rows in (((2, 2, 2), False), ((2, 2, 2), True), ((0, 2, 1), True)):
+        if rows and not rows_ok:
+            continue
+        tb = _lib.time_bias([(m, t_rows)])[0] if rows else None
+        got = {}
+        config.set_tile_points(130)
+        try:
+            for form in ("persistent", "tile"):
+                if form == "tile":
+                    monkeypatch.setenv("NSFF_NO_PERSIST", "1")
+                else:
+                    monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
+                raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
+                _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows, t_bias=tb)
+                torch.cuda.synchronize()
+                got[form] = (raw.cpu().numpy(), _lib.last_field_grid(), _lib.last_field_kernel())
+        finally:
+            config.set_tile_points(0)
+            monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
+        (a, ga, ka), (b, gb, kb) = got["persistent"], got["tile"]
+        assert ka == kb and ka.startswith("h3a"), (ka, kb)
+        assert gb == (2 * tiles if sm else tiles)
+        assert ga == (n_cus if can else gb), (ARCHS[arch], (sm, tm, fh), rows, ga, gb)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (ARCHS[arch], (sm, tm, fh), rows)
