@@ -1073,8 +1073,8 @@ struct H3AArgs {
     H3AHeadSel hsel[2];                 // ... and what that means (h3a_head_sel of the host): one scalar load in the kernel
     // PERSISTENT launch (p_mode != 0): the grid is one workgroup per CU and a workgroup walks tiles tile0, tile0 + stride, ... of ONE
     // trunk -- everything that does not depend on the tile (the plain bias rows, the head biases, the record image's zeros) is set
-    // up once, and the next tile's first eight weight slots are requested behind the body, so that they cross the CU's vector-memory
-    // path while the records of this tile are stored.  1: one trunk in the launch (whole records); 2: both trunks -- workgroup b runs
+    // up once, the next tile's first eight weight slots are requested by the last trunk phase of the current one (B16LP: the phase
+    // programs of such a launch went through h3a_make_persistent) and its point by the body's first instructions.  1: one trunk in the launch (whole records); 2: both trunks -- workgroup b runs
     // on XCD b % 8 (observed, not promised: only L2 locality depends on it), XCDs 0..3 take the static trunk, 4..7 the dynamic one,
     // each trunk's 2.3 MB of weights stay in its XCDs' L2s; 3: the dynamic trunk of a launch whose static trunk is another kernel's;
     // 4: both trunks of unequal cost (a view-direction static trunk is 23 % longer): workgroups [0, p_split) take the static trunk,
@@ -1092,7 +1092,7 @@ static_assert(sizeof(H3AArgs) <= 4096, "kernel arguments must fit the 4 KiB kern
 struct H3APre {
     unsigned long long pk = 0;
     unsigned r1 = 0, r2 = 0, n1 = 0, lane16 = 0;
-    bool on = false;          // (wave-uniform) false: the slots of this tile were requested behind the previous tile's body (persistent launch)
+    bool on = false;          // (wave-uniform) false: the slots of this tile were requested by the previous tile's B16LP phase (persistent launch)
     template <int K> __device__ __forceinline__ void slot() const {
         if (!on) return;
         const unsigned off = (K < (int)n1 ? r1 : r2) + 4096u * K;
