@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      27
+#define NSFF_ABI_VERSION      28
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -226,6 +226,20 @@ typedef struct NsffRngJob {
     uint32_t grid;
 } NsffRngJob;
 int nsff_rng_draws(const NsffRngJob* jobs, int32_t n_jobs, uint64_t seed, void* stream);
+/* The same launch also makes the coarse depths (reference rendering.py:314-324, 332; nsff_coarse_samples is the stand-alone
+ * form) from the stratified-sampling draw, where that draw is made: job `job` is the uniform (n_rays, n_samples) draw of
+ * rendering.py:321 (its `out` may be NULL: nobody else reads it), zs / xyz as nsff_coarse_samples writes them (perturb > 0). */
+typedef struct NsffRngCoarse {
+    const float* rays;       /* (n_rays, 6)                       */
+    const float* z_lin;      /* (n_samples)                       */
+    float*       zs;         /* (n_rays, n_samples)               */
+    float*       xyz;        /* (n_rays, n_samples, 3)            */
+    int32_t      n_samples;
+    float        perturb;
+    int32_t      job;
+    int32_t      pad_;
+} NsffRngCoarse;
+int nsff_rng_draws_coarse(const NsffRngJob* jobs, int32_t n_jobs, uint64_t seed, const NsffRngCoarse* coarse, void* stream);
 
 /* ---- a3: the same for a view-direction model's per-ray inputs (reference nerf.py:183-185, rendering.py:153-172 repeat the
  * direction embedding and the appearance code over a ray's samples):

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 27
+ABI_VERSION = 28
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -62,6 +62,11 @@ class RngJob(C.Structure):
 
 
 MAX_RNG_JOBS = 12
+
+
+class RngCoarse(C.Structure):
+    _fields_ = [("rays", _fp), ("z_lin", _fp), ("zs", _fp), ("xyz", _fp), ("n_samples", C.c_int32), ("perturb", C.c_float),
+                ("job", C.c_int32), ("pad_", C.c_int32)]
 
 
 _COMPOSITE_PTRS_IN = ["raw", "raw_fw", "raw_bw", "zs", "xyz", "xyz_fw", "xyz_bw",
@@ -160,6 +165,7 @@ _SIGNATURES = {
     "nsff_time_bias_rows": (C.c_int, [C.POINTER(ModelDesc)]),
     "nsff_time_bias": (C.c_int, [C.POINTER(TimeBiasJob), C.c_int32, C.c_int64, C.c_void_p]),
     "nsff_rng_draws": (C.c_int, [C.POINTER(RngJob), C.c_int32, C.c_uint64, C.c_void_p]),
+    "nsff_rng_draws_coarse": (C.c_int, [C.POINTER(RngJob), C.c_int32, C.c_uint64, C.POINTER(RngCoarse), C.c_void_p]),
     "nsff_side_bias": (C.c_int, [C.POINTER(ModelDesc), _fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_void_p]),
     "nsff_last_hip_error": (C.c_char_p, []),
     "nsff_packed_bytes": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_size_t)]),
@@ -421,11 +427,13 @@ def side_bias(model, dir_rows, a_rows=None):
 _DEVICE_RNG_GEOMETRY = {}
 
 
-def fused_draws(plan, device, values=True):
+def fused_draws(plan, device, values=True, coarse=None):
     """The draws ``[(kind, shape)]`` (kind "rand" | "randn") of torch's default generator of `device`, in order, by ONE launch
     (nsff_rng_draws): bit-identical to calling torch.rand / torch.randn in that order, and the generator is left where those
     calls would leave it.  values=False for entries whose numbers nobody reads: give a list of booleans -- such a draw only
-    advances the generator (its tensor is None).  -> list of float32 tensors."""
+    advances the generator (its tensor is None).  -> list of float32 tensors.
+    coarse = (rays, z_lin, perturb, zs, xyz): plan[0] is the stratified-sampling draw of the call (perturb > 0); the launch
+    computes the coarse depths from it where it is drawn (nsff_rng_draws_coarse) -- `coarse_samples` is not needed then."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _DEVICE_RNG_GEOMETRY:
@@ -449,7 +457,10 @@ def fused_draws(plan, device, values=True):
             outs.append(torch.empty(*shape, device=dev, dtype=torch.float32))
             continue
         grid = min(max_grid, (numel + 255) // 256)
-        if want:
+        if coarse is not None and not outs and not want:     # the perturbation draw: consumed by the launch itself
+            jobs.append((None, numel, offset, 0, grid))
+            outs.append(None)
+        elif want:
             t = buf[at:at + numel].view(*shape)
             at += numel
             jobs.append((t, numel, offset, 1 if kind == "randn" else 0, grid))
@@ -457,13 +468,20 @@ def fused_draws(plan, device, values=True):
         else:
             outs.append(None)
         offset += ((numel - 1) // (1024 * grid) + 1) * 4
+    hook = None
+    if coarse is not None:
+        rays, z_lin, perturb, zs, xyz = coarse
+        assert plan and plan[0][0] == "rand" and tuple(plan[0][1]) == (rays.shape[0], z_lin.shape[0]) and perturb > 0
+        if sizes[0]:
+            hook = RngCoarse(_ptr(rays), _ptr(z_lin), _ptr(zs), _ptr(xyz), int(z_lin.shape[0]), float(perturb), 0, 0)
     for k in range(0, len(jobs), MAX_RNG_JOBS):
         part = jobs[k:k + MAX_RNG_JOBS]
         arr = (RngJob * len(part))()
         for j, (t, numel, off, kind, grid) in enumerate(part):
-            arr[j].out, arr[j].numel, arr[j].offset, arr[j].kind, arr[j].grid = t.data_ptr(), numel, off, kind, grid
+            arr[j].out, arr[j].numel, arr[j].offset, arr[j].kind, arr[j].grid = (None if t is None else t.data_ptr()), numel, off, kind, grid
         with torch.cuda.device(idx):
-            _check(load().nsff_rng_draws(arr, len(part), seed, _stream()), "nsff_rng_draws")
+            _check(load().nsff_rng_draws_coarse(arr, len(part), seed, C.byref(hook) if (hook is not None and k == 0) else None, _stream()),
+                   "nsff_rng_draws")
     gen.set_offset(offset)
     return outs
 

@@ -61,8 +61,12 @@ class _Draws:
     NSFF_TORCH_RNG=1, or when torch.rand / torch.randn are not torch's own (the parity tests replay recorded draws through them)
     every draw is the torch call it mirrors."""
 
-    def __init__(self, device, n_rays, N_samples, N_importance, perturb, noise_std, test_time, models, kwargs):
+    def __init__(self, device, n_rays, N_samples, N_importance, perturb, noise_std, test_time, models, kwargs, coarse=None):
+        """coarse = (rays, z_lin, zs, xyz): with perturb > 0 the launch that draws also computes the coarse depths from the
+        stratified-sampling draw (rendering.py:314-324, 332) -- ``coarse_done`` tells the caller that nsff_coarse_samples is not
+        needed; the draw itself is then not kept (nothing else reads it)."""
         self.device = device
+        self.coarse_done = False
         self.fused = (device.type == "cuda" and torch.rand is _TORCH_RAND and torch.randn is _TORCH_RANDN
                       and not os.environ.get("NSFF_TORCH_RNG") and not torch.cuda.is_current_stream_capturing())
         self.at = 0
@@ -77,8 +81,11 @@ class _Draws:
         def add(kind, need_values, *shape):
             plan.append((kind, shape))
             need.append(bool(need_values))
+        hook = None
         if perturb > 0:
-            add("rand", True, n_rays, N_samples)
+            add("rand", coarse is None, n_rays, N_samples)
+            if coarse is not None and n_rays:
+                hook = (coarse[0], coarse[1], float(perturb), coarse[2], coarse[3])
         S = N_samples
         if N_importance > 0:
             add("randn", noisy, n_rays, S)
@@ -96,7 +103,8 @@ class _Draws:
                 add("randn", noisy, n_rays, S)
                 add("randn", noisy, n_rays, S)
         self.plan = plan
-        self.values = _lib.fused_draws(plan, device, need)
+        self.values = _lib.fused_draws(plan, device, need, coarse=hook)
+        self.coarse_done = hook is not None
 
     def take(self, kind, *shape):
         if not self.fused:
@@ -413,11 +421,12 @@ def _render_rays(models, embeddings, rays, ts, max_t, N_samples, perturb, noise_
 
         # coarse depths: one linspace shared by all rays, optional stratified jitter
         z_lin = _unit_linspace(N_samples, rays.device)
-        ctx.draws = _Draws(rays.device, n_rays, N_samples, N_importance, perturb, noise_std, test_time, models, kwargs)
-        perturb_rand = ctx.draws.take("rand", n_rays, N_samples) if perturb > 0 else None
         zs = _new(rays, n_rays, N_samples)
         xyz_coarse = _new(rays, n_rays, N_samples, 3)
-        if n_rays:
+        ctx.draws = _Draws(rays.device, n_rays, N_samples, N_importance, perturb, noise_std, test_time, models, kwargs,
+                           coarse=(rays, z_lin, zs, xyz_coarse))
+        perturb_rand = ctx.draws.take("rand", n_rays, N_samples) if perturb > 0 else None
+        if n_rays and not ctx.draws.coarse_done:
             _lib.coarse_samples(rays, z_lin, perturb, perturb_rand, zs, xyz_coarse)
 
         t_embedded = None
