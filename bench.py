@@ -107,12 +107,28 @@ class Bench:
         self.live = dist.is_initialized()       # a process group exists (torchrun / self-launch; world size 1 included)
         self.gather_spans = []                  # (start, end) of every pixel all-gather: HIP events on the GPU, seconds on the CPU
 
-    def gather(self, out, keys, counts=None):
-        """The step's one collective, OVERLAPPED: issued on the gather side stream behind this step's render and
-        joined one step later, so it runs beside the next step's kernels; bracketed by events on that stream so that rank 0
-        can report the collective's own time.  `finish()` joins what is still in flight (timed() calls it inside the timed
-        region, before the closing synchronize)."""
+    def gather(self, out, keys, counts=None, overlap=True):
+        """The step's one collective.  overlap=True (frames: SURVEY 8e): issued on the gather side stream behind this step's
+        render and joined one step later, so it runs beside the next step's kernels; bracketed by events on that stream so
+        that rank 0 can report the collective's own time.  `finish()` joins what is still in flight (timed() calls it inside
+        the timed region, before the closing synchronize).
+        overlap=False (the 2 ms render step): the collective on the render stream itself.  Measured at world size 1 under
+        torchrun, same box, 100 steps: no gather 1.959 ms, on the render stream 1.995 ms, overlapped 2.030 ms -- the side
+        stream's pack / collective kernels can only run in the gaps of a render stream whose field launches hold every CU, and
+        the two cross-stream joins cost more than the 20 us collective they hide; a 10-30 ms frame shard is a different
+        trade.  NSFF_GATHER_ASYNC=1 / NSFF_GATHER_SYNC=1 force either form (A/B on a multi-GPU node)."""
         from nsff_pl_amd import dist as ndist
+        if os.environ.get("NSFF_GATHER_ASYNC"):
+            overlap = True
+        if os.environ.get("NSFF_GATHER_SYNC"):
+            overlap = False
+        if self.device.type == "cuda" and not overlap:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            merged = ndist.all_gather_pixels(out, keys, counts=counts)
+            ev[1].record()
+            self.gather_spans.append(ev)
+            return merged
         if self.device.type == "cuda":
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             handle = ndist.all_gather_pixels_async(out, keys, counts=counts, events=ev)
@@ -162,7 +178,7 @@ class Bench:
                 out = A.render_rays(self.models, self.emb, self.rays, self.ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
                                     N_IMPORTANCE, 1024 * 32, test_time=False, **self.kw)
             if live:
-                self.gather(out, ("rgb_fine", "depth_fine"))
+                self.gather(out, ("rgb_fine", "depth_fine"), overlap=False)
             return out
         return step
 
@@ -569,6 +585,8 @@ def main():
                        "settle_ms": args.settle_ms,
                        "rays_per_gpu": N_RAYS, "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE,
                        "parallelism": f"ray-shard x{world}, pixel all-gather" if bench.live else "single GPU",
+                       "field_launch": ("persistent (one workgroup per CU)" if config.get_persistent() else
+                                        "one workgroup per tile (a collective kernel runs beside the render stream)"),
                        "rays_per_s": world * N_RAYS * args.steps / elapsed,
                        "mlp_tflops_whole_step": world * N_RAYS * args.steps * FLOP_PER_RAY_C2_TRAIN / elapsed / 1e12},
         }

@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      28
+#define NSFF_ABI_VERSION      29
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -175,7 +175,12 @@ typedef struct NsffFieldArgs {
      * of the last trunk layer.  dir_emb / a_emb must be given either way (every other kernel variant reads them). */
     const float* s_bias;
     int32_t s_bias_rows;     /* 1, or 0                                             */
-    int32_t reserved1;
+    /* 0: the library's choice -- large hand-scheduled launches are PERSISTENT (one workgroup per compute unit walking its tiles,
+     * nsff_last_field_grid); 1: one workgroup per 128-point tile (bit-identical records).  A persistent launch holds every
+     * compute unit until it ends: a caller whose collective kernel runs beside the render stream (the overlapped pixel
+     * all-gather of a multi-GPU evaluation, nsff_pl_amd/dist.py::all_gather_pixels_async) asks for 1, so that the collective gets
+     * a compute unit at the next tile boundary and a render workgroup never waits behind it for a whole launch. */
+    int32_t launch_form;
 } NsffFieldArgs;
 
 int nsff_field_query(const NsffModelDesc* desc, const void* packed,

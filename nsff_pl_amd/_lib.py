@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 28
+ABI_VERSION = 29
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -45,7 +45,7 @@ class FieldArgs(C.Structure):
                 ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
                 ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp), ("save_masks", _fp),
                 ("save_side", _fp), ("t_bias", _fp), ("t_bias_rows", C.c_int32), ("reserved0", C.c_int32),
-                ("s_bias", _fp), ("s_bias_rows", C.c_int32), ("reserved1", C.c_int32)]
+                ("s_bias", _fp), ("s_bias_rows", C.c_int32), ("launch_form", C.c_int32)]
 
 
 class TimeBiasJob(C.Structure):
@@ -383,6 +383,7 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     packed = model.packed(prec, inference=True)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()
+    a.launch_form = 0 if config.get_persistent() else 1
     a.n_points, a.pts_per_ray = int(n_points), int(pts_per_ray)
     a.static_mode, a.transient_mode, a.flow_heads = int(static_mode), int(transient_mode), int(flow_heads)
     a.xyz = _ptr(xyz)

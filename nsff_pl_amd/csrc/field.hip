@@ -573,6 +573,7 @@ int nsff_field_query(const NsffModelDesc* desc, const void* packed_v, const Nsff
     if (g.precision != NSFF_PREC_F32 && g.precision != NSFF_PREC_F16X3) return NSFF_ERR_INVALID;
     if (g.tile_points != 0 && g.tile_points != 64 && g.tile_points != 130 && g.tile_points != 131) return NSFF_ERR_INVALID;
     if (g.transient_mode && !d.has_transient) return NSFF_ERR_INVALID;
+    if (g.launch_form != 0 && g.launch_form != 1) return NSFF_ERR_INVALID;
     if (g.n_points == 0) return NSFF_OK;
     if (!g.raw) return NSFF_ERR_NULL;
     if ((uintptr_t)packed & 15) return NSFF_ERR_ALIGN;

@@ -2432,7 +2432,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         static const int n_cus = [] { int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
             return n; }();
-        const bool no_persist = getenv("NSFF_NO_PERSIST") != nullptr;       // (read per launch: tests flip it)
+        const bool no_persist = g.launch_form == 1 || getenv("NSFF_NO_PERSIST") != nullptr;       // (the variable is read per launch: tests flip it)
         const bool can_persist = !no_persist && n_cus >= 8 && n_cus % 8 == 0;
         auto cost = [&](const H3APhase* ph) {
             int c = 0;

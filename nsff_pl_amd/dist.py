@@ -206,6 +206,11 @@ def all_gather_pixels_async(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group
             return _unpack(out, results, keys, widths, counts, pad_to, world)
         return PendingPixels(finish_cpu)
     dev = ref.device
+    if dist.is_initialized() and dist.get_world_size(group) > 1 and not os.environ.get("NSFF_PERSIST_MULTI"):
+        # a collective kernel that waits for its peers now runs BESIDE the render stream: no field launch may hold every
+        # compute unit until it ends (config.set_persistent; the variable keeps the persistent form for A/B on a multi-GPU node)
+        from . import config
+        config.set_persistent(False)
     if dev not in _GATHER_STREAM:
         _GATHER_STREAM[dev] = torch.cuda.Stream(device=dev)
     side, cur = _GATHER_STREAM[dev], torch.cuda.current_stream(dev)

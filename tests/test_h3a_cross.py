@@ -329,6 +329,18 @@ def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, m
         finally:
             config.set_tile_points(0)
             monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
+        # the per-call switch (NsffFieldArgs::launch_form through config.set_persistent: what a multi-GPU run selects)
+        config.set_tile_points(130)
+        config.set_persistent(False)
+        try:
+            raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
+            _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs, t_bias=tb,
+                             s_bias=sb)
+            torch.cuda.synchronize()
+            assert _lib.last_field_grid() == got["tile"][1] and np.array_equal(raw.cpu().numpy().view(np.uint32), got["tile"][0].view(np.uint32))
+        finally:
+            config.set_persistent(True)
+            config.set_tile_points(0)
         (a, ga, ka), (b, gb, kb) = got["persistent"], got["tile"]
         both = sm and tm and (m is not viewdir or side)
         assert ka == kb and ka.startswith("h3a"), (ka, kb)
