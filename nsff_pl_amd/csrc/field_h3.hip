@@ -1269,6 +1269,7 @@ __device__ __forceinline__ void h3a_kernel() {
     // lies inside one ray, the host checked pts_per_ray % 64 == 0 and n_points < 2^31 -- and the body never sees a time-code column;
     // the static trunk of a view-direction model has per-ray rows of its own: static_dir_encoding's [dir | a] part, nsff_side_bias)
     uint32_t boff[H3A_MAX_BIAS];
+    uint32_t ray_rows = 0u;     // bit r: table row r is a per-ray row (the only rows a later tile of the workgroup reloads)
     int nb;
     unsigned has_rows;          // (an integer in a scalar register: a parked bool becomes a lane mask in a vector register)
     unsigned last_pt, ppr, row_bytes;
@@ -1290,6 +1291,8 @@ __device__ __forceinline__ void h3a_kernel() {
         }
 #pragma unroll
         for (int r = 0; r < H3A_MAX_BIAS; ++r) boff[r] = r < nb ? boff[r] : 0u;
+#pragma unroll
+        for (int r = 0; r < H3A_MAX_BIAS; ++r) ray_rows |= (boff[r] >> 31) << r;
     }
 #pragma unroll 1
   for (int it = 0; tile < tile_end; ++it, tile += tile_stride) {
@@ -1313,9 +1316,8 @@ __device__ __forceinline__ void h3a_kernel() {
     const bool tb = tr == 1 && has_rows != 0u;
     float bv[H3A_MAX_BIAS];
     // (opaque copies: what is derived from the parked scalars is derived per tile, not parked as well)
-    uint32_t bo[H3A_MAX_BIAS];
-#pragma unroll
-    for (int r = 0; r < H3A_MAX_BIAS; ++r) { bo[r] = boff[r]; asm volatile("" : "+s"(bo[r])); }
+    uint32_t rr = ray_rows;
+    asm volatile("" : "+s"(rr));
     {
         // row r's bytes from the packed buffer's start (wave-uniform, branch-free): a plain row is a word offset, a per-ray row
         // lies rows_delta = t_bias - packed further on, at the ray of its half.  Rows past the table's end read the buffer's
@@ -1331,7 +1333,8 @@ __device__ __forceinline__ void h3a_kernel() {
         if (it == 0) {
 #pragma unroll
             for (int r = 0; r < H3A_MAX_BIAS; ++r) {
-                const uint32_t off = bo[r];
+                uint32_t off = boff[r];
+                asm volatile("" : "+s"(off));
                 // (selects as mask arithmetic: the compiler turns the conditional form into two scalar branches per row)
                 const long long per_ray = -(long long)(off >> 31), half_b = -(long long)((off >> 8) & 1u);
                 const long long at_ray = tb_at[0] + (half_b & (tb_at[1] - tb_at[0])) + (long long)((off & 0xffu) * (NSFF_W * 4));
@@ -1342,9 +1345,10 @@ __device__ __forceinline__ void h3a_kernel() {
             // a later tile of a persistent launch: only the per-ray rows change (at most six: one scalar branch per table row)
 #pragma unroll
             for (int r = 0; r < H3A_MAX_BIAS; ++r) {
-                const uint32_t off = bo[r];
                 bv[r] = 0.f;
-                if (off >> 31) {
+                if ((rr >> r) & 1u) {
+                    uint32_t off = boff[r];
+                    asm volatile("" : "+s"(off));
                     const long long at = tb_at[(off >> 8) & 1u] + (long long)((off & 0xffu) * (NSFF_W * 4));
                     bv[r] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + at)[tid_];
                 }
@@ -1353,10 +1357,25 @@ __device__ __forceinline__ void h3a_kernel() {
     }
     // (the heads' biases -- 32 floats -- travel with the table: the records loop below reads them from LDS)
     float hbias = 0.f, sig_b = 0.f;
+    float act5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     H3APre pre;
     pre.on = it == 0;
     if (it == 0) {      // (a later tile of a persistent workgroup finds them in LDS / its weight slots resident)
         hbias = reinterpret_cast<const float*>(pk)[aa.hsel[tr].b_off + (tid_ & 31)];
+        // what the records loop applies to float 4 q + e of a record (thread tid = 4 q + e < 16 fills entry tid of the table in
+        // the spare floats of the bias table's last row): the head row's bias, and its activation as
+        // y = fma(1 / (1 + 2^(c x)), ya, yb)  -- sigmoid: c = -log2 e, (ya, yb) = (1, 0); flow: c = 2 log2 e, (-2 s, s) = s tanh(x);
+        // none: x itself
+        {
+            const int row = (int)(tid_ & 15) - aa.hsel[tr].slot0;
+            const bool on = row >= 0 && row < aa.hsel[tr].n_rows;
+            const unsigned kind = on ? (aa.hsel[tr].kinds >> (2 * (row & 15))) & 3u : (unsigned)ACT_NONE;
+            act5[0] = on ? reinterpret_cast<const float*>(pk)[aa.hsel[tr].b_off + (row & 31)] : 0.f;
+            act5[1] = kind == ACT_SIGMOID ? -1.4426950408889634f : (kind == ACT_FLOW ? 2.8853900817779268f : 0.f);
+            act5[2] = kind == ACT_FLOW ? -2.0f * a.flow_scale : 1.0f;
+            act5[3] = kind == ACT_FLOW ? a.flow_scale : 0.f;
+            act5[4] = (kind != ACT_SIGMOID && kind != ACT_FLOW) ? 1.f : 0.f;
+        }
         sig_b = reinterpret_cast<const float*>(pk)[(tr == 0 && aa.sig_ride != 0) ? aa.sig_b_off : 0u];
         const auto& d0 = aa.ph[tr][0];
         pre.pk = (unsigned long long)(uintptr_t)pk;
@@ -1388,10 +1407,14 @@ __device__ __forceinline__ void h3a_kernel() {
             if (r < nb) sBias[r * NSFF_W + tid_] = bv[r];
         if (tid_ < 32) sBias[H3A_MAX_BIAS * NSFF_W + tid_] = hbias;
         if (tid_ == 32) sBias[H3A_MAX_BIAS * NSFF_W + 32] = sig_b;
+        if (tid_ < 16) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sBias[H3A_MAX_BIAS * NSFF_W + 64 + 16 * k + tid_] = act5[k];
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < H3A_MAX_BIAS; ++r)
-            if (bo[r] >> 31) sBias[r * NSFF_W + tid_] = bv[r];
+            if ((rr >> r) & 1u) sBias[r * NSFF_W + tid_] = bv[r];
     }
     // (the body itself requests the NEXT tile's point into px -- registers the body leaves to the compiler -- from this address;
     //  the last tile requests its own point again)
@@ -1477,29 +1500,19 @@ __device__ __forceinline__ void h3a_kernel() {
     const unsigned tix = tid_;          // (opaque: an output of the body's statement)
     [[maybe_unused]] const int lane = tix & 63;
     [[maybe_unused]] const int wave_id = __builtin_amdgcn_readfirstlane(tix >> 6);
-    const H3AHeadSel hs = {aa.hsel[tr].w_off, aa.hsel[tr].b_off, aa.hsel[tr].n_rows, aa.hsel[tr].slot0, aa.hsel[tr].kinds};
     const bool sig_ride = tr == 0 && aa.sig_ride != 0;
     const long long p0 = tile * M;
     H3A_TSTAMP(54);
     H3A_TSTAMP(55);
     H3A_TSTAMP(56);
     {
-        // per thread, for its four record floats: bias, and the activation as  y = fma(1 / (1 + 2^(c x)), ya, yb)  -- sigmoid:
-        // c = -log2 e, (ya, yb) = (1, 0); flow: c = 2 log2 e, (-2 s, s) = s tanh(x); none: x itself -- branch-free
+        // per thread, for its four record floats: bias and activation constants from the table the first tile left in LDS
         const int q4 = (int)tix & 3;
-        float hb[4], hc[4], ya[4], yb[4];
-        bool plain[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = 4 * q4 + e - hs.slot0;
-            const bool on = row >= 0 && row < hs.n_rows;
-            const unsigned kind = on ? (hs.kinds >> (2 * (row & 15))) & 3u : (unsigned)ACT_NONE;
-            hb[e] = on ? sBias[H3A_MAX_BIAS * NSFF_W + (row & 31)] : 0.f;
-            plain[e] = kind != ACT_SIGMOID && kind != ACT_FLOW;
-            hc[e] = kind == ACT_SIGMOID ? -1.4426950408889634f : (kind == ACT_FLOW ? 2.8853900817779268f : 0.f);
-            ya[e] = kind == ACT_FLOW ? -2.0f * a.flow_scale : 1.0f;
-            yb[e] = kind == ACT_FLOW ? a.flow_scale : 0.f;
-        }
+        const float4* act = reinterpret_cast<const float4*>(sBias + H3A_MAX_BIAS * NSFF_W + 64);
+        const float4 hb4 = act[q4], hc4 = act[4 + q4], ya4 = act[8 + q4], yb4 = act[12 + q4], pl4 = act[16 + q4];
+        const float hb[4] = {hb4.x, hb4.y, hb4.z, hb4.w}, hc[4] = {hc4.x, hc4.y, hc4.z, hc4.w};
+        const float ya[4] = {ya4.x, ya4.y, ya4.z, ya4.w}, yb[4] = {yb4.x, yb4.y, yb4.z, yb4.w};
+        const bool plain[4] = {pl4.x != 0.f, pl4.y != 0.f, pl4.z != 0.f, pl4.w != 0.f};
         for (int i = (int)tix; i < M * (NSFF_RAW_STRIDE / 4); i += THREADS) {
             const long long p = p0 + i / (NSFF_RAW_STRIDE / 4);
             if (p < a.n_points && (piece == 0 || (piece == 1) == (q4 == 0))) {
