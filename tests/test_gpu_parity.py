@@ -374,7 +374,8 @@ def test_chunk_parallel_composite_equals_the_serial_form(hip_lib, monkeypatch):
     """65..256 samples per ray: one ray per workgroup, one wave per 64-sample chunk (composite_kernel_chunks) against the one-wave-
     per-ray form (NSFF_SERIAL_COMPOSITE=1): every per-sample output bit-identical (a chunk's transmittance starts at its
     predecessors' products, multiplied in the serial form's order), the per-ray sums equal up to their summation order"""
-    for name, n_samples, n_imp in (("g3_nsff_train", 64, 64), ("g5_nsff_test_vis", 64, 32), ("g1_static_c1", 128, 0)):
+    for name, n_samples, n_imp in (("g3_nsff_train", 64, 64), ("g3_nsff_train", 80, 17), ("g5_nsff_test_vis", 64, 32), ("g1_static_c1", 128, 0),
+                                   ("g1_static_c1", 65, 0), ("g1_static_c1", 255, 0), ("g1_static_c1", 256, 0)):
         cfg = dict(scenes.CASES[name], n_rays=96)
         rays, ts = scenes.synthetic_rays(96, 11)
         models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
