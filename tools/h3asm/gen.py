@@ -193,7 +193,7 @@ class Stream:
 
 # ----------------------------------------------------------------------------------------------------------------------
 NOSWAP_STORES = os.environ.get("H3A_NOSWAP_STORES", "1") == "1"    # 0: the v_permlane32_swap + 16-byte store form (A/B builds)
-EXP = os.environ.get("H3A_EXP", "")          # timing experiments (results are garbage): nomix, noswap, nowrite, noride, andsub
+EXP = os.environ.get("H3A_EXP", "")          # timing experiments (results are garbage): nomix, noswap, nowrite, noride, andsub, nolo, nolh
 
 
 def epilogue_unit(half, u, tset, sig=False):
@@ -344,7 +344,12 @@ def mfmas(half, ks, second_xl=False):
             for nt in range(2):
                 d = acc(half, mt, nt)
                 bop = xh(b, nt) if xsel == "h" else (xl2(nt) if second_xl else xl(nt))
-                out.append(I_mfma(d, wslot(ks, mt, part), bop, d))
+                # (timing experiments, results garbage: "nolo" drops the Wh.xl products -- what a two-slot scheme would issue --,
+                #  "nolh" the Wl.xh products as well: one MFMA per product)
+                if ("nolo" in EXP or "nolh" in EXP) and xsel == "l" or ("nolh" in EXP and part == 1):
+                    out.append(raw("s_nop 0"))
+                else:
+                    out.append(I_mfma(d, wslot(ks, mt, part), bop, d))
     return out
 
 
