@@ -96,6 +96,10 @@ def test_layout_and_argument_validation_without_gpu():
     a = _lib.FieldArgs()
     a.n_points, a.pts_per_ray, a.static_mode = 64, 1, 2
     assert lib.nsff_field_query(C.byref(d), None, C.byref(a), None) == -2
+    bad = _lib.FieldArgs(); bad.launch_form, bad.n_points = 2, 4
+    assert lib.nsff_field_query(C.byref(d), (C.c_char * 64)(), C.byref(bad), None) == -1   # launch_form: 0 (library's choice) or 1 (one workgroup per tile)
+    from nsff_pl_amd import config
+    assert config.get_persistent() is True
     assert lib.nsff_time_bias_rows(C.byref(d)) == 2                            # layer 0 + the skip layer
     two = _lib.model_desc(m); two.skip = 0; two.skip_mask = 0b100100
     assert lib.nsff_time_bias_rows(C.byref(two)) == 3
