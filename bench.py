@@ -141,6 +141,27 @@ class Bench:
         prev, self.pending = getattr(self, "pending", None), handle
         return prev.wait() if prev is not None else None
 
+    def render_scope(self, overlap=True):
+        """Scope of the renders of a step whose gather is issued with gather(..., overlap=overlap): when that gather will run
+        BESIDE the next step's render (and the world is larger than one rank) the field launches inside take the
+        one-workgroup-per-tile form -- chosen here, per step, restored on exit (nsff_pl_amd.dist.beside_a_collective)."""
+        import contextlib
+        from nsff_pl_amd import dist as ndist
+        if os.environ.get("NSFF_GATHER_ASYNC"):
+            overlap = True
+        if os.environ.get("NSFF_GATHER_SYNC"):
+            overlap = False
+        return ndist.beside_a_collective() if (overlap and self.live) else contextlib.nullcontext()
+
+    def field_launch_form(self, workload):
+        """What the timed steps' field launches ran as (for the JSON line): the form render_scope selects for this workload."""
+        from nsff_pl_amd import config
+        overlap = workload in ("eval", "eval_interp")
+        with self.render_scope(overlap=overlap):
+            persistent = config.get_persistent()
+        return ("persistent (one workgroup per CU)" if persistent else
+                "one workgroup per tile (a collective kernel runs beside the render stream)")
+
     def finish(self):
         prev, self.pending = getattr(self, "pending", None), None
         return prev.wait() if prev is not None else None
@@ -174,7 +195,7 @@ class Bench:
         def step():
             # the render workload measures the forward path (inference launches); train_forward=True keeps autograd on, so
             # the same call runs the TRAINING forward kernels (every layer executed, activations kept for the backward pass)
-            with torch.set_grad_enabled(train_forward):
+            with torch.set_grad_enabled(train_forward), self.render_scope(overlap=False):
                 out = A.render_rays(self.models, self.emb, self.rays, self.ts, scenes.N_FRAMES - 1, N_SAMPLES, 1.0, 1.0,
                                     N_IMPORTANCE, 1024 * 32, test_time=False, **self.kw)
             if live:
@@ -228,7 +249,8 @@ class Bench:
             if self.standin:                               # CPU plumbing check (tests): constant pixels of this rank's block
                 out = {"rgb_fine": torch.full((hi - lo, 3), float(rank)), "depth_fine": torch.zeros(hi - lo)}
             else:
-                out = render_t(7, ("rgb_fine", "depth_fine"))
+                with self.render_scope(overlap=not to_host):
+                    out = render_t(7, ("rgb_fine", "depth_fine"))
             if self.live and not to_host:
                 counts = [b - a_ for a_, b in (ndist.shard_bounds(H * W, world, r) for r in range(world))]
                 self.gather(out, ("rgb_fine", "depth_fine"), counts=counts)
@@ -502,8 +524,8 @@ def main():
                          "while the CPU baseline runs) and its power management settles; 0 = none.  Reported in config.settle_ms")
     ap.add_argument("--no-aux", action="store_true", help="skip the aux block (other configurations after the headline)")
     ap.add_argument("--precision", default=os.environ.get("NSFF_PRECISION", "f16x3"), choices=["f32", "f16x3"],
-                    help="arithmetic of the dense layers; f32 and f16x3 pass the same 1e-4 parity tests, f16 is the "
-                         "labelled fast mode")
+                    help="arithmetic of the dense layers; f32 (exact fp32 MFMA) and f16x3 (three f16 products per MAC, the "
+                         "default) pass the same 1e-4 parity tests")
     ap.add_argument("--workload", default="render", choices=["render", "train", "eval", "eval_interp"],
                     help="render = C2 (headline, default); train = C4: the same batch through NSFFTrainer.step "
                          "(HIP forward, NeRFWLoss, native HIP backward, flat RCCL gradient all-reduce, Adam); eval = C3: one "
@@ -585,8 +607,7 @@ def main():
                        "settle_ms": args.settle_ms,
                        "rays_per_gpu": N_RAYS, "N_samples": N_SAMPLES, "N_importance": N_IMPORTANCE,
                        "parallelism": f"ray-shard x{world}, pixel all-gather" if bench.live else "single GPU",
-                       "field_launch": ("persistent (one workgroup per CU)" if config.get_persistent() else
-                                        "one workgroup per tile (a collective kernel runs beside the render stream)"),
+                       "field_launch": bench.field_launch_form(args.workload),
                        "rays_per_s": world * N_RAYS * args.steps / elapsed,
                        "mlp_tflops_whole_step": world * N_RAYS * args.steps * FLOP_PER_RAY_C2_TRAIN / elapsed / 1e12},
         }

@@ -354,6 +354,24 @@ typedef struct NsffFoldGradArgs {
 } NsffFoldGradArgs;
 int nsff_fold_grads(const NsffFoldGradArgs* args, void* stream);
 
+/* The same algebra for a folded layer of ANY height (n_rows <= 256) whose weights are one strided matrix -- the view-direction
+ * layer static_dir_encoding (reference models/nerf.py:83-91,183-186: it reads [*_final | dir | a]; its first 256 columns are the
+ * folded part, ld_head = 256 + in_dir + in_a) -- and for callers that want the results as tensors instead of accumulated
+ * (accumulate = 0: every output element is STORED):
+ *   g (n_rows, 256) [+ g2: a second summand, the fp16 rounding-remainder rows of a heads' job, or NULL], gb (n_rows) [+ gb2]
+ *   d_w_head[r * ld_dhead + o] (+)= sum_i G[r][i] W_final[o][i] + gb[r] b_final[o]      d_b_head[r] (+)= gb[r]
+ *   d_w_final[o][i] (+)= sum_r W_head[r * ld_head + o] G[r][i]                          d_b_final[o] (+)= sum_r W_head[r * ld_head + o] gb[r]
+ * Two launches (rows of the head layer / neurons of *_final); fp32 FMAs in a fixed order: deterministic.  This is what ran
+ * through torch.addmm / `@` (rocBLAS) for view-direction models and for gradients returned as tensors until round 5.       */
+typedef struct NsffFoldDenseArgs {
+    int32_t n_rows, accumulate;
+    int32_t ld_head, ld_dhead;
+    const float* g; const float* g2; const float* gb; const float* gb2;
+    const float* w_head; const float* w_final; const float* b_final;
+    float* d_w_head; float* d_b_head; float* d_w_final; float* d_b_final;
+} NsffFoldDenseArgs;
+int nsff_fold_grads_dense(const NsffFoldDenseArgs* args, void* stream);
+
 /* out[0] = max |x[i]| (0 for n == 0): the device scalar `gmax` of nsff_field_backward / nsff_weight_grad without a
  * host round trip (replaces d_raw.abs().max()).  x 16-byte aligned.                                                */
 int nsff_absmax(const float* x, int64_t n, float* out, void* stream);

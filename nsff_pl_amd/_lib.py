@@ -122,6 +122,12 @@ class FoldGradArgs(C.Structure):
                 ("w_head", _fp * 16), ("d_w_head", _fp * 16), ("d_b_head", _fp * 16), ("d_w_final", _fp), ("d_b_final", _fp)]
 
 
+class FoldDenseArgs(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("accumulate", C.c_int32), ("ld_head", C.c_int32), ("ld_dhead", C.c_int32),
+                ("g", _fp), ("g2", _fp), ("gb", _fp), ("gb2", _fp), ("w_head", _fp), ("w_final", _fp), ("b_final", _fp),
+                ("d_w_head", _fp), ("d_b_head", _fp), ("d_w_final", _fp), ("d_b_final", _fp)]
+
+
 class SplatArgs(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("n_planes", C.c_int32), ("K4", C.c_float * 4),
                 ("P", C.c_float * 12), ("scale", C.c_float),
@@ -200,6 +206,7 @@ _SIGNATURES = {
     "nsff_weight_grad_accumulate_aux": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, C.c_int64,
                                                   _fp, _fp, _fp, _fp]),
     "nsff_fold_grads": (C.c_int, [C.POINTER(FoldGradArgs), _fp]),
+    "nsff_fold_grads_dense": (C.c_int, [C.POINTER(FoldDenseArgs), _fp]),
     "nsff_pack_weights_bwd_ex": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp, _fp]),
     "nsff_absmax": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "nsff_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double, _fp]),
@@ -380,7 +387,7 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     prec = config.precision_code(model) if precision is None else precision
     saves = not (save_acts is None and save_xin is None and save_masks is None and save_side is None)
     # (training forwards run the folded step program too: one pack form)
-    packed = model.packed(prec, inference=True)
+    packed = model.packed(prec)
     a = FieldArgs()
     a.precision, a.tile_points = prec, config.get_tile_points()
     a.launch_form = 0 if config.get_persistent() else 1
@@ -417,7 +424,7 @@ def side_bias(model, dir_rows, a_rows=None):
     desc = model_desc(model)
     n_rays = int(dir_rows.shape[0])
     assert dir_rows.shape == (n_rays, desc.in_dir) and (desc.in_a == 0 or (a_rows is not None and a_rows.shape == (n_rays, desc.in_a)))
-    packed = model.packed(config.PRECISIONS["f16x3"], inference=True)      # (the folded bias row lives in the inference pack)
+    packed = model.packed(config.PRECISIONS["f16x3"])      # (the folded bias row lives in the inference pack)
     w = model.static_dir_encoding[0].weight.detach()
     out = torch.empty(n_rays, 1, 256, device=dir_rows.device, dtype=torch.float32)
     _check(load().nsff_side_bias(C.byref(desc), _ptr(packed), _ptr(w), _ptr(dir_rows), _ptr(a_rows) if desc.in_a > 0 else None,
@@ -487,6 +494,51 @@ def fused_draws(plan, device, values=True, coarse=None):
     return outs
 
 
+_FUSED_DRAWS_OK = {}
+
+
+def fused_draws_match_torch(device):
+    """True when :func:`fused_draws` reproduces torch's generator on `device` -- checked ONCE per device, on first use: fused_draws
+    restates three ATen internals (the launch geometry of calc_execution_policy, the Philox offset accounting, the uniform /
+    normal transforms), and a torch or hiprand upgrade could change any of them without an error.  A few thousand rand / randn
+    numbers (several grid sizes, a size that is not a multiple of four) are drawn both ways from the same saved generator state
+    and compared bit for bit, the generator's final offset included; the state is restored afterwards, so the check draws
+    nothing from the caller's stream of numbers.  On a mismatch the render path uses the torch calls (as NSFF_TORCH_RNG=1 does)
+    and says so once."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _FUSED_DRAWS_OK:
+        return _FUSED_DRAWS_OK[idx]
+    if torch.cuda.is_current_stream_capturing():          # (never decided inside a capture: the caller draws with torch there anyway)
+        return False
+    gen = torch.cuda.default_generators[idx]
+    state = gen.get_state()
+    ok = True
+    try:
+        plan = [("rand", (7, 64)), ("randn", (1031,)), ("rand", (3, 5, 2)), ("randn", (70000,)), ("rand", (300001,))]
+        gen.manual_seed(0x5EED1234)
+        gen.set_offset(8)
+        mine = fused_draws(plan, torch.device("cuda", idx))
+        end_mine = gen.get_offset()
+        gen.manual_seed(0x5EED1234)
+        gen.set_offset(8)
+        with torch.cuda.device(idx):
+            ref = [(torch.rand if k == "rand" else torch.randn)(*shape, device=torch.device("cuda", idx)) for k, shape in plan]
+        end_ref = gen.get_offset()
+        ok = end_mine == end_ref and all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(mine, ref))
+    except Exception:                                      # an API that moved is a mismatch as well
+        ok = False
+    finally:
+        gen.set_state(state)
+    if not ok:
+        import warnings
+        warnings.warn("nsff_pl_amd: the fused generator kernel (nsff_rng_draws) no longer reproduces torch.rand / torch.randn on "
+                      f"cuda:{idx} (torch {torch.__version__}); render_rays draws with the torch calls instead (slower by ~1 %, same "
+                      "numbers as the reference)")
+    _FUSED_DRAWS_OK[idx] = ok
+    return ok
+
+
 def time_bias_rows(model):
     """rows per ray of time_bias() for this model (0: no dynamic trunk)"""
     return load().nsff_time_bias_rows(C.byref(model_desc(model)))
@@ -505,7 +557,7 @@ def time_bias(jobs, index=None):
     rows_of = {}
     if index is not None:
         table, ts, max_t = index
-        assert ts.dtype == torch.int64 and ts.is_cuda and ts.is_contiguous()
+        assert ts.dtype == torch.int64 and ts.is_cuda and ts.is_contiguous() and ts.dim() == 1, "ts: one int64 frame index per ray"
         n_rays, width = int(ts.shape[0]), int(table.shape[1])
         deltas = sorted({int(d) for _, d in jobs})
         if 1 in deltas and -1 in deltas:
@@ -696,6 +748,22 @@ def fold_grads(g, gb, w_final, b_final, head_rows, d_w_final, d_b_final):
     for r, (w, dw, db) in enumerate(head_rows):
         a.w_head[r], a.d_w_head[r], a.d_b_head[r] = w.data_ptr(), dw.data_ptr(), db.data_ptr()
     _check(load().nsff_fold_grads(C.byref(a), _stream()), "nsff_fold_grads")
+
+
+def fold_grads_dense(g, gb, w_head, w_final, b_final, d_w_head, d_b_head, d_w_final, d_b_final, accumulate, g2=None, gb2=None):
+    """nsff_fold_grads_dense: g (R, 256) [+ g2], gb (R,) [+ gb2]: dense sum / row sums of the folded layer's job; w_head (R, >= 256)
+    a (possibly column-sliced) view of the folded layer's weight -- its row stride is passed on --, d_w_head likewise; w_final
+    (256, 256), b_final (256,).  accumulate: add to / store into the d_* tensors (fp32 GPU tensors, rows contiguous)."""
+    R = int(g.shape[0])
+    for t in (g, g2, gb, gb2, w_final, b_final, d_w_final, d_b_final, d_b_head):
+        assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+    for t in (w_head, d_w_head):
+        assert t.is_cuda and t.dtype == torch.float32 and t.shape[0] == R and t.shape[1] == 256 and t.stride(1) == 1
+    a = FoldDenseArgs(n_rows=R, accumulate=1 if accumulate else 0, ld_head=int(w_head.stride(0)), ld_dhead=int(d_w_head.stride(0)),
+                      g=g.data_ptr(), g2=None if g2 is None else g2.data_ptr(), gb=gb.data_ptr(), gb2=None if gb2 is None else gb2.data_ptr(),
+                      w_head=w_head.data_ptr(), w_final=w_final.data_ptr(), b_final=b_final.data_ptr(), d_w_head=d_w_head.data_ptr(),
+                      d_b_head=d_b_head.data_ptr(), d_w_final=d_w_final.data_ptr(), d_b_final=d_b_final.data_ptr())
+    _check(load().nsff_fold_grads_dense(C.byref(a), _stream()), "nsff_fold_grads_dense")
 
 
 def absmax(x):

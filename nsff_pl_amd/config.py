@@ -56,13 +56,38 @@ _persistent = True
 
 def set_persistent(on):
     """Large launches of the hand-scheduled field kernel are persistent by default (one workgroup per compute unit walking its
-    tiles; same records bit for bit, ~1.4 % faster).  False: one workgroup per 128-point tile -- what
-    ``dist.all_gather_pixels_async`` selects at world sizes above one: a persistent launch holds every compute unit until it
-    ends, and that gather's RCCL kernel -- which waits for its peers -- runs BESIDE the render stream; with one workgroup per
-    tile it gets a compute unit at the next tile boundary and no render workgroup waits behind a collective for a whole launch."""
+    tiles; same records bit for bit, ~1.4 % faster).  False: one workgroup per 128-point tile.  This is the process default;
+    code that needs the other form for a stretch of calls uses :func:`launch_form` (scoped, restored on exit) -- nothing in the
+    package changes this default behind the caller's back."""
     global _persistent
     _persistent = bool(on)
 
 
 def get_persistent():
     return _persistent
+
+
+class launch_form:
+    """``with config.launch_form(persistent=False): ...`` -- field launches issued inside the block take the given form
+    (``NsffFieldArgs::launch_form``, a per-call field of the C-ABI), the previous setting is restored on exit, also on an
+    exception.  ``persistent=None`` leaves the setting alone (callers that decide at run time).
+
+    Who uses it: the sharded frame loops (``evaluate.render_sequence_sharded``, ``bench.py --workload eval``) at world sizes
+    above one -- there a frame's pixel all-gather (a RCCL kernel that waits for its peers) runs on a side stream BESIDE the next
+    frame's render, and a persistent launch holds every compute unit until it ends; with one workgroup per tile the collective
+    gets a compute unit at the next tile boundary (:func:`nsff_pl_amd.dist.beside_a_collective` makes the choice)."""
+
+    def __init__(self, persistent=None):
+        self.want = persistent
+
+    def __enter__(self):
+        global _persistent
+        self.old = _persistent
+        if self.want is not None:
+            _persistent = bool(self.want)
+        return self
+
+    def __exit__(self, *exc):
+        global _persistent
+        _persistent = self.old
+        return False

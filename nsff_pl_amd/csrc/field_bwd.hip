@@ -58,7 +58,6 @@ struct TrunkLayoutB {
                                          // inference launches do, and this tile holds (W_head W_final)^T -- the 256 x 256 *_final layer
                                          // is executed neither forward nor backward (its gradients: field_grad._folded_grads).
                                          // View-direction static trunk: static_rgb reads static_dir_encoding -- its own transpose.
-    uint32_t fin;                        // (unused since the fold: rows = last trunk activation, K = 256)
     uint32_t layer[NSFF_MAX_LAYERS];     // l = 1..D-1: rows = activation of layer l-1, K = 256 (pre-activations of l)
     uint32_t x0;                         // rows = trunk input (xin_rows used), K = 256 (pre-activations of layer 0)
     uint32_t xskip[NSFF_MAX_LAYERS];     // the same for every skip layer l (NSFF_NONE elsewhere)
@@ -88,7 +87,6 @@ inline int make_layout_b(const NsffModelDesc& d, LayoutB& L) {
     auto take = [&](uint32_t halfs) { uint32_t o = off; off += halfs / 2; return o; };
     auto trunk = [&](TrunkLayoutB& T, bool xparts) {
         T.head = take(256 * 64);
-        T.fin = take(256 * 256);
         for (int l = 0; l < NSFF_MAX_LAYERS; ++l) T.layer[l] = NSFF_NONE;
         for (int l = 1; l < d.D; ++l) T.layer[l] = take(256 * 256);
         T.x0 = NSFF_NONE;
@@ -861,6 +859,73 @@ __global__ __launch_bounds__(256) void fold_grads_kernel(const NsffFoldGradArgs 
     if (i == 0) a.d_b_final[o] += dbf;
 }
 
+// The dense form (NsffFoldDenseArgs).  Kernel H: four rows of the folded layer per workgroup, thread = neuron o of *_final:
+//   d_w_head[r][o] = sum_i G[r][i] W_final[o][i] + gb[r] b_final[o]  -- the thread streams its row of W_final as float4s (a 16-byte
+//   read per 1 KiB stride: every 64-byte sector is fetched by four consecutive iterations, the 256 KiB matrix stays in L2), the
+//   four G rows are broadcast reads from LDS.
+// Kernel F: one workgroup per neuron o of *_final, thread = input column i:  d_w_final[o][i] = sum_r W_head[r][o] G[r][i]  (G read
+//   coalesced along i, W_head[., o] staged in LDS), d_b_final[o] by thread 0 in row order.
+constexpr int FOLD_ROWS = 4;
+__global__ __launch_bounds__(256) void fold_dense_head_kernel(const NsffFoldDenseArgs a) {
+    __shared__ __attribute__((aligned(16))) float sG[FOLD_ROWS][256];
+    __shared__ float sGb[FOLD_ROWS];
+    const int r0 = blockIdx.x * FOLD_ROWS, o = threadIdx.x;
+    for (int k = 0; k < FOLD_ROWS; ++k) {
+        const int r = r0 + k;
+        float v = 0.f;
+        if (r < a.n_rows) { v = a.g[r * 256 + o]; if (a.g2) v += a.g2[r * 256 + o]; }
+        sG[k][o] = v;
+    }
+    if (o < FOLD_ROWS) {
+        const int r = r0 + o;
+        float v = 0.f;
+        if (r < a.n_rows) { v = a.gb[r]; if (a.gb2) v += a.gb2[r]; }
+        sGb[o] = v;
+    }
+    __syncthreads();
+    float acc[FOLD_ROWS];
+#pragma unroll
+    for (int k = 0; k < FOLD_ROWS; ++k) acc[k] = 0.f;
+    const float4* wf = reinterpret_cast<const float4*>(a.w_final + (long long)o * 256);
+#pragma unroll 4
+    for (int i4 = 0; i4 < 64; ++i4) {
+        const float4 w = wf[i4];
+#pragma unroll
+        for (int k = 0; k < FOLD_ROWS; ++k) {
+            const float4 gq = *reinterpret_cast<const float4*>(&sG[k][4 * i4]);
+            acc[k] = fmaf(gq.x, w.x, acc[k]); acc[k] = fmaf(gq.y, w.y, acc[k]);
+            acc[k] = fmaf(gq.z, w.z, acc[k]); acc[k] = fmaf(gq.w, w.w, acc[k]);
+        }
+    }
+    const float bf = a.b_final[o];
+#pragma unroll
+    for (int k = 0; k < FOLD_ROWS; ++k) {
+        const int r = r0 + k;
+        if (r >= a.n_rows) break;
+        const float v = fmaf(sGb[k], bf, acc[k]);
+        float* d = a.d_w_head + (long long)r * a.ld_dhead + o;
+        *d = a.accumulate ? *d + v : v;
+        if (o == 0) a.d_b_head[r] = a.accumulate ? a.d_b_head[r] + sGb[k] : sGb[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void fold_dense_final_kernel(const NsffFoldDenseArgs a) {
+    __shared__ float sW[256];
+    const int o = blockIdx.x, i = threadIdx.x, R = a.n_rows;
+    sW[i] = i < R ? a.w_head[(long long)i * a.ld_head + o] : 0.f;
+    __syncthreads();
+    float acc = 0.f;
+    if (a.g2) { for (int r = 0; r < R; ++r) acc = fmaf(sW[r], a.g[r * 256 + i] + a.g2[r * 256 + i], acc); }
+    else { for (int r = 0; r < R; ++r) acc = fmaf(sW[r], a.g[r * 256 + i], acc); }
+    float* d = a.d_w_final + (long long)o * 256 + i;
+    *d = a.accumulate ? *d + acc : acc;
+    if (i == 0) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t = fmaf(sW[r], a.gb[r] + (a.gb2 ? a.gb2[r] : 0.f), t);
+        a.d_b_final[o] = a.accumulate ? a.d_b_final[o] + t : t;
+    }
+}
+
 // max |x| as a device scalar (the global scale of nsff_field_backward): non-negative floats order like their bits
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* out) {
     float m = 0.f;
@@ -896,6 +961,17 @@ int nsff_fold_grads(const NsffFoldGradArgs* args, void* stream) {
     if (!a.g || !a.gb || !a.w_final || !a.b_final || !a.d_w_final || !a.d_b_final) return NSFF_ERR_NULL;
     for (int r = 0; r < a.n_rows; ++r) if (!a.w_head[r] || !a.d_w_head[r] || !a.d_b_head[r]) return NSFF_ERR_NULL;
     hipLaunchKernelGGL(fold_grads_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    return nsff_launch_status();
+}
+
+int nsff_fold_grads_dense(const NsffFoldDenseArgs* args, void* stream) {
+    if (!args) return NSFF_ERR_NULL;
+    const NsffFoldDenseArgs& a = *args;
+    if (a.n_rows < 1 || a.n_rows > 256 || a.ld_head < 256 || a.ld_dhead < 256) return NSFF_ERR_INVALID;
+    if (!a.g || !a.gb || !a.w_head || !a.w_final || !a.b_final || !a.d_w_head || !a.d_b_head || !a.d_w_final || !a.d_b_final) return NSFF_ERR_NULL;
+    if ((uintptr_t)a.w_final & 15) return NSFF_ERR_ALIGN;
+    hipLaunchKernelGGL(fold_dense_head_kernel, dim3((a.n_rows + FOLD_ROWS - 1) / FOLD_ROWS), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(fold_dense_final_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
     return nsff_launch_status();
 }
 

@@ -1077,10 +1077,18 @@ struct H3AArgs {
     // programs of such a launch went through h3a_make_persistent) and its point by the body's first instructions.  1: one trunk in the launch (whole records); 2: both trunks -- workgroup b runs
     // on XCD b % 8 (observed, not promised: only L2 locality depends on it), XCDs 0..3 take the static trunk, 4..7 the dynamic one,
     // each trunk's 2.3 MB of weights stay in its XCDs' L2s; 3: the dynamic trunk of a launch whose static trunk is another kernel's;
-    // 4: both trunks of unequal cost (a view-direction static trunk is 23 % longer): workgroups [0, p_split) take the static trunk,
-    // the others the dynamic one -- p_split = the static trunk's share of the matrix steps, so that both kinds finish together.
+    // 4: both trunks of unequal cost (a view-direction static trunk is 23 % longer, the time code through the matrix pipe makes the
+    // dynamic one 7 % longer): trunk by XCD exactly as in mode 2 -- an XCD's 4 MB L2 holds ONE trunk's weights (both are 4.7 MB:
+    // the earlier split by workgroup index put both trunks on every XCD and fetched ~2.7 GB per launch, 18x the algorithmic
+    // bytes) -- and the LONGER trunk p_long keeps only its tiles [0, p_split) for its own XCDs: tiles [p_split, p_tiles) are a SECOND
+    // ROUND of workgroups (grid = 2 x compute units; blockIdx.x >= gridDim.x / 2), which the dispatcher starts where compute
+    // units free up first -- on the XCDs of the shorter trunk, whose second-round workgroups take the longer trunk's tail (one L2
+    // refill per XCD and launch); second-round workgroups that land on the longer trunk's XCDs have no tile and leave at once.
+    // p_split is chosen so that both kinds of XCD finish together.  Every (tile, trunk) pair is computed exactly once whatever
+    // the dispatcher does: only L2 locality depends on where a workgroup runs.
     int p_mode, p_split;
     long long p_tiles;                  // 128-point tiles of the launch
+    int p_long;                         // mode 4: the longer trunk (0 static, 1 dynamic)
     int sig_ride;                       // static trunk with the view-direction branch: sigma = sum of the 8 partial sums the body's
                                         // sigma ride left at floats 4..11 of the record image + the bias at packed word sig_b_off
     uint32_t sig_b_off;
@@ -1241,10 +1249,17 @@ __device__ __forceinline__ void h3a_kernel() {
             tile = (long long)(blockIdx.x >> 3) * 4 + (x & 3);
             tile_stride = gridDim.x >> 1;
         } else if (aa.p_mode == 3) { tr = 1; piece = 2; }
-        else if (aa.p_mode == 4) {
-            tr = (int)blockIdx.x >= aa.p_split ? 1 : 0; piece = tr + 1;
-            tile = tr ? (long long)blockIdx.x - aa.p_split : (long long)blockIdx.x;
-            tile_stride = tr ? (long long)gridDim.x - aa.p_split : (long long)aa.p_split;
+        else if (aa.p_mode == 4) {                  // trunk by XCD + a second round of workgroups for the longer trunk's tail
+            const int x = blockIdx.x & 7, round1 = (int)(gridDim.x >> 1);
+            const bool second = (int)blockIdx.x >= round1;
+            const int b = second ? (int)blockIdx.x - round1 : (int)blockIdx.x;
+            tr = x >> 2;
+            tile = (long long)(b >> 3) * 4 + (x & 3);
+            tile_stride = round1 >> 1;
+            if (!second) { if (tr == aa.p_long) tile_end = aa.p_split; }
+            else if (tr == aa.p_long) tile = tile_end;          // (nothing to do on the longer trunk's own XCDs)
+            else { tr = aa.p_long; tile += aa.p_split; }
+            piece = tr + 1;
         }
     } else if (a.split_trunks) {
         if (tile < a.grid_tiles) { tr = 0; piece = 1; }
@@ -2282,6 +2297,19 @@ extern "C" int nsff_side_bias(const NsffModelDesc* desc, const void* packed_f16x
 // which kernel the last f16 / f16x3 launch of this process took (nsff_last_field_kernel: tests assert that large inference
 // launches really run the hand-scheduled body instead of silently falling back)
 int g_nsff_last_h3_kernel = 0;
+// compute units of the CURRENT device (per device id: a process may drive several devices, and a persistent grid / trunk-by-XCD
+// split sized for another part would be wrong for this one -- results would stay correct, occupancy not)
+static int h3a_device_cus() {
+    static int cus[64];                 // 0 = not asked yet, -1 = the query failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+
 int g_nsff_last_h3_grid = 0;          // workgroups of that launch when it was a hand-scheduled inference launch (nsff_last_field_grid)
 
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
@@ -2442,9 +2470,7 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         // least one tile.  Each workgroup keeps ONE trunk: trunks of equal cost split the chip by XCD, unequal ones (the
         // view-direction static trunk is 23 % longer than the dynamic one) by their share of the matrix steps.
         // NSFF_NO_PERSIST=1: one workgroup per tile (A/B).
-        static const int n_cus = [] { int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-            return n; }();
+        const int n_cus = h3a_device_cus();
         const bool no_persist = g.launch_form == 1 || getenv("NSFF_NO_PERSIST") != nullptr;       // (the variable is read per launch: tests flip it)
         const bool can_persist = !no_persist && n_cus >= 8 && n_cus % 8 == 0;
         auto cost = [&](const H3APhase* ph) {
@@ -2480,13 +2506,17 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
             if (can_persist && both2 && tiles >= n_cus / 2) {
                 const int cs = cost(ka.ph[0]), cd = cost(ka.ph[1]);
                 const bool equal = 25 * std::abs(cs - cd) <= std::max(cs, cd);
-                // (unequal trunks: the static trunk's workgroups by its share of the matrix steps; every workgroup needs a tile)
-                const int split = equal ? n_cus / 2 : (int)(((long long)n_cus * cs + (cs + cd) / 2) / (cs + cd));
+                // Unequal trunks (mode 4, see H3AArgs): the longer trunk (cost cl per tile) hands its last `steal` tiles to the
+                // second round, run by the shorter trunk's XCDs behind their own tiles:  (tiles - steal) cl = tiles cs' + steal cl
+                const int cl = std::max(cs, cd), csh = std::min(cs, cd);
+                const long long steal = equal ? 0 : (tiles * (cl - csh) + cl) / (2LL * cl);
                 H3APhase keep[H3A_MAX_PHASES];
                 for (int i = 0; i < H3A_MAX_PHASES; ++i) keep[i] = ka.ph[0][i];
-                if (split >= 1 && split < n_cus && tiles >= std::max(split, n_cus - split) && h3a_make_persistent(ka.ph[0])) {
+                if (tiles - steal >= n_cus / 2 && h3a_make_persistent(ka.ph[0])) {       // (every first-round workgroup needs a tile)
                     if (h3a_make_persistent(ka.ph[1])) {
-                        ka.p_mode = equal ? 2 : 4; ka.p_split = split; ka.p_tiles = tiles; grid = (unsigned)n_cus;
+                        ka.p_tiles = tiles; grid = (unsigned)n_cus;
+                        if (steal == 0) ka.p_mode = 2;
+                        else { ka.p_mode = 4; ka.p_long = cs > cd ? 0 : 1; ka.p_split = (int)(tiles - steal); grid = 2u * (unsigned)n_cus; }
                     } else for (int i = 0; i < H3A_MAX_PHASES; ++i) ka.ph[0][i] = keep[i];
                 }
             }

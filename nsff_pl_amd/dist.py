@@ -168,6 +168,20 @@ def all_gather_pixels(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group=None)
 _GATHER_STREAM = {}
 
 
+def beside_a_collective(group=None):
+    """Scope for a frame loop whose pixel gathers overlap the NEXT frame's render (:func:`all_gather_pixels_async`):
+    ``with dist.beside_a_collective(): <render frames, start gathers, join them>``.  At world sizes above one the field
+    launches issued inside take the one-workgroup-per-tile form (``config.launch_form(persistent=False)`` -- the per-call
+    ``NsffFieldArgs::launch_form``): the RCCL kernel waits for its peers BESIDE the render stream, and a persistent launch
+    would hold every compute unit until it ends.  The previous setting is restored on exit; at world size one (or with
+    ``NSFF_PERSIST_MULTI=1``, the A/B switch for a multi-GPU node) nothing changes.  The choice is made here, once, where the
+    process group is known -- not inside the gather: the first frame's launches already have the form of the later ones, and
+    a graph captured inside the scope is keyed on it (``graphs.GraphedRender``)."""
+    from . import config
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1 and not os.environ.get("NSFF_PERSIST_MULTI")
+    return config.launch_form(persistent=False if multi else None)
+
+
 class PendingPixels:
     """Handle of an overlapped pixel all-gather (:func:`all_gather_pixels_async`); ``wait()`` returns the merged dict and
     makes the caller's current stream (GPU) / thread (CPU) wait for the collective -- not before."""
@@ -208,11 +222,6 @@ def all_gather_pixels_async(results, keys=DEFAULT_PIXEL_KEYS, counts=None, group
             return _unpack(out, results, keys, widths, counts, pad_to, world)
         return PendingPixels(finish_cpu)
     dev = ref.device
-    if dist.is_initialized() and dist.get_world_size(group) > 1 and not os.environ.get("NSFF_PERSIST_MULTI"):
-        # a collective kernel that waits for its peers now runs BESIDE the render stream: no field launch may hold every
-        # compute unit until it ends (config.set_persistent; the variable keeps the persistent form for A/B on a multi-GPU node)
-        from . import config
-        config.set_persistent(False)
     if dev not in _GATHER_STREAM:
         _GATHER_STREAM[dev] = torch.cuda.Stream(device=dev)
     side, cur = _GATHER_STREAM[dev], torch.cuda.current_stream(dev)

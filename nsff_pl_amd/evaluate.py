@@ -191,8 +191,11 @@ def render_sequence_sharded(models, embeddings, samples, max_t, N_samples, N_imp
         for per_ray in ("view_dir", "t_embedded", "a_embedded"):
             if per_ray in kw and kw[per_ray] is not None:
                 kw[per_ray] = kw[per_ray][lo:hi]
-        local = render_frame(models, embeddings, rays[lo:hi], None if ts is None else ts[lo:hi], max_t, N_samples,
-                             N_importance, chunk, keys=gather_keys, **kw)
+        # (the scope is entered per frame, not around the generator's yields: the caller's own launches between two frames keep
+        # the process default, and an abandoned generator leaves nothing changed)
+        with ndist.beside_a_collective():
+            local = render_frame(models, embeddings, rays[lo:hi], None if ts is None else ts[lo:hi], max_t, N_samples,
+                                 N_importance, chunk, keys=gather_keys, **kw)
         handle = ndist.all_gather_pixels_async(local, gather_keys, counts=[b - a for a, b in bounds])
         if pending is not None:
             yield emit(pending)                     # frame i - 1: its gather ran beside this frame's render

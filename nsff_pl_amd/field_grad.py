@@ -337,17 +337,30 @@ def _fold_heads(model, t):
 
 def _fold_in_place(model, static, transient, meta, plist, dense, dense_bias):
     """The folded parameters' gradients ADDED to their .grad (every one exists: the in-place path): one nsff_fold_grads launch
-    per trunk; the view-direction static trunk (two 256^3 products) through torch's GEMMs."""
+    per trunk (the heads' rows are addressed one by one: they live in four modules); the view-direction static trunk -- its
+    folded layer is static_dir_encoding, 256 rows of one strided matrix -- through nsff_fold_grads_dense, accumulating."""
     viewdir = bool(model.use_viewdir and static)
     res = {tag: i for i, tag in enumerate(meta)}
-    torch_trunks = set()
+    tensor_trunks = set()
     for t in ([0] if static else []) + ([1] if transient else []):
         prefix = "static" if t == 0 else "transient"
         fin = _lin(getattr(model, f"{prefix}_xyz_encoding_final"))
+        if t == 0 and viewdir:
+            layer = _lin(model.static_dir_encoding)
+            involved = [fin.weight, fin.bias, layer.weight, layer.bias]
+            if not all(q.requires_grad and q.grad is not None for q in involved):
+                tensor_trunks.add(t)
+                continue
+            ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
+            n_side = model.in_channels_dir + model.in_channels_a
+            _lib.fold_grads_dense(dense(ih), dense_bias(ih), layer.weight.detach()[:, :256], fin.weight.detach(), fin.bias.detach(),
+                                  layer.weight.grad[:, :256], layer.bias.grad, fin.weight.grad, fin.bias.grad, accumulate=True)
+            layer.weight.grad[:, 256:].add_(dense(ix)[:, :n_side])      # (the [dir | a] columns: an ordinary job's slice)
+            continue
         heads = _fold_heads(model, t)
         involved = [fin.weight, fin.bias] + [q for m, _, _ in heads for q in (_lin(m).weight, _lin(m).bias)]
-        if (t == 0 and viewdir) or not all(q.requires_grad and q.grad is not None for q in involved):
-            torch_trunks.add(t)
+        if not all(q.requires_grad and q.grad is not None for q in involved):
+            tensor_trunks.add(t)
             continue
         i = res[("head", t, 0)]
         rows = []
@@ -356,24 +369,25 @@ def _fold_in_place(model, static, transient, meta, plist, dense, dense_bias):
             for r in range(b - a):
                 rows.append((lin.weight.detach()[r], lin.weight.grad[r], lin.bias.grad[r:r + 1]))
         _lib.fold_grads(dense(i), dense_bias(i), fin.weight.detach(), fin.bias.detach(), rows, fin.weight.grad, fin.bias.grad)
-    if torch_trunks:
+    if tensor_trunks:       # (some parameter of the fold is frozen or has no .grad yet: results as tensors, added where a .grad exists)
         with torch.no_grad():
-            for i, g_ in _folded_grads(model, static, transient, meta, plist, dense, dense_bias, only=torch_trunks).items():
+            for i, g_ in _folded_grads(model, static, transient, meta, plist, dense, dense_bias, only=tensor_trunks).items():
                 if plist[i].requires_grad:
                     plist[i].grad.add_(g_)
 
 
 def _folded_grads(model, static, transient, meta, plist, result, bias_of, only=None):
-    """{index in plist: gradient} of the parameters the fold touches.  *_xyz_encoding_final is a Linear without activation
+    """{index in plist: gradient tensor} of the parameters the fold touches.  *_xyz_encoding_final is a Linear without activation
     (reference nerf.py:170,195) that the kernels never execute: a head that reads it is evaluated as (W_head W_final) h + (W_head
     b_final + b_head) on the last trunk activation h, and the backward kernels differentiate that folded map.  With
     G = sum_p dpre_p (x) h_p (the folded head's weight gradient, a job of the weight-gradient GEMM) and gb = sum_p dpre_p:
         dW_head = G W_final^T + gb (x) b_final      db_head = gb
         dW_final = W_head^T G                       db_final = W_head^T gb
-    -- exactly what autograd of the two layers gives.  The view-direction layer static_dir_encoding (which reads [*_final | dir |
-    a]) takes W_head's place for the static trunk of such a model; its [dir | a] columns are an ordinary job.
-    result(i) / bias_of(i): dense (a_rows, b_rows) sum and row sums of job i (fp32 tensors)."""
-    D = model.D
+    -- exactly what autograd of the two layers gives (tests/torch_path.py::folded_grads_reference is this algebra in torch; a CPU
+    test holds it to float64 autograd, a GPU test holds this function to it).  The view-direction layer static_dir_encoding
+    (which reads [*_final | dir | a]) takes W_head's place for the static trunk of such a model; its [dir | a] columns are an
+    ordinary job.  The products run in nsff_fold_grads_dense (two launches per trunk, fp32, deterministic).
+    result(i) / bias_of(i): dense (a_rows, b_rows) sum and row sums of job i (fp32 GPU tensors)."""
     viewdir = bool(model.use_viewdir and static)
     index = {id(q): i for i, q in enumerate(plist)}
     res = {tag: i for i, tag in enumerate(meta)}
@@ -383,34 +397,35 @@ def _folded_grads(model, static, transient, meta, plist, result, bias_of, only=N
             continue
         prefix = "static" if t == 0 else "transient"
         fin = _lin(getattr(model, f"{prefix}_xyz_encoding_final"))
-        w_f, b_f = fin.weight.detach(), fin.bias.detach()
+        w_f, b_f = fin.weight.detach().contiguous(), fin.bias.detach().contiguous()
+        d_wf, d_bf = torch.empty_like(w_f), torch.empty_like(b_f)
         if t == 0 and viewdir:
             ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
-            g, gb = result(ih), bias_of(ih)                           # (256, 256), (256)
             layer = _lin(model.static_dir_encoding)
-            w_dh = layer.weight.detach()[:, :256]
             n_side = model.in_channels_dir + model.in_channels_a
-            out[index[id(layer.weight)]] = torch.cat([torch.addmm(torch.outer(gb, b_f), g, w_f.t()), result(ix)[:, :n_side]], 1)
-            out[index[id(layer.bias)]] = gb.clone()
-            out[index[id(fin.weight)]] = w_dh.t() @ g
-            out[index[id(fin.bias)]] = w_dh.t() @ gb
+            d_w = torch.empty_like(layer.weight)
+            d_b = torch.empty_like(layer.bias)
+            _lib.fold_grads_dense(result(ih).contiguous(), bias_of(ih).contiguous(), layer.weight.detach()[:, :256], w_f, b_f,
+                                  d_w[:, :256], d_b, d_wf, d_bf, accumulate=False)
+            d_w[:, 256:] = result(ix)[:, :n_side]
+            out[index[id(layer.weight)]], out[index[id(layer.bias)]] = d_w, d_b
+            out[index[id(fin.weight)]], out[index[id(fin.bias)]] = d_wf, d_bf
             continue
         i = res[("head", t, 0)]
-        hw, hb = result(i), bias_of(i)
-        g, gb = hw[0:16] + hw[16:32], hb[0:16] + hb[16:32]           # fp16 value + rounding remainder rows
+        hw, hb = result(i), bias_of(i)                                            # rows r and 16 + r: fp16 value + rounding remainder
         heads = _fold_heads(model, t)
         n_rows = heads[-1][2]                                                      # (the folded rows are rows 0 .. R - 1 of the job)
         w_h = torch.cat([_lin(m).weight.detach() for m, _, _ in heads], 0)        # (R, 256)
-        g_r, gb_r = g[:n_rows], gb[:n_rows]
-        d_heads = torch.addmm(torch.outer(gb_r, b_f), g_r, w_f.t())               # (R, 256)
+        d_heads, d_hb = torch.empty_like(w_h), torch.empty(n_rows, device=w_h.device, dtype=w_h.dtype)
+        _lib.fold_grads_dense(hw[0:n_rows].contiguous(), hb[0:n_rows].contiguous(), w_h, w_f, b_f, d_heads, d_hb, d_wf, d_bf,
+                              accumulate=False, g2=hw[16:16 + n_rows].contiguous(), gb2=hb[16:16 + n_rows].contiguous())
         k = 0
         for m, a, b in heads:
             lin = _lin(m)
             out[index[id(lin.weight)]] = d_heads[k:k + (b - a)]
-            out[index[id(lin.bias)]] = gb[a:b].clone()
+            out[index[id(lin.bias)]] = d_hb[a:b]
             k += b - a
-        out[index[id(fin.weight)]] = w_h.t() @ g_r
-        out[index[id(fin.bias)]] = w_h.t() @ gb_r
+        out[index[id(fin.weight)]], out[index[id(fin.bias)]] = d_wf, d_bf
     return out
 
 

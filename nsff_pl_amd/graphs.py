@@ -40,7 +40,7 @@ class GraphedRender:
         """Packed weights live in buffers whose addresses the graphs hold: re-pack (eagerly, in place) whatever changed."""
         prec = config.PRECISIONS[config.get_precision()]
         for m in self.models.values():
-            m.packed(prec, inference=True)
+            m.packed(prec)
 
     def _capture(self, key, rays, ts):
         dev = rays.device
@@ -65,11 +65,13 @@ class GraphedRender:
     def __call__(self, rays, ts=None):
         if not rays.is_cuda:
             raise RuntimeError("GraphedRender needs GPU tensors (there is no CPU path)")
-        shape_key = (int(rays.shape[0]), ts is not None, config.get_precision(), config.get_tile_points())
+        # (the launch form is part of the key: a graph captured with persistent launches keeps replaying them, so a caller inside
+        # config.launch_form(persistent=False) -- a sharded frame loop beside a collective -- gets a capture of its own)
+        shape_key = (int(rays.shape[0]), ts is not None, config.get_precision(), config.get_tile_points(), config.get_persistent())
         key = shape_key + (self._param_addresses(),)
         entry = self._graphs.get(key)
         if entry is None:
-            for stale in [k for k in self._graphs if k[:4] == shape_key]:      # captured against parameters that moved since
+            for stale in [k for k in self._graphs if k[:5] == shape_key]:      # captured against parameters that moved since
                 del self._graphs[stale]
             entry = self._capture(key, rays, ts)
         graph, s_rays, s_ts, results = entry

@@ -115,9 +115,9 @@ class NeRF(nn.Module):
     def has_flow_heads(self):
         return hasattr(self, "transient_flow_fw")
 
-    def packed(self, precision=0, inference=True):
+    def packed(self, precision=0):
         """Device buffer with this model's weights in the kernel's MFMA tile order."""
-        return self._pack_cache.get(self, precision, inference)
+        return self._pack_cache.get(self, precision)
 
     def forward(self, x, sigma_only=False, output_static=True, output_transient=True,
                 output_transient_flow=[]):

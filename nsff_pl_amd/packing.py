@@ -14,20 +14,16 @@ class PackCache:
     def __init__(self):
         self._key = {}
         self._buf = {}
-        self._folded = {}
 
     def invalidate(self):
         self._key = {}
 
-    def get(self, model, precision=0, inference=True):
-        """inference=False: the buffer is wanted for a training forward, which does not read the folded head rows of the
-        f16 kernels (nsff_fold_heads); they are added the first time an inference launch asks for the same weights."""
+    def get(self, model, precision=0):
+        """The packed buffer of `model` for `precision` (a forward arithmetic of config.PRECISIONS, or _lib.BWD_PACK: the transposed
+        tiles of the backward kernel).  Forward packs always carry the folded head rows (nsff_fold_heads): inference AND training
+        launches evaluate the heads on the last trunk activation."""
         params = _lib.param_list(model)
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if key == self._key.get(precision) and inference and not self._folded.get(precision, True):
-            with torch.cuda.device(params[0].device):
-                _lib.fold_heads(_lib.model_desc(model), params, self._buf[precision], precision)
-            self._folded[precision] = True
         if key != self._key.get(precision):
             dev = params[0].device
             _lib.require_gpu_tensor(params[0], "model parameter")
@@ -39,9 +35,8 @@ class PackCache:
             with torch.cuda.device(dev):
                 if precision == _lib.BWD_PACK:
                     # (the folded products W_head W_final come from the forward pack of the same weights)
-                    _lib.pack_weights_bwd(desc, params, buf, self.get(model, 1, True))
+                    _lib.pack_weights_bwd(desc, params, buf, self.get(model, 1))
                 else:
-                    _lib.pack_weights(desc, params, buf, precision, fold=inference)
-                    self._folded[precision] = bool(inference)
+                    _lib.pack_weights(desc, params, buf, precision)
             self._key[precision] = key
         return self._buf[precision]

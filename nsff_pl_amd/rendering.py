@@ -58,8 +58,9 @@ class _Draws:
     follow from the call's arguments, so ONE launch makes them all when the call starts (_lib.fused_draws: torch's own generator,
     bit for bit, the generator left where the separate calls leave it); draws whose values nobody reads (noise with
     noise_std = 0: the reference multiplies them by zero) only advance the generator.  While a hipGraph is captured, with
-    NSFF_TORCH_RNG=1, or when torch.rand / torch.randn are not torch's own (the parity tests replay recorded draws through them)
-    every draw is the torch call it mirrors."""
+    NSFF_TORCH_RNG=1, when torch.rand / torch.randn are not torch's own (the parity tests replay recorded draws through them),
+    or when the launch's first-use self-check against torch fails on this device (_lib.fused_draws_match_torch: a torch /
+    hiprand upgrade that changed the generator's geometry) every draw is the torch call it mirrors."""
 
     def __init__(self, device, n_rays, N_samples, N_importance, perturb, noise_std, test_time, models, kwargs, coarse=None):
         """coarse = (rays, z_lin, zs, xyz): with perturb > 0 the launch that draws also computes the coarse depths from the
@@ -68,7 +69,8 @@ class _Draws:
         self.device = device
         self.coarse_done = False
         self.fused = (device.type == "cuda" and torch.rand is _TORCH_RAND and torch.randn is _TORCH_RANDN
-                      and not os.environ.get("NSFF_TORCH_RNG") and not torch.cuda.is_current_stream_capturing())
+                      and not os.environ.get("NSFF_TORCH_RNG") and not torch.cuda.is_current_stream_capturing()
+                      and _lib.fused_draws_match_torch(device))      # (checked once per device against torch itself)
         self.at = 0
         if not self.fused:
             return
@@ -180,7 +182,8 @@ def _time_codes(ctx, models, kwargs, N_samples, N_importance, output_transient, 
             plan.append((typ, 't', model, 0))
     plain = (override is None and isinstance(m, torch.nn.Embedding) and m.padding_idx is None and m.max_norm is None
              and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()
-             and torch.is_tensor(ts) and ts.is_cuda and ts.dtype == torch.int64)
+             and torch.is_tensor(ts) and ts.is_cuda and ts.dtype == torch.int64
+             and ts.dim() == 1 and ts.shape[0] == n_rays)      # (a malformed ts takes the gather below and the reference's shape error)
     if (plan and plain and all(mod.in_channels_t == m.weight.shape[1] for _, _, mod, _ in plan)
             and not os.environ.get('NSFF_NO_TIME_INDEX')):          # (`NSFF_NO_TIME_INDEX=1`: separate gather / neighbour-row launches, A/B)
         outs, rows = _lib.time_bias([(mod, d) for _, _, mod, d in plan], index=(m.weight.detach(), ts.contiguous(), ctx.max_t))

@@ -68,12 +68,32 @@ def _worker(rank, world, port, n_rays, ret):
     ok = ok and all(torch.equal(first[k], sync[k]) and torch.equal(first[k], full[k]) for k in keys)
     ok = ok and all(torch.equal(later[k], both[k]) for k in keys) and h1.wait() is first
     # the sharded frame loop: every rank ends up with every complete frame, one frame behind its renders
-    from nsff_pl_amd import evaluate
+    # The launch form of the field kernels is chosen per frame, scoped (nsff_pl_amd.dist.beside_a_collective): inside the sharded
+    # loop's renders -- a collective runs beside them at world size 2 -- one workgroup per tile; nothing the loop or a gather does
+    # changes the process default (round 5's gather flipped a process-global and never restored it).
+    from nsff_pl_amd import evaluate, config
     real = evaluate.render_frame
-    evaluate.render_frame = lambda m, e, r_, t_, *a, keys=None, **kw: {k: v for k, v in fn(m, e, r_, t_).items() if k in keys}
+    forms = []
+
+    def fake_frame(m, e, r_, t_, *a, keys=None, **kw):
+        forms.append(config.get_persistent())
+        return {k: v for k, v in fn(m, e, r_, t_).items() if k in keys}
+    evaluate.render_frame = fake_frame
+    ok = ok and config.get_persistent() is True               # (the two async gathers above left it alone)
     try:
         samples = [dict(rays=rays, ts=ts), dict(rays=rays.flip(0), ts=ts.flip(0))]
         frames = list(evaluate.render_sequence_sharded(models, emb, samples, 29, 64, 64, (n_rays, 1)))
+        ok = ok and forms == [False, False] and config.get_persistent() is True
+        # an abandoned generator (the caller stops after the first frame) leaves the default alone as well
+        gen = evaluate.render_sequence_sharded(models, emb, samples, 29, 64, 64, (n_rays, 1))
+        next(gen)
+        ok = ok and config.get_persistent() is True
+        list(gen)
+        os.environ["NSFF_PERSIST_MULTI"] = "1"                # the A/B switch of a multi-GPU node: persistent launches stay
+        forms.clear()
+        list(evaluate.render_sequence_sharded(models, emb, samples, 29, 64, 64, (n_rays, 1)))
+        ok = ok and forms == [True, True]
+        del os.environ["NSFF_PERSIST_MULTI"]
     finally:
         evaluate.render_frame = real
     ok = ok and [f[0] for f in frames] == ["000", "001"]

@@ -338,3 +338,56 @@ def test_time_rows_node_matches_embedding_autograd(hip_lib):
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
     only, _, _ = ag.time_rows(emb, ts, max_t, False)                     # no neighbours: the plain gather
     assert torch.equal(only, emb(ts))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("viewdir", [False, True])
+def test_fold_gradient_kernels_match_the_torch_algebra(viewdir, hip_lib):
+    """The gradients of *_xyz_encoding_final and of the layers that read it are small products of the folded layer's weight-gradient
+    sums.  Until round 5 two of the three code paths computed them with torch.addmm / `@` (rocBLAS); now every path is a HIP
+    kernel: nsff_fold_grads (heads, accumulating), nsff_fold_grads_dense (the 256-row view-direction layer, and every caller that
+    wants tensors).  Both forms -- tensors returned (field_grad._folded_grads) and accumulated in place (_fold_in_place, onto
+    non-zero gradients) -- against tests/torch_path.py::folded_grads_reference in float64; fp32 products of 256 terms: 2e-6."""
+    from nsff_pl_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    model = A.NeRF('fine', use_viewdir=viewdir, encode_appearance=viewdir, in_channels_a=48 if viewdir else 0, encode_transient=True,
+                   output_flow=True).to(dev)
+    plist = _lib.param_list(model)
+    meta = field_grad._wgrad_jobs(model, True, True)
+    mats = {i: torch.randn(field_grad.job_shape(model, k), device=dev) for i, (k, _, _) in enumerate(meta)}
+    rows = {i: torch.randn(256, device=dev) for i in mats}
+    m64 = copy.deepcopy(model).double()
+    ref = torch_path.folded_grads_reference(m64, True, True, meta, _lib.param_list(m64), lambda i: mats[i].double(), lambda i: rows[i].double())
+    got = field_grad._folded_grads(model, True, True, meta, plist, lambda i: mats[i], lambda i: rows[i])
+    torch.cuda.synchronize()
+    assert set(got) == set(ref) and len(got) == 14
+    names = {id(p): n for n, p in model.named_parameters()}
+    for i, g in got.items():
+        r = ref[i]
+        assert g.shape == r.shape == plist[i].shape, names[id(plist[i])]
+        err = (g.double() - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        assert err < 2e-6, (names[id(plist[i])], err)
+    # in place, onto gradients that are already there
+    for p in plist:
+        p.grad = torch.randn_like(p)
+    before = {i: plist[i].grad.clone() for i in ref}
+    field_grad._fold_in_place(model, True, True, meta, plist, lambda i: mats[i], lambda i: rows[i])
+    torch.cuda.synchronize()
+    for i, r in ref.items():
+        want = before[i].double() + r
+        err = (plist[i].grad.double() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        assert err < 2e-6, (names[id(plist[i])], err)
+    # a frozen member of the fold: the trunk takes the tensor route, frozen parameters receive nothing
+    fin = model.transient_xyz_encoding_final
+    fin.weight.requires_grad_(False)
+    for p in plist:
+        p.grad = torch.zeros_like(p) if p.requires_grad else None
+    field_grad._fold_in_place(model, True, True, meta, plist, lambda i: mats[i], lambda i: rows[i])
+    torch.cuda.synchronize()
+    assert fin.weight.grad is None
+    for i, r in ref.items():
+        if plist[i] is fin.weight:
+            continue
+        err = (plist[i].grad.double() - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        assert err < 2e-6, (names[id(plist[i])], err)

@@ -281,9 +281,10 @@ def test_training_forward_on_the_hand_scheduled_kernel(arch, hip_lib):
 
 def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, monkeypatch):
     """Large launches of the hand-scheduled kernel are persistent (include/nsff_render.h::nsff_last_field_grid): one workgroup per
-    compute unit walks tiles of ONE trunk -- both trunks split by XCD when they cost the same (time code as per-ray bias rows), by
-    their share of the matrix steps when they do not (time code through the matrix pipe; a view-direction static trunk with its
-    per-ray rows), one trunk in static-only / dynamic-only launches and for the dynamic half of a view-direction model without rows.
+    compute unit walks tiles of ONE trunk -- both trunks split by XCD; when they do not cost the same (time code through the matrix
+    pipe; a view-direction static trunk with its per-ray rows) the longer trunk's last tiles are a SECOND ROUND of workgroups
+    (grid = 2 x compute units) that the shorter trunk's XCDs run behind their own tiles -- one trunk in static-only /
+    dynamic-only launches and for the dynamic half of a view-direction model without rows.
     Every tile is computed by the same instruction stream from the same inputs whichever workgroup runs it: the records are
     bit-identical to the one-workgroup-per-tile form (NSFF_NO_PERSIST=1), including a ragged last tile; the grid tells which form ran."""
     torch.manual_seed(5)
@@ -297,11 +298,14 @@ def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, m
     S = 64
     cases = [  # model, rays, (static, transient, flow heads), per-ray time rows?, per-ray [dir | a] rows?, grid of the persistent form (None: never persistent)
         (plain, 2 * n_cus + 3, (2, 2, 2), True, False, n_cus),     # both trunks, equal cost: trunk by XCD
-        (plain, 2 * n_cus + 3, (2, 2, 2), False, False, n_cus),    # time code through the matrix pipe: the dynamic trunk is 7 % longer
+        (plain, 2 * n_cus + 3, (2, 2, 2), False, False, 2 * n_cus),  # time code through the matrix pipe: the dynamic trunk is 7 % longer
+                                                                     # -> trunk by XCD + a second round of workgroups for its tail
         (plain, 2 * n_cus + 5, (2, 0, 0), False, False, n_cus),    # static only
         (plain, 2 * n_cus + 5, (0, 2, 1), True, False, n_cus),     # dynamic only
         (viewdir, 2 * n_cus + 1, (2, 2, 2), True, False, n_cus),   # static trunk on the eight-wave kernel, dynamic one persistent
-        (viewdir, 2 * n_cus + 7, (2, 2, 2), True, True, n_cus),    # view-direction static trunk (23 % longer) beside the dynamic one
+        (viewdir, 2 * n_cus + 7, (2, 2, 2), True, True, 2 * n_cus),  # view-direction static trunk (23 % longer) beside the dynamic one:
+                                                                     # its tail tiles are run by the dynamic trunk's XCDs (second round)
+        (viewdir, 9 * n_cus + 5, (2, 2, 2), True, True, 2 * n_cus),  # ... several tiles per second-round workgroup, ragged
         (viewdir, 2 * n_cus + 7, (2, 0, 0), False, True, n_cus),   # ... alone
         (plain, n_cus // 8, (2, 2, 2), True, False, None),         # fewer tiles than workgroups
     ]
@@ -329,17 +333,17 @@ def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, m
         finally:
             config.set_tile_points(0)
             monkeypatch.delenv("NSFF_NO_PERSIST", raising=False)
-        # the per-call switch (NsffFieldArgs::launch_form through config.set_persistent: what a multi-GPU run selects)
+        # the per-call switch (NsffFieldArgs::launch_form through the scoped config.launch_form: what a sharded frame loop selects)
         config.set_tile_points(130)
-        config.set_persistent(False)
         try:
-            raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
-            _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs, t_bias=tb,
-                             s_bias=sb)
-            torch.cuda.synchronize()
-            assert _lib.last_field_grid() == got["tile"][1] and np.array_equal(raw.cpu().numpy().view(np.uint32), got["tile"][0].view(np.uint32))
+            with config.launch_form(persistent=False):
+                raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
+                _lib.field_query(m, raw, P, S, sm, tm, fh, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs, t_bias=tb,
+                                 s_bias=sb)
+                torch.cuda.synchronize()
+                assert _lib.last_field_grid() == got["tile"][1] and np.array_equal(raw.cpu().numpy().view(np.uint32), got["tile"][0].view(np.uint32))
+            assert config.get_persistent() is True
         finally:
-            config.set_persistent(True)
             config.set_tile_points(0)
         (a, ga, ka), (b, gb, kb) = got["persistent"], got["tile"]
         both = sm and tm and (m is not viewdir or side)
@@ -395,5 +399,6 @@ def test_persistent_launch_on_random_architectures(arch, hip_lib, monkeypatch):
         (a, ga, ka), (b, gb, kb) = got["persistent"], got["tile"]
         assert ka == kb and ka.startswith("h3a"), (ka, kb)
         assert gb == (2 * tiles if sm else tiles)
-        assert ga == (n_cus if can else gb), (ARCHS[arch], (sm, tm, fh), rows, ga, gb)
+        # (both trunks of unequal cost -- the time code through the matrix pipe -- run a second round of workgroups: 2 x compute units)
+        assert (ga in ((n_cus, 2 * n_cus) if sm else (n_cus,))) if can else ga == gb, (ARCHS[arch], (sm, tm, fh), rows, ga, gb)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (ARCHS[arch], (sm, tm, fh), rows)

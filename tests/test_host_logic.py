@@ -259,7 +259,10 @@ def test_gradient_map_names_the_same_elements_as_the_tensor_assembly(kw, static,
         got = fetch(ix.ja, ix.ea) + fetch(ix.jb, ix.eb)
         np.testing.assert_array_equal(got, g.numpy())
     # every parameter of the evaluated trunks has exactly one source: a slice of the jobs (above) or the fold's products
-    folded = fg._folded_grads(model, static, transient, meta, plist, lambda i: torch.from_numpy(mats[i]), lambda i: torch.from_numpy(rows[i]))
+    # (which parameters those are: the torch restatement of the fold; the GPU suite holds the product's kernels to the same key set)
+    import torch_path
+    folded = torch_path.folded_grads_reference(model, static, transient, meta, plist, lambda i: torch.from_numpy(mats[i]),
+                                               lambda i: torch.from_numpy(rows[i]))
     direct = {i for i, g in enumerate(tens) if g is not None}
     assert not (direct & set(folded)) and all(tuple(g.shape) == tuple(plist[i].shape) for i, g in folded.items())
     expect = sum(1 for n, _ in model.named_parameters()
@@ -271,9 +274,10 @@ def test_gradient_map_names_the_same_elements_as_the_tensor_assembly(kw, static,
 
 @pytest.mark.parametrize("viewdir", [False, True])
 def test_folded_gradients_are_autograds(viewdir):
-    """*_xyz_encoding_final is never executed as a layer: field_grad._folded_grads turns the folded heads' weight gradient
-    G = sum_p dpre_p (x) h_p into the gradients of *_final and of the heads (of static_dir_encoding with view directions) --
-    against float64 autograd of the unfolded layers on random activations and cotangents."""
+    """*_xyz_encoding_final is never executed as a layer: the folded heads' weight gradient G = sum_p dpre_p (x) h_p becomes the
+    gradients of *_final and of the heads (of static_dir_encoding with view directions) by four small products -- the algebra
+    (tests/torch_path.py::folded_grads_reference) against float64 autograd of the unfolded layers on random activations and
+    cotangents; the product's HIP kernels are held to the same algebra by tests/test_field_grad.py (GPU)."""
     from nsff_pl_amd import field_grad as fg
     torch.manual_seed(3)
     model = A.NeRF('fine', use_viewdir=viewdir, encode_appearance=viewdir, in_channels_a=48 if viewdir else 0, encode_transient=True,
@@ -307,7 +311,8 @@ def test_folded_gradients_are_autograds(viewdir):
         mats[i][:pre.shape[1]] = cot.t() @ h                      # rows 0..R-1 (the remainder rows 16.. stay zero)
         rows[i][:pre.shape[1]] = cot.sum(0)
     loss.backward()
-    got = fg._folded_grads(model, True, True, meta, plist, lambda i: mats[i], lambda i: rows[i])
+    import torch_path
+    got = torch_path.folded_grads_reference(model, True, True, meta, plist, lambda i: mats[i], lambda i: rows[i])
     names = {id(p): n for n, p in model.named_parameters()}
     assert len(got) == (4 + 8 + 2 if not viewdir else 4 + 8 + 2)          # static: final + (rgb | dir layer); dynamic: final + four heads
     for i, g in got.items():

@@ -236,3 +236,48 @@ def recompute(models, embeddings, rays, ts, max_t, rec, field_fn=None):
                 dict(static=rec.get("fine_static"), transient=rec.get("fine_transient"),
                      warp_fw=rec.get("fine_warp_fw"), warp_bw=rec.get("fine_warp_bw")), False, field_fn)
     return results
+
+
+def folded_grads_reference(model, static, transient, meta, plist, result, bias_of):
+    """The algebra of nsff_pl_amd.field_grad._folded_grads in torch (any device / dtype): *_xyz_encoding_final is a Linear without
+    activation (reference nerf.py:170,195), so with G = sum_p dpre_p (x) h_p and gb = sum_p dpre_p of the FOLDED heads
+        dW_head = G W_final^T + gb (x) b_final,  db_head = gb,  dW_final = W_head^T G,  db_final = W_head^T gb.
+    Test infrastructure: the CPU suite holds it to float64 autograd of the two layers, the GPU suite holds the product's HIP
+    kernels (nsff_fold_grads, nsff_fold_grads_dense) to it."""
+    from nsff_pl_amd import field_grad as fg
+    viewdir = bool(model.use_viewdir and static)
+    index = {id(q): i for i, q in enumerate(plist)}
+    res = {tag: i for i, tag in enumerate(meta)}
+    out = {}
+    for t in ([0] if static else []) + ([1] if transient else []):
+        prefix = "static" if t == 0 else "transient"
+        fin = fg._lin(getattr(model, f"{prefix}_xyz_encoding_final"))
+        w_f, b_f = fin.weight.detach(), fin.bias.detach()
+        if t == 0 and viewdir:
+            ih, ix = res[("dir_h", 0, 0)], res[("dir_x", 0, 0)]
+            g, gb = result(ih), bias_of(ih)
+            layer = fg._lin(model.static_dir_encoding)
+            w_dh = layer.weight.detach()[:, :256]
+            n_side = model.in_channels_dir + model.in_channels_a
+            out[index[id(layer.weight)]] = torch.cat([torch.addmm(torch.outer(gb, b_f), g, w_f.t()), result(ix)[:, :n_side]], 1)
+            out[index[id(layer.bias)]] = gb.clone()
+            out[index[id(fin.weight)]] = w_dh.t() @ g
+            out[index[id(fin.bias)]] = w_dh.t() @ gb
+            continue
+        i = res[("head", t, 0)]
+        hw, hb = result(i), bias_of(i)
+        g, gb = hw[0:16] + hw[16:32], hb[0:16] + hb[16:32]           # fp16 value + rounding remainder rows
+        heads = fg._fold_heads(model, t)
+        n_rows = heads[-1][2]
+        w_h = torch.cat([fg._lin(m).weight.detach() for m, _, _ in heads], 0)
+        g_r, gb_r = g[:n_rows], gb[:n_rows]
+        d_heads = torch.addmm(torch.outer(gb_r, b_f), g_r, w_f.t())
+        k = 0
+        for m, a, b in heads:
+            lin = fg._lin(m)
+            out[index[id(lin.weight)]] = d_heads[k:k + (b - a)]
+            out[index[id(lin.bias)]] = gb[a:b].clone()
+            k += b - a
+        out[index[id(fin.weight)]] = w_h.t() @ g_r
+        out[index[id(fin.bias)]] = w_h.t() @ gb_r
+    return out
