@@ -116,6 +116,24 @@ def I_ds_read_tr(d, addr, off=0):
     return Inst("ds_read_b64_tr_b16", f"ds_read_b64_tr_b16 {d}, {addr} offset:{off}", [addr], [d], "lds_r", dict(d=d, addr=addr, off=off))
 
 
+def I_ds_read_b64(d, addr, off=0):
+    assert 0 <= off < 65536 and d.n == 2
+    return Inst("ds_read_b64", f"ds_read_b64 {d}, {addr} offset:{off}", [addr], [d], "lds_r", dict(d=d, addr=addr, off=off))
+
+
+def I_ds_read_b32(d, addr, off=0):
+    assert 0 <= off < 65536 and d.n == 1
+    return Inst("ds_read_b32", f"ds_read_b32 {d}, {addr} offset:{off}", [addr], [d], "lds_r", dict(d=d, addr=addr, off=off))
+
+
+def I_gload_s(d, voff, sbase, off=0):
+    """global_load_dword[x2|x4] d, voff, s[base:base+1] offset  (address = sbase + zext(voff) + off)"""
+    assert -4096 <= off <= 4095 and d.n in (1, 2, 4) and sbase.n == 2
+    suffix = {1: "dword", 2: "dwordx2", 4: "dwordx4"}[d.n]
+    return Inst("gload_s", f"global_load_{suffix} {d}, {voff}, {sbase} offset:{off}", [voff, sbase], [d], "vmem",
+                dict(d=d, voff=voff, sbase=sbase, off=off))
+
+
 def I_gstore_s(voff, data, sbase, off=0):
     """global_store_dword[x2|x4] voff, data, s[base:base+1] offset  (address = sbase + zext(voff) + off)"""
     assert 0 <= off <= 4095 and data.n in (1, 2, 4) and sbase.n == 2
@@ -357,20 +375,21 @@ class Sim:
     def add_buffer(self, base, arr_u32):
         self.mem[base] = np.ascontiguousarray(arr_u32).view(np.uint32).reshape(-1)
 
-    def _gread(self, addr):
-        """addr: (NL,) uint64 byte addresses, 16-byte loads -> (4, NL) u32"""
-        out = np.zeros((4, NL), np.uint32)
+    def _gread(self, addr, n_dw=4):
+        """addr: (NL,) uint64 byte addresses, 4 n_dw-byte loads -> (n_dw, NL) u32"""
+        out = np.zeros((n_dw, NL), np.uint32)
+        nb = np.uint64(4 * n_dw)
         for base, arr in self.mem.items():
-            m = (addr >= base) & (addr + 16 <= base + arr.size * 4)
+            m = (addr >= base) & (addr + nb <= base + arr.size * 4)
             if m.any():
                 idx = ((addr[m] - base) // 4).astype(np.int64)
                 if ((addr[m] - base) % 4).any():
                     raise SimError("unaligned global load")
-                for k in range(4):
+                for k in range(n_dw):
                     out[k, m] = arr[idx + k]
         ok = np.zeros(NL, bool)
         for base, arr in self.mem.items():
-            ok |= (addr >= base) & (addr + 16 <= base + arr.size * 4)
+            ok |= (addr >= base) & (addr + nb <= base + arr.size * 4)
         return out, ok
 
     # ---- register access with pending checks ----
@@ -523,8 +542,9 @@ class Sim:
             return None
         if k == "lds_r":
             addr = self._rv(w, a["addr"]).astype(np.int64) + a["off"]
-            out = self._lds_access(w, addr, 4, False)
-            for r4 in range(4):
+            n_dw = a["d"].n
+            out = self._lds_access(w, addr, n_dw, False)
+            for r4 in range(n_dw):
                 self._wv(w, a["d"], out[r4], r4)
             regs = set(a["d"].regs())
             w.lds_q.append(regs)
@@ -572,11 +592,11 @@ class Sim:
                 lo = self._rv(w, a["vaddr"], 0).astype(np.uint64)
                 hi = self._rv(w, a["vaddr"], 1).astype(np.uint64)
                 addr = (lo | (hi << np.uint64(32))) + np.uint64(a["off"])
-            out, ok = self._gread(addr)
+            out, ok = self._gread(addr, a["d"].n)
             if not ok[w.exec].all():
                 raise SimError(f"wave {w.id} pc {w.pc}: `{ins.text}` reads unmapped global memory (lane {int(np.argmin(ok | ~w.exec))}, "
                                f"address {int(addr[np.argmin(ok | ~w.exec)]):#x})")
-            for r4 in range(4):
+            for r4 in range(a["d"].n):
                 self._wv(w, a["d"], out[r4], r4)
             regs = set(a["d"].regs())
             w.vm_q.append(regs)
@@ -669,6 +689,24 @@ class Sim:
             out = (((s[0] & 0xFFFFFF).astype(np.uint64) * (s[1] & 0xFFFFFF).astype(np.uint64)) + s[2]).astype(np.uint32)
         elif op == "v_min_u32":
             out = np.minimum(s[0], s[1])
+        elif op == "v_bfe_i32":              # sign-extended bit field: src, offset, width
+            off_, wid = int(s[1][0]) & 31, int(s[2][0]) & 31
+            fld = (s[0] >> np.uint32(off_)) & np.uint32((1 << wid) - 1)
+            out = np.where((fld >> np.uint32(wid - 1)) & 1, fld | np.uint32((0xFFFFFFFF << wid) & 0xFFFFFFFF), fld).astype(np.uint32)
+        elif op == "v_med3_f32":
+            out = np.median(np.stack([f32(s[0]), f32(s[1]), f32(s[2])]), axis=0).astype(np.float32).view(np.uint32)
+        elif op == "v_mul_f32":
+            out = (f32(s[0]) * f32(s[1])).astype(np.float32).view(np.uint32)
+        elif op == "v_cvt_pk_f16_f32":       # round to nearest even (the mode register's default), overflow -> inf
+            with np.errstate(over="ignore"):
+                lo = f32(s[0]).astype(np.float16)
+                hi = f32(s[1]).astype(np.float16)
+            out = lo.view(np.uint16).astype(np.uint32) | (hi.view(np.uint16).astype(np.uint32) << 16)
+        elif op == "v_pk_mul_f16":
+            with np.errstate(over="ignore", under="ignore"):
+                lo = (halfs_of(s[0])[0] * halfs_of(s[1])[0]).astype(np.float16)       # (the exact fp32 product of two halfs, rounded once)
+                hi = (halfs_of(s[0])[1] * halfs_of(s[1])[1]).astype(np.float16)
+            out = lo.view(np.uint16).astype(np.uint32) | (hi.view(np.uint16).astype(np.uint32) << 16)
         elif op == "v_mbcnt_lo_u32_b32":
             mask = int(s[0][0])
             out = np.array([bin(mask & ((1 << min(l, 32)) - 1)).count("1") for l in range(NL)], np.uint32) + s[1]
@@ -729,6 +767,12 @@ class Sim:
             w.scc = int(s[1] > s[0])
         elif op == "s_mul_i32":
             r = (s[0] * s[1]) & 0xFFFFFFFF
+        elif op == "s_mul_hi_u32":
+            r = ((s[0] * s[1]) >> 32) & 0xFFFFFFFF
+        elif op == "s_subb_u32":
+            t = s[0] - s[1] - w.scc
+            w.scc = int(t < 0)
+            r = t & 0xFFFFFFFF
         elif op == "s_lshl_b32":
             r = (s[0] << (s[1] & 31)) & 0xFFFFFFFF
             w.scc = int(r != 0)
