@@ -685,6 +685,8 @@ class Sim:
             out = s[1] << (s[0] & 31)
         elif op == "v_mul_u32_u24":
             out = ((s[0] & 0xFFFFFF).astype(np.uint64) * (s[1] & 0xFFFFFF).astype(np.uint64)).astype(np.uint32)
+        elif op == "v_mul_lo_u32":
+            out = (s[0].astype(np.uint64) * s[1].astype(np.uint64)).astype(np.uint32)
         elif op == "v_mad_u32_u24":
             out = (((s[0] & 0xFFFFFF).astype(np.uint64) * (s[1] & 0xFFFFFF).astype(np.uint64)) + s[2]).astype(np.uint32)
         elif op == "v_min_u32":
