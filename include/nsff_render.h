@@ -293,6 +293,17 @@ typedef struct NsffFieldBwdArgs {
     float* d_side;              /* OUT or NULL (use_viewdir models, static_mode 2)           */
 } NsffFieldBwdArgs;
 int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
+/* Which kernel the last nsff_field_backward launch took: 1 = nsff_field_bwd_kernel_h3b, the hand-scheduled body (128-point
+ * workgroups, one wave per SIMD, resident transposed weights, epilogues / fragment copies / refills riding in the other half's MFMA
+ * gaps: tools/h3asm/gen_bwd.py) -- launches with an even number of 64-point tiles whose trunks it executes (no view-direction static
+ * trunk, at most one skip layer with a trunk-input gradient, none at the last layer); 0 = nsff_field_bwd_kernel (compiler-scheduled,
+ * 64-point workgroups; NSFF_BWD_KERNEL=c forces it).  Both leave bit-identical dpre / dhead / d_xin. */
+int nsff_last_bwd_kernel(void);
+/* Host-only (no GPU): the hand-scheduled body's phase program for one trunk of `desc` (dynamic: the transient trunk, with or without
+ * the trunk-input gradient) at n_tiles 64-point tiles -> out[max_phases][8] uint32 descriptors; seg_offsets (or NULL): byte offsets of
+ * the trunk's step segments in the transposed pack.  Returns the number of descriptors, 0 when the body does not cover the trunk. */
+int nsff_field_bwd_phase_program(const NsffModelDesc* desc, int32_t dynamic, int32_t want_xin, int64_t n_tiles, uint32_t* out,
+                                 int32_t max_phases, uint32_t* seg_offsets, int32_t max_segs);
 
 /* d_xin (P, xin_rows) of nsff_field_backward -> gradient w.r.t. the points (derivative of PosEmbedding, reference
  * nerf.py:17-30) and w.r.t. the per-ray time codes (sum over the ray's pts_per_ray consecutive points, the repeat of

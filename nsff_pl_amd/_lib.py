@@ -205,6 +205,9 @@ _SIGNATURES = {
                                               _fp, _fp, _fp]),
     "nsff_weight_grad_accumulate_aux": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, C.c_int64,
                                                   _fp, _fp, _fp, _fp]),
+    "nsff_last_bwd_kernel": (C.c_int, []),
+    "nsff_field_bwd_phase_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_uint32), C.c_int32,
+                                                C.POINTER(C.c_uint32), C.c_int32]),
     "nsff_fold_grads": (C.c_int, [C.POINTER(FoldGradArgs), _fp]),
     "nsff_fold_grads_dense": (C.c_int, [C.POINTER(FoldDenseArgs), _fp]),
     "nsff_pack_weights_bwd_ex": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_fp), _fp, _fp, _fp]),
@@ -681,6 +684,25 @@ def pack_weights_bwd(desc, params, packed, fwd_packed=None):
     """fwd_packed: the f16x3 forward pack of the same weights (folded heads): its fp32 scratch supplies the folded products."""
     arr = (_fp * len(params))(*[p.data_ptr() for p in params])
     _check(load().nsff_pack_weights_bwd_ex(C.byref(desc), arr, _ptr(packed), _ptr(fwd_packed), _stream()), "nsff_pack_weights_bwd_ex")
+
+
+def last_bwd_kernel():
+    """'h3b' (the hand-scheduled body) or 'c' (compiler-scheduled): which kernel the last field_backward launch took"""
+    return "h3b" if load().nsff_last_bwd_kernel() == 1 else "c"
+
+
+def field_bwd_phase_program(model, dynamic, want_xin, n_tiles, max_phases=32):
+    """(descriptors (n, 8) uint32 numpy, segment byte offsets) of the hand-scheduled backward body for one trunk, or (None, offsets)
+    when it does not cover the trunk (host-only: no GPU needed)."""
+    import numpy as np
+    desc = model_desc(model)
+    out = (C.c_uint32 * (8 * max_phases))()
+    segs = (C.c_uint32 * 48)()
+    n = load().nsff_field_bwd_phase_program(C.byref(desc), 1 if dynamic else 0, 1 if want_xin else 0, int(n_tiles), out, max_phases, segs, 48)
+    if n < 0:
+        raise RuntimeError(f"nsff_field_bwd_phase_program failed ({n})")
+    offs = np.array(list(segs), np.uint32)
+    return (np.array(list(out), np.uint32).reshape(max_phases, 8)[:n] if n > 0 else None), offs
 
 
 def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side=None):

@@ -188,3 +188,95 @@ def test_compiled_kernel_audit():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "h3asm", "audit.py"), os.path.join(ROOT, "nsff_pl_amd", "csrc", "field_h3.hip")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+# ---- the backward body (round 6): tools/h3asm/gen_bwd.py -> csrc/field_bwd_h3b_body.inc, nsff_field_bwd_kernel_h3b
+import gen_bwd      # noqa: E402
+import check_bwd    # noqa: E402
+
+
+def test_committed_backward_body_is_the_generators_output(monkeypatch):
+    committed = open(os.path.join(ROOT, "nsff_pl_amd", "csrc", "field_bwd_h3b_body.inc")).read()
+    monkeypatch.setattr(sys, "argv", ["gen_bwd.py"])
+    real_open = open
+    captured = {}
+
+    class Sink(io.StringIO):
+        def close(self):
+            captured["text"] = self.getvalue()
+            super().close()
+
+    def fake_open(path, mode="r", *a, **k):
+        if "w" in mode and str(path).endswith(".inc"):
+            return Sink()
+        return real_open(path, mode, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gen_bwd.main()
+    assert captured["text"] == committed, "run `python tools/h3asm/gen_bwd.py` and commit nsff_pl_amd/csrc/field_bwd_h3b_body.inc"
+
+
+def test_backward_stream_passes_the_hazard_lint():
+    prog, bodies = gen_bwd.build()
+    assert gen_bwd.lint(bodies) == []
+    for name in ("A16", "B16", "A16S", "B16S", "A16F", "B16L", "AX", "BX", "AXS", "BXS", "BXD"):
+        assert sum(i.kind == "mfma" for i in bodies[name]) == 64, name
+    assert sum(i.kind == "mfma" for i in bodies["AH"]) == 16 and sum(i.kind == "mfma" for i in bodies["BH"]) == 16
+
+
+@pytest.mark.parametrize("kind", ["static", "dynamic", "noskip", "short", "ragged"])
+def test_simulated_backward_chain_is_bit_identical_to_numpy(kind):
+    """every fragment slot of the chain, d(trunk input) under its exec masks and the last tile in LDS, bit for bit; nothing else
+    written (the simulator refuses a global dword stored twice or outside the mapped buffers)"""
+    assert check_bwd.run_case(kind, verbose=False)
+
+
+def test_backward_simulator_notices_a_missing_wait(monkeypatch):
+    """the test of the test: drop the waits for the sign words -> the epilogue reads a register with a load still in flight"""
+    orig = gen_bwd.LogStream.need_vm
+    monkeypatch.setattr(gen_bwd.LogStream, "need_vm", lambda self, tag: None if isinstance(tag, str) and tag.startswith("msk") else orig(self, tag))
+    with pytest.raises(isa.SimError, match="outstanding"):
+        check_bwd.run_case("static", verbose=False)
+
+
+@pytest.mark.parametrize("arch", range(len(ARCHS)))
+def test_cxx_backward_phase_program_equals_the_simulated_builder(arch):
+    """csrc/field_bwd.hip::h3b_build_program (through the host-only C-ABI nsff_field_bwd_phase_program) against
+    check_bwd.build_program, the builder the simulator runs; trunks the body does not cover are refused by both"""
+    import torch
+    import nsff_pl_amd as A
+    from nsff_pl_amd import _lib
+    D, skips, n_freqs, n_tau = ARCHS[arch]
+    torch.manual_seed(0)
+    m = A.NeRF("fine", D=D, skips=skips, in_channels_xyz=3 + 6 * n_freqs, use_viewdir=False, encode_transient=True,
+               in_channels_t=n_tau, output_flow=True)
+    n_tiles = 48
+    sk = sorted(set(skips))
+    for dynamic, want_xin in ((False, False), (True, True), (True, False)):
+        got, offs = _lib.field_bwd_phase_program(m, dynamic, want_xin, n_tiles)
+        tail = dynamic and want_xin
+        stash_l = sk[0] if (tail and sk) else None
+        # the step list as csrc/field_bwd.hip::bwd_step_program builds it: head, layers D-1 .. 1, (x0, xskip)
+        steps = [dict(off=int(offs[0]), nks=4, stash=(stash_l == D - 1))]
+        covered = True
+        j = 1
+        for l in range(D - 1, 0, -1):
+            if tail and l in sk and l != stash_l:
+                covered = False             # (a further skip layer: its trunk-input step sits inside the chain)
+                j += 1
+            steps.append(dict(off=int(offs[j]), nks=16, stash=(stash_l == l - 1)))
+            j += 1
+        if tail and (D - 1) in sk and (D - 1) != stash_l:
+            covered = False
+        if tail:
+            steps.append(dict(off=int(offs[j]), nks=16, stash=False)); j += 1
+            if stash_l is not None:
+                steps.append(dict(off=int(offs[j]), nks=16, stash=False)); j += 1
+        want = check_bwd.build_program(steps, tail, stash_l is not None, slot_bytes=(n_tiles * 64 * 256 * 2, n_tiles * 256 * 8)) if covered else None
+        if D < 3 and want is not None and len(steps) - (2 if stash_l is not None else (1 if tail else 0)) < 2:
+            want = None
+        if want is None:
+            assert got is None, (ARCHS[arch], dynamic, want_xin)
+        else:
+            assert got is not None, (ARCHS[arch], dynamic, want_xin)
+            assert np.array_equal(got, want[:len(got)]) and len(got) == len(want), (ARCHS[arch], dynamic, want_xin, got, want)
