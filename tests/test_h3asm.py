@@ -217,14 +217,14 @@ def test_committed_backward_body_is_the_generators_output(monkeypatch):
 
 
 def test_backward_stream_passes_the_hazard_lint():
-    prog, bodies = gen_bwd.build()
-    assert gen_bwd.lint(bodies) == []
+    pre, prog, bodies = gen_bwd.build()
+    assert gen_bwd.lint(bodies) == [] and all(i.kind != "mfma" for i in pre)
     for name in ("A16", "B16", "A16S", "B16S", "A16F", "B16L", "AX", "BX", "AXS", "BXS", "BXD"):
         assert sum(i.kind == "mfma" for i in bodies[name]) == 64, name
     assert sum(i.kind == "mfma" for i in bodies["AH"]) == 16 and sum(i.kind == "mfma" for i in bodies["BH"]) == 16
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic", "noskip", "short", "ragged"])
+@pytest.mark.parametrize("kind", ["static", "dynamic", "noskip", "short", "ragged", "overflow"])
 def test_simulated_backward_chain_is_bit_identical_to_numpy(kind):
     """every fragment slot of the chain, d(trunk input) under its exec masks and the last tile in LDS, bit for bit; nothing else
     written (the simulator refuses a global dword stored twice or outside the mapped buffers)"""

@@ -88,3 +88,34 @@ def test_c2_sized_backward_launches_take_the_hand_scheduled_kernel(hip_lib, monk
         out = _run(m, P, static, True, True, d_raw, raw, masks, False, monkeypatch)
         assert out[3] == "h3b"
         assert np.isfinite(out[2].view(np.float32)).all()
+
+
+def test_overflowing_gradients_clamp_like_the_compiler_scheduled_kernel(hip_lib, monkeypatch):
+    """Pre-activation gradients that leave the fp16 range: nsff_field_bwd_kernel clamps with v_med3_f32 in front of the conversion, the
+    hand-scheduled body runs with MODE.FP16_OVFL set (the conversion itself saturates at +-65504, no instruction).  Weights x 40 drive
+    thousands of values per tile out of range; both kernels must leave the same bits -- no infinity, no NaN."""
+    torch.manual_seed(9)
+    m = A.NeRF("fine", D=4, skips=[2], use_viewdir=False, encode_transient=True, in_channels_t=48, output_flow=True)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(".weight") and "encoding" in name:
+                p.mul_(40.0)
+    m.to(DEV)
+    g = torch.Generator().manual_seed(10)
+    P = 128 * 11
+    tiles = P // 64
+    d_raw = torch.randn(P, _lib.RAW_STRIDE, generator=g).to(DEV)
+    raw = (torch.rand(P, _lib.RAW_STRIDE, generator=g) * 0.2).to(DEV)
+    masks = torch.full((field_grad.n_slots(m), tiles, 256), -1, dtype=torch.int64).to(DEV)       # (every ReLU open: nothing masks the growth)
+    a = _run(m, P, True, True, True, d_raw, raw, masks, False, monkeypatch)
+    b = _run(m, P, True, True, True, d_raw, raw, masks, True, monkeypatch)
+    assert a[3] == "h3b" and b[3] == "c"
+    written = [s_ for s_ in range(field_grad.n_slots(m)) if not (b[0][s_] == np.float16(7.0).view(np.uint16)).all()]
+    bits = b[0][written]
+    vals = bits.view(np.float16).astype(np.float32)
+    # (what reaches HBM is the tile times the point's factor G / s_p = 2^-k: a saturated value shows as 65504 * 2^-k -- an fp16 whose
+    #  ten mantissa bits are all ones; among random values one in 1024 looks like that)
+    assert np.isfinite(vals).all() and np.isfinite(b[2].view(np.float32)).all()
+    big = np.abs(vals) >= 1024
+    assert ((bits[big] & 0x3FF) == 0x3FF).mean() > 0.02, ((bits[big] & 0x3FF) == 0x3FF).mean()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

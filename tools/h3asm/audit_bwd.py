@@ -19,21 +19,27 @@ name = m.group(1)
 body = txt[m.end():]
 body = body[:body.index(".Lfunc_end")]
 n_asm, inasm, cur, before, after, seen, n_mfma, first_after = 0, False, 0, 0, 0, False, 0, ""
+n_pre, pre_loads, between, agpr_between, curl = 0, 0, False, [], 0
 for ln in body.split("\n"):
     if "#ASMSTART" in ln:
-        inasm, cur = True, 0
+        inasm, cur, curl = True, 0, 0
         continue
     if "#ASMEND" in ln:
         inasm = False
         if cur > 100:
             n_asm, seen, n_mfma = n_asm + 1, True, cur
+        elif curl >= 8:
+            n_pre, pre_loads, between = n_pre + 1, pre_loads + curl, True
         continue
     t = ln.strip()
     if inasm:
         cur += "v_mfma" in t
+        curl += t.startswith("global_load_dwordx4 a[")
         continue
     if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
         continue
+    if between and not seen and (re.search(r"\ba\[?\d", t.split(";")[0]) or "accvgpr" in t):
+        agpr_between.append(t)
     if seen:
         after += 1
         if after == 1:
@@ -50,6 +56,8 @@ spill_s = int(re.search(r"\.sgpr_spill_count:\s*(\d+)", md).group(1))
 print(f"{name}: asm statements {n_asm} ({n_mfma} MFMAs in the body), compiler instructions in front of the body {before}, first instruction behind it: {first_after}")
 print(f"  next_free_vgpr {get('next_free_vgpr')}  accum_offset {get('accum_offset')}  next_free_sgpr {get('next_free_sgpr')}  "
       f"scratch {get('private_segment_fixed_size')} B  LDS {get('group_segment_fixed_size')} B  spills: {spill_v} VGPR, {spill_s} SGPR")
-ok = (n_asm == 1 and spill_v == 0 and spill_s == 0 and int(get("private_segment_fixed_size")) == 0 and int(get("next_free_vgpr")) >= 384
+print(f"  pre-issue statements {n_pre} ({pre_loads} weight-slot loads in flight across the head stage); compiler instructions touching "
+      f"accumulation registers between it and the body: {len(agpr_between)}")
+ok = (n_asm == 1 and n_pre == 1 and pre_loads == 32 and not agpr_between and spill_v == 0 and spill_s == 0 and int(get("private_segment_fixed_size")) == 0 and int(get("next_free_vgpr")) >= 384
       and first_after == "s_endpgm" and int(get("group_segment_fixed_size")) <= 160 * 1024)
 sys.exit(0 if ok else "AUDIT FAILED: " + kernel)

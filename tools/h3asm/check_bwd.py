@@ -5,7 +5,7 @@ in LDS -- with a numpy evaluation of the same chain in the same arithmetic (csrc
 one f16 product per MAC accumulated in fp32 k-step by k-step, ReLU mask from sign words, clamp, fp16 to nearest, the two per-point
 power-of-two factors of the fragment copy): BIT FOR BIT.
 
-    python tools/h3asm/check_bwd.py [static|dynamic|noskip|short|ragged] ...
+    python tools/h3asm/check_bwd.py [static|dynamic|noskip|short|ragged|overflow] ...
 
 What this proves before any GPU time is spent: register allocation, every s_waitcnt count, barrier placement (cross-wave LDS race
 detector), the weight-slot refill order, the running slot pointers, the exec-masked d_xin stores, the phase program
@@ -83,7 +83,7 @@ def build_program(steps, dynamic, skip, slot_bytes=(N_TILES64 * 64 * 256 * 2, N_
                 return None               # (its half B epilogue would ride in AX)
             desc(B["B16S"] if st.get("stash") else B["B16"], steps[i + 1])
     if not dynamic:
-        desc(B["EPI_B"]); desc(B["COPY_LAST"])
+        desc(B["EPI_B"])
     else:
         desc(B["AX"])
         if skip:
@@ -97,9 +97,9 @@ def build_program(steps, dynamic, skip, slot_bytes=(N_TILES64 * 64 * 256 * 2, N_
 
 def make_case(kind, seed=0):
     rng = np.random.RandomState(seed)
-    dynamic = kind in ("dynamic", "noskip", "ragged", "short")
-    D = {"static": 8, "dynamic": 8, "noskip": 5, "short": 2, "ragged": 4}[kind]
-    skip_l = {"static": None, "dynamic": 4, "noskip": None, "short": None, "ragged": 1}[kind]       # the skip LAYER whose tile is stashed
+    dynamic = kind in ("dynamic", "noskip", "ragged", "short", "overflow")
+    D = {"static": 8, "dynamic": 8, "noskip": 5, "short": 2, "ragged": 4, "overflow": 4}[kind]
+    skip_l = {"static": None, "dynamic": 4, "noskip": None, "short": None, "ragged": 1, "overflow": 2}[kind]     # the skip LAYER whose tile is stashed
     if not dynamic:
         skip_l = None
     xin_rows = 128
@@ -119,7 +119,8 @@ def make_case(kind, seed=0):
     Wh[:, :16] = (rng.randn(256, 16) * 0.3).astype(np.float16)
     add(Wh, stash=(skip_l == D - 1), out_slot=D - 1)
     for l in range(D - 1, 0, -1):           # layer l: tile of slot l -> slot l - 1
-        add((rng.randn(256, 256) * (1.6 / 16)).astype(np.float16), stash=(skip_l == l - 1), out_slot=l - 1)
+        # ("overflow": weights large enough that pre-activation gradients leave the fp16 range: the conversion must clamp to +-65504)
+        add((rng.randn(256, 256) * ((40.0 if kind == "overflow" else 1.6) / 16)).astype(np.float16), stash=(skip_l == l - 1), out_slot=l - 1)
     if dynamic:
         Wx = np.zeros((256, 256), np.float16)
         Wx[:xin_rows] = (rng.randn(xin_rows, 256) * 0.1).astype(np.float16)
@@ -202,6 +203,7 @@ def reference(case):
             a = gemm(st["Wt"], T[:, :st["Wt"].shape[1]])
             a = np.where(mask_of(case, st["out_slot"]), a, np.float32(0))
             with np.errstate(over="ignore"):
+                case["n_clamped"] = case.get("n_clamped", 0) + int((np.abs(a) > 65504.0).sum())
                 T = np.clip(a, -65504.0, 65504.0).astype(np.float16)
             tiles[st["out_slot"]] = T
             if st["stash"]:
@@ -218,8 +220,8 @@ def reference(case):
 
 def run_case(kind, seed=0, verbose=True):
     case = make_case(kind, seed)
-    prog, _ = gb.build()
-    sim = Sim(prog)
+    pre, prog, _ = gb.build()
+    sim = Sim(pre + prog)                      # the two asm statements back to back (the head stage between them is C++)
     sim.add_buffer(PK_BASE, case["pk"])
     phases = build_program(case["steps"], case["dynamic"], case["skip"])
     assert phases is not None
@@ -255,6 +257,10 @@ def run_case(kind, seed=0, verbose=True):
                           ("ld4", case["ld"] * 4), ("nvalid", case["n_valid"] if rows_here else 0)):
             w.s[I_S[name].i] = int(val)
         w.v[I_V["tid"].i] = tid
+        # the pre-issue statement's operands
+        w.s[gb.PRE_S["off0"].i] = case["steps"][0]["off"] + w.id * 4 * 2048
+        w.s[gb.PRE_S["off1"].i] = case["steps"][1]["off"] + w.id * 16 * 2048 + 4 * 2048
+        w.v[gb.PRE_V["lane16"].i] = (tid & 63) << 4
     t0 = time.time()
     sim.run()
     dt = time.time() - t0
@@ -290,11 +296,12 @@ def run_case(kind, seed=0, verbose=True):
         print(f"{kind:9s} phases {len(phases) - 3:2d}  MFMAs/wave {n_mf} (expected {want_mf})  instructions/wave {sim.waves[0].n_inst}  "
               f"slots {sorted(tiles)}  d_xin {'yes' if dxin is not None else 'no'}  bit-identical  ({dt:.1f} s)")
     assert n_mf == want_mf
+    assert kind != "overflow" or case["n_clamped"] > 1000, case.get("n_clamped")
     return True
 
 
 if __name__ == "__main__":
-    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "short", "ragged"]
+    kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "short", "ragged", "overflow"]
     for k in kinds:
         try:
             run_case(k)

@@ -25,7 +25,7 @@ How it is scheduled (the mirror image of the forward body, tools/h3asm/gen.py):
 
 Register map (asm-owned; the compiler keeps v0..v23, s0..s39 and VCC):
     v24..v35 addresses / scratch   v36..v39 sign words (A: mt 0, 1; B: mt 0, 1)   v40..v63 epilogue temporaries
-    v64..v75 copy temporaries      v76..v99 fragments XF[2][2], XF2[2]            v100..v105 d_xin addresses, 1/scale, clamp bounds
+    v64..v75 copy temporaries      v76..v107 fragments XF[4][2]                   v108..v112 d_xin addresses, 1/scale
     v128..v191 acc_A               v192..v255 acc_B
     a[8 ks .. 8 ks + 7] weight slot ks = k-step ks of the resident segment: [row tile 0 | row tile 1] x 4 registers
 """
@@ -46,9 +46,8 @@ V_RD, V_RDS, V_WR, V_WRS, V_CP, V_CPOFF, V_REL, V_LANE16, V_OFF, V_MOFF, V_INVA,
 MSK = {"A": (V(36), V(37)), "B": (V(38), V(39))}
 T0 = 40                     # v40..v63
 CPT = 64                    # v64..v75
-XF0 = 76                    # XF[b][nt] = v[76 + 8 b + 4 nt : +4]
-XF2 = 92                    # XF2[nt] = v[92 + 4 nt : +4]: the fragments of a phase's LAST k-step
-V_DX, V_INV, V_CLO, V_CHI, V_L31 = V(100, 2), V(102, 2), V(104), V(105), V(106)      # V_DX[nt]: d_xin offsets of the current half
+XF0 = 76                    # XF[b][nt] = v[76 + 8 b + 4 nt : +4], b = k-step & 3: four rotating buffers, requested two k-steps ahead
+V_DX, V_INV, V_L31 = V(108, 2), V(110, 2), V(112)      # V_DX[nt]: d_xin offsets of the current half
 ACC = {"A": 128, "B": 192}
 
 # ---- SGPRs (asm-owned: s40..s99)
@@ -66,7 +65,7 @@ S_DXIN = S(76, 2)
 S_LD4, S_NVALID = S(78), S(79)
 D_BODY, D_FLAGS, D_R1, D_R1W = range(4)
 
-BODY = dict(END=0, AH=1, BH=2, A16F=3, A16=4, B16=5, A16S=6, B16S=7, B16L=8, EPI_B=9, COPY_LAST=10, AX=11, BX=12, AXS=13, BXS=14,
+BODY = dict(END=0, AH=1, BH=2, A16F=3, A16=4, B16=5, A16S=6, B16S=7, B16L=8, EPI_B=9, AX=11, BX=12, AXS=13, BXS=14,
             BXD=15, EPI_DXB=16)
 
 IN_SB = dict(pk=S(0, 2), phases=S(2, 2), lds=S(4), stash=S(5), wave=S(6), invlds=S(7), rellds=S(8), act=S(10, 2), mask=S(12, 2),
@@ -86,10 +85,6 @@ def in_vb(dst, name):
 
 def xf(b, nt):
     return V(XF0 + 8 * b + 4 * nt, 4)
-
-
-def xf2(nt):
-    return V(XF2 + 4 * nt, 4)
 
 
 def acc(half, mt, nt):
@@ -122,7 +117,7 @@ def gstore_nt(voff, data, sbase, off=0):
 # ----------------------------------------------------------------------------------------------------------------------
 def epilogue_mask_unit(half, u, tset, stash):
     """(tile u >> 1 = (mt, nt), quad pair p = u & 1) of `half`'s accumulators: ReLU mask from the sign words (bit 16 nt + 4 q + e of
-    word mt: the sign-extended bit ANDed onto the value) -> clamp to the fp16 range -> fp16, round to nearest -> two 8-byte LDS
+    word mt: the sign-extended bit ANDed onto the value) -> fp16, round to nearest, clamped to the fp16 range -> two 8-byte LDS
     stores (rows 8 p + 4 h .. + 3 and 16 + 8 p + 4 h .. + 3 of the 32-row tile, h = lane >> 5); stash: the same data once more into
     the stash tile (the skip layer's pre-activation gradient, needed again by the trunk-input steps)."""
     t, p = u >> 1, u & 1
@@ -137,9 +132,8 @@ def epilogue_mask_unit(half, u, tset, stash):
         out.append(I_valu("v_bfe_i32", M[j], MSK[half][mt], bit, 1))
     for j in range(8):
         out.append(I_valu("v_and_b32", x[j], M[j], x[j], text=f"v_and_b32_e32 {x[j]}, {M[j]}, {x[j]}"))
-    for j in range(8):
-        out.append(I_valu("v_med3_f32", x[j], x[j], V_CLO, V_CHI))
-    for k in range(4):
+    for k in range(4):          # (MODE.FP16_OVFL is set while the body runs: a conversion that overflows gives +-65504, not infinity --
+                                #  the clamp of field_bwd.hip's epilogue, v_med3_f32 per value, without an instruction)
         out.append(I_valu("v_cvt_pk_f16_f32", H[k], x[2 * k], x[2 * k + 1]))
     off = half_off(half) + NT_B * nt + 64 * mt + 16 * p
     out += [I_ds_write_b64(V_WR, V(H[0].i, 2), off), I_ds_write_b64(V_WR, V(H[2].i, 2), off + 32)]
@@ -240,22 +234,24 @@ def frag_reads(half, ks, dst, src="x"):
     return [I_ds_read_b128(dst(nt), base, half_off(half) + NT_B * nt + 32 * ks) for nt in range(2)]
 
 
-def mfmas(half, ks, init, last):
-    """the four MFMAs of k-step ks; init: the first k-step starts from zero (the inline constant); last: its fragments are in XF2"""
+def mfmas(half, ks, init):
+    """the four MFMAs of k-step ks; init: the first k-step starts from zero (the inline constant)"""
     out = []
     for mt in range(2):
         for nt in range(2):
             d = acc(half, mt, nt)
-            b = xf2(nt) if last else xf(ks & 1, nt)
+            b = xf(ks & 3, nt)
             out.append(I_mfma(d, wslot(ks, mt), b, d if not (init and ks == 0) else 0))
     return out
 
 
 def refill(ks):
-    """slot ks <- k-step ks of the next segment (stream S_R1 of the dispatcher: V_OFF runs through it): [load, load + step]"""
-    return [[I_gload_x4_s(A(8 * ks, 4), V_OFF, S_PK, 0)],
-            [I_gload_x4_s(A(8 * ks + 4, 4), V_OFF, S_PK, 1024),
-             I_valu("v_add_u32", V_OFF, 2048, V_OFF, text=f"v_add_u32_e32 {V_OFF}, 0x800, {V_OFF}")]]
+    """slot ks <- k-step ks of the next segment (stream S_R1 of the dispatcher: V_OFF runs through it, one step per two k-steps):
+    [load, load (+ step)]"""
+    o = 2048 * (ks & 1)
+    return [[I_gload_x4_s(A(8 * ks, 4), V_OFF, S_PK, o)],
+            [I_gload_x4_s(A(8 * ks + 4, 4), V_OFF, S_PK, o + 1024)] +
+            ([I_valu("v_add_u32", V_OFF, 4096, V_OFF, text=f"v_add_u32_e32 {V_OFF}, 0x1000, {V_OFF}")] if ks & 1 else [])]
 
 
 def emit_ride(s, item):
@@ -275,6 +271,7 @@ def emit_ride(s, item):
 
 
 RIDE_CAP = int(os.environ.get("H3B_RIDE_CAP", "8"))
+EXP = os.environ.get("H3B_EXP", "")      # timing experiments (results are garbage; only the time is read): nostore, nocopy, noepi, norefill, nomfma
 
 
 class LogStream(Stream):
@@ -310,15 +307,23 @@ def phase_body(name, half, nks, init=True, src="x", ride=None, copy=False, refil
     oh = other(half)
     last = nks - 1
     bar = (last - 1, 0)
-    for nt in range(2):
-        s.lds_q.append((("xf", 0), None))
+    for k0 in range(2):         # the phase in front requested the fragments of k-steps 0 and 1 behind its barrier
+        for nt in range(2):
+            s.lds_q.append((("xf", k0), None))
     for tg in (vm_seed or []):
         s.vm_q.append((tg, None))
     ride_ins = {None: [], "mask": epilogue_mask(oh), "mask_stash": epilogue_mask(oh, True), "dxin": epilogue_dxin(oh)}[ride]
-    if copy:
-        ride_ins = merge_ride(ride_ins, [x for g in copy_groups(half, half == "B") for x in [g]])
+    if "noepi" in EXP and ride in ("mask", "mask_stash"):
+        ride_ins = [("NEED_VM", "msk" + oh)]
+    if copy and "nocopy" not in EXP:
+        cg = copy_groups(half, half == "B")
+        if "nostore" in EXP:
+            cg = [[it for it in g if not (isinstance(it, tuple) and it[1] == "cpst")] for g in cg]
+        ride_ins = merge_ride(ride_ins, [x for g in cg for x in [g]])
     if msk:
         ride_ins = mask_load(half) + ride_ins
+    if "norefill" in EXP:
+        refills = None if refills is None else []
     if refills is not None:
         s.emit(vadd_s(V_OFF, S_R1, V_LANE16))
     # gaps: behind every MFMA in front of the barrier; a ride that does not fit them (short phases) runs RIDE_CAP per gap through
@@ -333,11 +338,12 @@ def phase_body(name, half, nks, init=True, src="x", ride=None, copy=False, refil
     ri = 0
 
     def tail_reads():
-        if tail:
-            for r in frag_reads(oh, 0, lambda nt: xf(0, nt), tail_src):
-                s.emit(r, ("xf'", 0))
+        if tail:                # (buffers 0 and 1: their last users, k-steps last - 3 and last - 2, were issued long ago)
+            for k0 in range(2):
+                for r in frag_reads(oh, k0, lambda nt: xf(k0, nt), tail_src):
+                    s.emit(r, ("xf'", k0))
     for ks in range(nks):
-        for m, mf in enumerate(mfmas(half, ks, init, ks == last)):
+        for m, mf in enumerate(mfmas(half, ks, init)):
             if m == 0:
                 if vm_seed is not None:
                     s.need_vm(("w", ks))
@@ -345,16 +351,15 @@ def phase_body(name, half, nks, init=True, src="x", ride=None, copy=False, refil
             if (ks, m) == bar and not late_barrier:
                 s.wait(lgkm=0)
                 s.emit(I_barrier())
-            s.emit(mf)
-            if m == 0:
-                # fragments of the next k-step; the LAST k-step's go to the third buffer and are requested a k-step early
-                nxt = ks + 1
-                if nxt < last:
-                    for r in frag_reads(half, nxt, lambda nt: xf(nxt & 1, nt), src):
-                        s.emit(r, ("xf", nxt))
-                if nxt == last - 1 or (last == 1 and ks == 0):
-                    for r in frag_reads(half, last, xf2, src):
-                        s.emit(r, ("xf", last))
+            if "nomfma" in EXP:
+                s.emit(raw("s_nop 0"))
+            else:
+                s.emit(mf)
+            if m == 0 and ks + 2 <= last:
+                # fragments two k-steps ahead (256 matrix-pipe cycles: an LDS round trip under load), into the buffer k-step ks - 2 used
+                nxt = ks + 2
+                for r in frag_reads(half, nxt, lambda nt: xf(nxt & 3, nt), src):
+                    s.emit(r, ("xf", nxt))
             if refills is not None and ks >= 1 and (ks - 1) in refills and m in (1, 2):
                 for r in refill(ks - 1)[m - 1]:
                     s.emit(r, ("w", ks - 1))
@@ -363,8 +368,8 @@ def phase_body(name, half, nks, init=True, src="x", ride=None, copy=False, refil
                 n -= max(1, n_insts([ride_ins[ri]])) if late_barrier else 1
                 emit_ride(s, ride_ins[ri])
                 ri += 1
-            if (ks, m) == (last - 1, 3) and not late_barrier:
-                tail_reads()                    # (k-step last - 1 was the last user of fragment buffer 0)
+            if (ks, m) == bar and not late_barrier:
+                tail_reads()
     if refills is not None and last in refills:
         for piece in refill(last):
             for r in piece:
@@ -396,17 +401,48 @@ def bare_epilogue(name, half, kind, vm_seed=None):
     return s.ins
 
 
-def copy_last_body():
-    """the trunk's last tile (both halves, complete behind EPI_B's barrier; a static trunk has no trunk-input steps to ride in)"""
+def static_tail_body(vm_seed=None):
+    """End of a static trunk (no trunk-input steps to ride in): the epilogue of half B with the HBM copy of half A's last tile
+    between its instructions (that tile is complete behind the last B phase's barrier), the workgroup barrier that publishes half
+    B's tile, then its copy."""
     s = LogStream()
-    s.emit(I_label("L_COPY_LAST"))
-    for half in ("A", "B"):
-        for grp in copy_groups(half, half == "B"):
-            for item in grp:
-                emit_ride(s, item)
+    s.emit(I_label("L_EPI_B"))
+    for tg in (vm_seed or []):
+        s.vm_q.append((tg, None))
+    s.wait(lgkm=0)                              # (fragments the phase in front requested for a next phase that does not exist)
+    s.emit(I_nop(7)); s.emit(I_nop(7))          # the last MFMAs on these accumulators were issued a few states ago
+    for item in merge_ride(epilogue_mask("B"), [g for g in copy_groups("A", False)]):
+        emit_ride(s, item)
+    s.wait(lgkm=0)
+    s.emit(I_barrier())
+    for grp in copy_groups("B", True):
+        emit_ride(s, grp)
     s.wait(lgkm=0)
     s.emit(I_branch("s_branch", "L_dispatch"))
     return s.ins
+
+
+PRE_S = dict(pk=S(0, 2), off0=S(20), off1=S(21))
+PRE_V = dict(lane16=V(1))
+
+
+def pre_issue():
+    """The FIRST asm statement of the kernel, in front of the C++ head stage: weight slots 0..3 <- the head segment, slots 4..15 <-
+    k-steps 4..15 of the first 16-k-step segment, so that the 32 loads of a wave cross the CU's vector-memory path while the head
+    stage loads and computes.  Operands: %[pk] s64, %[off0] s32 = head segment + wave stride, %[off1] s32 = first segment + wave
+    stride + 4 k-steps, %[lane16] v32 = 16 (tid & 63).  Only the loads in flight survive the statement."""
+    def ins(dst, name, table, op):
+        src = table[name]
+        return Inst(op, f"{op} {dst}, %[{name}]", [src], [dst], "salu" if op.startswith("s_") else "valu", dict(d=dst, s=[src]))
+    o = [ins(S_PK, "pk", PRE_S, "s_mov_b64"), ins(S_T0, "off0", PRE_S, "s_mov_b32"), ins(S_T1, "off1", PRE_S, "s_mov_b32"),
+         ins(V_LANE16, "lane16", PRE_V, "v_mov_b32")]
+    o.append(vadd_s(V_OFF, S_T0, V_LANE16))
+    for ks in range(4):
+        o += [x for piece in refill(ks) for x in piece]
+    o.append(vadd_s(V_OFF, S_T1, V_LANE16))
+    for ks in range(4, 16):
+        o += [x for piece in refill(ks) for x in piece]
+    return o
 
 
 def prologue():
@@ -430,23 +466,10 @@ def prologue():
     e(I_salu("s_add_u32", S(46), S(46), 64, scc=True)); e(I_salu("s_addc_u32", S(47), S(47), 0, scc=True))
     e(I_wait(lgkm=0))
     e(I_salu("s_mov_b32", S_ASTRIDE, S(S_CUR + 6))); e(I_salu("s_mov_b32", S_MSTRIDE, S(S_CUR + 7)))
-    e(I_salu("s_mov_b32", S_T0, S(S_CUR + 4))); e(I_salu("s_mov_b32", S_T1, S(S_CUR + 5))); e(I_salu("s_mov_b32", S_R1, S(S_CUR + 2)))
     lane, l31, h = V(T0), V_L31, V(T0 + 2)
     e(I_valu("v_and_b32", lane, 63, V_TID)); e(I_valu("v_and_b32", l31, 31, V_TID)); e(I_valu("v_lshrrev_b32", h, 5, lane))
     e(I_valu("v_lshlrev_b32", V_LANE16, 4, lane))
-    # weight slots: head segment k-steps 0..3 -> slots 0..3; the first 16-k-step segment's k-steps 4..15 -> slots 4..15 (its k-steps
-    # 0..3 follow in BH, behind the head step's use of those slots)
-    e(I_salu("s_mul_i32", S_T1, S_WAVE, S_T1)); e(I_salu("s_add_u32", S_T0, S_T0, S_T1, scc=True))
-    e(vadd_s(V_OFF, S_T0, V_LANE16))
-    for ks in range(4):
-        for r in [x for piece in refill(ks) for x in piece]:
-            e(r)
-    e(I_salu("s_mul_i32", S_T1, S_WAVE, S(S_CUR + 3))); e(I_salu("s_add_u32", S_T0, S_R1, S_T1, scc=True))
-    e(I_salu("s_add_u32", S_T0, S_T0, 4 * 2048, scc=True))
-    e(vadd_s(V_OFF, S_T0, V_LANE16))
-    for ks in range(4, 16):
-        for r in [x for piece in refill(ks) for x in piece]:
-            e(r)
+    # (the weight slots were requested by the pre-issue statement in front of the head stage)
     # rd = lds + l31 * 528 + 16 h ; rds = stash + ...
     t3 = V(T0 + 3)
     e(I_valu("v_mul_u32_u24", V_RD, LDH_B, l31)); e(I_valu("v_lshlrev_b32", t3, 4, h)); e(I_valu("v_add_u32", V_RD, V_RD, t3))
@@ -474,19 +497,34 @@ def prologue():
     e(I_valu("v_lshlrev_b32", a_, 4, h)); e(I_valu("v_add_u32", V_DXB, V_DXB, a_))
     e(I_salu("s_lshl_b32", S_T0, S_WAVE, 8, scc=True)); e(vadd_s(V_DXB, S_T0, V_DXB))
     e(I_valu("v_lshlrev_b32", a_, 2, l31)); e(vadd_s(V_INVA, S_INVLDS, a_))
-    e(I_valu("v_mov_b32", V_CLO, -65504.0, text=f"v_mov_b32 {V_CLO}, 0xc77fe000")); e(I_valu("v_mov_b32", V_CHI, 65504.0, text=f"v_mov_b32 {V_CHI}, 0x477fe000"))
+    # MODE.FP16_OVFL (bit 23): an fp16 conversion that overflows is clamped to +-65504 (restored at L_end)
+    e(Inst("s_setreg", "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1", [], [], "salu", dict(d=None, s=[1], field="fp16_ovfl")))
     e(I_wait(lgkm=0))
-    for r in frag_reads("A", 0, lambda nt: xf(0, nt)):
-        e(r)
+    for k0 in range(2):
+        for r in frag_reads("A", k0, lambda nt: xf(k0, nt)):
+            e(r)
     return o
 
 
-DISPATCH_ORDER = ("A16", "B16", "A16S", "B16S", "AH", "BH", "A16F", "B16L", "EPI_B", "COPY_LAST", "AX", "BX", "AXS", "BXS", "BXD", "EPI_DXB")
+TIMING = False              # --timing: every dispatcher visit stores an s_memtime stamp (lane 0) at *s[80:81] (+= 4): debug builds only
+
+
+def timing_store():
+    """lane 0 stores the low dword of s_memtime at s[80:81] and advances the pointer.  The store is one more entry of the in-order
+    VMEM queue: counted waits for older loads only get stricter."""
+    return [raw("s_memtime s[82:83]"), raw("s_waitcnt lgkmcnt(0)"), raw("v_mov_b32 v120, s82"), raw("v_mov_b32 v121, 0"),
+            raw("s_mov_b64 s[84:85], exec"), raw("s_mov_b64 exec, 1"), raw("global_store_dword v121, v120, s[80:81]"),
+            raw("s_mov_b64 exec, s[84:85]"), raw("s_add_u32 s80, s80, 4"), raw("s_addc_u32 s81, s81, 0")]
+
+
+DISPATCH_ORDER = ("A16", "B16", "A16S", "B16S", "AH", "BH", "A16F", "B16L", "EPI_B", "AX", "BX", "AXS", "BXS", "BXD", "EPI_DXB")
 
 
 def dispatcher(bodies):
     o = [I_label("L_dispatch")]
     e = o.append
+    if TIMING:
+        o.extend(timing_store())
     for k in range(8):
         e(I_salu("s_mov_b32", S(S_CUR + k), S(S_NXT + k)))
     e(I_s_load(S(S_NXT, 8), S_PH, 0))
@@ -502,7 +540,7 @@ def dispatcher(bodies):
 
 
 def build():
-    """-> (program, bodies).  The VMEM operations a phase may find outstanding at its entry are those of the phase(s) in front of
+    """-> (pre-issue statement, program, bodies).  The VMEM operations a phase may find outstanding at its entry are those of the phase(s) in front of
     it, as generated: the seed of its wait-count model (every counted wait is then exact or stricter, never too weak -- and the
     simulator, which keeps the real queues, runs every phase program the host builder can emit)."""
     bodies = {}
@@ -518,28 +556,30 @@ def build():
     b16 = gen("B16", "B", 16, ride="mask", copy=True, refills=list(range(16)), msk=True, vm_seed=a_like)
     assert gen("B16S", "B", 16, ride="mask_stash", copy=True, refills=list(range(16)), msk=True, vm_seed=a_like) == b16
     a16 = gen("A16", "A", 16, ride="mask", copy=True, msk=True, vm_seed=b16)
-    assert a16 == a_like, a16
+    assert EXP or a16 == a_like, a16
     assert gen("A16S", "A", 16, ride="mask_stash", copy=True, msk=True, vm_seed=b16) == a16
     gen("B16L", "B", 16, ride="mask", copy=True, msk=True, vm_seed=a_like)
-    bodies["EPI_B"] = bare_epilogue("EPI_B", "B", "mask", vm_seed=["mskB"] + ["cpst"] * 8)
-    bodies["COPY_LAST"] = copy_last_body()
+    bodies["EPI_B"] = static_tail_body(vm_seed=["mskB"] + ["cpst"] * 8)
     # the trunk-input steps of a dynamic trunk: x0 from the tile (the layer-0 pre-activation gradient), then -- one skip layer --
     # the skip layer's input part from the stash, accumulated on top; d_xin leaves in fp32
     ax = gen("AX", "A", 16, ride="mask", copy=True, vm_seed=b16)
-    assert ax == ["cpst"] * 8
+    assert EXP or ax == ["cpst"] * 8
     bx = gen("BX", "B", 16, copy=True, refills=list(range(16)), tail_src="s")
     gen("AXS", "A", 16, init=False, src="s", vm_seed=bx, tail_src="s")
     gen("BXS", "B", 16, init=False, src="s", ride="dxin", tail=False)
     gen("BXD", "B", 16, ride="dxin", copy=True, tail=False)
     bodies["EPI_DXB"] = bare_epilogue("EPI_DXB", "B", "dxin")
-    prog = prologue()
+    prog = ([raw("s_mov_b64 s[80:81], %[dbg]")] if TIMING else []) + prologue()
     prog.append(I_branch("s_branch", "L_dispatch"))
     for name in bodies:
         prog += bodies[name]
     prog += dispatcher(bodies)
     prog.append(I_label("L_end"))
     prog.append(I_wait(vm=0, lgkm=0))
-    return prog, bodies
+    prog.append(Inst("s_setreg", "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0", [], [], "salu", dict(d=None, s=[0], field="fp16_ovfl")))
+    if TIMING:
+        prog += timing_store() + [I_wait(vm=0, lgkm=0)]
+    return pre_issue(), prog, bodies
 
 
 def render_b(prog):
@@ -562,19 +602,26 @@ def lint(bodies):
 
 
 def main():
-    prog, bodies = build()
+    global TIMING
+    TIMING = "--timing" in sys.argv
+    pre, prog, bodies = build()
     errs = lint(bodies)
     for e_ in errs[:40]:
         print("LINT:", e_)
     if errs:
         sys.exit(f"{len(errs)} hazard(s)")
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "nsff_pl_amd", "csrc", "field_bwd_h3b_body.inc")
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "nsff_pl_amd", "csrc",
+                       "field_bwd_h3b_body_timing.inc" if TIMING else (f"field_bwd_h3b_body_{EXP}.inc" if EXP else "field_bwd_h3b_body.inc"))
     clob = ", ".join([f'"v{i}"' for i in range(24, 256)] + [f'"a{i}"' for i in range(128)] + [f'"s{i}"' for i in range(40, 100)] +
                      ['"vcc"', '"scc"', '"memory"'])
     consts = "".join(f"#define H3B_BODY_{k} {v}\n" for k, v in BODY.items())
     macro = lambda name, insts: f"#define {name} \\\n" + render_b(insts).replace("\n", " \\\n").rstrip(" \\\n") + "\n"
+    pre_wr = sorted({r for i in pre for r in i.wr if r[0] in ("v", "a") or (r[0] == "s" and r[1] < 100)})
+    pre_clob = ", ".join([f'"{f}{i}"' for f, i in pre_wr] + ['"scc"', '"memory"'])
     text = ("// GENERATED by tools/h3asm/gen_bwd.py -- do not edit.  The hand-scheduled body of nsff_field_bwd_kernel_h3b (the data-gradient\n"
-            "// chain of one 128-point tile and one trunk; registers v24..v255, a0..a127, s40..s99 are its own while it runs).\n" + consts +
+            "// chain of one 128-point tile and one trunk; registers v24..v255, a0..a127, s40..s99 are its own while it runs) and H3B_PRE,\n"
+            "// the statement in front of the head stage that requests the first sixteen weight slots.\n" + consts +
+            "#define H3B_PRE_CLOBBERS " + pre_clob + "\n" + macro("H3B_PRE", pre) +
             "#define H3B_CLOBBERS " + clob + "\n" + macro("H3B_BODY", prog))
     with open(out, "w") as f:
         f.write(text)

@@ -699,10 +699,14 @@ class Sim:
             out = np.median(np.stack([f32(s[0]), f32(s[1]), f32(s[2])]), axis=0).astype(np.float32).view(np.uint32)
         elif op == "v_mul_f32":
             out = (f32(s[0]) * f32(s[1])).astype(np.float32).view(np.uint32)
-        elif op == "v_cvt_pk_f16_f32":       # round to nearest even (the mode register's default), overflow -> inf
+        elif op == "v_cvt_pk_f16_f32":       # round to nearest even (the mode register's default); overflow -> inf, or +-65504 under FP16_OVFL
             with np.errstate(over="ignore"):
                 lo = f32(s[0]).astype(np.float16)
                 hi = f32(s[1]).astype(np.float16)
+            if getattr(w, "fp16_ovfl", False):
+                for h_, src_ in ((lo, f32(s[0])), (hi, f32(s[1]))):
+                    m_ = np.isinf(h_) & np.isfinite(src_)
+                    h_[m_] = np.where(src_[m_] > 0, np.float16(65504.0), np.float16(-65504.0))
             out = lo.view(np.uint16).astype(np.uint32) | (hi.view(np.uint16).astype(np.uint32) << 16)
         elif op == "v_pk_mul_f16":
             with np.errstate(over="ignore", under="ignore"):
@@ -721,6 +725,9 @@ class Sim:
 
     def _salu(self, w, ins):
         op, a = ins.op, ins.args
+        if op == "s_setreg":             # (only MODE.FP16_OVFL is modelled: overflowing fp16 conversions clamp instead of giving infinity)
+            w.fp16_ovfl = bool(a["s"][0])
+            return
         if op == "s_and_saveexec_b64":
             bits = 0
             for l in range(NL):
