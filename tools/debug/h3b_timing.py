@@ -54,9 +54,8 @@ for dyn in ([False, True] if which == "both" else [which == "dynamic"]):
     n_ph = seq.index("END")
     print(f"-- {'dynamic' if dyn else 'static'} trunk: {n_ph} phases; mean cycles (s_memtime ticks at 100 MHz x clock ratio are NOT cycles: see below)")
     print(f"   entry -> head stage done {d(tt[:, :, 0], tt[:, :, 1]).mean():8.0f}")
-    hs = ["entry -> in front of the pre-issue statement", "the pre-issue statement (32 weight-slot loads issued)", "record loads issued",
-          "head arithmetic, half A (waits for its records -- and, in order, for the weight slots)", "head arithmetic, half B", "barrier",
-          "head-gradient stores issued"]
+    hs = ["entry -> in front of the record loads", "record loads of both halves issued", "the pre-issue statement (8 head-segment loads issued)",
+          "head arithmetic, half A (waits for its records)", "head arithmetic, half B", "barrier", "head-gradient stores issued"]
     prev = tt[:, :, 0]
     for k, nm in enumerate(hs):
         print(f"      {nm:90s} {d(prev, tt[:, :, 56 + k]).mean():8.0f}")

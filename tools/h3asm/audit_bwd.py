@@ -28,7 +28,7 @@ for ln in body.split("\n"):
         inasm = False
         if cur > 100:
             n_asm, seen, n_mfma = n_asm + 1, True, cur
-        elif curl >= 8:
+        elif curl >= 4:
             n_pre, pre_loads, between = n_pre + 1, pre_loads + curl, True
         continue
     t = ln.strip()
@@ -58,6 +58,6 @@ print(f"  next_free_vgpr {get('next_free_vgpr')}  accum_offset {get('accum_offse
       f"scratch {get('private_segment_fixed_size')} B  LDS {get('group_segment_fixed_size')} B  spills: {spill_v} VGPR, {spill_s} SGPR")
 print(f"  pre-issue statements {n_pre} ({pre_loads} weight-slot loads in flight across the head stage); compiler instructions touching "
       f"accumulation registers between it and the body: {len(agpr_between)}")
-ok = (n_asm == 1 and n_pre == 1 and pre_loads == 32 and not agpr_between and spill_v == 0 and spill_s == 0 and int(get("private_segment_fixed_size")) == 0 and int(get("next_free_vgpr")) >= 384
+ok = (n_asm == 1 and n_pre == 1 and pre_loads == 8 and not agpr_between and spill_v == 0 and spill_s == 0 and int(get("private_segment_fixed_size")) == 0 and int(get("next_free_vgpr")) >= 384
       and first_after == "s_endpgm" and int(get("group_segment_fixed_size")) <= 160 * 1024)
 sys.exit(0 if ok else "AUDIT FAILED: " + kernel)

@@ -65,7 +65,7 @@ def build_program(steps, dynamic, skip, slot_bytes=(N_TILES64 * 64 * 256 * 2, N_
         ph.append([body, 0, nxt["off"] if nxt else 0, nxt["nks"] * 2048 if nxt else 0, 0, 0, 0, 0])
     # descriptor 0 is not a phase: the trunk's constants (first 16-k-step segment, head segment, bytes per fragment / sign-word slot)
     ph.append([0, 0, steps[1]["off"], 16 * 2048, steps[0]["off"], 4 * 2048, slot_bytes[0], slot_bytes[1]])
-    desc(B["AH"])
+    desc(B["AH"], steps[1])               # (its gaps carry the loads of weight slots 4..15)
     desc(B["BH"], steps[1])
     for j, st in enumerate(layers):
         i = 1 + j
@@ -259,7 +259,6 @@ def run_case(kind, seed=0, verbose=True):
         w.v[I_V["tid"].i] = tid
         # the pre-issue statement's operands
         w.s[gb.PRE_S["off0"].i] = case["steps"][0]["off"] + w.id * 4 * 2048
-        w.s[gb.PRE_S["off1"].i] = case["steps"][1]["off"] + w.id * 16 * 2048 + 4 * 2048
         w.v[gb.PRE_V["lane16"].i] = (tid & 63) << 4
     t0 = time.time()
     sim.run()

@@ -25,7 +25,7 @@ How it is scheduled (the mirror image of the forward body, tools/h3asm/gen.py):
 
 Register map (asm-owned; the compiler keeps v0..v23, s0..s39 and VCC):
     v24..v35 addresses / scratch   v36..v39 sign words (A: mt 0, 1; B: mt 0, 1)   v40..v63 epilogue temporaries
-    v64..v75 copy temporaries      v76..v107 fragments XF[4][2]                   v108..v112 d_xin addresses, 1/scale
+    v64..v75, v114..v125 copy temporaries (two sets)   v76..v107 fragments XF[4][2]   v108..v112 d_xin addresses, 1/scale
     v128..v191 acc_A               v192..v255 acc_B
     a[8 ks .. 8 ks + 7] weight slot ks = k-step ks of the resident segment: [row tile 0 | row tile 1] x 4 registers
 """
@@ -47,7 +47,7 @@ MSK = {"A": (V(36), V(37)), "B": (V(38), V(39))}
 T0 = 40                     # v40..v63
 CPT = 64                    # v64..v75
 XF0 = 76                    # XF[b][nt] = v[76 + 8 b + 4 nt : +4], b = k-step & 3: four rotating buffers, requested two k-steps ahead
-V_DX, V_INV, V_L31 = V(108, 2), V(110, 2), V(112)      # V_DX[nt]: d_xin offsets of the current half
+V_DX, V_INV, V_L31 = V(108, 2), V(110, 2), V(113)      # V_DX[nt]: d_xin offsets of the current half
 ACC = {"A": 128, "B": 192}
 
 # ---- SGPRs (asm-owned: s40..s99)
@@ -182,28 +182,41 @@ def copy_groups(half, last_of_slot):
     """The HBM copy of the gradient tile of `half` (64 points x 256 rows -> 32 one-KiB blocks in the fragment order of the
     weight-gradient GEMM, eight per wave; layout and arithmetic of field_bwd.hip::fragment_block: two transposing LDS reads, the two
     per-point power-of-two factors as packed fp16 multiplies, ONE contiguous 16-byte store per lane) as a list of GROUPS of ride
-    items.  last_of_slot: half B -- the slot pointer moves on to the next (lower) slot."""
+    items.  Software-pipelined two blocks deep: block u + 2's LDS reads are requested where block u is multiplied and stored (two
+    register sets, the factors of a 16-point pair likewise), so that an LDS round trip -- 100+ cycles under load, more than the ride
+    instructions between two groups cover -- is never waited for.  last_of_slot: half B -- the slot pointer moves on."""
     hb = 0 if half == "A" else 1
-    t = [V(CPT + k) for k in range(4)]
-    r1a, r1b, r2a, r2b = V(CPT + 4, 2), V(CPT + 6, 2), V(CPT + 8, 2), V(CPT + 10, 2)
-    groups = [[I_salu("s_lshl_b32", S_T0, S_WAVE, 10, scc=True), vadd_s(V_CPOFF, S_T0, V_LANE16)] +
-              ([I_valu("v_add_u32", V_CPOFF, 32768, V_CPOFF, text=f"v_add_u32_e32 {V_CPOFF}, 0x8000, {V_CPOFF}")] if hb else [])]
-    for u in range(8):      # block wave + 4 u = (16-point group u >> 1, 32-row block wave + 4 (u & 1))
+    T = [[V(CPT + 4 * b + k) for k in range(4)] for b in range(2)]                       # v64..v71
+    REL = [[V(CPT + 8, 2), V(CPT + 10, 2), V(114, 2), V(116, 2)], [V(118, 2), V(120, 2), V(122, 2), V(124, 2)]]     # [pair parity][r1a, r1b, r2a, r2b]
+
+    def tr_reads(u):
         imm = half_off(half) + (u >> 1) * 16 * LDH_B + (u & 1) * 256
-        g0 = []
-        if (u & 1) == 0:    # the factors of this 16-point group: rel1 / rel2 of points pt0 .. pt0 + 3 and pt0 + 4 .. pt0 + 7 of the lane
-            ro = 128 * hb + 32 * (u >> 1)
-            g0 += [(I_ds_read_b64(r1a, V_REL, ro), ("rel", u)), (I_ds_read_b64(r1b, V_REL, ro + 8), ("rel", u)),
-                   (I_ds_read_b64(r2a, V_REL, ro + 256), ("rel", u)), (I_ds_read_b64(r2b, V_REL, ro + 264), ("rel", u))]
-        g0 += [(I_ds_read_tr(V(t[0].i, 2), V_CP, imm), ("cp", u)), (I_ds_read_tr(V(t[2].i, 2), V_CP, imm + 4 * LDH_B), ("cp", u))]
-        groups[-1] += g0
-        groups.append([("NEED_LDS", ("cp", u)),
-                       I_valu("v_pk_mul_f16", t[0], t[0], r1a.sub(0)), I_valu("v_pk_mul_f16", t[1], t[1], r1a.sub(1)),
-                       I_valu("v_pk_mul_f16", t[2], t[2], r1b.sub(0)), I_valu("v_pk_mul_f16", t[3], t[3], r1b.sub(1))])
-        groups.append([I_valu("v_pk_mul_f16", t[0], t[0], r2a.sub(0)), I_valu("v_pk_mul_f16", t[1], t[1], r2a.sub(1)),
-                       I_valu("v_pk_mul_f16", t[2], t[2], r2b.sub(0)), I_valu("v_pk_mul_f16", t[3], t[3], r2b.sub(1)),
-                       (gstore_nt(V_CPOFF, V(t[0].i, 4), S_ACT, 0), "cpst"),
-                       I_valu("v_add_u32", V_CPOFF, 4096, V_CPOFF, text=f"v_add_u32_e32 {V_CPOFF}, 0x1000, {V_CPOFF}")])
+        t = T[u & 1]
+        return [(I_ds_read_tr(V(t[0].i, 2), V_CP, imm), ("cp", u)), (I_ds_read_tr(V(t[2].i, 2), V_CP, imm + 4 * LDH_B), ("cp", u))]
+
+    def rel_reads(pair):    # the factors of 16-point group `pair`: rel1 / rel2 of points pt0 .. pt0 + 3 and pt0 + 4 .. pt0 + 7 of the lane
+        ro = 128 * hb + 32 * pair
+        r = REL[pair & 1]
+        return [(I_ds_read_b64(r[0], V_REL, ro), ("rel", pair)), (I_ds_read_b64(r[1], V_REL, ro + 8), ("rel", pair)),
+                (I_ds_read_b64(r[2], V_REL, ro + 256), ("rel", pair)), (I_ds_read_b64(r[3], V_REL, ro + 264), ("rel", pair))]
+    groups = [[I_salu("s_lshl_b32", S_T0, S_WAVE, 10, scc=True), vadd_s(V_CPOFF, S_T0, V_LANE16)] +
+              ([I_valu("v_add_u32", V_CPOFF, 32768, V_CPOFF, text=f"v_add_u32_e32 {V_CPOFF}, 0x8000, {V_CPOFF}")] if hb else []) +
+              rel_reads(0) + tr_reads(0),
+              tr_reads(1) + rel_reads(1)]
+    for u in range(8):      # block wave + 4 u = (16-point group u >> 1, 32-row block wave + 4 (u & 1))
+        t, r = T[u & 1], REL[(u >> 1) & 1]
+        groups.append([("NEED_LDS", ("cp", u)), ("NEED_LDS", ("rel", u >> 1)),
+                       I_valu("v_pk_mul_f16", t[0], t[0], r[0].sub(0)), I_valu("v_pk_mul_f16", t[1], t[1], r[0].sub(1)),
+                       I_valu("v_pk_mul_f16", t[2], t[2], r[1].sub(0)), I_valu("v_pk_mul_f16", t[3], t[3], r[1].sub(1))])
+        g2 = [I_valu("v_pk_mul_f16", t[0], t[0], r[2].sub(0)), I_valu("v_pk_mul_f16", t[1], t[1], r[2].sub(1)),
+              I_valu("v_pk_mul_f16", t[2], t[2], r[3].sub(0)), I_valu("v_pk_mul_f16", t[3], t[3], r[3].sub(1)),
+              (gstore_nt(V_CPOFF, V(t[0].i, 4), S_ACT, 0), "cpst"),
+              I_valu("v_add_u32", V_CPOFF, 4096, V_CPOFF, text=f"v_add_u32_e32 {V_CPOFF}, 0x1000, {V_CPOFF}")]
+        if u + 2 < 8:
+            g2 += tr_reads(u + 2)
+            if (u & 1) == 1:                # (both blocks of pair u >> 1 are done with its factors: the registers take pair (u >> 1) + 2's)
+                g2 += rel_reads((u >> 1) + 2)
+        groups.append(g2)
     if last_of_slot:
         groups[-1] += [I_salu("s_sub_u32", S(S_ACT.i), S(S_ACT.i), S_ASTRIDE, scc=True), I_salu("s_subb_u32", S(S_ACT.i + 1), S(S_ACT.i + 1), 0, scc=True)]
     return groups
@@ -218,14 +231,18 @@ def mask_load(half):
     return out
 
 
-def merge_ride(main, groups):
-    """`groups` spread evenly through the list `main` (each group stays contiguous)"""
+def merge_ride(main, groups, tail_groups=0):
+    """`groups` spread evenly through the list `main` (each group stays contiguous); the last `tail_groups` groups follow the end of
+    `main` -- the copy's last multiplies and stores (no LDS operation among them) then sit between the epilogue's last LDS stores and
+    the phase barrier, whose lgkmcnt(0) would otherwise wait out a fresh store's round trip"""
     if not groups:
         return list(main)
-    out, n, g = [], len(main), len(groups)
+    out, n, g = [], len(main), len(groups) - tail_groups
     for k in range(g):
         out += groups[k]
         out += main[k * n // g:(k + 1) * n // g]
+    for k in range(g, len(groups)):
+        out += groups[k]
     return out
 
 
@@ -292,7 +309,7 @@ def n_insts(items):
 
 
 def phase_body(name, half, nks, init=True, src="x", ride=None, copy=False, refills=None, msk=False, vm_seed=None, tail_src="x",
-               tail=True):
+               tail=True, stream=None):
     """One phase: `nks` k-steps of MFMAs on acc_<half> from the tile (src 'x') or the stash tile ('s') of <half>.
     ride: None | 'mask' | 'mask_stash' | 'dxin' -- the epilogue of the OTHER half in the MFMA gaps
     copy: this half's tile goes to HBM while the phase multiplies it
@@ -301,6 +318,9 @@ def phase_body(name, half, nks, init=True, src="x", ride=None, copy=False, refil
     vm_seed: None, or the tags of the VMEM operations that may be outstanding at entry, oldest first (the phases in front, as
              generated): the phase then waits for weight slot ks in front of k-step ks
     tail_src: where the first fragments of the NEXT phase (the other half) are read from behind the barrier; tail=False: none
+    stream: None | list of weight slots whose loads ride in this phase from its first gap on (AH: slots 4..15 <- k-steps 4..15 of
+            the first 16-k-step segment -- nothing else rides there, and a workgroup's start is bound by what crosses the CU's
+            vector-memory path: round 6 measured 2.2 k cycles just to ISSUE all 32 loads of a wave in front of the head stage)
     -> (instructions, tags of the VMEM operations issued, in order)"""
     s = LogStream()
     s.emit(I_label(f"L_{name}"))
@@ -319,9 +339,14 @@ def phase_body(name, half, nks, init=True, src="x", ride=None, copy=False, refil
         cg = copy_groups(half, half == "B")
         if "nostore" in EXP:
             cg = [[it for it in g if not (isinstance(it, tuple) and it[1] == "cpst")] for g in cg]
-        ride_ins = merge_ride(ride_ins, [x for g in cg for x in [g]])
+        ride_ins = merge_ride(ride_ins, [x for g in cg for x in [g]], tail_groups=3 if ride_ins else 0)
     if msk:
         ride_ins = mask_load(half) + ride_ins
+    if stream:
+        pieces = [[I_salu("s_add_u32", S_T0, S_R1, 2048 * stream[0], scc=True), vadd_s(V_OFF, S_T0, V_LANE16)]]
+        for slot in stream:
+            pieces += [[(x, ("w", slot)) for x in piece] for piece in refill(slot)]
+        ride_ins = merge_ride(ride_ins, pieces)
     if "norefill" in EXP:
         refills = None if refills is None else []
     if refills is not None:
@@ -422,25 +447,20 @@ def static_tail_body(vm_seed=None):
     return s.ins
 
 
-PRE_S = dict(pk=S(0, 2), off0=S(20), off1=S(21))
+PRE_S = dict(pk=S(0, 2), off0=S(20))
 PRE_V = dict(lane16=V(1))
 
 
 def pre_issue():
-    """The FIRST asm statement of the kernel, in front of the C++ head stage: weight slots 0..3 <- the head segment, slots 4..15 <-
-    k-steps 4..15 of the first 16-k-step segment, so that the 32 loads of a wave cross the CU's vector-memory path while the head
-    stage loads and computes.  Operands: %[pk] s64, %[off0] s32 = head segment + wave stride, %[off1] s32 = first segment + wave
-    stride + 4 k-steps, %[lane16] v32 = 16 (tid & 63).  Only the loads in flight survive the statement."""
+    """The FIRST asm statement of the kernel, between the record loads of the C++ head stage and its arithmetic: weight slots 0..3 <-
+    the head segment (8 loads per wave; slots 4..15 ride in the AH phase).  Operands: %[pk] s64, %[off0] s32 = head segment + wave
+    stride, %[lane16] v32 = 16 (tid & 63).  Only the loads in flight survive the statement."""
     def ins(dst, name, table, op):
         src = table[name]
         return Inst(op, f"{op} {dst}, %[{name}]", [src], [dst], "salu" if op.startswith("s_") else "valu", dict(d=dst, s=[src]))
-    o = [ins(S_PK, "pk", PRE_S, "s_mov_b64"), ins(S_T0, "off0", PRE_S, "s_mov_b32"), ins(S_T1, "off1", PRE_S, "s_mov_b32"),
-         ins(V_LANE16, "lane16", PRE_V, "v_mov_b32")]
+    o = [ins(S_PK, "pk", PRE_S, "s_mov_b64"), ins(S_T0, "off0", PRE_S, "s_mov_b32"), ins(V_LANE16, "lane16", PRE_V, "v_mov_b32")]
     o.append(vadd_s(V_OFF, S_T0, V_LANE16))
     for ks in range(4):
-        o += [x for piece in refill(ks) for x in piece]
-    o.append(vadd_s(V_OFF, S_T1, V_LANE16))
-    for ks in range(4, 16):
         o += [x for piece in refill(ks) for x in piece]
     return o
 
@@ -512,8 +532,8 @@ TIMING = False              # --timing: every dispatcher visit stores an s_memti
 def timing_store():
     """lane 0 stores the low dword of s_memtime at s[80:81] and advances the pointer.  The store is one more entry of the in-order
     VMEM queue: counted waits for older loads only get stricter."""
-    return [raw("s_memtime s[82:83]"), raw("s_waitcnt lgkmcnt(0)"), raw("v_mov_b32 v120, s82"), raw("v_mov_b32 v121, 0"),
-            raw("s_mov_b64 s[84:85], exec"), raw("s_mov_b64 exec, 1"), raw("global_store_dword v121, v120, s[80:81]"),
+    return [raw("s_memtime s[82:83]"), raw("s_waitcnt lgkmcnt(0)"), raw("v_mov_b32 v126, s82"), raw("v_mov_b32 v127, 0"),
+            raw("s_mov_b64 s[84:85], exec"), raw("s_mov_b64 exec, 1"), raw("global_store_dword v127, v126, s[80:81]"),
             raw("s_mov_b64 exec, s[84:85]"), raw("s_add_u32 s80, s80, 4"), raw("s_addc_u32 s81, s81, 0")]
 
 
@@ -548,8 +568,8 @@ def build():
     def gen(name, *a, **k):
         bodies[name], log = phase_body(name, *a, **k)
         return log
-    pro_vm = [("w", ks) for ks in range(16) for _ in range(2)]
-    ah = gen("AH", "A", 4, msk=True, vm_seed=pro_vm)
+    pro_vm = [("w", ks) for ks in range(4) for _ in range(2)]
+    ah = gen("AH", "A", 4, msk=True, vm_seed=pro_vm, stream=list(range(4, 16)))
     bh = gen("BH", "B", 4, ride="mask", refills=[0, 1, 2, 3], msk=True, vm_seed=pro_vm + ah)
     a_like = ["mskA"] + ["cpst"] * 8            # what an A phase of a 16-k-step layer issues (every B16* follows one)
     gen("A16F", "A", 16, ride="mask", copy=True, msk=True, vm_seed=pro_vm + ah + bh)
@@ -598,6 +618,10 @@ def lint(bodies):
     errs = []
     for name, ins in bodies.items():
         errs += lint_straight(ins, name)
+        for i in ins:       # gfx90a and later: a VGPR / AGPR tuple starts at an even register
+            for x in list(i.args.values()) + [y for v_ in i.args.values() if isinstance(v_, list) for y in v_]:
+                if isinstance(x, Reg) and x.f in ("v", "a") and x.n >= 2 and x.i % 2:
+                    errs.append(f"{name}: `{i.text}` uses the odd-aligned tuple {x}")
     return errs
 
 
