@@ -293,7 +293,8 @@ typedef struct NsffFieldBwdArgs {
     float* d_side;              /* OUT or NULL (use_viewdir models, static_mode 2)           */
 } NsffFieldBwdArgs;
 int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
-/* Which kernel the last nsff_field_backward launch took: 1 = nsff_field_bwd_kernel_h3b, the hand-scheduled body (128-point
+/* Which kernel the last nsff_field_backward launch took: 2 = both (a view-direction model's launch of both trunks: the static trunk
+ * on nsff_field_bwd_kernel, the dynamic one on the hand-scheduled body, as two launches); 1 = nsff_field_bwd_kernel_h3b, the hand-scheduled body (128-point
  * workgroups, one wave per SIMD, resident transposed weights, epilogues / fragment copies / refills riding in the other half's MFMA
  * gaps: tools/h3asm/gen_bwd.py) -- launches with an even number of 64-point tiles whose trunks it executes (no view-direction static
  * trunk, at most one skip layer with a trunk-input gradient, none at the last layer); 0 = nsff_field_bwd_kernel (compiler-scheduled,

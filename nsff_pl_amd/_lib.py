@@ -687,8 +687,9 @@ def pack_weights_bwd(desc, params, packed, fwd_packed=None):
 
 
 def last_bwd_kernel():
-    """'h3b' (the hand-scheduled body) or 'c' (compiler-scheduled): which kernel the last field_backward launch took"""
-    return "h3b" if load().nsff_last_bwd_kernel() == 1 else "c"
+    """'h3b' (the hand-scheduled body), 'c' (compiler-scheduled) or 'c+h3b' (a view-direction model's both-trunk launch: static trunk
+    on the compiler-scheduled kernel, dynamic trunk on the hand-scheduled one): which kernel(s) the last field_backward launch took"""
+    return {0: "c", 1: "h3b", 2: "c+h3b"}[load().nsff_last_bwd_kernel()]
 
 
 def field_bwd_phase_program(model, dynamic, want_xin, n_tiles, max_phases=32):

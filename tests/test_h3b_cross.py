@@ -119,3 +119,23 @@ def test_overflowing_gradients_clamp_like_the_compiler_scheduled_kernel(hip_lib,
     big = np.abs(vals) >= 1024
     assert ((bits[big] & 0x3FF) == 0x3FF).mean() > 0.02, ((bits[big] & 0x3FF) == 0x3FF).mean()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_view_direction_model_runs_its_dynamic_trunk_on_the_hand_scheduled_kernel(hip_lib, monkeypatch):
+    """The reference's README configuration (use_viewdir: static_dir_encoding between the static trunk and static_rgb, nerf.py:183-186):
+    the body does not execute that static trunk, so a launch of both trunks runs as two -- the static trunk on nsff_field_bwd_kernel,
+    the dynamic one on the hand-scheduled body -- and the re-query launches (dynamic trunk alone) on the body; same bits as the
+    compiler-scheduled kernel for everything."""
+    torch.manual_seed(21)
+    m = A.NeRF("fine", use_viewdir=True, encode_appearance=False, encode_transient=True, in_channels_t=48, output_flow=True).to(DEV)
+    g = torch.Generator().manual_seed(22)
+    for static, want in ((True, "c+h3b"), (False, "h3b")):
+        P = 128 * 19 - 7
+        tiles = (P + 63) // 64
+        d_raw = torch.randn(P, _lib.RAW_STRIDE, generator=g).to(DEV)
+        raw = (torch.rand(P, _lib.RAW_STRIDE, generator=g) * 0.2).to(DEV)
+        masks = torch.randint(-2 ** 62, 2 ** 62, (field_grad.n_slots(m), tiles, 256), generator=g, dtype=torch.int64).to(DEV)
+        a = _run(m, P, static, True, True, d_raw, raw, masks, False, monkeypatch)
+        b = _run(m, P, static, True, True, d_raw, raw, masks, True, monkeypatch)
+        assert (a[3], b[3]) == (want, "c")
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
