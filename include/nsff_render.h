@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      29
+#define NSFF_ABI_VERSION      30
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -146,11 +146,12 @@ typedef struct NsffFieldArgs {
     int32_t off_xyz, off_dir, off_a, off_t;  /* column offsets in x_emb, -1 = absent */
     float*  raw;             /* (P, NSFF_RAW_STRIDE) output                         */
     /* training forward (F16X3, input A): also keep what nsff_field_backward / nsff_weight_grad need.  T = ceil(P/64) point
-     * tiles; any of them may be NULL.  NS = 2*D+2 activation slots (+1 when use_viewdir).  XR / t_row0 / SR: nsff_train_dims.
+     * tiles; any of them may be NULL.  NS = 2*D+2 activation slots.  XR / t_row0 / SR: nsff_train_dims.
      *   save_acts : fp16 (NS, T, 4, 256, 16): slot l = ReLU output of static layer l (l < D), slots D+1 .. 2*D the same for
-     *               the transient trunk, slot 2*D+2 = static_dir_encoding output; slots D and 2*D+1 (the *_xyz_encoding_final
-     *               outputs of earlier ABI versions) are never written: *_final is folded into the heads in training as in
-     *               inference (slots of a trunk that is not evaluated stay unwritten too).  Inside a tile: [16-point
+     *               the transient trunk, slot D = static_dir_encoding output (use_viewdir; ABI 30 -- it was slot 2*D+2); slot 2*D+1
+     *               (and slot D without view directions: the *_xyz_encoding_final outputs of earlier ABI versions) is never
+     *               written: *_final is folded into the heads in training as in inference (slots of a trunk that is not
+     *               evaluated stay unwritten too).  Inside a tile: [16-point
      *               group][neuron][point] = the fragment order of the weight-gradient GEMM (K = points);
      *   save_xin  : fp16 (T, 4, XR, 16) trunk input, rows [0,in_xyz) xyz embedding, rows [t_row0, t_row0+in_t) time code
      *               (t_row0 = ceil64(in_xyz); XR = 128 or 256); rows from ceil64 of what the launch encodes up stay unwritten;
@@ -263,7 +264,7 @@ int nsff_side_bias(const NsffModelDesc* desc, const void* packed_f16x3, const fl
  * streams (same parameter order as nsff_pack_weights).
  * nsff_field_backward: d_raw (P,16) -> d(trunk input) and the pre-activation gradients of every layer:
  *   dpre : fp16 (NS, T, 4, 256, 16)  slot t*(D+1)+l = trunk t (0 static, 1 transient) layer l < D (slot l = D, *_final, is
- *          never written: the layer is folded into the heads), slot 2*D+2 = static_dir_encoding (use_viewdir); values = true
+ *          never written: the layer is folded into the heads), slot D = static_dir_encoding (use_viewdir); values = true
  *          gradient * G, fragment order as save_acts;
  *   dhead: fp16 (2, T, 4, 32, 16) head pre-activation gradients * G, rows 0..15: static rgb(3) sigma(1);
  *          transient rgb(3) sigma(1) fw(3) bw(3); rows 16..31: the fp16 rounding remainder of rows 0..15 (the head
@@ -297,8 +298,8 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
  * on nsff_field_bwd_kernel, the dynamic one on the hand-scheduled body, as two launches); 1 = nsff_field_bwd_kernel_h3b, the hand-scheduled body (128-point
  * workgroups, one wave per SIMD, resident transposed weights, epilogues / fragment copies / refills riding in the other half's MFMA
  * gaps: tools/h3asm/gen_bwd.py) -- launches with an even number of 64-point tiles whose trunks it executes (no view-direction static
- * trunk, at most one skip layer with a trunk-input gradient, none at the last layer); 0 = nsff_field_bwd_kernel (compiler-scheduled,
- * 64-point workgroups; NSFF_BWD_KERNEL=c forces it).  Both leave bit-identical dpre / dhead / d_xin. */
+ * trunk, at most one skip layer with a trunk-input gradient, none at the last layer); 0 = the kernel nsff_field_bwd_kernel -- compiler-scheduled,
+ * 64-point workgroups; NSFF_BWD_KERNEL=c forces it.  Both leave bit-identical dpre / dhead / d_xin. */
 int nsff_last_bwd_kernel(void);
 /* Host-only (no GPU): the hand-scheduled body's phase program for one trunk of `desc` (dynamic: the transient trunk, with or without
  * the trunk-input gradient) at n_tiles 64-point tiles -> out[max_phases][8] uint32 descriptors; seg_offsets (or NULL): byte offsets of

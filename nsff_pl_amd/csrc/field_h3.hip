@@ -1707,7 +1707,7 @@ static bool h3a_build_program(const H3KArgs& k, int s0, int s1, bool dynamic, bo
     const H3AHeadSel hd = h3a_head_sel(k.L, head);
     Seg tile = segs[0];
     tile.off = hd.w_off * 4u; tile.stride = 0u;
-    if (save && (side_fold || fold_t)) return false;
+    if (save && fold_t) return false;                     // (the training forward keeps the time code on the matrix pipe: its columns' weight gradients need the saved tile)
     bool done = put(H3A_BODY_EPI_B, 0u, 0, hd.n_rows, tile, tile) && (!save || put(H3A_BODY_SAVE_LAST, 0u, 0, hd.n_rows, tile, tile)) &&
                 put(H3A_BODY_HEAD, 0u, 0, hd.n_rows, tile, tile);
     if (done) ph[np - 1].d[2] = 4u * (uint32_t)hd.slot0;
@@ -1993,7 +1993,9 @@ static int h3_step_program(const NsffModelDesc& d, int static_mode, int transien
         s.pre = (uint8_t)pre; s.post = (uint8_t)post; s.head = (uint8_t)head;
         s.save = (uint8_t)(slot + 1);
     };
-    // activation slots of the training forward: trunk layer l -> slot0 + l, *_final -> slot0 + D
+    // activation slots of the training forward: trunk layer l -> slot0 + l; slot0 + D was *_final's (folded into the heads since round
+    // 5: never written) -- the static trunk's slot D now is static_dir_encoding's (round 6: consecutive with the trunk's, so that the
+    // SAVE build's running slot pointers reach it without a jump; it was 2 D + 2)
     auto trunk = [&](const NsffTrunkLayoutH3& T, int pre_kind, int last_head, int slot0) {
         for (int l = 0; l < d.D; ++l) {
             const int head = (l == d.D - 1) ? last_head : HEAD_NONE;
@@ -2013,18 +2015,18 @@ static int h3_step_program(const NsffModelDesc& d, int static_mode, int transien
         trunk(k.L.st, PRE_INPUT, HEAD_S_FOLD, 0);
     } else if (static_mode == 2 && fold && side_fold) {
         trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
-        push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
+        push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_RELU, HEAD_S_RGB, d.D);
     } else if (static_mode == 2 && fold) {               // view directions: *_final folded into static_dir_encoding
         trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
         push(k.L.dir_h_fold, k.L.dir_b_fold, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
-        push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
+        push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, d.D);
     } else if (static_mode) {
         trunk(k.L.st, PRE_INPUT, HEAD_S_SIGMA, 0);
         if (static_mode == 2) {
             push(k.L.st.final_w, k.L.st.final_b, NSFF_W, PRE_NONE, POST_LINEAR, d.use_viewdir ? HEAD_NONE : HEAD_S_RGB, d.D);
             if (d.use_viewdir) {
                 push(k.L.dir_h, k.L.dir_b, NSFF_W, PRE_NONE, POST_NONE, HEAD_NONE);
-                push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, 2 * d.D + 2);
+                push(k.L.dir_x, NSFF_NONE, k.L.side_k, PRE_SIDE, POST_RELU, HEAD_S_RGB, d.D);
             }
         }
     }
@@ -2312,6 +2314,37 @@ static int h3a_device_cus() {
 
 int g_nsff_last_h3_grid = 0;          // workgroups of that launch when it was a hand-scheduled inference launch (nsff_last_field_grid)
 
+// The [dir | a] input tile of static_dir_encoding as the weight-gradient GEMM of those columns reads it (NsffFieldArgs::save_side:
+// fp16, per 64-point tile [16-point group][32-row block][lane = row + 32 (8-point group)][8 points]; rows [0, in_dir) the direction
+// embedding, [in_dir, in_dir + in_a) the appearance code, zeros behind) -- from the per-RAY rows (rendering.py:153-172 repeat them over
+// a ray's samples).  The hand-scheduled training forward never sees these columns (they arrive as bias rows): one 16-byte store per
+// thread and block here instead.
+namespace {
+struct SideTileArgs { const float* dir_emb; const float* a_emb; _Float16* out; long long n_points; int pts_per_ray, in_dir, in_a, side_rows; };
+__global__ __launch_bounds__(256) void nsff_side_tile_kernel(const SideTileArgs a) {
+    const long long tile = blockIdx.x, p0 = tile * 64;
+    const int lane = threadIdx.x & 63, rblocks = a.side_rows >> 5;
+    _Float16* dst = a.out + tile * (64LL * a.side_rows);
+    for (int blk = threadIdx.x >> 6; blk < 4 * rblocks; blk += 4) {
+        const int ks = blk / rblocks, rb = blk % rblocks;
+        const int row = 32 * rb + (lane & 31), pt0 = 16 * ks + 8 * (lane >> 5);
+        h8 out;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const long long p = p0 + pt0 + t;
+            float v = 0.f;
+            if (p < a.n_points) {
+                const long long ray = p / a.pts_per_ray;
+                if (row < a.in_dir) v = a.dir_emb[ray * a.in_dir + row];
+                else if (row < a.in_dir + a.in_a) v = a.a_emb[ray * a.in_a + (row - a.in_dir)];
+            }
+            out[t] = (_Float16)v;
+        }
+        *reinterpret_cast<h8*>(dst + (((long long)ks * rblocks + rb) * 64 + lane) * 8) = out;
+    }
+}
+}  // namespace
+
 int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const NsffFieldArgs* args,
                         int points_per_block, hipStream_t st, unsigned long long* span) {
     const NsffModelDesc& d = *desc;
@@ -2378,23 +2411,44 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         // points_per_block == 131 -- eight waves of 32 neurons, compiler-scheduled.
         H3AArgs ka{};
         ka.n_bias[0] = ka.n_bias[1] = 0; ka.head[0] = ka.head[1] = HEAD_NONE;
-        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 && !(g.static_mode == 2 && d.use_viewdir) &&
-                        k.save_acts != nullptr && k.save_masks != nullptr && k.save_side == nullptr && (k.n_tiles & 1) == 0 &&
+        // A view-direction static trunk (round 6; the reference's documented training configuration, README.md:226-233): covered when
+        // the caller supplied its per-ray rows (nsff_side_bias) and no 64-point half straddles two rays -- the launch then runs the
+        // side-fold step program of the inference launches (static_dir_encoding as one folded 256-wide segment with per-ray bias
+        // rows, sigma as a ride of the last trunk layer's epilogues) in its SAVE build; the [dir | a] input tile the weight-gradient
+        // GEMM of those columns reads (save_side) is written by a small launch of its own from the per-ray rows.
+        const bool viewdir_static = g.static_mode == 2 && d.use_viewdir;
+        H3KArgs ks = k;
+        bool side = false;
+        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 &&
+                        k.save_acts != nullptr && k.save_masks != nullptr && (k.n_tiles & 1) == 0 &&
                         k.n_tiles * (64LL * NSFF_W * 2) < 0x100000000LL && g.n_points <= 0x7fffffffLL;
+        if (asm_body && viewdir_static)
+            asm_body = g.s_bias != nullptr && g.s_bias_rows == 1 && g.pts_per_ray > 0 && g.pts_per_ray % 64 == 0 && g.dir_emb != nullptr &&
+                       (d.in_a == 0 || g.a_emb != nullptr) && h3_step_program(d, g.static_mode, g.transient_mode, true, ks, true) == NSFF_OK;
+        else if (asm_body)
+            asm_body = k.save_side == nullptr;
         if (asm_body && g.transient_mode)
             asm_body = k.L.kt == 64 && (d.in_t & 3) == 0 && ((uintptr_t)g.t_emb & 15) == 0;
         if (asm_body) {
-            ka.k = k;
-            if (k.n_static_steps > 0)
-                asm_body = h3a_build_program(k, 0, k.n_static_steps, false, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0],
-                                             nullptr, false, nullptr, true);
-            if (asm_body && n > k.n_static_steps)
-                asm_body = h3a_build_program(k, k.n_static_steps, n, true, false, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1],
+            if (viewdir_static) { ks.s_bias = g.s_bias; ks.sb_rows = 1; side = true; }
+            ka.k = ks;
+            if (ks.n_static_steps > 0)
+                asm_body = h3a_build_program(ks, 0, ks.n_static_steps, false, false, ka.ph[0], ka.bias_off[0], ka.n_bias[0], ka.head[0],
+                                             nullptr, side, side ? &ka.sig_ride : nullptr, true);
+            if (asm_body && ks.n_steps > ks.n_static_steps)
+                asm_body = h3a_build_program(ks, ks.n_static_steps, ks.n_steps, true, false, ka.ph[1], ka.bias_off[1], ka.n_bias[1], ka.head[1],
                                              nullptr, false, nullptr, true);
         }
         if (asm_body) {
             const long long tiles = (g.n_points + 127) / 128;
             if (tiles * 2 > 0x7fffffffLL) return NSFF_ERR_INVALID;
+            if (side) {
+                ka.sig_b_off = k.L.s_sigma_b;
+                if (k.save_side != nullptr) {
+                    SideTileArgs sa{g.dir_emb, g.a_emb, k.save_side, g.n_points, g.pts_per_ray, d.in_dir, d.in_a, k.side_rows};
+                    hipLaunchKernelGGL(nsff_side_tile_kernel, dim3((unsigned)k.n_tiles), dim3(256), 0, st, sa);
+                }
+            }
             ka.hsel[0] = h3a_head_sel(k.L, ka.head[0]); ka.hsel[1] = h3a_head_sel(k.L, ka.head[1]);
             ka.k.grid_tiles = tiles;
             ka.k.split_trunks = both ? 1 : 0;

@@ -62,10 +62,10 @@ def supported(model, xyz):
 
 
 def n_slots(model):
-    """Activation / pre-activation-gradient slots: trunk t layer l -> t*(D+1)+l, 2D+2: static_dir_encoding.  (Slot l = D of a
-    trunk -- *_xyz_encoding_final in earlier versions -- keeps its number but is never written: the layer is folded into the
-    heads that read it, forward and backward.)"""
-    return 2 * model.D + 2 + (1 if model.use_viewdir else 0)
+    """Activation / pre-activation-gradient slots: trunk t layer l -> t*(D+1)+l; slot D of the STATIC trunk: static_dir_encoding
+    (view-direction models).  (Slot l = D of a trunk was *_xyz_encoding_final's in earlier versions; the layer is folded into the
+    heads that read it, forward and backward, so the dynamic trunk's slot D is never written.)"""
+    return 2 * model.D + 2
 
 
 def _lin(m):
@@ -143,7 +143,7 @@ class _FieldFn(torch.autograd.Function):
             return (None, None if not ctx.needs_input_grad[1] else torch.zeros_like(xyz), None, None, None) + (None,) * len(params)
         static, transient = cfg["static"], cfg["transient"]
         viewdir = bool(model.use_viewdir and static)
-        S_DIR = 2 * D + 2
+        S_DIR = D
         n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
         d_raw = d_raw.contiguous()
         gmax = _lib.absmax(d_raw)

@@ -232,9 +232,12 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
     # trunk of a view-direction model then runs on the hand-scheduled f16x3 kernel (inference launches with 128-point tiles and
     # samples per ray a multiple of 64; the others read dir_emb / a_emb as before).
     # (`NSFF_NO_SIDE_BIAS=1`: the earlier form for A/B -- static workgroups on the eight-wave kernel as a launch of their own.)
-    if (side["dir_emb"] is not None and ctx.rec is None and P and S % 64 == 0 and config.get_precision() == "f16x3"
-            and (config.get_tile_points() == 130 or (config.get_tile_points() == 0 and P >= 32768))
-            and not os.environ.get('NSFF_NO_SIDE_BIAS')):
+    # Round 6: training forwards too -- the launch that keeps the activations for the backward pass runs the same side-fold program in
+    # the SAVE build of the body (the reference's documented training configuration, README.md:226-233, is a view-direction model);
+    # a training forward takes 128-point tiles at any size.
+    big_enough = ctx.rec is not None or config.get_tile_points() == 130 or (config.get_tile_points() == 0 and P >= 32768)
+    if (side["dir_emb"] is not None and P and S % 64 == 0 and config.get_precision() == "f16x3" and config.get_tile_points() in (0, 130)
+            and big_enough and not os.environ.get('NSFF_NO_SIDE_BIAS')):
         side["s_bias"] = _lib.side_bias(model, side["dir_emb"], side["a_emb"])
 
     def query(tag, raw_out, pts, static_mode, transient_mode, flow_heads, t_rows, which='t', **extra):

@@ -279,6 +279,72 @@ def test_training_forward_on_the_hand_scheduled_kernel(arch, hip_lib):
             assert n_diff <= 2e-4 * masks_a[slot].numel() * 64, (ARCHS[arch], S, slot, n_diff)
 
 
+@pytest.mark.parametrize("in_a", [0, 48])
+def test_view_direction_training_forward_on_the_hand_scheduled_kernel(in_a, hip_lib):
+    """Round 6: the TRAINING forward of a view-direction model -- the reference's documented training configuration (README.md:226-233:
+    --use_viewdir --N_samples 128 --N_importance 0) -- on the SAVE build of the hand-scheduled body: given the per-ray [dir | a] rows
+    (nsff_side_bias), nsff_field_kernel_h3a_save runs the static trunk with static_dir_encoding as a folded segment and sigma as a ride
+    of the last trunk layer's epilogues, and saves what the backward kernels read: every trunk layer's activation and sign words,
+    static_dir_encoding's in the static trunk's slot D, the [dir | a] input tile (a small launch of its own).  Against the eight-wave
+    training forward, which multiplies the [dir | a] columns: records 2e-5, saves equal up to fp16 rounding on < 1 % of the values."""
+    from nsff_pl_amd import field_grad
+    torch.manual_seed(77 + in_a)
+    emb, emb_d = A.PosEmbedding(9, 10), A.PosEmbedding(3, 4)
+    m = A.NeRF("fine", use_viewdir=True, encode_appearance=in_a > 0, in_channels_a=max(in_a, 1), encode_transient=True, output_flow=True)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(".weight"):
+                p.mul_(2.5)
+    m.to(DEV)
+    D = m.D
+    freqs = [float(f) for f in emb.freqs]
+    g = torch.Generator().manual_seed(5 + in_a)
+    config.set_precision("f16x3")
+    for S, n_rays, sm, tm in ((128, 12, 2, 2), (64, 6, 2, 0)):
+        P = S * n_rays
+        xyz = (torch.rand(P, 3, generator=g) * 2.4 - 1.2).to(DEV)
+        t_rows = torch.randn(n_rays, 48, generator=g).to(DEV)
+        dirs = emb_d(torch.randn(n_rays, 3, generator=g).to(DEV)).contiguous()
+        a_rows = torch.randn(n_rays, in_a, generator=g).to(DEV) if in_a else None
+        out = {}
+        for tile, rows in ((130, True), (131, False)):
+            config.set_tile_points(tile)
+            raw = torch.full((P, _lib.RAW_STRIDE), float("nan"), device=DEV)
+            acts, xin, masks, side = field_grad.alloc_saves(m, P, DEV, bool(tm), True)
+            acts.view(torch.int16).fill_(0x7e01); masks.fill_(-2)             # (fill patterns: what the launch does not write keeps them)
+            try:
+                _lib.field_query(m, raw, P, S, sm, tm, 2 if tm else 0, xyz=xyz, freqs=freqs, t_emb=t_rows if tm else None, dir_emb=dirs, a_emb=a_rows,
+                                 save_acts=acts, save_xin=xin, save_masks=masks, save_side=side,
+                                 s_bias=_lib.side_bias(m, dirs, a_rows) if rows else None)
+                torch.cuda.synchronize()
+                out[tile] = (raw.cpu().numpy(), acts.cpu(), masks.cpu(), side.cpu(), _lib.last_field_kernel())
+            finally:
+                config.set_tile_points(0)
+        (a, acts_a, masks_a, side_a, ka), (b, acts_b, masks_b, side_b, kb) = out[130], out[131]
+        assert ka == "h3a_save" and kb == "h3_save", (ka, kb)
+        for lo, hi in ((0, 4),) + (((4, 8), (8, 14)) if tm else ()):
+            scale = max(np.abs(b[:, lo:hi]).max(), 1e-30)
+            assert np.abs(a[:, lo:hi] - b[:, lo:hi]).max() <= 2e-5 * scale, (in_a, S, sm, tm, lo, np.abs(a[:, lo:hi] - b[:, lo:hi]).max() / scale)
+        # the [dir | a] tile: the eight-wave kernel rounds hi + lo halfs, the side-tile launch the fp32 row -- one fp16 rounding apart at most
+        n_side = m.in_channels_dir + (in_a if in_a else 0)
+        ds = (side_a.float() - side_b.float()).abs()
+        assert float(ds.max()) <= 2.0 ** -9 * float(side_b.float().abs().max()) and float((ds > 0).float().mean()) < 0.01
+        assert float(side_a.float().abs().max()) > 0.5
+        written = [l for l in range(D + 1)] + ([D + 1 + l for l in range(D)] if tm else [])       # (static: the trunk's slots AND slot D, static_dir_encoding)
+        for slot in range(acts_a.shape[0]):
+            xa, xb = acts_a[slot].float(), acts_b[slot].float()
+            if slot not in written:
+                assert (acts_a[slot].view(torch.int16) == 0x7e01).all() and (masks_a[slot] == -2).all(), slot
+                assert (acts_b[slot].view(torch.int16) == 0x7e01).all(), slot
+                continue
+            dif = (xa - xb).abs()
+            assert bool((dif <= xb.abs() * 2.0 ** -9 + 4e-6 * float(xb.abs().max())).all()), (in_a, S, slot, float(dif.max()))
+            assert float((dif > 0).float().mean()) < 0.01
+            diff_bits = (masks_a[slot] ^ masks_b[slot])
+            n_diff = sum(bin(int(v) & 0xFFFFFFFFFFFFFFFF).count("1") for v in diff_bits.reshape(-1)[diff_bits.reshape(-1) != 0].tolist())
+            assert n_diff <= 2e-4 * masks_a[slot].numel() * 64, (in_a, S, slot, n_diff)
+
+
 def test_persistent_launch_is_bit_identical_to_one_workgroup_per_tile(hip_lib, monkeypatch):
     """Large launches of the hand-scheduled kernel are persistent (include/nsff_render.h::nsff_last_field_grid): one workgroup per
     compute unit walks tiles of ONE trunk -- both trunks split by XCD; when they do not cost the same (time code through the matrix

@@ -432,7 +432,8 @@ def run_case(kind, seed=0, verbose=True):
 
 if __name__ == "__main__":
     kinds = sys.argv[1:] or ["static", "dynamic", "noskip", "twoskips", "dynamic_tb", "twoskips_tb", "viewdir",
-                             "static_save", "dynamic_save", "twoskips_save", "static_persist", "dynamic_tb_persist", "viewdir_persist"]
+                             "static_save", "dynamic_save", "twoskips_save", "viewdir_save", "static_persist", "dynamic_tb_persist",
+                             "viewdir_persist"]
     for k in kinds:
         try:
             run_case(k)

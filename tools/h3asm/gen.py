@@ -956,12 +956,13 @@ def _build():
         "EPI_B": bare_epilogue("EPI_B", "B"),
         "HEAD": head_body(),
     }
+    # the sigma ride of a view-direction static trunk: the last trunk layer's B phase and the A phase behind it (round 6: in the SAVE
+    # build too -- the reference's documented training configuration, README.md:226-233, is a view-direction model)
+    bodies["B16RS"] = phase_body("B16RS", "B", 16, ride="epi_sig_ws", refills=True, tail_init=True, one_stream=True, copy=cp)
+    bodies["A16RS"] = phase_body("A16RS", "A", 16, ride="epi_sig", tail_init=True, vm_mode="formula", copy=cp)
     if SAVE:
         bodies["SAVE_LAST"] = save_last_body()
     else:
-        # the sigma ride of a view-direction static trunk: the last trunk layer's B phase and the A phase behind it
-        bodies["B16RS"] = phase_body("B16RS", "B", 16, ride="epi_sig_ws", refills=True, tail_init=True, one_stream=True)
-        bodies["A16RS"] = phase_body("A16RS", "A", 16, ride="epi_sig", tail_init=True, vm_mode="formula")
         # the last segment's B phase of a persistent workgroup: the next tile's weight slots 0..7 behind its k-steps 1..8
         bodies["B16LP"] = phase_body("B16LP", "B", 16, ride="epi", refills=True, refill_slots=range(8))
     dispatcher.bodies = set(bodies)
