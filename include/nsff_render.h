@@ -286,7 +286,8 @@ typedef struct NsffFieldBwdArgs {
     int32_t transient_mode;     /* 0 skip, 2                                                */
     const float* d_raw;         /* (P, NSFF_RAW_STRIDE) gradient w.r.t. the raw record      */
     const float* raw;           /* (P, NSFF_RAW_STRIDE) forward outputs (activation derivatives) */
-    const float* gmax;          /* device scalar: max |d_raw|                                */
+    const float* gmax;          /* device float[16]: max |d_raw| per record column (nsff_absmax_raw): each trunk's fragments are on
+                                 * the power-of-two scale of its largest column, every head row of dhead on its own        */
     const void*  masks;         /* save_masks of the forward call                            */
     void*  dpre;                /* OUT */
     void*  dhead;               /* OUT */
@@ -325,6 +326,7 @@ typedef struct NsffWgradJob {
     const void* a;  const void* b;
     int32_t a_rows, b_rows;
     int64_t out_off;            /* floats */
+    int32_t trunk, pad_;        /* 0 static / 1 dynamic: which of the two scales (gmax[trunk]) the job's A operand is on */
 } NsffWgradJob;
 int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits);
 int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,
@@ -388,6 +390,12 @@ int nsff_fold_grads_dense(const NsffFoldDenseArgs* args, void* stream);
 /* out[0] = max |x[i]| (0 for n == 0): the device scalar `gmax` of nsff_field_backward / nsff_weight_grad without a
  * host round trip (replaces d_raw.abs().max()).  x 16-byte aligned.                                                */
 int nsff_absmax(const float* x, int64_t n, float* out, void* stream);
+/* out16[c] = max |d_raw[:, c]| for the 16 floats of a record: the `gmax` vector of nsff_field_backward / nsff_weight_grad*.  A trunk's
+ * fragments (dpre) are on the scale of its largest column (static: 0..3, dynamic: 4..13), every head row of dhead on its own: in a
+ * real NSFF step the columns' gradients are 10^6-10^7 apart (the 2D flow terms of the loss are in pixels); on a common scale the
+ * smaller ones' fp16 fragments fall into the subnormal range, which the weight-gradient MFMAs read as zero (round 6, golden g20:
+ * static weight gradients 40-70 % too small at 512 rays, transient_sigma.weight 25 %). */
+int nsff_absmax_raw(const float* d_raw, int64_t n_points, float* out16, void* stream);
 
 /* ---- N1: the optimizer step: torch.optim.Adam(lr, betas, eps, weight_decay) as the reference builds it
  * (utils/__init__.py:45-47 get_optimizer, used by train.py:140-146), amsgrad off, on flat fp32 buffers of n elements

@@ -114,7 +114,8 @@ class FieldBwdArgs(C.Structure):
 
 
 class WgradJob(C.Structure):
-    _fields_ = [("a", _fp), ("b", _fp), ("a_rows", C.c_int32), ("b_rows", C.c_int32), ("out_off", C.c_int64)]
+    _fields_ = [("a", _fp), ("b", _fp), ("a_rows", C.c_int32), ("b_rows", C.c_int32), ("out_off", C.c_int64), ("trunk", C.c_int32),
+                ("pad_", C.c_int32)]
 
 
 class FoldGradArgs(C.Structure):
@@ -205,6 +206,7 @@ _SIGNATURES = {
                                               _fp, _fp, _fp]),
     "nsff_weight_grad_accumulate_aux": (C.c_int, [C.POINTER(WgradJob), C.c_int32, C.c_int64, C.c_int32, _fp, _fp, C.c_int64,
                                                   _fp, _fp, _fp, _fp]),
+    "nsff_absmax_raw": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "nsff_last_bwd_kernel": (C.c_int, []),
     "nsff_field_bwd_phase_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_uint32), C.c_int32,
                                                 C.POINTER(C.c_uint32), C.c_int32]),
@@ -737,8 +739,9 @@ def field_input_backward(d_xin, t_row0, xyz, pts_per_ray, freqs, in_t, want_xyz,
 
 
 def weight_grad(jobs, n_tiles, n_splits, out, bias, gmax):
-    """jobs: list of (a_ptr, b_ptr, a_rows, b_rows, out_off); out / bias receive the final (summed, unscaled) gradients."""
-    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=j[4]) for j in jobs])
+    """jobs: list of (a_ptr, b_ptr, a_rows, b_rows, out_off, trunk); out / bias receive the final (summed, unscaled) gradients;
+    gmax: the pair of per-trunk maxima (absmax of the raw-record gradient)."""
+    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=j[4], trunk=j[5]) for j in jobs])
     n = load().nsff_weight_grad_scratch(arr, len(jobs), int(n_tiles), int(n_splits))
     if n < 0:
         raise RuntimeError("nsff_weight_grad_scratch failed")
@@ -751,7 +754,7 @@ def weight_grad_accumulate(jobs, n_tiles, n_splits, grad_map, grad_base_ptr, gma
     """The same GEMMs, accumulated straight into the parameters' gradient memory.  grad_map: (n,4) int32 device tensor of
     NsffGradMapEntry rows; grad_base_ptr: device address the map's `dst` offsets count from; aux: fp32 tensor that receives
     the entries with dst < 0 (dense sums for the folded parameters)."""
-    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=0) for j in jobs])
+    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=0, trunk=j[5]) for j in jobs])
     n = load().nsff_weight_grad_scratch(arr, len(jobs), int(n_tiles), int(n_splits))
     if n < 0:
         raise RuntimeError("nsff_weight_grad_scratch failed")
@@ -790,8 +793,13 @@ def fold_grads_dense(g, gb, w_head, w_final, b_final, d_w_head, d_b_head, d_w_fi
 
 
 def absmax(x):
-    """max |x| as a device scalar (one launch, no host round trip)."""
+    """max |x| as a device scalar (one launch, no host round trip).  For a raw-record gradient (P, RAW_STRIDE): the 16 COLUMN
+    maxima -- what field_backward / weight_grad* derive their scales from (one per trunk for the fragments, one per head row)."""
     x = x.contiguous()
+    if x.dim() == 2 and x.shape[1] == RAW_STRIDE:
+        out = torch.empty(RAW_STRIDE, device=x.device, dtype=torch.float32)
+        _check(load().nsff_absmax_raw(_ptr(x), x.shape[0], _ptr(out), _stream()), "nsff_absmax_raw")
+        return out
     out = torch.empty((), device=x.device, dtype=torch.float32)
     _check(load().nsff_absmax(_ptr(x), x.numel(), _ptr(out), _stream()), "nsff_absmax")
     return out

@@ -146,7 +146,7 @@ class _FieldFn(torch.autograd.Function):
         S_DIR = D
         n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
         d_raw = d_raw.contiguous()
-        gmax = _lib.absmax(d_raw)
+        gmax = _lib.absmax(d_raw)                 # [static, dynamic]: one power-of-two scale per trunk (see nsff_absmax_raw)
         dpre = torch.empty(n_slots(model), tiles, 64 * 256, device=dev, dtype=torch.float16)
         dhead = torch.empty(2, tiles, 64 * 32, device=dev, dtype=torch.float16)
         want_in = transient and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
@@ -172,7 +172,7 @@ class _FieldFn(torch.autograd.Function):
                 a_, b_, rows = dhead[0], acts[base + D - 1], (32, 256)
             else:                                                 # the (folded) heads read the last trunk activation as well
                 a_, b_, rows = dhead[t], acts[S_DIR if (t == 0 and viewdir) else base + D - 1], (32, 256)
-            jobs.append([a_.data_ptr(), b_.data_ptr(), rows[0], rows[1], 0])
+            jobs.append([a_.data_ptr(), b_.data_ptr(), rows[0], rows[1], 0, t])      # (t: the trunk whose scale gmax[t] dpre / dhead are on)
             sizes.append(rows[0] * rows[1])
         # requested split-K factor; the library rounds it to whole rounds of the 256 CUs (16 -> one round of 14 splits x 18 jobs:
         # 7.52 ms per C2 step against 7.63 at 32 = two rounds, 7.79 at 48: fewer partial sums for the accumulate pass to read)

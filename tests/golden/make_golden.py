@@ -62,6 +62,36 @@ def to_np(d):
     return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in d.items()}
 
 
+def make_g20(scenes, NeRF, PosEmbedding, render_rays, ref_losses):
+    # ---- the README training configuration at batch size 512 (g20): statistics only, fp32 and fp64 ----
+    torch.set_grad_enabled(True)
+    cfg = scenes.README_TRAIN_CASE
+    rays, ts = scenes.synthetic_rays(cfg["n_rays"], cfg["seed"])
+    save = {}
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        models, embeddings = scenes.build_scene(NeRF, PosEmbedding, cfg)
+        for m in list(models.values()) + [embeddings["t"]]:
+            m.to(dt)
+        kw = scenes.render_kwargs(cfg)
+        loss_fn = ref_losses.NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0)
+        Ks, Ps, max_t = scenes.camera_buffers()
+        loss_fn.register_buffer("Ks", Ks.to(dt)); loss_fn.register_buffer("Ps", Ps.to(dt)); loss_fn.max_t = max_t
+        targets = {k: (v.to(dt) if v.is_floating_point() else v)
+                   for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+        res = render_rays({"fine": models["fine"]}, embeddings, rays.to(dt), ts, scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, 0,
+                          1024 * 32, test_time=False, **kw)
+        ld = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+        total = sum(ld.values())
+        total.backward()
+        stats, _ = scenes.grad_stats({"fine": models["fine"]}, embeddings)
+        save["terms" + tag] = np.frombuffer(json.dumps({k: float(v) for k, v in ld.items()}).encode(), dtype=np.uint8)
+        save["stats" + tag] = np.frombuffer(json.dumps(stats).encode(), dtype=np.uint8)
+        print(f"g20 README training configuration fp{tag}: total {float(total):.6f}  terms {len(ld)}  {len(stats)} parameter tensors")
+    np.savez_compressed(os.path.join(HERE, "g20_loss_readme_train_512.npz"), **save)
+    torch.set_grad_enabled(False)
+
+
+
 def main():
     import scenes
     from oracle import nsff_oracle as orc
@@ -69,6 +99,11 @@ def main():
     torch.set_grad_enabled(False)
     DRAW_SEED = 4242
 
+    if "--g20" in sys.argv:            # only the README-training-configuration statistics (python tests/golden/make_golden.py --g20)
+        sys.path.insert(0, REF)
+        import losses as ref_losses
+        make_g20(scenes, NeRF, PosEmbedding, render_rays, ref_losses)
+        return
     only = None
     if "--only" in sys.argv:
         only = sys.argv[sys.argv.index("--only") + 1].split(",")
@@ -200,6 +235,8 @@ def main():
             print(f"loss golden {name} fp{tag}: total {float(total):.6f}  terms {len(ld)}")
         np.savez_compressed(os.path.join(HERE, "g10_loss_" + name + ".npz"), **save)
     torch.set_grad_enabled(False)
+
+    make_g20(scenes, NeRF, PosEmbedding, render_rays, ref_losses)
 
     # ---- stage goldens ----
     g = torch.Generator().manual_seed(77)

@@ -259,6 +259,11 @@ def grad_stats(models, embeddings):
 # ---- trainer-side synthetic data for the loss goldens (reference losses.py / train.py:136-138,178-198) ----
 LOSS_CASES = ("g3_nsff_train", "g7_nsff_train_noise")
 LOSS_EPOCH = 5
+# The reference's documented TRAINING configuration at its real batch size (README.md:226-233: --use_viewdir --N_samples 128
+# --N_importance 0 --batch_size 512, encode_t): the golden g20 holds STATISTICS only -- loss terms and per-parameter gradient
+# statistics of the reference in fp32 and fp64 (the per-sample outputs of 512 x 128 points would be 15 MB)
+README_TRAIN_CASE = dict(n_rays=512, N_samples=128, N_importance=0, transient=True, viewdir=True, appearance=False,
+                         test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=20)
 
 
 def camera_buffers():

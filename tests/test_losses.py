@@ -307,3 +307,64 @@ def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, topk, thi
     assert sorted(g1) == sorted(g0), sorted(set(g1) ^ set(g0))
     for k in g0:
         parity.assert_close("d loss / d " + k, g1[k], g0[k], 2e-4)
+
+
+@pytest.mark.gpu
+def test_readme_training_configuration_at_batch_size_512_matches_reference_statistics(hip_lib):
+    """The reference's documented training configuration at its real batch size (README.md:226-233: --use_viewdir --N_samples 128
+    --N_importance 0 --batch_size 512, encode_t, flows fw / bw / disocc): one forward + NeRFWLoss + backward of the build against
+    golden g20 -- the reference's own loss terms and per-parameter gradient statistics (sum g, sum |g|, <g, r>) in fp32 and fp64,
+    generated by tests/golden/make_golden.py --g20 (statistics only: the per-sample outputs of 65 536 points would be 15 MB).
+    Compared with the fp64 values within the suite's bounds (1e-4 per term, 2e-3 |g|_1 per tensor) + 3 x the reference's own
+    fp32 - fp64 distance; every field launch must have run the hand-scheduled kernels (training forward: h3a_save for BOTH trunks)."""
+    from test_gpu_parity import _to_dev, DEV
+    from test_gradients import GRAD_RTOL
+    from nsff_pl_amd import _lib
+    z = np.load(common.GOLDEN_DIR + "/g20_loss_readme_train_512.npz")
+    t32, t64 = (json.loads(bytes(z["terms" + t]).decode()) for t in ("32", "64"))
+    s32, s64 = (json.loads(bytes(z["stats" + t]).decode()) for t in ("32", "64"))
+    cfg = scenes.README_TRAIN_CASE
+    A.set_precision("f16x3")
+    try:
+        rays, ts = scenes.synthetic_rays(cfg["n_rays"], cfg["seed"])
+        models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+        models = {"fine": models["fine"]}
+        _to_dev(models, emb)
+        kw = scenes.render_kwargs(cfg)
+        kernels = set()
+        orig_q = _lib.field_query
+
+        def q(*a, **k):
+            r = orig_q(*a, **k)
+            kernels.add(_lib.last_field_kernel())
+            return r
+        _lib.field_query = q
+        try:
+            res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, 0, 1024 * 32,
+                                test_time=False, **kw)
+        finally:
+            _lib.field_query = orig_q
+        assert kernels == {"h3a_save"}, kernels
+        loss_fn = NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0)
+        Ks, Ps, max_t = scenes.camera_buffers()
+        loss_fn.register_buffer("Ks", Ks); loss_fn.register_buffer("Ps", Ps); loss_fn.max_t = max_t
+        loss_fn.to(DEV)
+        targets = {k: v.to(DEV) for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+        terms = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+        assert sorted(terms) == sorted(t64)
+        for k, v in t64.items():
+            g = float(terms[k].detach())
+            assert abs(g - v) <= TERM_RTOL * max(abs(v), 1e-6) + 3 * abs(t32[k] - v), (k, g, v, t32[k])
+        sum(terms.values()).backward()
+        torch.cuda.synchronize()
+        assert _lib.last_bwd_kernel() in ("h3b", "c+h3b")
+        stats, _ = scenes.grad_stats(models, emb)
+        assert sorted(stats) == sorted(s64)
+        scale = max(abs(v[1]) for v in s64.values())
+        for pname, want in s64.items():
+            mag = max(want[1], 1e-6 * scale)
+            for i in range(3):
+                tol = GRAD_RTOL * mag + 3 * abs(s32[pname][i] - want[i])
+                assert abs(stats[pname][i] - want[i]) <= tol, (pname, i, stats[pname], want, s32[pname], tol)
+    finally:
+        A.set_precision(A.config.DEFAULT_PRECISION)
