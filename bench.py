@@ -583,7 +583,10 @@ def aux_block(bench, args):
         t, _, _ = timed(bench.train_step(), 5, 3 if not graph else 1, 1, dev)
         aux["train_ms_per_step" + ("_graph" if graph else "_eager")] = t / 5 * 1e3
         bench.models = cfg_models
-    aux["train_ray_samples_per_s"] = N_RAYS * (N_SAMPLES + N_IMPORTANCE) / (aux["train_ms_per_step_graph"] * 1e-3)
+    # (the trainer's default form is the eager step -- NSFFTrainer(graph=False); the two-hipGraph replay is 2-3 % slower on this
+    #  stack: a replayed node costs what an eager launch costs, the host already runs ahead of the GPU, and the replay adds a fixed
+    #  cost per graph launch: DESIGN.md section 7)
+    aux["train_ray_samples_per_s"] = N_RAYS * (N_SAMPLES + N_IMPORTANCE) / (aux["train_ms_per_step_eager"] * 1e-3)
     return aux
 
 
