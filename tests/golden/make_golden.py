@@ -92,6 +92,46 @@ def make_g20(scenes, NeRF, PosEmbedding, render_rays, ref_losses):
 
 
 
+def make_g21(scenes, NeRF, PosEmbedding, render_rays, ref_losses):
+    # ---- the C2 training configuration at 512 rays (g21): statistics + the fine depths, fp32 and fp64 ----
+    torch.set_grad_enabled(True)
+    import models.rendering as R
+    cfg = scenes.C2_TRAIN_CASE
+    rays, ts = scenes.synthetic_rays(cfg["n_rays"], cfg["seed"])
+    save = {}
+    zs32 = None
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        models, embeddings = scenes.build_scene(NeRF, PosEmbedding, cfg)
+        for m in list(models.values()) + [embeddings["t"]]:
+            m.to(dt)
+        kw = scenes.render_kwargs(cfg)
+        loss_fn = ref_losses.NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0)
+        Ks, Ps, max_t = scenes.camera_buffers()
+        loss_fn.register_buffer("Ks", Ks.to(dt)); loss_fn.register_buffer("Ps", Ps.to(dt)); loss_fn.max_t = max_t
+        targets = {k: (v.to(dt) if v.is_floating_point() else v)
+                   for k, v in scenes.synthetic_targets(cfg["n_rays"], ts, cfg["seed"]).items()}
+        orig_sort = R.torch.sort
+        if dt == torch.float64:             # the fp64 run at the fp32 run's depths (sampling is not differentiated)
+            R.torch.sort = lambda *a, **k_: (zs32.double(), None)
+        try:
+            res = render_rays(models, embeddings, rays.to(dt), ts, scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, cfg["N_importance"],
+                              1024 * 32, test_time=False, **kw)
+        finally:
+            R.torch.sort = orig_sort
+        if dt == torch.float32:
+            zs32 = res["zs_fine"].detach().clone()
+            save["zs_fine"] = zs32.numpy()
+        ld = loss_fn(res, targets, epoch=scenes.LOSS_EPOCH, **kw)
+        total = sum(ld.values())
+        total.backward()
+        stats, _ = scenes.grad_stats(models, embeddings)
+        save["terms" + tag] = np.frombuffer(json.dumps({k: float(v) for k, v in ld.items()}).encode(), dtype=np.uint8)
+        save["stats" + tag] = np.frombuffer(json.dumps(stats).encode(), dtype=np.uint8)
+        print(f"g21 C2 training configuration fp{tag}: total {float(total):.6f}  terms {len(ld)}  {len(stats)} parameter tensors")
+    np.savez_compressed(os.path.join(HERE, "g21_loss_c2_train_512.npz"), **save)
+    torch.set_grad_enabled(False)
+
+
 def main():
     import scenes
     from oracle import nsff_oracle as orc
@@ -99,10 +139,13 @@ def main():
     torch.set_grad_enabled(False)
     DRAW_SEED = 4242
 
-    if "--g20" in sys.argv:            # only the README-training-configuration statistics (python tests/golden/make_golden.py --g20)
+    if "--g20" in sys.argv or "--g21" in sys.argv:      # only the training-configuration statistics (python tests/golden/make_golden.py --g20 | --g21)
         sys.path.insert(0, REF)
         import losses as ref_losses
-        make_g20(scenes, NeRF, PosEmbedding, render_rays, ref_losses)
+        if "--g20" in sys.argv:
+            make_g20(scenes, NeRF, PosEmbedding, render_rays, ref_losses)
+        if "--g21" in sys.argv:
+            make_g21(scenes, NeRF, PosEmbedding, render_rays, ref_losses)
         return
     only = None
     if "--only" in sys.argv:
@@ -237,6 +280,7 @@ def main():
     torch.set_grad_enabled(False)
 
     make_g20(scenes, NeRF, PosEmbedding, render_rays, ref_losses)
+    make_g21(scenes, NeRF, PosEmbedding, render_rays, ref_losses)
 
     # ---- stage goldens ----
     g = torch.Generator().manual_seed(77)

@@ -262,6 +262,11 @@ LOSS_EPOCH = 5
 # The reference's documented TRAINING configuration at its real batch size (README.md:226-233: --use_viewdir --N_samples 128
 # --N_importance 0 --batch_size 512, encode_t): the golden g20 holds STATISTICS only -- loss terms and per-parameter gradient
 # statistics of the reference in fp32 and fp64 (the per-sample outputs of 512 x 128 points would be 15 MB)
+# ... and the bench's own training configuration (C2 / C4: 64 coarse + 64 importance samples -> 192 fine points, coarse and fine model,
+# flows + disocclusion) at 512 rays: golden g21 -- statistics, plus the reference's fine depths (sample_pdf is ill-conditioned:
+# gradients are compared at identical depths, tests/parity.py)
+C2_TRAIN_CASE = dict(n_rays=512, N_samples=64, N_importance=64, transient=True, viewdir=False, appearance=False,
+                     test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=21)
 README_TRAIN_CASE = dict(n_rays=512, N_samples=128, N_importance=0, transient=True, viewdir=True, appearance=False,
                          test_time=False, flow=['fw', 'bw', 'disocc'], gain=2.5, seed=20)
 

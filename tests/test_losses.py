@@ -309,26 +309,21 @@ def test_fused_loss_kernels_equal_the_torch_expression(n_rays, coarse, topk, thi
         parity.assert_close("d loss / d " + k, g1[k], g0[k], 2e-4)
 
 
-@pytest.mark.gpu
-def test_readme_training_configuration_at_batch_size_512_matches_reference_statistics(hip_lib):
-    """The reference's documented training configuration at its real batch size (README.md:226-233: --use_viewdir --N_samples 128
-    --N_importance 0 --batch_size 512, encode_t, flows fw / bw / disocc): one forward + NeRFWLoss + backward of the build against
-    golden g20 -- the reference's own loss terms and per-parameter gradient statistics (sum g, sum |g|, <g, r>) in fp32 and fp64,
-    generated by tests/golden/make_golden.py --g20 (statistics only: the per-sample outputs of 65 536 points would be 15 MB).
-    Compared with the fp64 values within the suite's bounds (1e-4 per term, 2e-3 |g|_1 per tensor) + 3 x the reference's own
-    fp32 - fp64 distance; every field launch must have run the hand-scheduled kernels (training forward: h3a_save for BOTH trunks)."""
+def _step_against_statistics(golden, cfg, models_of, forward_kernels, zs_key=None):
+    """One forward + NeRFWLoss + backward of the build against a statistics golden (terms32 / terms64 / stats32 / stats64 [+ zs_fine]):
+    compared with the fp64 values within the suite's bounds (1e-4 per term, 2e-3 |g|_1 per tensor) + 3 x the reference's own
+    fp32 - fp64 distance; asserts which kernels the field launches took."""
     from test_gpu_parity import _to_dev, DEV
     from test_gradients import GRAD_RTOL
     from nsff_pl_amd import _lib
-    z = np.load(common.GOLDEN_DIR + "/g20_loss_readme_train_512.npz")
+    z = np.load(common.GOLDEN_DIR + "/" + golden)
     t32, t64 = (json.loads(bytes(z["terms" + t]).decode()) for t in ("32", "64"))
     s32, s64 = (json.loads(bytes(z["stats" + t]).decode()) for t in ("32", "64"))
-    cfg = scenes.README_TRAIN_CASE
     A.set_precision("f16x3")
     try:
         rays, ts = scenes.synthetic_rays(cfg["n_rays"], cfg["seed"])
         models, emb = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
-        models = {"fine": models["fine"]}
+        models = models_of(models)
         _to_dev(models, emb)
         kw = scenes.render_kwargs(cfg)
         kernels = set()
@@ -339,12 +334,13 @@ def test_readme_training_configuration_at_batch_size_512_matches_reference_stati
             kernels.add(_lib.last_field_kernel())
             return r
         _lib.field_query = q
+        render = common.render_rays_at(z[zs_key] if zs_key else None)
         try:
-            res = A.render_rays(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, 0, 1024 * 32,
-                                test_time=False, **kw)
+            res = render(models, emb, rays.to(DEV), ts.to(DEV), scenes.N_FRAMES - 1, cfg["N_samples"], 0, 0, cfg["N_importance"], 1024 * 32,
+                         test_time=False, **kw)
         finally:
             _lib.field_query = orig_q
-        assert kernels == {"h3a_save"}, kernels
+        assert kernels == forward_kernels, kernels
         loss_fn = NeRFWLoss(lambda_geo=0.04, thickness=1, topk=1.0)
         Ks, Ps, max_t = scenes.camera_buffers()
         loss_fn.register_buffer("Ks", Ks); loss_fn.register_buffer("Ps", Ps); loss_fn.max_t = max_t
@@ -357,7 +353,7 @@ def test_readme_training_configuration_at_batch_size_512_matches_reference_stati
             assert abs(g - v) <= TERM_RTOL * max(abs(v), 1e-6) + 3 * abs(t32[k] - v), (k, g, v, t32[k])
         sum(terms.values()).backward()
         torch.cuda.synchronize()
-        assert _lib.last_bwd_kernel() in ("h3b", "c+h3b")
+        bwd = _lib.last_bwd_kernel()
         stats, _ = scenes.grad_stats(models, emb)
         assert sorted(stats) == sorted(s64)
         scale = max(abs(v[1]) for v in s64.values())
@@ -366,5 +362,30 @@ def test_readme_training_configuration_at_batch_size_512_matches_reference_stati
             for i in range(3):
                 tol = GRAD_RTOL * mag + 3 * abs(s32[pname][i] - want[i])
                 assert abs(stats[pname][i] - want[i]) <= tol, (pname, i, stats[pname], want, s32[pname], tol)
+        return bwd
     finally:
         A.set_precision(A.config.DEFAULT_PRECISION)
+
+
+@pytest.mark.gpu
+def test_readme_training_configuration_at_batch_size_512_matches_reference_statistics(hip_lib):
+    """The reference's documented training configuration at its real batch size (README.md:226-233: --use_viewdir --N_samples 128
+    --N_importance 0 --batch_size 512, encode_t, flows fw / bw / disocc): one forward + NeRFWLoss + backward of the build against
+    golden g20 -- the reference's own loss terms and per-parameter gradient statistics (sum g, sum |g|, <g, r>) in fp32 and fp64,
+    generated by tests/golden/make_golden.py --g20 (statistics only: the per-sample outputs of 65 536 points would be 15 MB).
+    Every field launch must have run the hand-scheduled kernels (training forward: h3a_save for BOTH trunks).  When this test was
+    written it FAILED: static-trunk weight gradients 40-70 % too small -- one power-of-two scale per launch put the smaller record
+    columns' fp16 gradient fragments into the subnormal range, which the weight-gradient MFMAs read as zero (DESIGN.md section 9);
+    the 16-ray goldens cannot see that: the outliers that set the scale come with the batch size."""
+    bwd = _step_against_statistics("g20_loss_readme_train_512.npz", scenes.README_TRAIN_CASE, lambda m: {"fine": m["fine"]}, {"h3a_save"})
+    assert bwd in ("h3b", "c+h3b")
+
+
+@pytest.mark.gpu
+def test_c2_training_configuration_at_512_rays_matches_reference_statistics(hip_lib):
+    """The bench's own training configuration (C2 / C4: 64 coarse + 64 importance samples -> 192 fine points, coarse and fine model,
+    flows + disocclusion) at 512 rays against golden g21 (tests/golden/make_golden.py --g21): the reference's loss terms and gradient
+    statistics of all 93 parameter tensors in fp32 and fp64, evaluated at the reference's fine depths (stored: sample_pdf is
+    ill-conditioned, tests/parity.py)."""
+    bwd = _step_against_statistics("g21_loss_c2_train_512.npz", scenes.C2_TRAIN_CASE, lambda m: m, {"h3a_save"}, zs_key="zs_fine")
+    assert bwd == "h3b"
