@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      30
+#define NSFF_ABI_VERSION      31
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -182,6 +182,11 @@ typedef struct NsffFieldArgs {
      * all-gather of a multi-GPU evaluation, nsff_pl_amd/dist.py::all_gather_pixels_async) asks for 1, so that the collective gets
      * a compute unit at the next tile boundary and a render workgroup never waits behind it for a whole launch. */
     int32_t launch_form;
+    /* Training forward for the THREE-PRODUCT backward (nsff_field_backward / nsff_weight_grad* with grad_x3): every saved tile is
+     * written twice -- the fp16 value `v = fp16(x)` as before and, save_lo_delta[i] ELEMENTS behind it in the same buffer
+     * (i = 0 save_acts, 1 save_xin, 2 save_side; 0 = not wanted), the remainder `fp16(x - v)`: the backward's GEMMs then multiply
+     * hi + lo operands as the forward does.  Eight-wave SAVE kernel only (the launch takes it when any delta is set). */
+    int64_t save_lo_delta[3];
 } NsffFieldArgs;
 
 int nsff_field_query(const NsffModelDesc* desc, const void* packed,
@@ -293,6 +298,12 @@ typedef struct NsffFieldBwdArgs {
     void*  dhead;               /* OUT */
     float* d_xin;               /* OUT or NULL                                               */
     float* d_side;              /* OUT or NULL (use_viewdir models, static_mode 2)           */
+    int64_t dpre_lo_delta;      /* 0: one fp16 product per multiply-accumulate (the measured path).  Otherwise THREE, as the forward
+                                 * multiplies: gradient tiles and weights as fp16 value + fp16 remainder, every pre-activation-gradient
+                                 * tile written twice -- dpre as above and its remainder this many ELEMENTS behind it (multiple of 8) --
+                                 * for nsff_weight_grad* jobs with a_lo_delta set.  The forward of such a step saves its activations
+                                 * the same way (NsffFieldArgs::save_lo_delta).  Gradients then match the reference's fp32 ones to
+                                 * ~1e-5 instead of ~1e-3; the chain runs at about a third of the speed. */
 } NsffFieldBwdArgs;
 int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const NsffFieldBwdArgs* args, void* stream);
 /* Which kernel the last nsff_field_backward launch took: 2 = both (a view-direction model's launch of both trunks: the static trunk
@@ -327,6 +338,10 @@ typedef struct NsffWgradJob {
     int32_t a_rows, b_rows;
     int64_t out_off;            /* floats */
     int32_t trunk, pad_;        /* 0 static / 1 dynamic: which of the two scales (gmax[trunk]) the job's A operand is on */
+    int64_t a_lo_delta, b_lo_delta;   /* 0 / 0: one fp16 product per multiply-accumulate.  Three products (the launches behind a
+                                 * nsff_field_backward with dpre_lo_delta): ELEMENTS from a / b to their remainder planes (dpre's twin,
+                                 * the forward's save_lo_delta twins); every job of a call or none; a_lo_delta stays 0 for the 32-row
+                                 * head jobs, whose A carries its remainder rows itself */
 } NsffWgradJob;
 int64_t nsff_weight_grad_scratch(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits);
 int nsff_weight_grad(const NsffWgradJob* jobs, int32_t n_jobs, int64_t n_tiles, int32_t n_splits,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 30
+ABI_VERSION = 31
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -45,7 +45,7 @@ class FieldArgs(C.Structure):
                 ("off_xyz", C.c_int32), ("off_dir", C.c_int32), ("off_a", C.c_int32),
                 ("off_t", C.c_int32), ("raw", _fp), ("save_acts", _fp), ("save_xin", _fp), ("save_masks", _fp),
                 ("save_side", _fp), ("t_bias", _fp), ("t_bias_rows", C.c_int32), ("reserved0", C.c_int32),
-                ("s_bias", _fp), ("s_bias_rows", C.c_int32), ("launch_form", C.c_int32)]
+                ("s_bias", _fp), ("s_bias_rows", C.c_int32), ("launch_form", C.c_int32), ("save_lo_delta", C.c_int64 * 3)]
 
 
 class TimeBiasJob(C.Structure):
@@ -110,12 +110,12 @@ class CompositeBwdArgs(C.Structure):
 class FieldBwdArgs(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("static_mode", C.c_int32), ("transient_mode", C.c_int32),
                 ("d_raw", _fp), ("raw", _fp), ("gmax", _fp), ("masks", _fp), ("dpre", _fp), ("dhead", _fp),
-                ("d_xin", _fp), ("d_side", _fp)]
+                ("d_xin", _fp), ("d_side", _fp), ("dpre_lo_delta", C.c_int64)]
 
 
 class WgradJob(C.Structure):
     _fields_ = [("a", _fp), ("b", _fp), ("a_rows", C.c_int32), ("b_rows", C.c_int32), ("out_off", C.c_int64), ("trunk", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("pad_", C.c_int32), ("a_lo_delta", C.c_int64), ("b_lo_delta", C.c_int64)]
 
 
 class FoldGradArgs(C.Structure):
@@ -386,7 +386,7 @@ def posenc(x, freqs, out):
 def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, flow_heads=0,
                 xyz=None, freqs=None, dir_emb=None, a_emb=None, t_emb=None,
                 x_emb=None, emb_offsets=(0, -1, -1, -1), save_acts=None, save_xin=None, save_masks=None, save_side=None,
-                precision=None, t_bias=None, s_bias=None):
+                precision=None, t_bias=None, s_bias=None, save_lo=False):
     from . import config
     desc = model_desc(model)
     prec = config.precision_code(model) if precision is None else precision
@@ -415,11 +415,23 @@ def field_query(model, raw, n_points, pts_per_ray, static_mode, transient_mode, 
     a.save_xin = None if save_xin is None else save_xin.data_ptr()
     a.save_masks = None if save_masks is None else save_masks.data_ptr()
     a.save_side = None if save_side is None else save_side.data_ptr()
+    if save_lo:                                 # (field_grad.alloc_saves: the remainder plane of a saved tensor directly behind it)
+        for i, t in enumerate((save_acts, save_xin, save_side)):
+            a.save_lo_delta[i] = 0 if t is None else lo_delta(t)
     if t_bias is not None:                      # (n_rays, rows, 256) from time_bias(): the time code's part of the input layers
         a.t_bias, a.t_bias_rows = _ptr(t_bias), int(t_bias.shape[1])
     if s_bias is not None:                      # (n_rays, 1, 256) from side_bias(): [dir | a]'s part of static_dir_encoding
         a.s_bias, a.s_bias_rows = _ptr(s_bias), int(s_bias.shape[1])
     _check(load().nsff_field_query(C.byref(desc), _ptr(packed), C.byref(a), _stream()), "nsff_field_query")
+
+
+def lo_delta(t):
+    """Elements from a tensor to its remainder twin: the three-product buffers are allocated as (2, ...) -- plane 0 the fp16 values
+    (the tensor every caller holds), plane 1 value - fp16(value) -- so the twin of any slice of plane 0 sits numel(plane) further on."""
+    n = t.numel()
+    if t.untyped_storage().nbytes() < (t.storage_offset() + 2 * n) * t.element_size():
+        raise RuntimeError("three-product backward: this buffer has no remainder plane behind it (field_grad.alloc_saves(..., x3=True))")
+    return n
 
 
 def side_bias(model, dir_rows, a_rows=None):
@@ -691,7 +703,7 @@ def pack_weights_bwd(desc, params, packed, fwd_packed=None):
 def last_bwd_kernel():
     """'h3b' (the hand-scheduled body), 'c' (compiler-scheduled) or 'c+h3b' (a view-direction model's both-trunk launch: static trunk
     on the compiler-scheduled kernel, dynamic trunk on the hand-scheduled one): which kernel(s) the last field_backward launch took"""
-    return {0: "c", 1: "h3b", 2: "c+h3b"}[load().nsff_last_bwd_kernel()]
+    return {0: "c", 1: "h3b", 2: "c+h3b", 3: "x3"}[load().nsff_last_bwd_kernel()]      # x3: the three-product kernel (config.set_grad_precision)
 
 
 def field_bwd_phase_program(model, dynamic, want_xin, n_tiles, max_phases=32):
@@ -708,11 +720,11 @@ def field_bwd_phase_program(model, dynamic, want_xin, n_tiles, max_phases=32):
     return (np.array(list(out), np.uint32).reshape(max_phases, 8)[:n] if n > 0 else None), offs
 
 
-def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side=None):
+def field_backward(model, n_points, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side=None, x3=False):
     desc = model_desc(model)
     a = FieldBwdArgs(n_points=int(n_points), static_mode=2 if static else 0, transient_mode=2 if transient else 0,
                      d_raw=_ptr(d_raw), raw=_ptr(raw), gmax=_ptr(gmax), masks=masks.data_ptr(), dpre=dpre.data_ptr(),
-                     dhead=dhead.data_ptr(), d_xin=_ptr(d_xin), d_side=_ptr(d_side))
+                     dhead=dhead.data_ptr(), d_xin=_ptr(d_xin), d_side=_ptr(d_side), dpre_lo_delta=lo_delta(dpre) if x3 else 0)
     _check(load().nsff_field_backward(C.byref(desc), _ptr(model.packed(BWD_PACK)), C.byref(a), _stream()),
            "nsff_field_backward")
 
@@ -738,10 +750,15 @@ def field_input_backward(d_xin, t_row0, xyz, pts_per_ray, freqs, in_t, want_xyz,
     return d_xyz, d_t
 
 
+def _wgrad_jobs(jobs, with_off):
+    return (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=j[4] if with_off else 0, trunk=j[5],
+                                             a_lo_delta=j[6] if len(j) > 6 else 0, b_lo_delta=j[7] if len(j) > 7 else 0) for j in jobs])
+
+
 def weight_grad(jobs, n_tiles, n_splits, out, bias, gmax):
-    """jobs: list of (a_ptr, b_ptr, a_rows, b_rows, out_off, trunk); out / bias receive the final (summed, unscaled) gradients;
-    gmax: the pair of per-trunk maxima (absmax of the raw-record gradient)."""
-    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=j[4], trunk=j[5]) for j in jobs])
+    """jobs: list of (a_ptr, b_ptr, a_rows, b_rows, out_off, trunk[, a_lo_delta, b_lo_delta]); out / bias receive the final (summed,
+    unscaled) gradients; gmax: the 16 column maxima of the raw-record gradient (absmax)."""
+    arr = _wgrad_jobs(jobs, True)
     n = load().nsff_weight_grad_scratch(arr, len(jobs), int(n_tiles), int(n_splits))
     if n < 0:
         raise RuntimeError("nsff_weight_grad_scratch failed")
@@ -754,7 +771,7 @@ def weight_grad_accumulate(jobs, n_tiles, n_splits, grad_map, grad_base_ptr, gma
     """The same GEMMs, accumulated straight into the parameters' gradient memory.  grad_map: (n,4) int32 device tensor of
     NsffGradMapEntry rows; grad_base_ptr: device address the map's `dst` offsets count from; aux: fp32 tensor that receives
     the entries with dst < 0 (dense sums for the folded parameters)."""
-    arr = (WgradJob * len(jobs))(*[WgradJob(a=j[0], b=j[1], a_rows=j[2], b_rows=j[3], out_off=0, trunk=j[5]) for j in jobs])
+    arr = _wgrad_jobs(jobs, False)
     n = load().nsff_weight_grad_scratch(arr, len(jobs), int(n_tiles), int(n_splits))
     if n < 0:
         raise RuntimeError("nsff_weight_grad_scratch failed")

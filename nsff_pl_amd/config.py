@@ -34,6 +34,35 @@ def get_precision():
     return _precision
 
 
+GRAD_PRECISIONS = ("f16", "f16x3")
+_grad_precision = os.environ.get("NSFF_GRAD_PRECISION", "f16")
+if _grad_precision not in GRAD_PRECISIONS:
+    raise RuntimeError(f"NSFF_GRAD_PRECISION must be one of {list(GRAD_PRECISIONS)}")
+
+
+def set_grad_precision(name):
+    """Arithmetic of the BACKWARD field kernels (csrc/field_bwd.hip).
+    "f16"   -- (default, the measured path) one fp16 product per multiply-accumulate, block floating point, fp32 accumulation:
+               gradients within ~1e-3 of the reference's fp32 autograd (tests/test_gradients.py).
+    "f16x3" -- what the forward does: gradient tiles, transposed weights and saved activations as fp16 value + fp16 remainder,
+               three products per multiply-accumulate in the data-gradient chain and in the weight-gradient GEMMs.  Gradients within
+               ~1e-5 of the reference's; twice the saved-activation memory, the backward kernels at about a third of the speed.
+               The training forward runs on the compiler-scheduled eight-wave kernel (it writes the remainder planes).
+    Read when the forward of a field node runs (the node's backward follows its forward)."""
+    global _grad_precision
+    if name not in GRAD_PRECISIONS:
+        raise ValueError(f"grad precision must be one of {list(GRAD_PRECISIONS)}")
+    _grad_precision = name
+
+
+def get_grad_precision():
+    return _grad_precision
+
+
+def grad_x3():
+    return _grad_precision == "f16x3"
+
+
 def set_tile_points(n):
     """f16x3 only: tiling of the field kernel.  0 = library default (130; inference launches below 32768 points: 64);
     64 = 64 points, four waves of 64 neurons, two workgroups per CU; 130 = 128 points per workgroup: the hand-scheduled

@@ -98,6 +98,7 @@ struct H3KArgs {
     int sb_rows;
     float* raw;
     // training forward (SAVE variant), all fragment-major so that the weight-gradient GEMM streams them:
+    long long lo_delta[3];     // elements from a saved tile to its remainder twin (save_acts, save_xin, save_side); 0: none (NsffFieldArgs::save_lo_delta)
     _Float16* save_acts;       // (slots, tiles, 4 ks, 256 rows, 16 pts) fp16 post-activation values, or null
     _Float16* save_xin;        // (tiles, 4 ks, 128 rows, 16 pts) fp16 trunk input [xyz emb | pad | t at row 64 | pad], or null
     unsigned long long* save_masks;   // (slots, tiles, 256 threads) ReLU sign bits in accumulator order, or null
@@ -439,29 +440,40 @@ typedef __fp16 fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ h4 lds_tr4(const _Float16* p) {
     return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp4*)p));
 }
+// lo_delta != 0 (training forward for the three-product backward): the remainder  (hi + lo) - fp16(hi + lo)  goes to the tile's twin
+// lo_delta elements further on -- (hi - v) is exact in fp16 (they differ by at most one unit in the last place), + lo rounds at lo's level.
 __device__ __forceinline__ void fragment_block(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows, int rows_copied,
-                                               int rblocks, int blk, int ks_end, int lane) {
+                                               int rblocks, int blk, int ks_end, int lane, long long lo_delta = 0) {
     const int rb = blk % rblocks, ks = blk / rblocks;
     if (ks >= ks_end) return;
     const int i = lane & 15, g = lane >> 4;
     const int at = (16 * ks + 8 * (g >> 1) + (i >> 2)) * LDH + 32 * rb + 16 * (g & 1) + 4 * (i & 3);
-    const h4 lo03 = lds_tr4(sXh + at) + lds_tr4(sXl + at);                           // points 0..3 of the lane's eight
-    const h4 lo47 = lds_tr4(sXh + at + 4 * LDH) + lds_tr4(sXl + at + 4 * LDH);       // points 4..7
+    const h4 h03 = lds_tr4(sXh + at), l03 = lds_tr4(sXl + at), h47 = lds_tr4(sXh + at + 4 * LDH), l47 = lds_tr4(sXl + at + 4 * LDH);
+    const h4 lo03 = h03 + l03;                                                       // points 0..3 of the lane's eight
+    const h4 lo47 = h47 + l47;                                                       // points 4..7
     h8 out;
 #pragma unroll
     for (int t = 0; t < 4; ++t) { out[t] = lo03[t]; out[4 + t] = lo47[t]; }
     _Float16* d = dst + (((long long)ks * (n_rows >> 5) + rb) * 64 + lane) * 8;
-    if (32 * rb + (lane & 31) < rows_copied)
+    if (32 * rb + (lane & 31) < rows_copied) {
         __builtin_nontemporal_store(out, reinterpret_cast<h8*>(d));          // written once, read once by nsff_weight_grad
+        if (lo_delta != 0) {
+            const h4 r03 = (h03 - lo03) + l03, r47 = (h47 - lo47) + l47;
+            h8 rem;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { rem[t] = r03[t]; rem[4 + t] = r47[t]; }
+            __builtin_nontemporal_store(rem, reinterpret_cast<h8*>(d + lo_delta));
+        }
+    }
 }
 // blocks of a tile: (16-point group, 32-row block), row block fastest
 template <int M> __device__ __forceinline__ int fragment_blocks(int rows_copied) { return ((rows_copied + 31) >> 5) * (M / 16); }
 template <int THREADS, int M>
 __device__ __forceinline__ void tile_to_fragments(const _Float16* sXh, const _Float16* sXl, _Float16* dst, int n_rows,
-                                                  int rows_copied, int ks_end) {
+                                                  int rows_copied, int ks_end, long long lo_delta = 0) {
     const int rblocks = (rows_copied + 31) >> 5;
     for (int blk = threadIdx.x >> 6; blk < rblocks * (M / 16); blk += THREADS / 64)
-        fragment_block(sXh, sXl, dst, n_rows, rows_copied, rblocks, blk, ks_end, threadIdx.x & 63);
+        fragment_block(sXh, sXl, dst, n_rows, rows_copied, rblocks, blk, ks_end, threadIdx.x & 63, lo_delta);
 }
 
 // four consecutive columns of one row -> one 8-byte store per plane
@@ -879,15 +891,16 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), (NT == 2 ? 2 : 1)) void nsff_
     // back until every store is acknowledged).  A tile that is rebuilt or abandoned first is flushed on the spot.
     [[maybe_unused]] _Float16* pend_dst = nullptr;
     [[maybe_unused]] int pend_rows = 0, pend_copied = 0, pend_rblocks = 1, pend_total = 0;
+    [[maybe_unused]] long long pend_lo = 0;
     [[maybe_unused]] const long long tile64 = tile * (M / 64);
     [[maybe_unused]] const int ks_end = (M == 128 && tile64 + 1 >= a.n_tiles) ? 4 : M / 16;
-    auto pend_set = [&](_Float16* dst, int n_rows, int rows_copied) {
-        pend_dst = dst; pend_rows = n_rows; pend_copied = rows_copied; pend_rblocks = (rows_copied + 31) >> 5;
+    auto pend_set = [&](_Float16* dst, int n_rows, int rows_copied, long long lo_delta) {
+        pend_dst = dst; pend_rows = n_rows; pend_copied = rows_copied; pend_rblocks = (rows_copied + 31) >> 5; pend_lo = lo_delta;
         pend_total = fragment_blocks<M>(rows_copied);
     };
     auto pend_flush = [&]() {
         if constexpr (SAVE) {
-            if (pend_dst != nullptr) tile_to_fragments<THREADS, M>(sXh, sXl, pend_dst, pend_rows, pend_copied, ks_end);
+            if (pend_dst != nullptr) tile_to_fragments<THREADS, M>(sXh, sXl, pend_dst, pend_rows, pend_copied, ks_end, pend_lo);
             pend_dst = nullptr;
         }
     };
@@ -923,12 +936,12 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), (NT == 2 ? 2 : 1)) void nsff_
             __syncthreads();
             if constexpr (SAVE) {
                 if (st.pre == PRE_SIDE) {
-                    if (a.save_side != nullptr) pend_set(a.save_side + tile64 * (64 * a.side_rows), a.side_rows, (int)a.L.side_k);
+                    if (a.save_side != nullptr) pend_set(a.save_side + tile64 * (64 * a.side_rows), a.side_rows, (int)a.L.side_k, a.lo_delta[2]);
                 } else if (a.save_xin != nullptr && st.bias_off != NSFF_NONE && (st.pre == PRE_INPUT_T || a.transient_mode == 0)) {
                     // trunk input of layer 0: columns [0, k0s) xyz embedding, [k0s, k0s + kt) time code; rows past what this
                     // launch encodes stay unwritten (the caller zeroes the buffer then)
                     pend_set(a.save_xin + tile64 * (64 * a.xin_rows), a.xin_rows,
-                             (int)a.L.k0s + (st.pre == PRE_INPUT_T ? (int)a.L.kt : 0));
+                             (int)a.L.k0s + (st.pre == PRE_INPUT_T ? (int)a.L.kt : 0), a.lo_delta[1]);
                 }
             }
         }
@@ -955,14 +968,14 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), (NT == 2 ? 2 : 1)) void nsff_
                     for (int u = 2 * j; u < 2 * j + 2; ++u) {
                         const int blk = wave_id + NW * u;
                         if (copy && blk < pend_total)
-                            fragment_block(sXh, sXl, pend_dst, pend_rows, pend_copied, pend_rblocks, blk, ks_end, lane);
+                            fragment_block(sXh, sXl, pend_dst, pend_rows, pend_copied, pend_rblocks, blk, ks_end, lane, pend_lo);
                     }
                 },
                 [&](int j) {
                     if (copy) {
 #pragma unroll 1
                         for (int blk = wave_id + NW * 2 * j; blk < pend_total; blk += NW) {
-                            fragment_block(sXh, sXl, pend_dst, pend_rows, pend_copied, pend_rblocks, blk, ks_end, lane);
+                            fragment_block(sXh, sXl, pend_dst, pend_rows, pend_copied, pend_rblocks, blk, ks_end, lane, pend_lo);
                             H3_PIN();
                         }
                     }
@@ -995,7 +1008,7 @@ __global__ __launch_bounds__(256 * WM * (3 - MTW), (NT == 2 ? 2 : 1)) void nsff_
             H3_STAMP(5);
             if constexpr (SAVE) {
                 if (st.save && a.save_acts != nullptr)
-                    pend_set(a.save_acts + (long long)(st.save - 1) * a.save_stride + tile64 * (64 * NSFF_W), NSFF_W, NSFF_W);
+                    pend_set(a.save_acts + (long long)(st.save - 1) * a.save_stride + tile64 * (64 * NSFF_W), NSFF_W, NSFF_W, a.lo_delta[0]);
             }
             if (st.head != HEAD_NONE) {
                 heads<NPT, NW, MTW>(sXh, sXl, sRed, pk, hs.w_off, hs.b_off, hs.n_rows, hs.kinds, a.flow_scale, sRaw, hs.slot0,
@@ -2365,6 +2378,13 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
     k.n_tiles = (g.n_points + 63) / 64;
     k.save_stride = k.n_tiles * 64 * NSFF_W;
     if ((g.save_acts || g.save_xin || g.save_masks || g.save_side) && !g.xyz) return NSFF_ERR_INVALID;
+    const void* const lo_of[3] = {g.save_acts, g.save_xin, g.save_side};
+    bool save_lo = false;
+    for (int i = 0; i < 3; ++i) {
+        if (g.save_lo_delta[i] < 0 || (g.save_lo_delta[i] & 7) || (g.save_lo_delta[i] != 0 && !lo_of[i])) return NSFF_ERR_INVALID;
+        k.lo_delta[i] = g.save_lo_delta[i];
+        save_lo = save_lo || g.save_lo_delta[i] != 0;
+    }
     k.xin_rows = (k.L.k0s + k.L.kt) <= 128 ? 128 : 256;          // row geometry of save_xin / save_side (nsff_train_dims)
     k.side_rows = k.L.side_k <= 128 ? 128 : 256;
     k.static_mode = g.static_mode; k.transient_mode = g.transient_mode;
@@ -2419,7 +2439,8 @@ int nsff_h3_field_query(const NsffModelDesc* desc, const void* packed, const Nsf
         const bool viewdir_static = g.static_mode == 2 && d.use_viewdir;
         H3KArgs ks = k;
         bool side = false;
-        bool asm_body = points_per_block != 131 && g.xyz != nullptr && k.L.k0s == 64 &&
+        // (remainder planes for the three-product backward, NsffFieldArgs::save_lo_delta: the eight-wave kernel writes them)
+        bool asm_body = points_per_block != 131 && !save_lo && g.xyz != nullptr && k.L.k0s == 64 &&
                         k.save_acts != nullptr && k.save_masks != nullptr && (k.n_tiles & 1) == 0 &&
                         k.n_tiles * (64LL * NSFF_W * 2) < 0x100000000LL && g.n_points <= 0x7fffffffLL;
         if (asm_body && viewdir_static)

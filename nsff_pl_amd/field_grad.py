@@ -72,22 +72,31 @@ def _lin(m):
     return m[0] if isinstance(m, torch.nn.Sequential) else m
 
 
-def alloc_saves(model, n_points, device, transient, static=True):
+def _planes(x3, *shape, device):
+    """An fp16 buffer of the backward pass; x3 (config.set_grad_precision("f16x3")): with its remainder plane directly behind it --
+    the caller gets plane 0 (`_lib.lo_delta` finds the twin)."""
+    if not x3:
+        return torch.empty(*shape, device=device, dtype=torch.float16), None
+    both = torch.empty(2, *shape, device=device, dtype=torch.float16)
+    return both[0], both
+
+
+def alloc_saves(model, n_points, device, transient, static=True, x3=False):
     """Buffers the training forward fills for the backward kernels (layouts: include/nsff_render.h, NsffFieldArgs):
     (acts, xin, masks, side) -- side is None unless the launch evaluates static_dir_encoding."""
     tiles = (n_points + 63) // 64
     xin_rows, t_row0, side_rows = _lib.train_dims(model)
-    acts = torch.empty(n_slots(model), tiles, 64 * 256, device=device, dtype=torch.float16)
-    xin = torch.empty(tiles, 64 * xin_rows, device=device, dtype=torch.float16)
+    acts, _ = _planes(x3, n_slots(model), tiles, 64 * 256, device=device)
+    xin, xin2 = _planes(x3, tiles, 64 * xin_rows, device=device)
     masks = torch.empty(n_slots(model), tiles, 256, device=device, dtype=torch.int64)
     written = t_row0 + ((model.in_channels_t + 63) // 64 * 64 if transient else 0)
     if written < xin_rows:
-        xin.zero_()                          # rows the launch does not encode are never written
+        (xin2 if x3 else xin).zero_()        # rows the launch does not encode are never written
     side = None
     if model.use_viewdir and static:
-        side = torch.empty(tiles, 64 * side_rows, device=device, dtype=torch.float16)
+        side, side2 = _planes(x3, tiles, 64 * side_rows, device=device)
         if (model.in_channels_dir + model.in_channels_a + 63) // 64 * 64 < side_rows:
-            side.zero_()
+            (side2 if x3 else side).zero_()
     return acts, xin, masks, side
 
 
@@ -105,6 +114,7 @@ class _FieldFn(torch.autograd.Function):
         static, transient = cfg["static"], cfg["transient"]
         P = xyz.shape[0]
         ctx.cfg, ctx.P = cfg, P
+        x3 = ctx.x3 = bool(cfg.get("x3"))        # (decided where the saves were / are allocated: field())
         if cfg.get("saved") is not None:         # render_rays' own launch was the training forward: nothing to redo
             raw, acts, xin, masks, xyz_c, side = cfg["saved"]
             ctx.has_side = side is not None
@@ -112,7 +122,7 @@ class _FieldFn(torch.autograd.Function):
             return raw.detach().view_as(raw)
         dev = xyz.device
         raw = torch.empty(P, _lib.RAW_STRIDE, device=dev)      # (the kernel writes whole records, zeros in unevaluated slots)
-        acts, xin, masks, side = alloc_saves(model, P, dev, transient, static)
+        acts, xin, masks, side = alloc_saves(model, P, dev, transient, static, x3)
         xyz_c = xyz.detach().contiguous()
         use_side = model.use_viewdir and static
         _lib.field_query(model, raw, P, s, 2 if static else 0, 2 if transient else 0,
@@ -121,7 +131,7 @@ class _FieldFn(torch.autograd.Function):
                          dir_emb=dir_rows.detach().contiguous() if use_side else None,
                          a_emb=a_rows.detach().contiguous() if (use_side and model.in_channels_a > 0) else None,
                          save_acts=acts, save_xin=xin, save_masks=masks, save_side=side,
-                         precision=config.PRECISIONS["f16x3"])
+                         precision=config.PRECISIONS["f16x3"], save_lo=x3)
         ctx.has_side = side is not None
         ctx.save_for_backward(raw, acts, xin, masks, xyz_c, *([side] if side is not None else []), *params)
         return raw
@@ -147,13 +157,14 @@ class _FieldFn(torch.autograd.Function):
         n_xyz, n_t = model.in_channels_xyz, (model.in_channels_t if transient else 0)
         d_raw = d_raw.contiguous()
         gmax = _lib.absmax(d_raw)                 # [static, dynamic]: one power-of-two scale per trunk (see nsff_absmax_raw)
-        dpre = torch.empty(n_slots(model), tiles, 64 * 256, device=dev, dtype=torch.float16)
+        x3 = ctx.x3
+        dpre, _ = _planes(x3, n_slots(model), tiles, 64 * 256, device=dev)
         dhead = torch.empty(2, tiles, 64 * 32, device=dev, dtype=torch.float16)
         want_in = transient and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         d_xin = torch.empty(P, xin_rows, device=dev) if want_in else None
         want_a = viewdir and model.in_channels_a > 0 and ctx.needs_input_grad[4]
         d_side = torch.empty(P, side_rows, device=dev) if want_a else None
-        _lib.field_backward(model, P, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side)
+        _lib.field_backward(model, P, static, transient, d_raw, raw, gmax, masks, dpre, dhead, d_xin, d_side, x3=x3)
 
         # ---- weight-gradient GEMMs: one batched launch per output shape ----
         meta = _wgrad_jobs(model, static, transient)             # (kind, trunk, layer)
@@ -173,6 +184,9 @@ class _FieldFn(torch.autograd.Function):
             else:                                                 # the (folded) heads read the last trunk activation as well
                 a_, b_, rows = dhead[t], acts[S_DIR if (t == 0 and viewdir) else base + D - 1], (32, 256)
             jobs.append([a_.data_ptr(), b_.data_ptr(), rows[0], rows[1], 0, t])      # (t: the trunk whose scale gmax[t] dpre / dhead are on)
+            if x3:                               # the operands' remainder planes (dhead carries its own: rows 16..31)
+                b_src = xin if kind == "x" else (side if kind == "dir_x" else acts)
+                jobs[-1] += [_lib.lo_delta(dpre) if rows[0] == 256 else 0, _lib.lo_delta(b_src)]
             sizes.append(rows[0] * rows[1])
         # requested split-K factor; the library rounds it to whole rounds of the 256 CUs (16 -> one round of 14 splits x 18 jobs:
         # 7.52 ms per C2 step against 7.63 at 32 = two rounds, 7.79 at 48: fewer partial sums for the accumulate pass to read)
@@ -598,7 +612,12 @@ def _flush_weight_grads():
 def field(model, xyz, freqs, t_rows, pts_per_ray, static, transient, saved=None, dir_rows=None, a_rows=None):
     """Differentiable field query on raw points: returns the (P,16) raw record (layout of include/nsff_render.h).
     dir_rows / a_rows: per-ray view-direction embedding and appearance code (use_viewdir models, static pass).
-    saved: (raw, acts, xin, masks, xyz, side) of an earlier training-forward launch on exactly these inputs, or None."""
+    saved: (raw, acts, xin, masks, xyz, side[, x3]) of an earlier training-forward launch on exactly these inputs, or None (x3:
+    the launch wrote the remainder planes of the three-product backward, config.set_grad_precision)."""
+    x3 = config.grad_x3()
+    if saved is not None:
+        x3 = bool(saved[6]) if len(saved) > 6 else False
+        saved = tuple(saved[:6])
     cfg = dict(model=model, freqs=[float(f) for f in freqs], pts_per_ray=int(pts_per_ray), static=bool(static),
-               transient=bool(transient), saved=saved)
+               transient=bool(transient), saved=saved, x3=x3)
     return _FieldFn.apply(cfg, xyz, t_rows, dir_rows, a_rows, *_lib.param_list(model))

@@ -245,9 +245,10 @@ def _inference(results, ctx, model, xyz, zs, output_transient, output_transient_
         already is the training forward: it keeps the activations the backward kernels need."""
         saves = {}
         if ctx.rec is not None and field_grad.forward_can_save(model, static_mode, transient_mode):
-            acts, xin, masks, side_rows = field_grad.alloc_saves(model, P, zs.device, bool(transient_mode), bool(static_mode))
-            saves = dict(save_acts=acts, save_xin=xin, save_masks=masks, save_side=side_rows)
-            ctx.rec.setdefault("saved", {})[tag] = (raw_out, acts, xin, masks, pts.view(-1, 3), side_rows)
+            x3 = config.grad_x3()           # (three-product backward: the launch writes the remainder planes too)
+            acts, xin, masks, side_rows = field_grad.alloc_saves(model, P, zs.device, bool(transient_mode), bool(static_mode), x3)
+            saves = dict(save_acts=acts, save_xin=xin, save_masks=masks, save_side=side_rows, save_lo=x3)
+            ctx.rec.setdefault("saved", {})[tag] = (raw_out, acts, xin, masks, pts.view(-1, 3), side_rows, x3)
         t_bias = ctx.tbias.get((typ, which)) if (transient_mode and not saves) else None
         _lib.field_query(model, raw_out, P, S, static_mode=static_mode, transient_mode=transient_mode,
                          flow_heads=flow_heads, xyz=pts, freqs=ctx.freqs_xyz, t_emb=t_rows, t_bias=t_bias, **saves, **extra)

@@ -56,16 +56,16 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 30
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 31
 
 
 def test_struct_layouts_match_the_header_sizes():
     # natural-alignment layout of the C structs (pointer = 8 bytes)
     assert C.sizeof(_lib.ModelDesc) == 48
-    assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 4 * _lib.MAX_FREQS + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8 + 8 + 8 + 16 and _lib.MAX_FREQS == 24
+    assert C.sizeof(_lib.FieldArgs) == 8 + 24 + 8 + 4 + 4 * _lib.MAX_FREQS + 4 + 3 * 8 + 8 + 4 * 5 + 4 + 8 + 4 * 8 + 8 + 8 + 16 + 24 and _lib.MAX_FREQS == 24
     assert C.sizeof(_lib.TimeBiasJob) == 8 + 64 + 64 + 16 + 16 + 16 + 8 + 8
     assert C.sizeof(_lib.RngJob) == 32 and _lib.MAX_RNG_JOBS == 12 and C.sizeof(_lib.RngCoarse) == 48
-    assert C.sizeof(_lib.FieldBwdArgs) == 16 + 8 * 8 and C.sizeof(_lib.WgradJob) == 40
+    assert C.sizeof(_lib.FieldBwdArgs) == 16 + 8 * 9 and C.sizeof(_lib.WgradJob) == 56
     assert C.sizeof(_lib.SplatArgs) == 12 + 16 + 48 + 4 + 5 * 8 + 16 and C.sizeof(_lib.MpiArgs) == 16 + 7 * 8
     assert C.sizeof(_lib.LossArgs) == 24 + 8 + 8 + 8 * (len(_lib._LOSS_IN) + 3 + len(_lib.LOSS_GRADS))
     n_ptr = len(_lib._COMPOSITE_PTRS_IN) + len(_lib._COMPOSITE_PTRS_OUT)
