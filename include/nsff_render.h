@@ -408,7 +408,7 @@ int nsff_absmax(const float* x, int64_t n, float* out, void* stream);
 /* out16[c] = max |d_raw[:, c]| for the 16 floats of a record: the `gmax` vector of nsff_field_backward / nsff_weight_grad*.  A trunk's
  * fragments (dpre) are on the scale of its largest column (static: 0..3, dynamic: 4..13), every head row of dhead on its own: in a
  * real NSFF step the columns' gradients are 10^6-10^7 apart (the 2D flow terms of the loss are in pixels); on a common scale the
- * smaller ones' fp16 fragments fall into the subnormal range, which the weight-gradient MFMAs read as zero (round 6, golden g20:
+ * smaller ones' fp16 fragments fall into and below the subnormal range -- a bit or two, then zero (round 6, golden g20:
  * static weight gradients 40-70 % too small at 512 rays, transient_sigma.weight 25 %). */
 int nsff_absmax_raw(const float* d_raw, int64_t n_points, float* out16, void* stream);
 

@@ -375,7 +375,7 @@ def test_readme_training_configuration_at_batch_size_512_matches_reference_stati
     generated by tests/golden/make_golden.py --g20 (statistics only: the per-sample outputs of 65 536 points would be 15 MB).
     Every field launch must have run the hand-scheduled kernels (training forward: h3a_save for BOTH trunks).  When this test was
     written it FAILED: static-trunk weight gradients 40-70 % too small -- one power-of-two scale per launch put the smaller record
-    columns' fp16 gradient fragments into the subnormal range, which the weight-gradient MFMAs read as zero (DESIGN.md section 9);
+    columns' fp16 gradient fragments into and below the subnormal range -- a bit or two, then zero (DESIGN.md section 9);
     the 16-ray goldens cannot see that: the outliers that set the scale come with the batch size."""
     bwd = _step_against_statistics("g20_loss_readme_train_512.npz", scenes.README_TRAIN_CASE, lambda m: {"fine": m["fine"]}, {"h3a_save"})
     assert bwd in ("h3b", "c+h3b")
