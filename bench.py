@@ -583,6 +583,18 @@ def aux_block(bench, args):
         t, _, _ = timed(bench.train_step(), 5, 3 if not graph else 1, 1, dev)
         aux["train_ms_per_step" + ("_graph" if graph else "_eager")] = t / 5 * 1e3
         bench.models = cfg_models
+    # (4b) the same eager step with the parity-grade backward (config.set_grad_precision("f16x3"): three products per multiply-
+    # accumulate in the data-gradient chain and the weight-gradient GEMMs, the forward on the eight-wave SAVE kernel that writes
+    # the remainder planes) -- what the option costs
+    bench.graph = False
+    config.set_grad_precision("f16x3")
+    try:
+        cfg_models = bench.models
+        t, _, _ = timed(bench.train_step(), 5, 3, 1, dev)
+        aux["train_ms_per_step_eager_grad_f16x3"] = t / 5 * 1e3
+        bench.models = cfg_models
+    finally:
+        config.set_grad_precision("f16")
     # (the trainer's default form is the eager step -- NSFFTrainer(graph=False); the two-hipGraph replay is 2-3 % slower on this
     #  stack: a replayed node costs what an eager launch costs, the host already runs ahead of the GPU, and the replay adds a fixed
     #  cost per graph launch: DESIGN.md section 7)
