@@ -31,7 +31,7 @@ extern "C" {
 #define NSFF_ERR_ALIGN       -3   /* pointer not 16-byte aligned where required    */
 #define NSFF_ERR_HIP         -4   /* a HIP runtime call failed (see nsff_last_hip_error) */
 
-#define NSFF_ABI_VERSION      31
+#define NSFF_ABI_VERSION      32
 #define NSFF_RAW_STRIDE      16   /* floats per point in a raw field record        */
 #define NSFF_MAX_FREQS       24
 #define NSFF_MAX_LAYERS       8
@@ -313,6 +313,10 @@ int nsff_field_backward(const NsffModelDesc* desc, const void* packed_bwd, const
  * trunk, at most one skip layer with a trunk-input gradient, none at the last layer); 0 = the kernel nsff_field_bwd_kernel -- compiler-scheduled,
  * 64-point workgroups; NSFF_BWD_KERNEL=c forces it.  Both leave bit-identical dpre / dhead / d_xin. */
 int nsff_last_bwd_kernel(void);
+/* Workgroups of the last hand-scheduled data-gradient launch (0: none since the last nsff_field_backward).  Launches that give
+ * every compute unit at least two (tile, trunk) items run PERSISTENT: one workgroup per compute unit, further items from a device
+ * counter, the next item's records brought into LDS behind the current item's body; NSFF_BWD_PERSIST=0: one workgroup per item. */
+int nsff_last_bwd_grid(void);
 /* Host-only (no GPU): the hand-scheduled body's phase program for one trunk of `desc` (dynamic: the transient trunk, with or without
  * the trunk-input gradient) at n_tiles 64-point tiles -> out[max_phases][8] uint32 descriptors; seg_offsets (or NULL): byte offsets of
  * the trunk's step segments in the transposed pack.  Returns the number of descriptors, 0 when the body does not cover the trunk. */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSFF_LIB") or os.path.join(_HERE, "libnsff_hip.so")
 
 RAW_STRIDE = 16
-ABI_VERSION = 31
+ABI_VERSION = 32
 MAX_FREQS = 24
 
 _ERR = {-1: "NSFF_ERR_INVALID (bad shape/flag/unsupported architecture)",
@@ -208,6 +208,7 @@ _SIGNATURES = {
                                                   _fp, _fp, _fp, _fp]),
     "nsff_absmax_raw": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "nsff_last_bwd_kernel": (C.c_int, []),
+    "nsff_last_bwd_grid": (C.c_int, []),
     "nsff_field_bwd_phase_program": (C.c_int, [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_uint32), C.c_int32,
                                                 C.POINTER(C.c_uint32), C.c_int32]),
     "nsff_fold_grads": (C.c_int, [C.POINTER(FoldGradArgs), _fp]),
@@ -704,6 +705,11 @@ def last_bwd_kernel():
     """'h3b' (the hand-scheduled body), 'c' (compiler-scheduled) or 'c+h3b' (a view-direction model's both-trunk launch: static trunk
     on the compiler-scheduled kernel, dynamic trunk on the hand-scheduled one): which kernel(s) the last field_backward launch took"""
     return {0: "c", 1: "h3b", 2: "c+h3b", 3: "x3"}[load().nsff_last_bwd_kernel()]      # x3: the three-product kernel (config.set_grad_precision)
+
+
+def last_bwd_grid():
+    """workgroups of the last hand-scheduled data-gradient launch (= compute units for a persistent one; 0: none)"""
+    return load().nsff_last_bwd_grid()
 
 
 def field_bwd_phase_program(model, dynamic, want_xin, n_tiles, max_phases=32):

@@ -75,19 +75,33 @@ def test_hand_scheduled_backward_is_bit_identical_to_the_compiler_scheduled_kern
 
 def test_c2_sized_backward_launches_take_the_hand_scheduled_kernel(hip_lib, monkeypatch):
     """the launches of a C2 training step (65 536 / 196 608 points; both trunks, and the dynamic trunk alone with its trunk-input
-    gradient): no silent fallback"""
+    gradient): no silent fallback, and the PERSISTENT form (one workgroup per compute unit, items from a device counter, the next
+    item's records brought into LDS behind the current body) -- same bits as one workgroup per item (NSFF_BWD_PERSIST=0), launch
+    after launch (the counter is left at zero by the launch's last fetch); a ragged point count and a launch too small to persist
+    beside them"""
     monkeypatch.delenv("NSFF_BWD_KERNEL", raising=False)
     torch.manual_seed(1)
     m = A.NeRF("fine", use_viewdir=False, encode_transient=True, in_channels_t=48, output_flow=True).to(DEV)
     g = torch.Generator().manual_seed(2)
-    for P, static in ((65536, True), (196608, True), (196608, False)):
-        tiles = P // 64
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for P, static in ((65536, True), (196608, True), (196608, False), (128 * 1531 - 13, True), (128 * (2 * n_cus - 1), False)):
+        tiles = (P + 63) // 64
+        items = tiles // 2 * (2 if static else 1)
         d_raw = torch.randn(P, _lib.RAW_STRIDE, generator=g).to(DEV)
         raw = (torch.rand(P, _lib.RAW_STRIDE, generator=g) * 0.2).to(DEV)
         masks = torch.randint(-2 ** 62, 2 ** 62, (field_grad.n_slots(m), tiles, 256), generator=g, dtype=torch.int64).to(DEV)
+        monkeypatch.delenv("NSFF_BWD_PERSIST", raising=False)
         out = _run(m, P, static, True, True, d_raw, raw, masks, False, monkeypatch)
         assert out[3] == "h3b"
+        assert _lib.last_bwd_grid() == (n_cus if items >= 2 * n_cus else items), (P, static, _lib.last_bwd_grid())
         assert np.isfinite(out[2].view(np.float32)).all()
+        again = _run(m, P, static, True, True, d_raw, raw, masks, False, monkeypatch)
+        monkeypatch.setenv("NSFF_BWD_PERSIST", "0")
+        one = _run(m, P, static, True, True, d_raw, raw, masks, False, monkeypatch)
+        assert one[3] == "h3b" and _lib.last_bwd_grid() == items
+        for k in range(3):
+            assert np.array_equal(out[k], one[k]) and np.array_equal(out[k], again[k]), (P, static, k)
+    monkeypatch.delenv("NSFF_BWD_PERSIST", raising=False)
 
 
 def test_overflowing_gradients_clamp_like_the_compiler_scheduled_kernel(hip_lib, monkeypatch):

@@ -56,7 +56,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), f"libnsff_hip.so does not export {sym}"
-    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 31
+    assert lib.nsff_abi_version() == _lib.ABI_VERSION == 32
 
 
 def test_struct_layouts_match_the_header_sizes():
