@@ -39,7 +39,9 @@ lib = _lib.load()
 n = 256 * 4 * 32 * 6
 buf = (C.c_uint * n)()
 assert lib.nsff_debug_read_bwd_timing(buf, n) == 0
-t = np.frombuffer(buf, dtype=np.uint32)[:256 * 4 * 64].reshape(256, 4, 64).astype(np.int64)
+later = len(sys.argv) > 2 and sys.argv[2] == "later"      # the workgroups' LAST later item instead of their first one (persistent launches)
+t = np.frombuffer(buf, dtype=np.uint32)[65536 if later else 0:][:256 * 4 * 64].reshape(256, 4, 64).astype(np.int64)
+print("items:", "a workgroup's last later item (entry = the top of its loop iteration)" if later else "a workgroup's first item", " grid", _lib.last_bwd_grid())
 names = {v: k for k, v in gen_bwd.BODY.items()}
 ph = {}
 for dyn in (False, True):
@@ -48,14 +50,15 @@ for dyn in (False, True):
 d = lambda x, y: ((y - x) & 0xffffffff).astype(np.float64)
 # workgroup b: trunk (b & 7) >> 2 when both trunks run
 for dyn in ([False, True] if which == "both" else [which == "dynamic"]):
-    sel = [b for b in range(256) if which != "both" or ((b & 7) >> 2) == int(dyn)]
+    sel = [b for b in range(256) if which != "both" or (b & 1) == int(dyn)]        # (items alternate between the trunks; 256 workgroups: a workgroup keeps its parity)
     tt = t[sel]
     seq = ph[dyn]
     n_ph = seq.index("END")
     print(f"-- {'dynamic' if dyn else 'static'} trunk: {n_ph} phases; mean cycles (s_memtime ticks at 100 MHz x clock ratio are NOT cycles: see below)")
     print(f"   entry -> head stage done {d(tt[:, :, 0], tt[:, :, 1]).mean():8.0f}")
-    hs = ["entry -> in front of the record loads", "record loads of both halves issued", "the pre-issue statement (8 head-segment loads issued)",
-          "head arithmetic, half A (waits for its records)", "head arithmetic, half B", "barrier", "head-gradient stores issued"]
+    hs = ["entry -> top of the item's loop iteration (first item: the record DMA and its wait)", "barrier (every wave done with the previous item)",
+          "counter fetch issued, records read from LDS, the pre-issue statement (8 head-segment loads)",
+          "head arithmetic, half A", "head arithmetic, half B", "barrier", "head-gradient stores issued"]
     prev = tt[:, :, 0]
     for k, nm in enumerate(hs):
         print(f"      {nm:90s} {d(prev, tt[:, :, 56 + k]).mean():8.0f}")
