@@ -263,6 +263,9 @@ def run_case(kind, seed=0, verbose=True):
     t0 = time.time()
     sim.run()
     dt = time.time() - t0
+    # the body ends without waiting for the vector-memory queue: only stores may be outstanding
+    for wid, pend in sim.pending_at_end.items():
+        assert not pend, (kind, "wave", wid, "ends with loads outstanding into", sorted(pend)[:8])
     tiles, dxin, T_last = reference(case)
     # ---- fragment slots: every tile of the chain, both halves; nothing else written
     a16 = acts.view(np.float16).reshape(n_slots, N_TILES64, 4, 8, 64, 8)

@@ -595,7 +595,11 @@ def build():
         prog += bodies[name]
     prog += dispatcher(bodies)
     prog.append(I_label("L_end"))
-    prog.append(I_wait(vm=0, lgkm=0))
+    # No wait for the vector-memory queue here: what is outstanding when the last phase ends are STORES (fragments, d_xin) --
+    # check_bwd.py asserts that no register has a load outstanding into it at this point --, and a persistent workgroup's next
+    # item starts its head stage while they drain.  (The kernel's record DMA for that item was issued before this statement and
+    # is older than every load the phases waited for: it has landed.)
+    prog.append(I_wait(lgkm=0) if not TIMING else I_wait(vm=0, lgkm=0))
     prog.append(Inst("s_setreg", "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0", [], [], "salu", dict(d=None, s=[0], field="fp16_ovfl")))
     if TIMING:
         prog += timing_store() + [I_wait(vm=0, lgkm=0)]

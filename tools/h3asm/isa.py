@@ -815,6 +815,10 @@ class Sim:
                 while True:
                     if w.pc >= n:
                         w.done = True
+                        # registers a load is still outstanding into when the program ends (the code behind an asm statement
+                        # may use them): {(file, index): queue}
+                        self.pending_at_end = getattr(self, "pending_at_end", {})
+                        self.pending_at_end[w.id] = dict(w.pending)
                         break
                     r = self.step(w)
                     progress = True
