@@ -439,10 +439,25 @@ def readme_train(bench, steps=10):
     finally:
         _lib.field_query, _lib.field_backward = orig_q, orig_b
     t, _, _ = timed(lambda: trainer.step(batch), steps, 2, 1, dev)
-    return {"config": "README.md:226-233: use_viewdir, N_samples=128, N_importance=0, batch_size=512, encode_t, flows fw/bw/disocc; one "
-                      "NSFFTrainer.step (forward, NeRFWLoss, backward, Adam), eager; random-init weights, synthetic rays and targets",
-            "ms_per_step": t / steps * 1e3, "ray_samples_per_s": 512 * 128 * steps / t,
-            "forward_kernels": sorted(kernels["forward"]), "data_gradient_kernels": sorted(kernels["backward"])}
+    out = {"config": "README.md:226-233: use_viewdir, N_samples=128, N_importance=0, batch_size=512, encode_t, flows fw/bw/disocc; one "
+                     "NSFFTrainer.step (forward, NeRFWLoss, backward, Adam), eager; random-init weights, synthetic rays and targets",
+           "ms_per_step": t / steps * 1e3, "ray_samples_per_s": 512 * 128 * steps / t,
+           "forward_kernels": sorted(kernels["forward"]), "data_gradient_kernels": sorted(kernels["backward"])}
+    # the same step as the trainer's two replayed hipGraphs (NSFFTrainer(graph=True), what graph="auto" picks at this size): a step is
+    # ~100 launches of 2.5 ms of kernels here -- the eager step is bound by the host's launch rate, the replay is not
+    try:
+        models_g, emb_g = scenes.build_scene(A.NeRF, A.PosEmbedding, cfg)
+        tg = NSFFTrainer({"fine": models_g["fine"]}, emb_g, scenes.N_FRAMES, dict(N_samples=128, N_importance=0), Ks, Ps,
+                         output_transient_flow=cfg["flow"], graph=True).to(dev)
+        tg.on_train_epoch_start(0)
+        for _ in range(3):
+            tg.step(batch)
+        t, _, _ = timed(lambda: tg.step(batch), steps, 1, 1, dev)
+        out["ms_per_step_graph"] = t / steps * 1e3
+    except Exception as e:                                   # (reported, not fatal: the eager figure above is the entry's subject)
+        out["ms_per_step_graph"] = None
+        out["graph_error"] = repr(e)[:200]
+    return out
 
 
 def backward_rooflines(bench, args, steps=4):

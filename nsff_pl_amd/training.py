@@ -64,7 +64,12 @@ class NSFFTrainer:
                  output_transient=True, output_transient_flow=("fw", "bw", "disocc"), graph=False, optimizer_cls=FlatAdam):
         """graph=True: the step is captured once into two hipGraphs (``torch.cuda.CUDAGraph``) and replayed: graph A =
         zero_grad + forward kernels + loss + backward kernels, graph B = Adam; between them -- outside any capture --
-        the flat RCCL gradient all-reduce when world > 1.  Needs fixed batch shapes and topk == 1."""
+        the flat RCCL gradient all-reduce when world > 1.  Needs fixed batch shapes and topk == 1.
+        graph="auto": decided at the first step from the batch -- replayed graphs when the step is SMALL (a step is ~100 launches
+        whatever its size: below ~450 k field-point evaluations the host's launch rate, not the GPU, bounds the eager step; the
+        reference's README configuration -- 512 rays x 128 samples -- takes 2.4 ms replayed against 4.3 ms eager, bench.py
+        aux.readme_train), the eager step otherwise (a replayed node costs what an eager launch costs and a replay adds a fixed
+        cost: the C2 step is 3-4 % faster eager); eager on CPU tensors and with topk < 1."""
         hp = dict(self.DEFAULTS)
         if hparams is not None:
             given = hparams if isinstance(hparams, dict) else vars(hparams)
@@ -73,7 +78,10 @@ class NSFFTrainer:
         self.models, self.embeddings, self.n_frames = models, embeddings, n_frames
         self.output_transient = output_transient
         self.output_transient_flow = list(output_transient_flow) if output_transient else []
-        self.graph = bool(graph)
+        self._graph_auto = isinstance(graph, str) and graph == "auto"
+        if isinstance(graph, str) and not self._graph_auto:
+            raise ValueError("graph must be True, False or 'auto'")
+        self.graph = False if self._graph_auto else bool(graph)
         self.optimizer_cls = optimizer_cls       # (tests drive the step on CPU with a torch-op twin of FlatAdam)
         self.loss = NeRFWLoss(lambda_geo=hp["lambda_geo_init"], thickness=hp["thickness"], topk=hp["topk"],
                               static_shapes=self.graph)
@@ -188,6 +196,8 @@ class NSFFTrainer:
         """zero_grad -> training_step -> backward -> gradient all-reduce -> Adam; returns the log dict."""
         if self.optimizer is None:
             self._make_optimizer()
+        if self._graph_auto:
+            self._resolve_graph(batch)
         if self.graph:
             return self._graph_step(batch)
         self._setup_flat_grads()
@@ -200,6 +210,20 @@ class NSFFTrainer:
         self.optimizer.step()
         self._invalidate_packs()
         return log
+
+    AUTO_GRAPH_POINT_EVALS = 450_000        # (see __init__: where the eager step stops being bound by the host)
+
+    def _resolve_graph(self, batch):
+        """graph='auto', first step: field-point evaluations of a step = rays x [coarse samples + (fine samples) x (1 + two
+        scene-flow re-queries)]."""
+        self._graph_auto = False
+        hp, rays = self.hp, batch["rays"]
+        fine = hp["N_samples"] + (2 if self.output_transient else 1) * hp["N_importance"]
+        evals = rays.shape[0] * ((hp["N_samples"] if hp["N_importance"] > 0 else 0) + fine * (3 if self.output_transient_flow else 1))
+        self.graph = bool(rays.is_cuda and hp["topk"] >= 1 and "weights" not in batch and evals <= self.AUTO_GRAPH_POINT_EVALS)
+        if self.graph:
+            self.loss.static_shapes = True
+            self.on_train_epoch_start(self.current_epoch)        # (the captured loss reads lambda_geo / the ramp from device scalars)
 
     def _graph_body_backward(self):
         self.zero_grad()

@@ -236,6 +236,21 @@ def test_trainer_steps_reduce_the_loss(hip_lib):
             assert abs(glogs[0][f"train/{k}"] - v) <= 2e-3 * max(abs(v), 1e-6), (k, glogs[0][f"train/{k}"], v)
         assert glogs[-1]["train/loss"] < glogs[0]["train/loss"]
         assert abs(glogs[-1]["train/loss"] - float(logs[-1]["train/loss"])) <= 0.05 * abs(float(logs[-1]["train/loss"]))
+        # graph="auto": a step this small is bound by the host's launch rate -> the replayed form, decided at the first step;
+        # a step of the C2 size stays eager
+        cfg, meta, rays, ts, models3, emb3, _, want = common.build_case(name, A.NeRF, A.PosEmbedding)
+        ta = NSFFTrainer(models3, emb3, scenes.N_FRAMES, hp, Ks, Ps, output_transient_flow=cfg["flow"], graph="auto").to(DEV)
+        ta.on_train_epoch_start(scenes.LOSS_EPOCH)
+        assert ta.graph is False
+        alog = {k: float(v) for k, v in ta.step(batch).items()}
+        assert ta.graph is True and ta._graph is not None
+        for k, v in gold.items():
+            assert abs(alog[f"train/{k}"] - v) <= 2e-3 * max(abs(v), 1e-6), (k, alog[f"train/{k}"], v)
+        big = NSFFTrainer(models3, emb3, scenes.N_FRAMES, dict(N_samples=64, N_importance=64), Ks, Ps, output_transient_flow=cfg["flow"], graph="auto")
+        big._resolve_graph({"rays": torch.empty(1024, 6, device=DEV)})
+        assert big.graph is False
+        with pytest.raises(ValueError):
+            NSFFTrainer(models3, emb3, scenes.N_FRAMES, hp, Ks, Ps, graph="sometimes")
     finally:
         A.set_precision(A.config.DEFAULT_PRECISION)
 
