@@ -115,6 +115,31 @@ def test_trainer_takes_the_reference_weight_decay_option():
         training.render_rays = old
 
 
+def test_trainer_graph_auto_is_decided_from_the_batch():
+    """NSFFTrainer(graph="auto"): replayed hipGraphs for steps the host's launch rate bounds (few field-point evaluations), the
+    eager step for large ones, for CPU tensors and for topk < 1; nothing else is accepted as a string"""
+    import nsff_pl_amd as A
+    from nsff_pl_amd.training import NSFFTrainer
+    models = {"fine": A.NeRF("fine", use_viewdir=False, encode_transient=True, output_flow=True)}
+    emb = {"xyz": A.PosEmbedding(9, 10), "dir": A.PosEmbedding(3, 4), "t": torch.nn.Embedding(30, 48)}
+
+    class Rays:                                  # (what _resolve_graph reads of batch["rays"]; no GPU in this test)
+        def __init__(self, n, cuda):
+            self.shape, self.is_cuda = (n, 6), cuda
+    cases = [(dict(N_samples=128, N_importance=0), 512, True, True),        # README.md:226-233: 512 x 128 x 3 = 197 k evaluations
+             (dict(N_samples=64, N_importance=64), 1024, True, False),      # C2: 1024 x (64 + 192 x 3) = 655 k
+             (dict(N_samples=128, N_importance=0), 512, False, False),      # CPU tensors
+             (dict(N_samples=128, N_importance=0, topk=0.5), 512, True, False)]
+    for hp, n, cuda, want in cases:
+        tr = NSFFTrainer(models, emb, 30, hp, torch.eye(3), torch.zeros(1, 30, 3, 4), graph="auto", optimizer_cls=common.cpu_flat_adam())
+        assert tr.graph is False
+        tr.on_train_epoch_start = lambda epoch: None            # (the captured loss's device scalars: not on a CPU run)
+        tr._resolve_graph({"rays": Rays(n, cuda)})
+        assert tr.graph is want and tr._graph_auto is False and tr.loss.static_shapes is want, (hp, n, cuda)
+    with pytest.raises(ValueError):
+        NSFFTrainer(models, emb, 30, None, torch.eye(3), torch.zeros(1, 30, 3, 4), graph="sometimes")
+
+
 def test_flat_adam_refuses_cpu_parameters():
     with pytest.raises(RuntimeError, match="HIP device only"):
         FlatAdam(_params(torch.device("cpu")))
