@@ -218,9 +218,19 @@ def test_a_backward_inside_a_backward_pass_keeps_the_enclosing_pass_entries(hip_
     assert torch.allclose(trunk.grad, want, rtol=1e-5, atol=2e-6 * float(want.abs().max()))
 
 
+@pytest.fixture(params=["f16", "f16x3"])
+def grad_precision(request):
+    """both backward arithmetics (config.set_grad_precision): one f16 product per multiply-accumulate, and three"""
+    A.config.set_grad_precision(request.param)
+    try:
+        yield request.param
+    finally:
+        A.config.set_grad_precision("f16")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,static", [("g3_nsff_train", True), ("g3_nsff_train", False), ("g13_viewdir_train", True)])
-def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_lib):
+def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_lib, grad_precision):
     """Deferred mode with .grad tensors in place: nsff_weight_grad_accumulate adds every gradient element straight into
     the parameters' own memory.  Result must be bit-identical to (existing .grad) + (what the node returns through
     autograd), for scattered .grad tensors and for views of one flat buffer, twice in a row (accumulation).  The FOLDED
@@ -277,6 +287,8 @@ def test_in_place_accumulation_equals_the_returned_gradients(scene, static, hip_
                 assert torch.equal(p.grad, expect), (layout, names[id(p)])
         assert n_folded >= (10 if static or not viewdir else 0)
     assert field_grad._GRAD_MAPS, "the in-place path was not taken"
+    from nsff_pl_amd import _lib
+    assert (_lib.last_bwd_kernel() == "x3") == (grad_precision == "f16x3")
 
 
 @pytest.mark.gpu
