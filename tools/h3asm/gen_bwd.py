@@ -288,7 +288,7 @@ def emit_ride(s, item):
 
 
 RIDE_CAP = int(os.environ.get("H3B_RIDE_CAP", "8"))
-EXP = os.environ.get("H3B_EXP", "")      # timing experiments (results are garbage; only the time is read): nostore, nocopy, noepi, norefill, nomfma
+EXP = os.environ.get("H3B_EXP", "")      # timing experiments (results are garbage; only the time is read): nostore, nocopy, noepi, norefill, nomfma, nostream (AH without the 24 riding weight loads)
 
 
 class LogStream(Stream):
@@ -569,7 +569,7 @@ def build():
         bodies[name], log = phase_body(name, *a, **k)
         return log
     pro_vm = [("w", ks) for ks in range(4) for _ in range(2)]
-    ah = gen("AH", "A", 4, msk=True, vm_seed=pro_vm, stream=list(range(4, 16)))
+    ah = gen("AH", "A", 4, msk=True, vm_seed=pro_vm, stream=None if "nostream" in EXP else list(range(4, 16)))
     bh = gen("BH", "B", 4, ride="mask", refills=[0, 1, 2, 3], msk=True, vm_seed=pro_vm + ah)
     a_like = ["mskA"] + ["cpst"] * 8            # what an A phase of a 16-k-step layer issues (every B16* follows one)
     gen("A16F", "A", 16, ride="mask", copy=True, msk=True, vm_seed=pro_vm + ah + bh)
