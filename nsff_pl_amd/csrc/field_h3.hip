@@ -1562,7 +1562,7 @@ __device__ __forceinline__ void h3a_kernel() {
                         v = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-                reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = v;
+                reinterpret_cast<float4*>(a.raw)[p0 * (NSFF_RAW_STRIDE / 4) + i] = v;       // (non-temporal: measured +-0, round 6)
             }
         }
     }

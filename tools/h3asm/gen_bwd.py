@@ -172,7 +172,9 @@ def epilogue_dxin(half):
             st = [I_salu("s_sub_u32", S_T0, S_NVALID, first, scc=True), I_salu("s_cselect_b32", S_T0, 0, S_T0),
                   I_v_cmp_gt_u32_vcc(S_T0, V_L31), I_s_and_saveexec(S_SAVE)]
             for q in range(4):
-                st.append((I_gstore_s(V_DX.sub(nt), a.sub(4 * q, 4), S_DXIN, 4 * (32 * mt + 8 * q)), "dxst"))
+                # (non-temporal like the fragment stores: d_xin is read once, by nsff_field_input_backward -- both trunks 488-502 ->
+                #  468-472 us, dynamic alone 256-263 -> 256-259, same box interleaved; H3B_EXP=tdx: plain stores, for A/B)
+                st.append(((I_gstore_s if "tdx" in EXP else gstore_nt)(V_DX.sub(nt), a.sub(4 * q, 4), S_DXIN, 4 * (32 * mt + 8 * q)), "dxst"))
             st.append(I_s_mov_exec(S_SAVE))
             out.append(st)
     return out
