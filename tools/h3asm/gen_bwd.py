@@ -227,7 +227,7 @@ def copy_groups(half, last_of_slot):
 def mask_load(half):
     """the sign words of the step whose epilogue of `half` comes next: 8 bytes per lane at S_MASK (this wave's 64 words of half
     A's 64-point tile; half B: + 2 KiB); behind half B's load the pointer moves on to the next (lower) slot"""
-    out = [(I_gload_s(V(MSK[half][0].i, 2), V_MOFF, S_MASK, 2048 if half == "B" else 0), "msk" + half)]
+    out = [(I_gload_s(V(MSK[half][0].i, 2), V_MOFF, S_MASK, 2048 if half == "B" else 0), "msk" + half)]     # (as `nt`: measured +-0)
     if half == "B":
         out += [I_salu("s_sub_u32", S(S_MASK.i), S(S_MASK.i), S_MSTRIDE, scc=True), I_salu("s_subb_u32", S(S_MASK.i + 1), S(S_MASK.i + 1), 0, scc=True)]
     return out
