@@ -110,7 +110,8 @@ def vadd_s(d, s_, v_):      # d = s + v  (VOP2: the scalar operand first)
 def gstore_nt(voff, data, sbase, off=0):
     """a store of data that is written once and read once by another kernel: non-temporal, as field_bwd.hip's fragment_block"""
     i = I_gstore_s(voff, data, sbase, off)
-    i.text += " nt"
+    if "tcp" not in EXP:            # (H3B_EXP=tcp: plain stores, for A/B)
+        i.text += " nt"
     return i
 
 
